@@ -1,0 +1,8 @@
+"""act3d-chained-diffuser_amd: MI355X-native hot path of Act3D / ChainedDiffuser.
+
+Import with ``importlib.import_module("act3d-chained-diffuser_amd")`` (the directory name carries a hyphen).
+Nothing here computes on the CPU: every op needs libact3d_hip.so and a gfx950 device.
+"""
+from . import lib  # noqa: F401
+from .build import build  # noqa: F401
+from . import ops  # noqa: F401,E402

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the act3d HIP library (gfx950 / CDNA4 only).
+// Everything here is internal; the public C-ABI lives in include/act3d_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define A3D_OK 0
+#define A3D_ERR_ARG (-22)      // EINVAL
+#define A3D_ERR_LAUNCH (-5)    // EIO
+#define A3D_ERR_NOMEM (-12)    // ENOMEM
+
+namespace a3d {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int HD = 15;    // head dim of both models (60/4, 120/8)
+constexpr int HDP = 16;   // padded head dim
+
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  unsigned int u = __float_as_uint(x);
+  unsigned int r = u + 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(r >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// x ~= hi + lo with hi, lo bf16 (16 mantissa bits kept in total)
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - bf2f(hi));
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// RoPE-3D frequency of pair index k inside one axis third (reference
+// model/utils/position_encodings.py:72-75): exp(-ln(1e4) * 2k / (E/3)).
+__device__ __forceinline__ float rope_freq(int k, int E) {
+  return expf((float)(2 * k) * (-9.210340371976184f / (float)(E / 3)));
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace a3d

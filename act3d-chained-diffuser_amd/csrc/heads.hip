@@ -1,0 +1,382 @@
+// Decoding heads, losses, ghost-point sampler and optimizer of the keypose path (all HBM/latency-bound, tiny).
+//
+//   a3d_mask_logits_{fwd,bwd}   einsum("bt c, npts bt c -> bt npts")            act3d.py:493-494
+//   a3d_argmax_gather           torch.max(mask).indices (first max) + coordinate gather   act3d.py:312-314, 512-513
+//   a3d_soft_ce_loss            label = softmax(-||ghost-gt||/spread); CE(logits, label)  main_keypose.py:382-405
+//   a3d_quat_sigmoid_{fwd,bwd}  normalise_quat + sigmoid of the 5-vector prediction        act3d.py:526-533, utils.py:51-52
+//   a3d_mse_loss / a3d_l1_loss  F.mse_loss / F.l1_loss (mean) with gradient               main_keypose.py:362-380, diffusion_model.py:315-323
+//   a3d_sample_ghost_points     Philox4x32-10 uniform cube / ball-rejection sampler        act3d.py:394-440, utils.py:68-84
+//   a3d_adamw_step              torch.optim.AdamW update on the flat parameter buffer      engine.py:89-102
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = -INFINITY;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, red[w]);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void mask_logits_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ F, float* __restrict__ out, int B, int Ng, int E) {
+  const size_t total = (size_t)B * Ng;
+  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < total;
+       row += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(row / Ng);
+    const float* f = F + row * E;
+    const float* qq = q + (size_t)b * E;
+    float s = 0.f;
+    for (int c = 0; c < E; ++c) s += qq[c] * f[c];
+    out[row] = s;
+  }
+}
+
+// dF[b][n][c] (+)= dlog[b][n] q[b][c];  dq[b][c] = sum_n dlog[b][n] F[b][n][c]
+__global__ __launch_bounds__(256) void mask_logits_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ F, const float* __restrict__ dlog,
+    float* __restrict__ dF, float* __restrict__ dq, int B, int Ng, int E, int accumulate_dF) {
+  __shared__ float part[4][128];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int c = t & 63, pr = t >> 6;
+  float a0 = 0.f, a1 = 0.f;
+  for (int n = pr; n < Ng; n += 4) {
+    const float d = dlog[(size_t)b * Ng + n];
+    const size_t base = ((size_t)b * Ng + n) * E;
+    if (c < E) {
+      a0 += d * F[base + c];
+      const float v = d * q[(size_t)b * E + c];
+      if (accumulate_dF) dF[base + c] += v; else dF[base + c] = v;
+    }
+    if (c + 64 < E) {
+      a1 += d * F[base + c + 64];
+      const float v = d * q[(size_t)b * E + c + 64];
+      if (accumulate_dF) dF[base + c + 64] += v; else dF[base + c + 64] = v;
+    }
+  }
+  part[pr][c] = a0;
+  part[pr][c + 64] = a1;
+  __syncthreads();
+  if (t < E) dq[(size_t)b * E + t] = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+}
+
+__global__ __launch_bounds__(256) void argmax_gather_kernel(
+    const float* __restrict__ logits, const float* __restrict__ ghost, long long* __restrict__ top_idx,
+    float* __restrict__ pos, int Ng) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float best = -INFINITY;
+  int besti = 0x7FFFFFFF;
+  for (int n = t; n < Ng; n += 256) {
+    const float v = logits[(size_t)b * Ng + n];
+    if (v > best || (v == best && n < besti) || besti == 0x7FFFFFFF) { best = v; besti = n; }
+  }
+  bv[t] = best; bi[t] = besti;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      const float v2 = bv[t + s];
+      const int i2 = bi[t + s];
+      if (i2 != 0x7FFFFFFF && (bi[t] == 0x7FFFFFFF || v2 > bv[t] || (v2 == bv[t] && i2 < bi[t]))) { bv[t] = v2; bi[t] = i2; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) top_idx[b] = bi[0];
+  if (t < 3 && pos) pos[b * 3 + t] = ghost[((size_t)b * Ng + bi[0]) * 3 + t];
+}
+
+// per sample: loss_b = -sum_n y_n log_softmax(z)_n,  y = (1-ls) softmax(-l2/spread) + ls/Ng
+// dz = gscale * (softmax(z) - y)     (sum_n y_n = 1)
+__global__ __launch_bounds__(256) void soft_ce_kernel(
+    const float* __restrict__ ghost, const float* __restrict__ gt, const float* __restrict__ logits,
+    float* __restrict__ loss_b, float* __restrict__ dlogits, int Ng, float spread, float label_smoothing,
+    float gscale) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float gx = gt[b * 3 + 0], gy = gt[b * 3 + 1], gz = gt[b * 3 + 2];
+  const float* z = logits + (size_t)b * Ng;
+  // pass 1: maxima
+  float mz = -INFINITY, ma = -INFINITY;
+  for (int n = t; n < Ng; n += 256) {
+    const float* p = ghost + ((size_t)b * Ng + n) * 3;
+    const float dx = p[0] - gx, dy = p[1] - gy, dz = p[2] - gz;
+    const float a = -sqrtf(dx * dx + dy * dy + dz * dz) / spread;
+    ma = fmaxf(ma, a);
+    mz = fmaxf(mz, z[n]);
+  }
+  ma = block_max(ma, red);
+  mz = block_max(mz, red);
+  float sa = 0.f, sz = 0.f;
+  for (int n = t; n < Ng; n += 256) {
+    const float* p = ghost + ((size_t)b * Ng + n) * 3;
+    const float dx = p[0] - gx, dy = p[1] - gy, dz = p[2] - gz;
+    const float a = -sqrtf(dx * dx + dy * dy + dz * dz) / spread;
+    sa += expf(a - ma);
+    sz += expf(z[n] - mz);
+  }
+  sa = block_sum(sa, red);
+  sz = block_sum(sz, red);
+  const float lse = mz + logf(sz);
+  float acc = 0.f;
+  for (int n = t; n < Ng; n += 256) {
+    const float* p = ghost + ((size_t)b * Ng + n) * 3;
+    const float dx = p[0] - gx, dy = p[1] - gy, dz = p[2] - gz;
+    const float a = -sqrtf(dx * dx + dy * dy + dz * dz) / spread;
+    const float y = (1.f - label_smoothing) * (expf(a - ma) / sa) + label_smoothing / (float)Ng;
+    const float lsm = z[n] - lse;
+    acc -= y * lsm;
+    if (dlogits) dlogits[(size_t)b * Ng + n] = gscale * (expf(lsm) - y);
+  }
+  acc = block_sum(acc, red);
+  if (t == 0) loss_b[b] = acc;
+}
+
+// out[0] = scale * sum(in[0..n))   (single workgroup; n is small)
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// kind 0: mse, 1: l1.  loss = coeff * mean(f(p - t)); grad = d loss / d p
+__global__ __launch_bounds__(256) void elem_loss_kernel(const float* __restrict__ p, const float* __restrict__ tg,
+                                                        int n, int kind, float coeff, float* __restrict__ loss,
+                                                        float* __restrict__ grad) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const float inv = coeff / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = p[i] - tg[i];
+    if (kind == 0) {
+      s += d * d;
+      if (grad) grad[i] = 2.f * d * inv;
+    } else {
+      s += fabsf(d);
+      if (grad) grad[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = s * inv;
+}
+
+__global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ y,
+                                       size_t n) {
+  const float s = sc[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+
+// pred [B][5] -> rot [B][4] = x / max(|x|, 1e-10), grip [B][1] = sigmoid
+__global__ void quat_sigmoid_fwd_kernel(const float* __restrict__ pred, float* __restrict__ rot,
+                                        float* __restrict__ grip, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + (size_t)b * 5;
+  const float nrm = fmaxf(sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]), 1e-10f);
+  for (int i = 0; i < 4; ++i) rot[b * 4 + i] = p[i] / nrm;
+  grip[b] = 1.f / (1.f + expf(-p[4]));
+}
+__global__ void quat_sigmoid_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ drot,
+                                        const float* __restrict__ dgrip, float* __restrict__ dpred, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + (size_t)b * 5;
+  const float n2 = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+  const float nrm = fmaxf(n2, 1e-10f);
+  float dot = 0.f;
+  for (int i = 0; i < 4; ++i) dot += (drot ? drot[b * 4 + i] : 0.f) * p[i];
+  for (int i = 0; i < 4; ++i) {
+    const float dy = drot ? drot[b * 4 + i] : 0.f;
+    // y = x / n: dx = dy / n - x (x.dy) / n^3   (the clamp branch has zero norm-gradient)
+    dpred[b * 5 + i] = (n2 > 1e-10f) ? (dy / nrm - p[i] * dot / (nrm * nrm * nrm)) : dy / nrm;
+  }
+  const float sg = 1.f / (1.f + expf(-p[4]));
+  dpred[b * 5 + 4] = (dgrip ? dgrip[b] : 0.f) * sg * (1.f - sg);
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. 2011)
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// state[0] = seed, state[1] = call offset (uint64 each).  anchor == null: uniform in [lo, hi].
+// else: uniform in ball(anchor, radius) intersected with the box clip(anchor -+ radius, lo, hi) by rejection
+// (at most max_attempts draws per point, then the clipped anchor itself).
+__global__ __launch_bounds__(256) void sample_ghost_kernel(
+    const unsigned long long* __restrict__ state, const float* __restrict__ bounds, const float* __restrict__ anchor,
+    float radius, float* __restrict__ out, int B, int Ng, int level, int max_attempts) {
+  const size_t total = (size_t)B * Ng;
+  const unsigned long long seed = state[0], offs = state[1];
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / Ng), i = (int)(idx - (size_t)b * Ng);
+    float lo[3], hi[3], ctr[3];
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = bounds[a]; hi[a] = bounds[3 + a];
+      if (anchor) {
+        ctr[a] = anchor[b * 3 + a];
+        lo[a] = fminf(fmaxf(__fsub_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
+        hi[a] = fminf(fmaxf(__fadd_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
+      }
+    }
+    float p[3] = {0.f, 0.f, 0.f};
+    bool ok = false;
+    const int tries = anchor ? max_attempts : 1;
+    for (int a = 0; a < tries && !ok; ++a) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)i, (uint32_t)b, (uint32_t)level | ((uint32_t)a << 8), (uint32_t)offs,
+                    (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offs >> 32), r);
+      // explicit round-to-nearest ops (no fma contraction): the CPU twin in oracle/sampling.py must match bit for bit
+      for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(lo[c], __fmul_rn(u01(r[c]), __fsub_rn(hi[c], lo[c])));
+      if (!anchor) { ok = true; break; }
+      const float dx = __fsub_rn(p[0], ctr[0]), dy = __fsub_rn(p[1], ctr[1]), dz = __fsub_rn(p[2], ctr[2]);
+      ok = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))) < radius;
+    }
+    if (!ok) for (int c = 0; c < 3; ++c) p[c] = fminf(fmaxf(ctr[c], bounds[c]), bounds[3 + c]);
+    for (int c = 0; c < 3; ++c) out[idx * 3 + c] = p[c];
+  }
+}
+__global__ void rng_advance_kernel(unsigned long long* state, unsigned long long n) { state[1] += n; }
+
+// ---------------------------------------------------------------- AdamW on the flat buffer
+// elements [0, n_nodecay) use weight decay wd0, the rest wd1.  step[0] holds the number of completed steps.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ step, size_t n, size_t n_nodecay,
+                                                    float lr, float beta1, float beta2, float eps, float wd0,
+                                                    float wd1, float gscale) {
+  const float t = step[0] + 1.0f;
+  const float bc1 = 1.0f - powf(beta1, t);
+  const float bc2 = 1.0f - powf(beta2, t);
+  const float step_size = lr / bc1;
+  const float bc2s = sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float wd = (i < n_nodecay) ? wd0 : wd1;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+__global__ void step_inc_kernel(float* step) { step[0] += 1.0f; }
+
+}  // namespace a3d
+
+using namespace a3d;
+
+static inline int grid_for(size_t n, int cap = 4096) { return (int)std::min<size_t>((n + 255) / 256, (size_t)cap); }
+
+extern "C" int a3d_mask_logits_fwd(const float* q, const float* F, float* out, int B, int Ng, int E, void* stream) {
+  if (!q || !F || !out || B <= 0 || Ng <= 0 || E <= 0) { set_error("a3d_mask_logits_fwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(mask_logits_fwd_kernel, dim3(grid_for((size_t)B * Ng)), dim3(256), 0, (hipStream_t)stream, q, F, out, B, Ng, E);
+  return check_launch("a3d_mask_logits_fwd");
+}
+extern "C" int a3d_mask_logits_bwd(const float* q, const float* F, const float* dlog, float* dF, float* dq, int B,
+                                   int Ng, int E, int accumulate_dF, void* stream) {
+  if (!q || !F || !dlog || !dF || !dq || B <= 0 || Ng <= 0 || E <= 0 || E > 128) { set_error("a3d_mask_logits_bwd: bad argument (E=%d)", E); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(mask_logits_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, F, dlog, dF, dq, B, Ng, E, accumulate_dF);
+  return check_launch("a3d_mask_logits_bwd");
+}
+extern "C" int a3d_argmax_gather(const float* logits, const float* ghost, long long* top_idx, float* pos, int B, int Ng,
+                                 void* stream) {
+  if (!logits || !top_idx || B <= 0 || Ng <= 0 || (pos && !ghost)) { set_error("a3d_argmax_gather: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(argmax_gather_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ghost, top_idx, pos, Ng);
+  return check_launch("a3d_argmax_gather");
+}
+extern "C" int a3d_soft_ce_loss(const float* ghost, const float* gt, const float* logits, float* loss_b, float* loss,
+                                float* dlogits, int B, int Ng, float spread, float label_smoothing, float coeff,
+                                void* stream) {
+  if (!ghost || !gt || !logits || !loss_b || !loss || B <= 0 || Ng <= 0 || spread <= 0.f) { set_error("a3d_soft_ce_loss: bad argument"); return A3D_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(soft_ce_kernel, dim3(B), dim3(256), 0, s, ghost, gt, logits, loss_b, dlogits, Ng, spread, label_smoothing, coeff / (float)B);
+  int rc = check_launch("a3d_soft_ce_loss");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, loss_b, B, coeff / (float)B, loss);
+  return check_launch("a3d_soft_ce_loss(reduce)");
+}
+extern "C" int a3d_elem_loss(const float* pred, const float* target, int n, int kind, float coeff, float* loss,
+                             float* grad, void* stream) {
+  if (!pred || !target || !loss || n <= 0 || (kind != 0 && kind != 1)) { set_error("a3d_elem_loss: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(elem_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, n, kind, coeff, loss, grad);
+  return check_launch("a3d_elem_loss");
+}
+extern "C" int a3d_scale_by_scalar(const float* x, const float* scalar, float* y, size_t n, void* stream) {
+  if (!x || !scalar || !y) { set_error("a3d_scale_by_scalar: null pointer"); return A3D_ERR_ARG; }
+  if (n == 0) return A3D_OK;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, n);
+  return check_launch("a3d_scale_by_scalar");
+}
+extern "C" int a3d_quat_sigmoid_fwd(const float* pred, float* rot, float* grip, int B, void* stream) {
+  if (!pred || !rot || !grip || B <= 0) { set_error("a3d_quat_sigmoid_fwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(quat_sigmoid_fwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pred, rot, grip, B);
+  return check_launch("a3d_quat_sigmoid_fwd");
+}
+extern "C" int a3d_quat_sigmoid_bwd(const float* pred, const float* drot, const float* dgrip, float* dpred, int B,
+                                    void* stream) {
+  if (!pred || !dpred || B <= 0) { set_error("a3d_quat_sigmoid_bwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(quat_sigmoid_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pred, drot, dgrip, dpred, B);
+  return check_launch("a3d_quat_sigmoid_bwd");
+}
+extern "C" int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds, const float* anchor,
+                                       float radius, float* out, int B, int Ng, int level, int max_attempts,
+                                       void* stream) {
+  if (!state || !bounds || !out || B <= 0 || Ng <= 0 || level < 0 || level > 255 || max_attempts < 1 || max_attempts > 65535 || (anchor && radius <= 0.f)) {
+    set_error("a3d_sample_ghost_points: bad argument");
+    return A3D_ERR_ARG;
+  }
+  hipLaunchKernelGGL(sample_ghost_kernel, dim3(grid_for((size_t)B * Ng)), dim3(256), 0, (hipStream_t)stream, state, bounds, anchor, radius, out, B, Ng, level, max_attempts);
+  return check_launch("a3d_sample_ghost_points");
+}
+extern "C" int a3d_rng_advance(unsigned long long* state, unsigned long long n, void* stream) {
+  if (!state) { set_error("a3d_rng_advance: null state"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, n);
+  return check_launch("a3d_rng_advance");
+}
+extern "C" void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+extern "C" int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, size_t n, size_t n_nodecay,
+                              float lr, float beta1, float beta2, float eps, float wd_nodecay, float wd_decay,
+                              float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step) { set_error("a3d_adamw_step: null pointer"); return A3D_ERR_ARG; }
+  if (n == 0) return A3D_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, p, g, m, v, step, n, n_nodecay, lr, beta1, beta2, eps, wd_nodecay, wd_decay, grad_scale);
+  int rc = check_launch("a3d_adamw_step");
+  if (rc) return rc;
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+  return check_launch("a3d_adamw_step(inc)");
+}

@@ -1,0 +1,364 @@
+// Small-E dense layers of the Act3D / ChainedDiffuser hot path on f32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Every Linear on the path has K,N <= 512 (E = 60/120, FFN 4E = 480, instruction 512) while the row
+// count M = B*tokens is large (up to B*4098), so these are streaming GEMMs: bound by HBM traffic of
+// X and Y, not by MFMA.  They use the exact-f32 matrix instruction (same numerics as an fmaf chain,
+// MI355X_MICROARCH.md "FP32-input MFMA") so the projections match the fp32 reference to rounding.
+//
+//   a3d_linear_fwd    Y = act(X W^T + b)            reference: F.linear in multihead_custom_attention.py:246-303,
+//                                                   layers.py:313-332 (FFN), diffusion_head.py:41-49,177-199
+//   a3d_linear_wgrad  dW += dY^T X, db += sum dY    (autograd of the same)
+//   a3d_add_layernorm_{fwd,bwd}  y = LN(a + r)      reference: layers.py:308-309, 329-331 (post-norm residual)
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int LT_BM = 64;   // rows per workgroup
+constexpr int LT_BN = 64;   // cols per workgroup
+constexpr int LT_KC = 16;   // contraction chunk (one ds_read_b128 per lane)
+constexpr int LT_LD = 20;   // padded LDS row stride in floats (80 B: conflict-free b128 column reads)
+
+// act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad]
+template <bool WT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(
+    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+    const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+    const float* __restrict__ mask, int ldm, int M, int N, int K, int act) {
+  __shared__ __attribute__((aligned(16))) float Xs[LT_BM * LT_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[LT_BN * LT_LD];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * LT_BM, n0 = blockIdx.y * LT_BN;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging assignment: thread -> (row, 4 consecutive k)
+  const int sr = t >> 2, sk = (t & 3) * 4;
+  const bool x_vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+  const bool w_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+
+  for (int k0 = 0; k0 < K; k0 += LT_KC) {
+    // ---- X tile [64][16]
+    {
+      const int m = m0 + sr, k = k0 + sk;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const float* p = X + (size_t)m * ldx + k;
+        if (x_vec && k + 3 < K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k + 0 < K) v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+          if (k + 3 < K) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&Xs[sr * LT_LD + sk]) = v;
+    }
+    // ---- W tile -> Ws[n][k]
+    if (!WT) {
+      const int n = n0 + sr, k = k0 + sk;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const float* p = W + (size_t)n * ldw + k;
+        if (w_vec && k + 3 < K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k + 0 < K) v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+          if (k + 3 < K) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&Ws[sr * LT_LD + sk]) = v;
+    } else {
+      // W stored [K][N] (dgrad): thread -> (k = t/16, 4 consecutive n)
+      const int kk = t >> 4, nn = (t & 15) * 4;
+      const int k = k0 + kk, n = n0 + nn;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K) {
+        const float* p = W + (size_t)k * ldw + n;
+        if (w_vec && n + 3 < N) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (n + 0 < N) v.x = p[0];
+          if (n + 1 < N) v.y = p[1];
+          if (n + 2 < N) v.z = p[2];
+          if (n + 3 < N) v.w = p[3];
+        }
+      }
+      Ws[(nn + 0) * LT_LD + kk] = v.x;
+      Ws[(nn + 1) * LT_LD + kk] = v.y;
+      Ws[(nn + 2) * LT_LD + kk] = v.z;
+      Ws[(nn + 3) * LT_LD + kk] = v.w;
+    }
+    __syncthreads();
+    // contraction index of MFMA step j in lane group g is k = g*4 + j on both operands
+    const float4 a = *reinterpret_cast<const float4*>(&Xs[(wave * 16 + li) * LT_LD + g * 4]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float4 b = *reinterpret_cast<const float4*>(&Ws[(nt * 16 + li) * LT_LD + g * 4]);
+      acc[nt] = mfma_f32_16x16x4(a.x, b.x, acc[nt]);
+      acc[nt] = mfma_f32_16x16x4(a.y, b.y, acc[nt]);
+      acc[nt] = mfma_f32_16x16x4(a.z, b.z, acc[nt]);
+      acc[nt] = mfma_f32_16x16x4(a.w, b.w, acc[nt]);
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + nt * 16 + li;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + g * 4 + r;
+      if (m >= M) continue;
+      float v = acc[nt][r] + bv;
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = (mask[(size_t)m * ldm + n] > 0.f) ? v : 0.f;
+      Y[(size_t)m * ldy + n] = v;
+    }
+  }
+}
+
+// dW[n][k] += sum_m dY[m][n] X[m][k];  column k == K of the virtual X is all ones -> db[n].
+constexpr int WG_MC = 16;    // rows of m staged per step
+constexpr int WG_LD = 68;    // padded LDS row stride (floats)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(
+    const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx,
+    float* __restrict__ dW, int lddw, float* __restrict__ db, int M, int N, int K, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float Ys[WG_MC * WG_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[WG_MC * WG_LD];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const int KE = db ? K + 1 : K;   // virtual ones column
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sm = t >> 4, sc = (t & 15) * 4;   // thread -> (m row, 4 consecutive cols)
+  for (int mb = mbeg; mb < mend; mb += WG_MC) {
+    const int m = mb + sm;
+    float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < mend) {
+      const float* py = dY + (size_t)m * lddy + n0 + sc;
+      if (n0 + sc + 0 < N) vy.x = py[0];
+      if (n0 + sc + 1 < N) vy.y = py[1];
+      if (n0 + sc + 2 < N) vy.z = py[2];
+      if (n0 + sc + 3 < N) vy.w = py[3];
+      const float* px = X + (size_t)m * ldx + k0 + sc;
+      const int k = k0 + sc;
+      vx.x = (k + 0 < K) ? px[0] : ((k + 0 == K && db) ? 1.f : 0.f);
+      vx.y = (k + 1 < K) ? px[1] : ((k + 1 == K && db) ? 1.f : 0.f);
+      vx.z = (k + 2 < K) ? px[2] : ((k + 2 == K && db) ? 1.f : 0.f);
+      vx.w = (k + 3 < K) ? px[3] : ((k + 3 == K && db) ? 1.f : 0.f);
+    }
+    *reinterpret_cast<float4*>(&Ys[sm * WG_LD + sc]) = vy;
+    *reinterpret_cast<float4*>(&Xs[sm * WG_LD + sc]) = vx;
+    __syncthreads();
+    // wave -> n tile `wave`; contraction index of step j in group g is m = g*4 + j
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = Ys[(g * 4 + j) * WG_LD + wave * 16 + li];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = Xs[(g * 4 + j) * WG_LD + kt * 16 + li];
+        acc[kt] = mfma_f32_16x16x4(a[j], b, acc[kt]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int k = k0 + kt * 16 + li;
+    if (k >= KE) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wave * 16 + g * 4 + r;
+      if (n >= N) continue;
+      const float v = acc[kt][r];
+      if (k < K) atomicAdd(&dW[(size_t)n * lddw + k], v);
+      else atomicAdd(&db[n], v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- residual + LayerNorm
+// one wave per row, E <= 512
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(
+    const float* __restrict__ A, const float* __restrict__ R, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ Y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, int M, int E, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  for (int m = wave_global; m < M; m += nwaves) {
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      float x = 0.f;
+      if (e < E) {
+        x = A[(size_t)m * E + e];
+        if (R) x += R[(size_t)m * E + e];
+      }
+      v[i] = x;
+      s += x;
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      if (e < E) { const float d = v[i] - mean; q += d * d; }
+    }
+    const float var = wave_sum(q) / (float)E;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      if (e < E) Y[(size_t)m * E + e] = (v[i] - mean) * rstd * gamma[e] + beta[e];
+    }
+    if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(
+    const float* __restrict__ A, const float* __restrict__ R, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const float* __restrict__ dY, float* __restrict__ dS, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int M, int E) {
+  __shared__ float red_g[4][512];
+  __shared__ float red_b[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+  float pg[8], pb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+  for (int m = wave_global; m < M; m += nwaves) {
+    const float mean = mean_in[m], rstd = rstd_in[m];
+    float xh[8], gy[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      xh[i] = 0.f; gy[i] = 0.f;
+      if (e < E) {
+        float x = A[(size_t)m * E + e];
+        if (R) x += R[(size_t)m * E + e];
+        const float dy = dY[(size_t)m * E + e];
+        xh[i] = (x - mean) * rstd;
+        gy[i] = dy * gamma[e];
+        pg[i] += dy * xh[i];
+        pb[i] += dy;
+        s1 += gy[i];
+        s2 += gy[i] * xh[i];
+      }
+    }
+    s1 = wave_sum(s1) / (float)E;
+    s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      if (e < E) dS[(size_t)m * E + e] = rstd * (gy[i] - s1 - xh[i] * s2);
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = lane + i * 64;
+      if (e < 512) { red_g[wave][e] = pg[i]; red_b[wave][e] = pb[i]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+      const float sg = red_g[0][e] + red_g[1][e] + red_g[2][e] + red_g[3][e];
+      const float sb = red_b[0][e] + red_b[1][e] + red_b[2][e] + red_b[3][e];
+      atomicAdd(&dgamma[e], sg);
+      atomicAdd(&dbeta[e], sb);
+    }
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias,
+                              float* Y, int ldy, const float* mask, int ldm, int M, int N, int K,
+                              int act, int w_transposed, void* stream) {
+  if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) {
+    set_error("a3d_linear_fwd: bad argument (M=%d N=%d K=%d ldx=%d ldy=%d)", M, N, K, ldx, ldy);
+    return A3D_ERR_ARG;
+  }
+  if (act == 2 && !mask) { set_error("a3d_linear_fwd: act=2 needs a mask"); return A3D_ERR_ARG; }
+  if (M == 0) return A3D_OK;
+  dim3 grid(cdiv(M, LT_BM), cdiv(N, LT_BN));
+  hipStream_t s = (hipStream_t)stream;
+  if (w_transposed)
+    hipLaunchKernelGGL(linear_fwd_kernel<true>, grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act);
+  else
+    hipLaunchKernelGGL(linear_fwd_kernel<false>, grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act);
+  return check_launch("a3d_linear_fwd");
+}
+
+extern "C" int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
+                                float* db, int M, int N, int K, void* stream) {
+  if (!dY || !X || !dW || M < 0 || N <= 0 || K <= 0) {
+    set_error("a3d_linear_wgrad: bad argument (M=%d N=%d K=%d)", M, N, K);
+    return A3D_ERR_ARG;
+  }
+  if (M == 0) return A3D_OK;
+  const int KE = db ? K + 1 : K;
+  // split the M reduction so that the launch has a few hundred workgroups
+  const int tiles = cdiv(N, 64) * cdiv(KE, 64);
+  int nsplit = max(1, min(cdiv(M, 256), cdiv(1024, tiles)));
+  int rows = cdiv(cdiv(M, nsplit), WG_MC) * WG_MC;
+  nsplit = cdiv(M, rows);
+  dim3 grid(cdiv(N, 64), cdiv(KE, 64), nsplit);
+  hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dW,
+                     lddw, db, M, N, K, rows);
+  return check_launch("a3d_linear_wgrad");
+}
+
+extern "C" int a3d_add_layernorm_fwd(const float* A, const float* R, const float* gamma, const float* beta,
+                                     float* Y, float* mean, float* rstd, int M, int E, float eps,
+                                     void* stream) {
+  if (!A || !gamma || !beta || !Y || !mean || !rstd || E <= 0 || E > 512 || M < 0) {
+    set_error("a3d_add_layernorm_fwd: bad argument (M=%d E=%d)", M, E);
+    return A3D_ERR_ARG;
+  }
+  if (M == 0) return A3D_OK;
+  const int grid = min(cdiv(M, 4), 4096);
+  hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, beta, Y,
+                     mean, rstd, M, E, eps);
+  return check_launch("a3d_add_layernorm_fwd");
+}
+
+extern "C" int a3d_add_layernorm_bwd(const float* A, const float* R, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dY, float* dS, float* dgamma,
+                                     float* dbeta, int M, int E, void* stream) {
+  if (!A || !gamma || !mean || !rstd || !dY || !dS || E <= 0 || E > 512 || M < 0 || (!dgamma != !dbeta)) {
+    set_error("a3d_add_layernorm_bwd: bad argument (M=%d E=%d)", M, E);
+    return A3D_ERR_ARG;
+  }
+  if (M == 0) return A3D_OK;
+  const int grid = min(cdiv(M, 16), 1024);
+  hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean,
+                     rstd, dY, dS, dgamma, dbeta, M, E);
+  return check_launch("a3d_add_layernorm_bwd");
+}

@@ -1,0 +1,300 @@
+// Scene-token construction for the Act3D coarse-to-fine loop: HBM-bound gather/select kernels.
+//
+//   a3d_pcd_downsample   reference: F.interpolate(pcd, 1/f, 'bilinear') + rearrange (act3d.py:379-383,
+//                        encoder.py:147-158).  For even f the bilinear sample is the mean of the 2x2 block at
+//                        (f*y + f/2 - 1, f*x + f/2 - 1); evaluated as 0.5*(0.5*p00+0.5*p01)+0.5*(0.5*p10+0.5*p11),
+//                        the order torch's separable kernel uses, so the result is bit-identical.
+//   a3d_knn_topk         reference: l2 = ((pos - pcd)**2).sum(-1).sqrt(); topk(k, largest=False).indices
+//                        (act3d.py:244-245).  Radix-select on the fp32 bit pattern + bitonic sort of the k
+//                        survivors in LDS; order = ascending (distance, index), i.e. torch's sorted order with a
+//                        defined tie-break.
+//   a3d_build_context    reference: per-sample python gathers + torch.cat with the gripper token
+//                        (act3d.py:247-260).  One pass: ctx[b] = [feat[b][idx[b]] | extra[b]].
+//   a3d_build_context_bwd scatter of d(ctx) back to the (zero-initialised) feature-map gradient.
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+__global__ __launch_bounds__(256) void pcd_downsample_kernel(
+    const float* __restrict__ pcd, float* __restrict__ out, int BC, int C, int Hin, int Win, int f) {
+  const int h = Hin / f, w = Win / f;
+  const size_t total = (size_t)BC * h * w;
+  const int off = f / 2 - 1;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % w);
+    const int y = (int)((idx / w) % h);
+    const int bc = (int)(idx / ((size_t)w * h));
+    const int y0 = f * y + off, x0 = f * x + off;
+    const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+    const int b = bc / C, cam = bc - b * C;
+    float* o = out + (((size_t)b * C + cam) * h * w + (size_t)y * w + x) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* p = pcd + ((size_t)bc * 3 + ch) * Hin * Win;
+      const float p00 = p[(size_t)y0 * Win + x0], p01 = p[(size_t)y0 * Win + x1];
+      const float p10 = p[(size_t)y1 * Win + x0], p11 = p[(size_t)y1 * Win + x1];
+      const float t0 = 0.5f * p00 + 0.5f * p01;
+      const float t1 = 0.5f * p10 + 0.5f * p11;
+      o[ch] = 0.5f * t0 + 0.5f * t1;
+    }
+  }
+}
+
+// d = sqrt((px-x)^2 + (py-y)^2 + (pz-z)^2) in the reference's operation order, no fma contraction
+__device__ __forceinline__ float l2_dist(float px, float py, float pz, const float* q) {
+  const float dx = __fsub_rn(px, q[0]), dy = __fsub_rn(py, q[1]), dz = __fsub_rn(pz, q[2]);
+  const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  return __fsqrt_rn(s);
+}
+
+constexpr int TK_THREADS = 1024;
+
+// One workgroup per sample.  dist_ws: [B][N] uint32 scratch.  keys: dynamic LDS, kpad uint64.
+__global__ __launch_bounds__(TK_THREADS) void knn_topk_kernel(
+    const float* __restrict__ pos, const float* __restrict__ xyz, unsigned int* __restrict__ dist_ws,
+    long long* __restrict__ idx_out, float* __restrict__ dist_out, int N, int k, int kpad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_prefix, sh_krem, sh_count, sh_neq;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float px = pos[b * 3 + 0], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  const float* pts = xyz + (size_t)b * N * 3;
+  unsigned int* dw = dist_ws + (size_t)b * N;
+
+  for (int i = t; i < N; i += TK_THREADS) dw[i] = __float_as_uint(l2_dist(px, py, pz, pts + (size_t)i * 3));
+  if (t == 0) { sh_prefix = 0; sh_krem = (unsigned int)k; }
+  __syncthreads();
+
+  // ---- 4 radix passes over the value bits (distances are >= 0: bit pattern is monotonic)
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const unsigned int prefix = sh_prefix;
+    const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = t; i < N; i += TK_THREADS) {
+      const unsigned int v = dw[i];
+      if ((v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned int krem = sh_krem, cum = 0;
+      int bin = 0;
+      for (; bin < 256; ++bin) {
+        if (cum + hist[bin] >= krem) break;
+        cum += hist[bin];
+      }
+      if (bin > 255) bin = 255;
+      sh_krem = krem - cum;
+      sh_prefix = prefix | ((unsigned int)bin << shift);
+      sh_neq = hist[bin];
+    }
+    __syncthreads();
+  }
+  const unsigned int T = sh_prefix;       // k-th smallest value
+  unsigned int need = sh_krem;            // how many elements == T are wanted
+  unsigned int idx_thr = 0xFFFFFFFFu;     // elements == T with idx <= idx_thr are taken
+  if (sh_neq != need) {
+    // ties at the threshold: select the `need` lowest indices among bits == T (3 radix passes on idx)
+    __syncthreads();
+    if (t == 0) { sh_prefix = 0; sh_krem = need; }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 16 - 8 * pass;
+      if (t < 256) hist[t] = 0;
+      __syncthreads();
+      const unsigned int prefix = sh_prefix;
+      const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = t; i < N; i += TK_THREADS) {
+        if (dw[i] == T && (((unsigned int)i) & himask) == prefix) atomicAdd(&hist[(((unsigned int)i) >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (t == 0) {
+        unsigned int krem = sh_krem, cum = 0;
+        int bin = 0;
+        for (; bin < 256; ++bin) {
+          if (cum + hist[bin] >= krem) break;
+          cum += hist[bin];
+        }
+        if (bin > 255) bin = 255;
+        sh_krem = krem - cum;
+        sh_prefix = prefix | ((unsigned int)bin << shift);
+      }
+      __syncthreads();
+    }
+    idx_thr = sh_prefix;
+  }
+  // ---- collect survivors
+  if (t == 0) sh_count = 0;
+  for (int i = t; i < kpad; i += TK_THREADS) keys[i] = 0xFFFFFFFFFFFFFFFFull;
+  __syncthreads();
+  for (int i = t; i < N; i += TK_THREADS) {
+    const unsigned int v = dw[i];
+    if (v < T || (v == T && (unsigned int)i <= idx_thr)) {
+      const unsigned int slot = atomicAdd(&sh_count, 1u);
+      if (slot < (unsigned int)kpad) keys[slot] = ((unsigned long long)v << 32) | (unsigned int)i;
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort of kpad 64-bit keys (value major, index minor)
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (kpad >> 1); i += TK_THREADS) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < k; i += TK_THREADS) {
+    const unsigned long long kk = keys[i];
+    idx_out[(size_t)b * k + i] = (long long)(kk & 0xFFFFFFFFull);
+    if (dist_out) dist_out[(size_t)b * k + i] = __uint_as_float((unsigned int)(kk >> 32));
+  }
+}
+
+// ctx[b][s][:] = s < k ? feat[b][idx ? idx[b][s] : s][:] : extra[b][s-k][:]   (rows of E floats, E % 4 == 0)
+__global__ __launch_bounds__(256) void build_context_kernel(
+    const float* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
+    float* __restrict__ ctx, int B, int Npts, int k, int X, int E4) {
+  const int S = k + X;
+  const size_t total = (size_t)B * S * E4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E4);
+    const size_t row = i / E4;
+    const int s = (int)(row % S), b = (int)(row / S);
+    float4 v;
+    if (s < k) {
+      const long long src = idx ? idx[(size_t)b * k + s] : (long long)s;
+      v = reinterpret_cast<const float4*>(feat)[((size_t)b * Npts + src) * E4 + e];
+    } else {
+      v = reinterpret_cast<const float4*>(extra)[((size_t)b * X + (s - k)) * E4 + e];
+    }
+    reinterpret_cast<float4*>(ctx)[i] = v;
+  }
+}
+
+// scalar-width variant for xyz rows (W floats per row)
+__global__ __launch_bounds__(256) void build_context_rows_kernel(
+    const float* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
+    float* __restrict__ ctx, int B, int Npts, int k, int X, int W) {
+  const int S = k + X;
+  const size_t total = (size_t)B * S * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % W);
+    const size_t row = i / W;
+    const int s = (int)(row % S), b = (int)(row / S);
+    float v;
+    if (s < k) {
+      const long long src = idx ? idx[(size_t)b * k + s] : (long long)s;
+      v = feat[((size_t)b * Npts + src) * W + e];
+    } else {
+      v = extra[((size_t)b * X + (s - k)) * W + e];
+    }
+    ctx[i] = v;
+  }
+}
+
+// dfeat[b][idx[b][s]][:] (+)= dctx[b][s][:]  (indices unique per sample); dextra[b][x][:] = dctx[b][k+x][:]
+__global__ __launch_bounds__(256) void build_context_bwd_kernel(
+    const float* __restrict__ dctx, const long long* __restrict__ idx, float* __restrict__ dfeat,
+    float* __restrict__ dextra, int B, int Npts, int k, int X, int E4, int accumulate) {
+  const int S = k + X;
+  const size_t total = (size_t)B * S * E4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E4);
+    const size_t row = i / E4;
+    const int s = (int)(row % S), b = (int)(row / S);
+    const float4 v = reinterpret_cast<const float4*>(dctx)[i];
+    if (s < k) {
+      if (!dfeat) continue;
+      const long long dst = idx ? idx[(size_t)b * k + s] : (long long)s;
+      float4* p = reinterpret_cast<float4*>(dfeat) + ((size_t)b * Npts + dst) * E4 + e;
+      if (accumulate) {
+        float4 o = *p;
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *p = o;
+      } else {
+        *p = v;
+      }
+    } else if (dextra) {
+      reinterpret_cast<float4*>(dextra)[((size_t)b * X + (s - k)) * E4 + e] = v;
+    }
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C, int Hin, int Win, int factor,
+                                  void* stream) {
+  if (!pcd || !out_xyz || B <= 0 || C <= 0 || factor < 2 || (factor & 1) || Hin % factor || Win % factor) {
+    set_error("a3d_pcd_downsample: bad argument (B=%d C=%d H=%d W=%d f=%d)", B, C, Hin, Win, factor);
+    return A3D_ERR_ARG;
+  }
+  const size_t total = (size_t)B * C * (Hin / factor) * (Win / factor);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(pcd_downsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcd, out_xyz, B * C, C,
+                     Hin, Win, factor);
+  return check_launch("a3d_pcd_downsample");
+}
+
+extern "C" size_t a3d_knn_topk_ws_bytes(int B, int N) { return (size_t)B * N * sizeof(unsigned int); }
+
+extern "C" int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long long* idx_out, float* dist_out,
+                            int B, int N, int k, void* stream) {
+  if (!pos || !xyz || !ws || !idx_out || B <= 0 || N <= 0 || k <= 0 || k > N || k > 16384) {
+    set_error("a3d_knn_topk: bad argument (B=%d N=%d k=%d; need 0 < k <= min(N, 16384))", B, N, k);
+    return A3D_ERR_ARG;
+  }
+  int kpad = 2;
+  while (kpad < k) kpad <<= 1;
+  const size_t lds = (size_t)kpad * sizeof(unsigned long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz,
+                     (unsigned int*)ws, idx_out, dist_out, N, k, kpad);
+  return check_launch("a3d_knn_topk");
+}
+
+extern "C" int a3d_build_context(const float* feat, const long long* idx, const float* extra, float* ctx, int B,
+                                 int Npts, int k, int X, int W, void* stream) {
+  if (!feat || !ctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (X > 0 && !extra) || (!idx && k != Npts)) {
+    set_error("a3d_build_context: bad argument (B=%d Npts=%d k=%d X=%d W=%d)", B, Npts, k, X, W);
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (W % 4 == 0) && ((((uintptr_t)feat | (uintptr_t)ctx | (uintptr_t)extra) & 15) == 0);
+  if (vec) {
+    const size_t total = (size_t)B * (k + X) * (W / 4);
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(build_context_kernel, dim3(grid), dim3(256), 0, s, feat, idx, extra, ctx, B, Npts, k, X, W / 4);
+  } else {
+    const size_t total = (size_t)B * (k + X) * W;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(build_context_rows_kernel, dim3(grid), dim3(256), 0, s, feat, idx, extra, ctx, B, Npts, k, X, W);
+  }
+  return check_launch("a3d_build_context");
+}
+
+extern "C" int a3d_build_context_bwd(const float* dctx, const long long* idx, float* dfeat, float* dextra, int B,
+                                     int Npts, int k, int X, int W, int accumulate, void* stream) {
+  if (!dctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || (!idx && k != Npts)) {
+    set_error("a3d_build_context_bwd: bad argument (B=%d Npts=%d k=%d X=%d W=%d)", B, Npts, k, X, W);
+    return A3D_ERR_ARG;
+  }
+  const size_t total = (size_t)B * (k + X) * (W / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(build_context_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dctx, idx, dfeat,
+                     dextra, B, Npts, k, X, W / 4, accumulate);
+  return check_launch("a3d_build_context_bwd");
+}

@@ -1,0 +1,125 @@
+"""ctypes binding of libact3d_hip.so (declared in include/act3d_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libact3d_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_z = C.c_size_t
+_u64 = C.c_ulonglong
+
+# name -> (restype, argtypes); mirrors include/act3d_hip.h one to one
+SIGNATURES = {
+    "a3d_version": (_i, []),
+    "a3d_last_error_string": (C.c_char_p, []),
+    "a3d_linear_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_linear_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "a3d_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "a3d_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "a3d_rope_split_qk": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_split_vt": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_rope_merge_bwd": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_attn_fwd_ws_floats": (_z, [_i, _i, _i, _i]),
+    "a3d_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_pcd_downsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_knn_topk_ws_bytes": (_z, [_i, _i]),
+    "a3d_knn_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "a3d_build_context": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_build_context_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_mask_logits_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_mask_logits_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_argmax_gather": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "a3d_soft_ce_loss": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p]),
+    "a3d_elem_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
+    "a3d_scale_by_scalar": (_i, [_p, _p, _p, _z, _p]),
+    "a3d_quat_sigmoid_fwd": (_i, [_p, _p, _p, _i, _p]),
+    "a3d_quat_sigmoid_bwd": (_i, [_p, _p, _p, _p, _i, _p]),
+    "a3d_sample_ghost_points": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
+    "a3d_rng_advance": (_i, [_p, _u64, _p]),
+    "a3d_philox4x32_10_host": (None, [_p, _p, _p]),
+    "a3d_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _z, _f, _f, _f, _f, _f, _f, _f, _p]),
+    "a3d_dbg_mfma_bf16": (_i, [_p, _p, _p, _p]),
+    "a3d_dbg_mfma_f32": (_i, [_p, _p, _p, _p]),
+    # diffusion.hip
+    "a3d_ddpm_add_noise": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_ddpm_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_adaln_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_adaln_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "a3d_sinusoidal_emb": (_i, [_p, _p, _i, _i, _p]),
+    "a3d_silu_fwd": (_i, [_p, _p, _z, _p]),
+    "a3d_silu_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "a3d_add_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_traj_update": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libact3d_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError("libact3d_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(SIGNATURES.keys())
+
+
+def last_error():
+    s = load().a3d_last_error_string()
+    return s.decode() if s else ""
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libact3d_hip %s failed with code %d: %s" % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libact3d_hip needs contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("act3d_amd ops run on an MI355X device tensor; got a %s tensor "
+                               "(there is no CPU fallback)" % t.device)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d: %s" % (name, rc, last_error()))

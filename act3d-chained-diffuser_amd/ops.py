@@ -1,0 +1,635 @@
+"""Autograd-level operators of the hot path: thin torch.autograd.Function wrappers that pair the forward and
+backward launches of libact3d_hip.so.  PyTorch only provides device memory, the stream and the autograd tape.
+
+Parameter gradients are accumulated by the wgrad kernels straight into ``param.grad`` (the flat gradient buffer
+when the model is wrapped by ``FlatParams``) instead of being returned through autograd; see DESIGN.md.
+"""
+import math
+
+import torch
+
+from . import lib as L
+
+F32 = torch.float32
+
+
+def ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def grad_buf(p):
+    """The tensor wgrad kernels accumulate into for parameter ``p`` (created zeroed on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+_freq_cache = {}
+
+
+def rope_freq(E, device):
+    """div_term of RotaryPositionEncoding3D (position_encodings.py:72-75), evaluated with the same torch ops."""
+    key = (E, str(device))
+    if key not in _freq_cache:
+        _freq_cache[key] = torch.exp(
+            torch.arange(0, E // 3, 2, dtype=F32, device=device) * (-math.log(10000.0) / (E // 3))).contiguous()
+    return _freq_cache[key]
+
+
+# ------------------------------------------------------------------------------------------------ raw launchers
+def linear_raw(x_ptr, ldx, W_ptr, ldw, b_ptr, M, N, K, device, act=0, mask_ptr=None, ldm=0, transposed=False,
+               out=None):
+    y = out if out is not None else torch.empty((M, N), device=device, dtype=F32)
+    L.call("a3d_linear_fwd", x_ptr, ldx, W_ptr, ldw, b_ptr, y.data_ptr(), N, mask_ptr, ldm, M, N, K, act,
+           1 if transposed else 0, L.stream())
+    return y
+
+
+def linear2d(x2d, W, b, act=0):
+    """y = act(x W^T + b) for contiguous x2d [M,K], W [N,K]."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    return linear_raw(x2d.data_ptr(), K, W.data_ptr(), W.shape[1], None if b is None else b.data_ptr(), M, N, K,
+                      x2d.device, act=act)
+
+
+def dgrad2d(dy2d, W, mask=None):
+    """dx = dy W (optionally masked by mask > 0) for dy [M,N], W [N,K] -> [M,K]."""
+    M, N = dy2d.shape
+    K = W.shape[1]
+    return linear_raw(dy2d.data_ptr(), N, W.data_ptr(), K, None, M, K, N, dy2d.device,
+                      act=2 if mask is not None else 0, mask_ptr=None if mask is None else mask.data_ptr(),
+                      ldm=K, transposed=True)
+
+
+def wgrad2d(dy2d, x2d, W, b):
+    """W.grad += dy^T x ; b.grad += sum dy   (W, b are Parameters or None)"""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    gW = grad_buf(W)
+    gb = grad_buf(b) if b is not None else None
+    L.call("a3d_linear_wgrad", dy2d.data_ptr(), N, x2d.data_ptr(), K, gW.data_ptr(), gW.shape[1],
+           None if gb is None else gb.data_ptr(), M, N, K, L.stream())
+
+
+def add_layernorm(a2d, r2d, g, b, eps=1e-5):
+    M, E = a2d.shape
+    y = torch.empty_like(a2d)
+    mean = torch.empty((M,), device=a2d.device, dtype=F32)
+    rstd = torch.empty((M,), device=a2d.device, dtype=F32)
+    L.call("a3d_add_layernorm_fwd", a2d.data_ptr(), None if r2d is None else r2d.data_ptr(), g.data_ptr(),
+           b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, E, eps, L.stream())
+    return y, mean, rstd
+
+
+def add_layernorm_bwd(a2d, r2d, g, b, mean, rstd, dy2d):
+    M, E = a2d.shape
+    ds = torch.empty_like(a2d)
+    gg, gb = grad_buf(g), grad_buf(b)
+    L.call("a3d_add_layernorm_bwd", a2d.data_ptr(), None if r2d is None else r2d.data_ptr(), g.data_ptr(),
+           mean.data_ptr(), rstd.data_ptr(), dy2d.data_ptr(), ds.data_ptr(), gg.data_ptr(), gb.data_ptr(), M, E,
+           L.stream())
+    return ds
+
+
+def pick_nsplit(B, H, Lqp, Sp):
+    wgs = B * H * ((Lqp + 63) // 64)
+    ns = max(1, min(16, Sp // 64, -(-768 // wgs)))
+    return ns
+
+
+def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device):
+    """rope + split the three projected row sets into the attention operand formats."""
+    Lqp, Sp = ceil_to(Lq, 64), ceil_to(S, 64)
+    scale = float(E // H) ** -0.5
+    freq = rope_freq(E, device)
+    Qs = torch.empty((B, H, Lqp, 32), device=device, dtype=torch.bfloat16)
+    Ks = torch.empty((B, H, Sp, 32), device=device, dtype=torch.bfloat16)
+    Vt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=torch.bfloat16)
+    st = L.stream()
+    L.call("a3d_rope_split_qk", q_pre_ptr, ldq, None if q_xyz is None else q_xyz.data_ptr(), freq.data_ptr(), scale,
+           Qs.data_ptr(), B, Lq, Lqp, E, H, st)
+    L.call("a3d_rope_split_qk", k_pre_ptr, ldk, None if k_xyz is None else k_xyz.data_ptr(), freq.data_ptr(), 1.0,
+           Ks.data_ptr(), B, S, Sp, E, H, st)
+    L.call("a3d_split_vt", v_pre_ptr, ldv, Vt.data_ptr(), B, S, Sp, E, H, st)
+    return Qs, Ks, Vt, Lqp, Sp, scale, freq
+
+
+def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
+    dev = Qs.device
+    E = H * 15
+    O = torch.empty((B, Lq, E), device=dev, dtype=F32)
+    LSE = torch.empty((B, H, Lqp), device=dev, dtype=F32)
+    ws = None
+    if nsplit > 1:
+        ws = torch.empty((nsplit * B * H * Lqp * 18,), device=dev, dtype=F32)
+    L.call("a3d_attn_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
+           O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
+           L.stream())
+    return O, LSE
+
+
+def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit):
+    dev = Qs.device
+    dOh = torch.empty((B, H, Lqp, 16), device=dev, dtype=F32)
+    D = torch.empty((B, H, Lqp), device=dev, dtype=F32)
+    dQp = torch.empty((nsplit, B, H, Lqp, 16), device=dev, dtype=F32)
+    dK = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
+    dV = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
+    L.call("a3d_attn_bwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
+           O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOh.data_ptr(), D.data_ptr(), dQp.data_ptr(), dK.data_ptr(),
+           dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
+    return dQp, dK, dV
+
+
+def rope_merge(dR, nsplit, xyz, freq, scale, out_ptr, ldy, B, N, Npad, E, H):
+    L.call("a3d_rope_merge_bwd", dR.data_ptr(), nsplit, None if xyz is None else xyz.data_ptr(), freq.data_ptr(),
+           scale, out_ptr, ldy, B, N, Npad, E, H, L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ fused blocks
+class AttnBlockFn(torch.autograd.Function):
+    """y = LayerNorm(resid + out_proj(MHA(q_in, k_in, v_in)))  with RoPE-3D on q/k from xyz.
+
+    Mirrors MultiheadCustomAttention.forward + the post-norm residual of RelativeCrossAttentionLayer
+    (layers.py:299-310) and ParallelAttentionLayer (layers.py:139-159,176-191) in the reference.
+    ``mode``: "kv" (key is value: packed k,v projection -- multihead_custom_attention.py:251-275),
+              "qk" (query is key, value differs -- :277-303), "none" (three inputs).
+    Returns (y, attn_out) where attn_out is the pre-residual attention output (rarely needed).
+    """
+
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode):
+        L.require_gpu(q_in, k_in, v_in, resid)
+        q_in, k_in, v_in, resid = _c(q_in), _c(k_in), _c(v_in), _c(resid)
+        B, Lq, E = q_in.shape
+        S = k_in.shape[1]
+        dev = q_in.device
+        if q_xyz is not None:
+            q_xyz, k_xyz = _c(q_xyz.to(F32)), _c(k_xyz.to(F32))
+        if kmask is not None:
+            kmask = _c(kmask.to(torch.uint8))
+        wp, bp = in_w.data_ptr(), in_b.data_ptr()
+        f4 = 4
+        # ---- projections
+        if mode == "qk":
+            qk_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, 2 * E, E, dev)            # [B*Lq, 2E]
+            q_ptr, ldq = qk_pre.data_ptr(), 2 * E
+            k_ptr, ldk = qk_pre.data_ptr() + E * f4, 2 * E
+            v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
+            v_ptr, ldv = v_pre.data_ptr(), E
+            keep = (qk_pre, v_pre)
+        else:
+            q_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, E, E, dev)
+            q_ptr, ldq = q_pre.data_ptr(), E
+            if mode == "kv":
+                kv_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, 2 * E, E, dev)
+                k_ptr, ldk = kv_pre.data_ptr(), 2 * E
+                v_ptr, ldv = kv_pre.data_ptr() + E * f4, 2 * E
+                keep = (q_pre, kv_pre)
+            else:
+                k_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, E, E, dev)
+                v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
+                k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
+                keep = (q_pre, k_pre, v_pre)
+        Qs, Ks, Vt, Lqp, Sp, scale, freq = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq, S,
+                                                         E, H, dev)
+        del keep
+        nsplit = pick_nsplit(B, H, Lqp, Sp)
+        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit)
+        Y = linear2d(O.view(B * Lq, E), out_w, out_b)
+        y, mean, rstd = add_layernorm(resid.view(B * Lq, E), Y, ln_g, ln_b)
+        ctx.save_for_backward(q_in, k_in, v_in, resid, Y, mean, rstd, Qs, Ks, Vt, O, LSE,
+                              q_xyz if q_xyz is not None else torch.empty(0, device=dev),
+                              k_xyz if k_xyz is not None else torch.empty(0, device=dev),
+                              kmask if kmask is not None else torch.empty(0, device=dev))
+        ctx.params = (in_w, in_b, out_w, out_b, ln_g, ln_b)
+        ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
+        return y.view(B, Lq, E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (q_in, k_in, v_in, resid, Y, mean, rstd, Qs, Ks, Vt, O, LSE, q_xyz, k_xyz, kmask) = ctx.saved_tensors
+        in_w, in_b, out_w, out_b, ln_g, ln_b = ctx.params
+        B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, has_xyz, has_mask = ctx.meta
+        dev = dy.device
+        if not has_xyz:
+            q_xyz = k_xyz = None
+        if not has_mask:
+            kmask = None
+        freq = rope_freq(E, dev)
+        dy = _c(dy).view(B * Lq, E)
+        f4 = 4
+        dS = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)      # = d resid = d Y
+        dO = dgrad2d(dS, out_w)
+        wgrad2d(dS, O.view(B * Lq, E), out_w, out_b)
+        dQp, dK, dV = attn_core_bwd(Qs, Ks, Vt, kmask, O, dO.view(B, Lq, E), LSE, B, H, Lq, Lqp, S, Sp, nsplit)
+        gW, gb = grad_buf(in_w), grad_buf(in_b)
+        st = L.stream()
+        need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        d_q_in = d_k_in = d_v_in = None
+        if mode == "qk":
+            dqk = torch.empty((B * Lq, 2 * E), device=dev, dtype=F32)
+            rope_merge(dQp, nsplit, q_xyz, freq, scale, dqk.data_ptr(), 2 * E, B, Lq, Lqp, E, H)
+            rope_merge(dK, 1, k_xyz, freq, 1.0, dqk.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
+            dv_pre = torch.empty((B * S, E), device=dev, dtype=F32)
+            rope_merge(dV, 1, None, freq, 1.0, dv_pre.data_ptr(), E, B, S, Sp, E, H)
+            L.call("a3d_linear_wgrad", dqk.data_ptr(), 2 * E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
+                   B * Lq, 2 * E, E, st)
+            L.call("a3d_linear_wgrad", dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4, E,
+                   gb.data_ptr() + 2 * E * f4, B * S, E, E, st)
+            if need_q or need_k:
+                d_q_in = linear_raw(dqk.data_ptr(), 2 * E, in_w.data_ptr(), E, None, B * Lq, E, 2 * E, dev,
+                                    transposed=True).view(B, Lq, E)
+            if need_v:
+                d_v_in = linear_raw(dv_pre.data_ptr(), E, in_w.data_ptr() + 2 * E * E * f4, E, None, B * S, E, E, dev,
+                                    transposed=True).view(B, S, E)
+        else:
+            dq_pre = torch.empty((B * Lq, E), device=dev, dtype=F32)
+            rope_merge(dQp, nsplit, q_xyz, freq, scale, dq_pre.data_ptr(), E, B, Lq, Lqp, E, H)
+            L.call("a3d_linear_wgrad", dq_pre.data_ptr(), E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
+                   B * Lq, E, E, st)
+            if need_q:
+                d_q_in = dgrad2d(dq_pre, in_w[:E]).view(B, Lq, E)
+            if mode == "kv":
+                dkv = torch.empty((B * S, 2 * E), device=dev, dtype=F32)
+                rope_merge(dK, 1, k_xyz, freq, 1.0, dkv.data_ptr(), 2 * E, B, S, Sp, E, H)
+                rope_merge(dV, 1, None, freq, 1.0, dkv.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
+                L.call("a3d_linear_wgrad", dkv.data_ptr(), 2 * E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
+                       gb.data_ptr() + E * f4, B * S, 2 * E, E, st)
+                if need_k or need_v:
+                    d_k_in = linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E,
+                                        dev, transposed=True).view(B, S, E)
+            else:
+                dk_pre = torch.empty((B * S, E), device=dev, dtype=F32)
+                dv_pre = torch.empty((B * S, E), device=dev, dtype=F32)
+                rope_merge(dK, 1, k_xyz, freq, 1.0, dk_pre.data_ptr(), E, B, S, Sp, E, H)
+                rope_merge(dV, 1, None, freq, 1.0, dv_pre.data_ptr(), E, B, S, Sp, E, H)
+                L.call("a3d_linear_wgrad", dk_pre.data_ptr(), E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
+                       gb.data_ptr() + E * f4, B * S, E, E, st)
+                L.call("a3d_linear_wgrad", dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4,
+                       E, gb.data_ptr() + 2 * E * f4, B * S, E, E, st)
+                if need_k:
+                    d_k_in = dgrad2d(dk_pre, in_w[E:2 * E]).view(B, S, E)
+                if need_v:
+                    d_v_in = dgrad2d(dv_pre, in_w[2 * E:]).view(B, S, E)
+        d_resid = dS.view(B, Lq, E) if ctx.needs_input_grad[3] else None
+        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 11
+
+
+def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H):
+    """mha: module with in_proj_weight/in_proj_bias/out_proj; norm: LayerNorm-like with weight/bias.
+
+    The projection path is chosen structurally (which inputs are the same tensor), replacing the reference's
+    data-dependent torch.equal checks (multihead_custom_attention.py:234-235) that force a host sync."""
+    if k_in is v_in:
+        mode = "kv"
+    elif q_in is k_in:
+        mode = "qk"
+    else:
+        mode = "none"
+    return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
+                             mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode)
+
+
+class MLPFn(torch.autograd.Function):
+    """out = W2 relu(W1 x + b1) + b2, optionally followed by LayerNorm(x + out) (FeedforwardLayer layers.py:313-332,
+    ffn_12 + norm_122 layers.py:205-209; plain MLP heads act3d.py:151-166, diffusion_head.py:41-49,177-199)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b):
+        L.require_gpu(x)
+        x = _c(x)
+        shp = x.shape
+        K = shp[-1]
+        x2 = x.view(-1, K)
+        h = linear2d(x2, w1, b1, act=1)
+        o = linear2d(h, w2, b2)
+        if ln_g is not None:
+            y, mean, rstd = add_layernorm(x2, o, ln_g, ln_b)
+            ctx.save_for_backward(x2, h, o, mean, rstd)
+        else:
+            y = o
+            ctx.save_for_backward(x2, h)
+        ctx.params = (w1, b1, w2, b2, ln_g, ln_b)
+        return y.view(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        w1, b1, w2, b2, ln_g, ln_b = ctx.params
+        dy = _c(dy)
+        if ln_g is not None:
+            x2, h, o, mean, rstd = ctx.saved_tensors
+            dS = add_layernorm_bwd(x2, o, ln_g, ln_b, mean, rstd, dy.view(-1, dy.shape[-1]))
+            do = dS
+        else:
+            x2, h = ctx.saved_tensors
+            dS = None
+            do = dy.view(-1, dy.shape[-1])
+        wgrad2d(do, h, w2, b2)
+        dpre = dgrad2d(do, w2, mask=h)          # relu backward fused: (do W2) * (h > 0)
+        wgrad2d(dpre, x2, w1, b1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dgrad2d(dpre, w1)
+            if dS is not None:
+                dx = dx + dS
+            dx = dx.view(*dy.shape[:-1], x2.shape[1])
+        return dx, None, None, None, None, None, None
+
+
+def mlp(x, lin1, lin2, norm=None):
+    return MLPFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, None if norm is None else norm.weight,
+                       None if norm is None else norm.bias)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (instruction encoder act3d.py:170, gripper encoders diffusion_head.py:50-52, AdaLN modulation)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        L.require_gpu(x)
+        x = _c(x)
+        x2 = x.view(-1, x.shape[-1])
+        y = linear2d(x2, w, b)
+        ctx.save_for_backward(x2)
+        ctx.params = (w, b)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        w, b = ctx.params
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        wgrad2d(dy2, x2, w, b)
+        dx = dgrad2d(dy2, w).view(*dy.shape[:-1], x2.shape[1]) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+def linear(x, lin):
+    return LinearFn.apply(x, lin.weight, lin.bias)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b):
+        x = _c(x)
+        x2 = x.view(-1, x.shape[-1])
+        y, mean, rstd = add_layernorm(x2, None, g, b)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params = (g, b)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        g, b = ctx.params
+        ds = add_layernorm_bwd(x2, None, g, b, mean, rstd, _c(dy).view(-1, dy.shape[-1]))
+        return ds.view(dy.shape), None, None
+
+
+# ------------------------------------------------------------------------------------------------ scene ops
+def pcd_downsample(pcd, factor):
+    """pcd (B, C, 3, H, W) -> (B, C*h*w, 3)   [no grad: act3d.py never differentiates w.r.t. xyz]"""
+    L.require_gpu(pcd)
+    pcd = _c(pcd.to(F32))
+    B, Cn, _, Hh, Ww = pcd.shape
+    h, w = Hh // factor, Ww // factor
+    out = torch.empty((B, Cn * h * w, 3), device=pcd.device, dtype=F32)
+    L.call("a3d_pcd_downsample", pcd.data_ptr(), out.data_ptr(), B, Cn, Hh, Ww, factor, L.stream())
+    return out
+
+
+def knn_topk(pos, xyz, k, return_dist=False):
+    """indices (B, k) int64 of the k nearest scene points, ascending (distance, index)."""
+    L.require_gpu(pos, xyz)
+    pos, xyz = _c(pos.to(F32)).view(-1, 3), _c(xyz.to(F32))
+    B, N, _ = xyz.shape
+    ws = torch.empty((B * N,), device=xyz.device, dtype=torch.int32)
+    idx = torch.empty((B, k), device=xyz.device, dtype=torch.int64)
+    dist = torch.empty((B, k), device=xyz.device, dtype=F32) if return_dist else None
+    L.call("a3d_knn_topk", pos.data_ptr(), xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(),
+           None if dist is None else dist.data_ptr(), B, N, k, L.stream())
+    return (idx, dist) if return_dist else idx
+
+
+def gather_rows(src, idx, extra=None):
+    """[src[b][idx[b]] | extra[b]] without autograd (xyz rows)."""
+    src = _c(src)
+    B, Npts, W = src.shape
+    k = idx.shape[1] if idx is not None else Npts
+    X = 0 if extra is None else extra.shape[1]
+    out = torch.empty((B, k + X, W), device=src.device, dtype=F32)
+    L.call("a3d_build_context", src.data_ptr(), None if idx is None else idx.data_ptr(),
+           None if extra is None else _c(extra).data_ptr(), out.data_ptr(), B, Npts, k, X, W, L.stream())
+    return out
+
+
+class BuildContextFn(torch.autograd.Function):
+    """ctx tokens = [feat[b][idx[b]] | extra[b]]  (act3d.py:247-260).  feat (B, Npts, E), extra (B, X, E)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx, extra):
+        L.require_gpu(feat)
+        feat, extra = _c(feat), _c(extra)
+        B, Npts, E = feat.shape
+        k = idx.shape[1] if idx is not None else Npts
+        X = extra.shape[1]
+        out = torch.empty((B, k + X, E), device=feat.device, dtype=F32)
+        L.call("a3d_build_context", feat.data_ptr(), None if idx is None else idx.data_ptr(), extra.data_ptr(),
+               out.data_ptr(), B, Npts, k, X, E, L.stream())
+        ctx.idx = idx
+        ctx.meta = (B, Npts, k, X, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        B, Npts, k, X, E = ctx.meta
+        dctx = _c(dctx)
+        idx = ctx.idx
+        dfeat = dextra = None
+        if ctx.needs_input_grad[0]:
+            dfeat = (torch.zeros if idx is not None else torch.empty)((B, Npts, E), device=dctx.device, dtype=F32)
+        if ctx.needs_input_grad[2]:
+            dextra = torch.empty((B, X, E), device=dctx.device, dtype=F32)
+        L.call("a3d_build_context_bwd", dctx.data_ptr(), None if idx is None else idx.data_ptr(),
+               None if dfeat is None else dfeat.data_ptr(), None if dextra is None else dextra.data_ptr(), B, Npts, k,
+               X, E, 0, L.stream())
+        return dfeat, None, dextra
+
+
+# ------------------------------------------------------------------------------------------------ heads / losses
+class MaskLogitsFn(torch.autograd.Function):
+    """logits[b, n] = <q[b], F[b, n]>   (act3d.py:493-494)"""
+
+    @staticmethod
+    def forward(ctx, q, Fm):
+        q, Fm = _c(q), _c(Fm)
+        B, Ng, E = Fm.shape
+        out = torch.empty((B, Ng), device=Fm.device, dtype=F32)
+        L.call("a3d_mask_logits_fwd", q.data_ptr(), Fm.data_ptr(), out.data_ptr(), B, Ng, E, L.stream())
+        ctx.save_for_backward(q, Fm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dlog):
+        q, Fm = ctx.saved_tensors
+        B, Ng, E = Fm.shape
+        dF = torch.empty_like(Fm)
+        dq = torch.empty_like(q)
+        L.call("a3d_mask_logits_bwd", q.data_ptr(), Fm.data_ptr(), _c(dlog).data_ptr(), dF.data_ptr(), dq.data_ptr(), B,
+               Ng, E, 0, L.stream())
+        return dq, dF
+
+
+def argmax_gather(logits, ghost):
+    """top_idx (B,) int64 = first maximum; position (B, 3) = ghost[b, top_idx]."""
+    logits, ghost = _c(logits), _c(ghost)
+    B, Ng = logits.shape
+    top = torch.empty((B,), device=logits.device, dtype=torch.int64)
+    pos = torch.empty((B, 3), device=logits.device, dtype=F32)
+    L.call("a3d_argmax_gather", logits.data_ptr(), ghost.data_ptr(), top.data_ptr(), pos.data_ptr(), B, Ng, L.stream())
+    return top, pos
+
+
+class SoftCEFn(torch.autograd.Function):
+    """coeff * mean_b CE(logits[b], softmax(-|ghost - gt| / spread))   (main_keypose.py:382-405)"""
+
+    @staticmethod
+    def forward(ctx, logits, ghost, gt, spread, label_smoothing, coeff):
+        logits, ghost, gt = _c(logits), _c(ghost), _c(gt.to(F32))
+        B, Ng = logits.shape
+        loss_b = torch.empty((B,), device=logits.device, dtype=F32)
+        loss = torch.empty((), device=logits.device, dtype=F32)
+        dlog = torch.empty_like(logits)
+        L.call("a3d_soft_ce_loss", ghost.data_ptr(), gt.data_ptr(), logits.data_ptr(), loss_b.data_ptr(),
+               loss.data_ptr(), dlog.data_ptr(), B, Ng, spread, label_smoothing, coeff, L.stream())
+        ctx.save_for_backward(dlog)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        out = torch.empty_like(dlog)
+        L.call("a3d_scale_by_scalar", dlog.data_ptr(), _c(g).data_ptr(), out.data_ptr(), dlog.numel(), L.stream())
+        return out, None, None, None, None, None
+
+
+class ElemLossFn(torch.autograd.Function):
+    """coeff * mean((p - t)^2) [kind 0] or coeff * mean(|p - t|) [kind 1]"""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, coeff):
+        pred, target = _c(pred), _c(target.to(F32))
+        loss = torch.empty((), device=pred.device, dtype=F32)
+        grad = torch.empty_like(pred)
+        L.call("a3d_elem_loss", pred.data_ptr(), target.data_ptr(), pred.numel(), kind, coeff, loss.data_ptr(),
+               grad.data_ptr(), L.stream())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        L.call("a3d_scale_by_scalar", grad.data_ptr(), _c(g).data_ptr(), out.data_ptr(), grad.numel(), L.stream())
+        return out, None, None, None
+
+
+class QuatSigmoidFn(torch.autograd.Function):
+    """pred (B,5) -> normalise_quat(pred[:, :4]), sigmoid(pred[:, 4:])   (act3d.py:526-533)"""
+
+    @staticmethod
+    def forward(ctx, pred):
+        pred = _c(pred)
+        B = pred.shape[0]
+        rot = torch.empty((B, 4), device=pred.device, dtype=F32)
+        grip = torch.empty((B, 1), device=pred.device, dtype=F32)
+        L.call("a3d_quat_sigmoid_fwd", pred.data_ptr(), rot.data_ptr(), grip.data_ptr(), B, L.stream())
+        ctx.save_for_backward(pred)
+        return rot, grip
+
+    @staticmethod
+    def backward(ctx, drot, dgrip):
+        (pred,) = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        L.call("a3d_quat_sigmoid_bwd", pred.data_ptr(), None if drot is None else _c(drot).data_ptr(),
+               None if dgrip is None else _c(dgrip).data_ptr(), dp.data_ptr(), pred.shape[0], L.stream())
+        return dp
+
+
+def sample_ghost_points(state, bounds, anchor, radius, B, Ng, level, max_attempts=64):
+    """Device Philox sampler (a-3 of SURVEY §8a).  state: uint64[2] device tensor {seed, offset}."""
+    out = torch.empty((B, Ng, 3), device=state.device, dtype=F32)
+    L.call("a3d_sample_ghost_points", state.data_ptr(), bounds.data_ptr(),
+           None if anchor is None else _c(anchor.to(F32)).data_ptr(), float(radius), out.data_ptr(), B, Ng, level,
+           max_attempts, L.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ diffusion pieces
+class AdaLNFn(torch.autograd.Function):
+    """x * (1 + scale) + shift with (scale, shift) = chunk(mod, 2)   (layers.py:281-290)"""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        x, mod = _c(x), _c(mod)
+        B, Ln, E = x.shape
+        y = torch.empty_like(x)
+        L.call("a3d_adaln_fwd", x.data_ptr(), mod.data_ptr(), y.data_ptr(), B, Ln, E, L.stream())
+        ctx.save_for_backward(x, mod)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mod = ctx.saved_tensors
+        B, Ln, E = x.shape
+        dx = torch.empty_like(x)
+        dmod = torch.empty_like(mod)
+        L.call("a3d_adaln_bwd", x.data_ptr(), mod.data_ptr(), _c(dy).data_ptr(), dx.data_ptr(), dmod.data_ptr(), B, Ln,
+               E, L.stream())
+        return dx, dmod
+
+
+class SiLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.call("a3d_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.call("a3d_silu_bwd", x.data_ptr(), _c(dy).data_ptr(), dx.data_ptr(), x.numel(), L.stream())
+        return dx
+
+
+def sinusoidal_emb(x, E):
+    x = _c(x.to(F32)).view(-1)
+    out = torch.empty((x.numel(), E), device=x.device, dtype=F32)
+    L.call("a3d_sinusoidal_emb", x.data_ptr(), out.data_ptr(), x.numel(), E, L.stream())
+    return out
+
+
+class AddRowsFn(torch.autograd.Function):
+    """x (B, L, E) + r (L, E) broadcast over the batch (r carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        x, r = _c(x), _c(r)
+        B, Ln, E = x.shape
+        y = torch.empty_like(x)
+        L.call("a3d_add_rows", x.data_ptr(), r.data_ptr(), y.data_ptr(), B, Ln, E, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None

@@ -1,0 +1,149 @@
+/* act3d_hip.h -- C-ABI of libact3d_hip.so: the MI355X (gfx950) kernels behind the Act3D keypose and
+ * ChainedDiffuser trajectory hot path.
+ *
+ * The reference (zhouxian/act3d-chained-diffuser) is pure Python/PyTorch and has no FFI of its own for this
+ * path; every entry point below replaces a sequence of aten ops, cited as reference file:line.  A maintainer
+ * binds them with ctypes; the package in this repo does exactly that.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch's allocator); the library never allocates
+ *     or frees device memory and keeps no state besides a thread-local error string;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*): no host synchronisation, no
+ *     default-stream use, so a sequence of calls is capturable with hipStreamBeginCapture / torch.cuda.graph;
+ *   - return value 0 = ok, negative errno-style code otherwise (-22 bad argument, -5 launch failure);
+ *     a3d_last_error_string() describes the last failure on the calling thread; no exceptions, no exit();
+ *   - tensors are contiguous row-major fp32 unless stated; token tensors are batch-first (B, N, E) -- the
+ *     reference's sequence-first (N, B, E) is a view concern of the Python shim;
+ *   - indices are int64 (long long) at the API, as torch.topk / torch.max return them.
+ *
+ * Attention operand formats (written by a3d_rope_split_qk / a3d_split_vt, read by a3d_attn_*):
+ *   QK : [B][H][Npad][32] bf16, row = hi(16) | lo(16), x ~= hi + lo, head dim 15 padded to 16 with zero
+ *   VT : [B][H][2][16][Npad] bf16, plane 0 = hi, plane 1 = lo (transposed: keys contiguous)
+ *   Npad % 64 == 0 for keys/values, Npad % 16 == 0 suffices for queries when written by a3d_rope_split_qk with
+ *   Npad % 64 == 0 (callers simply use a multiple of 64 everywhere).
+ */
+#ifndef ACT3D_HIP_H
+#define ACT3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int a3d_version(void);
+const char* a3d_last_error_string(void);
+
+/* ---- dense layers ------------------------------------------------------------------------------------ */
+/* Y[m,n] = act(sum_k X[m,k] * W(n,k) + bias[n]);  W(n,k) = W[n*ldw+k], or W[k*ldw+n] if w_transposed (dgrad).
+ * act: 0 none, 1 relu, 2 multiply by (mask[m*ldm+n] > 0) (ReLU backward fused into dgrad).
+ * Replaces F.linear at multihead_custom_attention.py:246-303,447; layers.py:88-94,313-332; diffusion_head.py:41-49. */
+int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                   const float* mask, int ldm, int M, int N, int K, int act, int w_transposed, void* stream);
+/* dW[n*lddw+k] += sum_m dY[m,n] X[m,k];  db[n] += sum_m dY[m,n] (db may be NULL).  Accumulates atomically. */
+int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db, int M,
+                     int N, int K, void* stream);
+/* Y = LayerNorm(A + R) * gamma + beta over the last dim (R may be NULL); saves mean/rstd per row.
+ * Replaces `output = self.norm(query + dropout(attn_output))` layers.py:308-309, 329-331, 158-159. */
+int a3d_add_layernorm_fwd(const float* A, const float* R, const float* gamma, const float* beta, float* Y,
+                          float* mean, float* rstd, int M, int E, float eps, void* stream);
+/* dS = d(A+R); dgamma/dbeta accumulate atomically (both NULL to skip). */
+int a3d_add_layernorm_bwd(const float* A, const float* R, const float* gamma, const float* mean, const float* rstd,
+                          const float* dY, float* dS, float* dgamma, float* dbeta, int M, int E, void* stream);
+
+/* ---- RoPE-3D + operand formatting ---------------------------------------------------------------------- */
+/* dst(QK format) = split_bf16(rope3d(Y[:, :E] * scale, xyz)); xyz NULL = no rotation.  freq: E/6 device floats
+ * = exp(arange(0,E/3,2) * (-ln(1e4)/(E/3))).  Replaces RotaryPositionEncoding3D.forward + embed_rotary
+ * (position_encodings.py:31-34,64-97) and `q = q * scaling` (multihead_custom_attention.py:325,348-359). */
+int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* dst, int B,
+                      int N, int Npad, int E, int H, void* stream);
+int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int E, int H, void* stream);
+/* dY[:, :E] = scale * R(xyz)^T * sum_s dR[s];  dR: [nsplit][B][H][Npad][16] fp32 (grad w.r.t. rotated rows). */
+int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq, float scale, float* dY,
+                       int ldy, int B, int N, int Npad, int E, int H, void* stream);
+
+/* ---- attention core ------------------------------------------------------------------------------------- */
+/* O[b,q,h*15+d] = softmax_k(q.k + mask) v ; LSE[b,h,q] saved for backward.  kmask: [B][S] uint8, 1 = padded key
+ * (may be NULL).  nsplit > 1 splits the key range over workgroups (ws >= a3d_attn_fwd_ws_floats floats).
+ * Replaces bmm/softmax/bmm + key_padding_mask of multihead_custom_attention.py:386-447. */
+int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, float* O, float* LSE,
+                 float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
+size_t a3d_attn_fwd_ws_floats(int B, int H, int Lqp, int nsplit);
+/* Backward of the above.  Scratch: dOh [B][H][Lqp][16], D [B][H][Lqp].  Outputs (grad w.r.t. rotated rows):
+ * dQp [nsplit][B][H][Lqp][16], dK [B][H][Sp][16], dV [B][H][Sp][16]. */
+int a3d_attn_bwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, const float* O,
+                 const float* dO, const float* LSE, float* dOh, float* D, float* dQp, float* dK, float* dV, int B,
+                 int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
+
+/* ---- scene tokens --------------------------------------------------------------------------------------- */
+/* out[b][(cam*h + y)*w + x][:] = bilinear(pcd[(b,cam)], 1/factor)  (act3d.py:379-383, encoder.py:147-158) */
+int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C, int Hin, int Win, int factor, void* stream);
+/* idx_out[b][:k] = indices of the k nearest points of xyz[b] to pos[b], ascending (distance, index)
+ * (act3d.py:244-245).  ws >= a3d_knn_topk_ws_bytes.  dist_out optional [B][k]. */
+size_t a3d_knn_topk_ws_bytes(int B, int N);
+int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long long* idx_out, float* dist_out, int B, int N,
+                 int k, void* stream);
+/* ctx[b] = [ feat[b][idx[b][0..k)] | extra[b][0..X) ], rows of W floats (idx NULL: identity, k == Npts)
+ * (act3d.py:247-260). */
+int a3d_build_context(const float* feat, const long long* idx, const float* extra, float* ctx, int B, int Npts,
+                      int k, int X, int W, void* stream);
+int a3d_build_context_bwd(const float* dctx, const long long* idx, float* dfeat, float* dextra, int B, int Npts,
+                          int k, int X, int W, int accumulate, void* stream);
+
+/* ---- decoding heads, losses, sampler, optimizer ----------------------------------------------------------- */
+int a3d_mask_logits_fwd(const float* q, const float* F, float* out, int B, int Ng, int E, void* stream);
+int a3d_mask_logits_bwd(const float* q, const float* F, const float* dlog, float* dF, float* dq, int B, int Ng,
+                        int E, int accumulate_dF, void* stream);
+int a3d_argmax_gather(const float* logits, const float* ghost, long long* top_idx, float* pos, int B, int Ng,
+                      void* stream);
+/* loss = coeff * mean_b CE(logits[b], softmax(-|ghost[b]-gt[b]|/spread)); dlogits optional. */
+int a3d_soft_ce_loss(const float* ghost, const float* gt, const float* logits, float* loss_b, float* loss,
+                     float* dlogits, int B, int Ng, float spread, float label_smoothing, float coeff, void* stream);
+/* kind 0 = MSE, 1 = L1; loss = coeff * mean; grad optional. */
+int a3d_elem_loss(const float* pred, const float* target, int n, int kind, float coeff, float* loss, float* grad,
+                  void* stream);
+int a3d_scale_by_scalar(const float* x, const float* scalar, float* y, size_t n, void* stream);
+int a3d_quat_sigmoid_fwd(const float* pred, float* rot, float* grip, int B, void* stream);
+int a3d_quat_sigmoid_bwd(const float* pred, const float* drot, const float* dgrip, float* dpred, int B, void* stream);
+/* state = {seed, offset} (2 x uint64, device).  anchor NULL: uniform box (utils.py:68-73); else ball rejection
+ * inside the clipped box (utils.py:76-84, act3d.py:417-436) with a bounded number of attempts. */
+int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds, const float* anchor, float radius,
+                            float* out, int B, int Ng, int level, int max_attempts, void* stream);
+int a3d_rng_advance(unsigned long long* state, unsigned long long n, void* stream);
+void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* torch.optim.AdamW semantics (engine.py:89-102) on a flat buffer; elements [0, n_nodecay) use wd_nodecay. */
+int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, size_t n, size_t n_nodecay, float lr,
+                   float beta1, float beta2, float eps, float wd_nodecay, float wd_decay, float grad_scale,
+                   void* stream);
+
+/* ---- DDPM trajectory denoiser (elementwise pieces) ------------------------------------------------------------ */
+/* x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) eps; channels [0,npos) use acp_pos, the rest acp_rot
+ * (DDPMScheduler.add_noise; diffusion_model.py:296-305).  t: [B] int64. */
+int a3d_ddpm_add_noise(const float* x0, const float* noise, const long long* t, const float* acp_pos,
+                       const float* acp_rot, float* out, int B, int L, int D, int npos, void* stream);
+/* One reverse step: inpaint (model_out[mask] = cond[mask]), then t == 0 ? out = model_out
+ * : out = c_x0[t]*clip(model_out,-1,1) + c_xt[t]*sample + sigma[t]*noise.  coef_*: [T][3] device tables
+ * (diffusion_model.py:100-117 + DDPMScheduler.step, prediction_type="sample", fixed_small). */
+int a3d_ddpm_step(const float* model_out, const float* sample, const float* noise, const float* cond_data,
+                  const unsigned char* cond_mask, const float* coef_pos, const float* coef_rot, float* out, int rows,
+                  int D, int npos, int t, void* stream);
+/* AdaLN: y = x * (1 + mod[:, :E]) + mod[:, E:]  (layers.py:273-290); mod: [B][2E], x: [B][L][E]. */
+int a3d_adaln_fwd(const float* x, const float* mod, float* y, int B, int L, int E, void* stream);
+int a3d_adaln_bwd(const float* x, const float* mod, const float* dy, float* dx, float* dmod, int B, int L, int E,
+                  void* stream);
+/* out[i] = [sin(x_i f_j) | cos(x_i f_j)], f_j = exp(-j ln(1e4)/(E/2-1))  (position_encodings.py:13-20). */
+int a3d_sinusoidal_emb(const float* x, float* out, int n, int E, void* stream);
+int a3d_silu_fwd(const float* x, float* y, size_t n, void* stream);
+int a3d_silu_bwd(const float* x, const float* dy, float* dx, size_t n, void* stream);
+/* y[b,l,:] = x[b,l,:] + r[l,:] */
+int a3d_add_rows(const float* x, const float* r, float* y, int B, int L, int E, void* stream);
+/* out = cat(traj[..., :npos] + upd[..., :npos], upd[..., npos:])  (diffusion_head.py:268-272) */
+int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, int D, int npos, void* stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------------------- */
+int a3d_dbg_mfma_bf16(const void* A16x32, const void* B32x16, float* D16x16, void* stream);
+int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACT3D_HIP_H */
