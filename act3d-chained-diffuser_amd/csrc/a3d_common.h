@@ -63,6 +63,23 @@ __device__ __forceinline__ float rope_freq(int k, int E) {
   return expf((float)(2 * k) * (-9.210340371976184f / (float)(E / 3)));
 }
 
+// IEEE round-to-nearest single operations that the compiler may NOT contract into an fma.  (HIP's __fadd_rn /
+// __fmul_rn are plain operators and __fsqrt_rn is the approximate native sqrt unless OCML_BASIC_ROUNDED_OPERATIONS
+// is defined, so they cannot be used where bit-exactness with the CPU oracle is required.)
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }   // correctly rounded (HIP default)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace a3d

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void sample_ghost_kernel(
       lo[a] = bounds[a]; hi[a] = bounds[3 + a];
       if (anchor) {
         ctr[a] = anchor[b * 3 + a];
-        lo[a] = fminf(fmaxf(__fsub_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
-        hi[a] = fminf(fmaxf(__fadd_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
+        lo[a] = fminf(fmaxf(sub_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
+        hi[a] = fminf(fmaxf(add_rn(ctr[a], radius), bounds[a]), bounds[3 + a]);
       }
     }
     float p[3] = {0.f, 0.f, 0.f};
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) void sample_ghost_kernel(
       philox4x32_10((uint32_t)i, (uint32_t)b, (uint32_t)level | ((uint32_t)a << 8), (uint32_t)offs,
                     (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offs >> 32), r);
       // explicit round-to-nearest ops (no fma contraction): the CPU twin in oracle/sampling.py must match bit for bit
-      for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(lo[c], __fmul_rn(u01(r[c]), __fsub_rn(hi[c], lo[c])));
+      for (int c = 0; c < 3; ++c) p[c] = add_rn(lo[c], mul_rn(u01(r[c]), sub_rn(hi[c], lo[c])));
       if (!anchor) { ok = true; break; }
-      const float dx = __fsub_rn(p[0], ctr[0]), dy = __fsub_rn(p[1], ctr[1]), dz = __fsub_rn(p[2], ctr[2]);
-      ok = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))) < radius;
+      const float dx = sub_rn(p[0], ctr[0]), dy = sub_rn(p[1], ctr[1]), dz = sub_rn(p[2], ctr[2]);
+      ok = sqrt_rn(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz))) < radius;
     }
     if (!ok) for (int c = 0; c < 3; ++c) p[c] = fminf(fmaxf(ctr[c], bounds[c]), bounds[3 + c]);
     for (int c = 0; c < 3; ++c) out[idx * 3 + c] = p[c];

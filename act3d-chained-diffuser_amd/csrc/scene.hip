@@ -2,8 +2,8 @@
 //
 //   a3d_pcd_downsample   reference: F.interpolate(pcd, 1/f, 'bilinear') + rearrange (act3d.py:379-383,
 //                        encoder.py:147-158).  For even f the bilinear sample is the mean of the 2x2 block at
-//                        (f*y + f/2 - 1, f*x + f/2 - 1); evaluated as 0.5*(0.5*p00+0.5*p01)+0.5*(0.5*p10+0.5*p11),
-//                        the order torch's separable kernel uses, so the result is bit-identical.
+//                        (f*y + f/2 - 1, f*x + f/2 - 1); the additions are ordered as ATen's CPU kernels order them
+//                        (see the kernel) so the result is bit-identical to the reference run on CPU.
 //   a3d_knn_topk         reference: l2 = ((pos - pcd)**2).sum(-1).sqrt(); topk(k, largest=False).indices
 //                        (act3d.py:244-245).  Radix-select on the fp32 bit pattern + bitonic sort of the k
 //                        survivors in LDS; order = ascending (distance, index), i.e. torch's sorted order with a
@@ -35,18 +35,26 @@ __global__ __launch_bounds__(256) void pcd_downsample_kernel(
       const float* p = pcd + ((size_t)bc * 3 + ch) * Hin * Win;
       const float p00 = p[(size_t)y0 * Win + x0], p01 = p[(size_t)y0 * Win + x1];
       const float p10 = p[(size_t)y1 * Win + x0], p11 = p[(size_t)y1 * Win + x1];
-      const float t0 = 0.5f * p00 + 0.5f * p01;
-      const float t1 = 0.5f * p10 + 0.5f * p11;
-      o[ch] = 0.5f * t0 + 0.5f * t1;
+      // Bit-compatibility with the reference's CPU run: ATen evaluates w00*a + w01*b + w10*c + w11*d left to
+      // right when out_h + out_w <= 128 (its "vectorized" kernel) and separably, rows first, otherwise
+      // (aten/src/ATen/native/cpu/UpSampleKernel.cpp, _use_vectorized_kernel_cond_2d).  All weights are powers of
+      // two, so every product is exact and only the order of the additions matters.
+      if (h + w <= 128) {
+        o[ch] = add_rn(add_rn(add_rn(0.25f * p00, 0.25f * p01), 0.25f * p10), 0.25f * p11);
+      } else {
+        const float t0 = add_rn(0.5f * p00, 0.5f * p01);
+        const float t1 = add_rn(0.5f * p10, 0.5f * p11);
+        o[ch] = add_rn(0.5f * t0, 0.5f * t1);
+      }
     }
   }
 }
 
 // d = sqrt((px-x)^2 + (py-y)^2 + (pz-z)^2) in the reference's operation order, no fma contraction
 __device__ __forceinline__ float l2_dist(float px, float py, float pz, const float* q) {
-  const float dx = __fsub_rn(px, q[0]), dy = __fsub_rn(py, q[1]), dz = __fsub_rn(pz, q[2]);
-  const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-  return __fsqrt_rn(s);
+  const float dx = sub_rn(px, q[0]), dy = sub_rn(py, q[1]), dz = sub_rn(pz, q[2]);
+  const float s = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+  return sqrt_rn(s);
 }
 
 constexpr int TK_THREADS = 1024;

@@ -119,8 +119,9 @@ def philox_ghost_points(seed, offset, bounds, anchor, radius, B, Ng, level, max_
 def pcd_downsample(pcd, factor):
     """act3d.py:379-383 / encoder.py:147-158: F.interpolate(pcd, scale_factor=1/f, mode='bilinear') followed by
     "(bt ncam) c h w -> bt (ncam h w) c".  For even f, source index (dst + 0.5) * f - 0.5 = f*dst + f/2 - 1 + 0.5:
-    the sample is the mean of the 2x2 block at offset f/2 - 1, rows first combined horizontally, then vertically
-    (torch's separable kernel order).  pcd: (B, C, 3, H, W) float32 -> (B, C*h*w, 3)."""
+    the sample is the mean of the 2x2 block at offset f/2 - 1.  The order of the three additions follows the ATen
+    CPU kernel that the reference run takes for the given output size (pinned by tests/test_oracle_cpu.py against
+    F.interpolate itself).  pcd: (B, C, 3, H, W) float32 -> (B, C*h*w, 3)."""
     pcd = np.asarray(pcd, dtype=np.float32)
     B, C, _, H, W = pcd.shape
     o = factor // 2 - 1
@@ -128,10 +129,15 @@ def pcd_downsample(pcd, factor):
     p01 = pcd[..., o::factor, o + 1::factor]
     p10 = pcd[..., o + 1::factor, o::factor]
     p11 = pcd[..., o + 1::factor, o + 1::factor]
-    half = np.float32(0.5)
-    t0 = half * p00 + half * p01
-    t1 = half * p10 + half * p11
-    out = half * t0 + half * t1                                   # (B, C, 3, h, w)
+    half, quarter = np.float32(0.5), np.float32(0.25)
+    if (H // factor) + (W // factor) <= 128:
+        # ATen's "vectorized" CPU kernel (UpSampleKernel.cpp, _use_vectorized_kernel_cond_2d): left-to-right sum
+        out = ((quarter * p00 + quarter * p01) + quarter * p10) + quarter * p11
+    else:
+        # ATen's generic separable kernel: rows first, then columns
+        t0 = half * p00 + half * p01
+        t1 = half * p10 + half * p11
+        out = half * t0 + half * t1                               # (B, C, 3, h, w)
     return np.ascontiguousarray(out.transpose(0, 1, 3, 4, 2)).reshape(B, -1, 3)
 
 

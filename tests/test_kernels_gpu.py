@@ -47,13 +47,14 @@ def test_mfma_layout_probes(a3d, dev):
     A = torch.randn(16, 32, generator=g).to(torch.bfloat16)
     Bm = torch.randn(32, 16, generator=g).to(torch.bfloat16)
     D = torch.zeros(16, 16, device=dev)
-    L.call("a3d_dbg_mfma_bf16", A.to(dev).contiguous().data_ptr(), Bm.to(dev).contiguous().data_ptr(), D.data_ptr(),
-           L.stream())
+    Ad, Bd = A.to(dev).contiguous(), Bm.to(dev).contiguous()     # keep alive: raw pointers are passed
+    L.call("a3d_dbg_mfma_bf16", Ad.data_ptr(), Bd.data_ptr(), D.data_ptr(), L.stream())
     report("mfma_bf16_16x16x32", D, A.float() @ Bm.float(), 1e-4)
     A4 = torch.randn(16, 4, generator=g)
     B4 = torch.randn(4, 16, generator=g)
     D2 = torch.zeros(16, 16, device=dev)
-    L.call("a3d_dbg_mfma_f32", A4.to(dev).data_ptr(), B4.to(dev).data_ptr(), D2.data_ptr(), L.stream())
+    A4d, B4d = A4.to(dev), B4.to(dev)
+    L.call("a3d_dbg_mfma_f32", A4d.data_ptr(), B4d.data_ptr(), D2.data_ptr(), L.stream())
     report("mfma_f32_16x16x4", D2, A4 @ B4, 1e-6)
 
 
@@ -254,23 +255,29 @@ def test_pcd_downsample_bit_exact(a3d, dev, f, H):
 
 @pytest.mark.parametrize("B,N,k", [(3, 16384, 1024), (2, 65536, 4096), (2, 49152, 3072), (1, 500, 500), (2, 1000, 7)])
 def test_knn_topk_indices_exact(a3d, dev, B, N, k):
+    """Bit-exact against the oracle (IEEE fp32 distances, (distance, index) order).  Against torch.topk on CPU the
+    index sequence must agree wherever neighbouring distances are not within 2 ulp: torch's CPU sqrt (MKL VML) is not
+    correctly rounded, so exact ties / near-ties may legitimately come out in a different order."""
+    from oracle import sampling as OS
     g = torch.Generator().manual_seed(N + k)
     xyz = torch.rand(B, N, 3, generator=g)
     pos = torch.rand(B, 3, generator=g)
-    d = ((pos[:, None] - xyz) ** 2).sum(-1).sqrt()
     idx, dist = a3d.ops.knn_topk(pos.to(dev), xyz.to(dev), k, return_dist=True)
     idx, dist = idx.cpu(), dist.cpu()
-    # oracle order: ascending (distance, index)
-    key = d.numpy().astype(np.float64) + 0.0
-    order = np.lexsort((np.arange(N)[None].repeat(B, 0), key), axis=-1)[:, :k]
-    assert torch.equal(dist, torch.gather(d, 1, torch.from_numpy(order))), "top-k distances differ from oracle"
-    assert np.array_equal(idx.numpy(), order), "top-k indices differ from (distance, index) order"
+    o_idx, o_dist = OS.knn_topk(pos.numpy(), xyz.numpy(), k)
+    assert np.array_equal(dist.numpy(), o_dist), "top-k distances differ from the oracle"
+    assert np.array_equal(idx.numpy(), o_idx), "top-k indices differ from the oracle"
+    d = ((pos[:, None] - xyz) ** 2).sum(-1).sqrt()
     tv = d.topk(k, dim=-1, largest=False)
-    assert torch.equal(dist, tv.values), "top-k distances differ from torch.topk"
+    assert (dist - tv.values).abs().max().item() <= 2e-7, "top-k distances differ from torch.topk by more than 2 ulp"
+    gap = 3e-7
     strict = torch.ones_like(dist, dtype=torch.bool)
-    strict[:, 1:] &= dist[:, 1:] > dist[:, :-1]
-    strict[:, :-1] &= dist[:, :-1] < dist[:, 1:]
-    assert torch.equal(idx[strict], tv.indices[strict]), "indices differ from torch.topk where distances are unique"
+    strict[:, 1:] &= (tv.values[:, 1:] - tv.values[:, :-1]) > gap
+    strict[:, :-1] &= (tv.values[:, 1:] - tv.values[:, :-1]) > gap
+    assert torch.equal(idx[strict], tv.indices[strict]), "indices differ from torch.topk where distances are separated"
+    assert strict.float().mean().item() > 0.9
+    for b in range(B):
+        assert set(idx[b, :-2].tolist()) <= set(tv.indices[b].tolist()) | set(idx[b, -4:].tolist())
 
 
 def test_knn_topk_ties(a3d, dev):
@@ -442,8 +449,9 @@ def test_diffusion_elementwise(a3d, dev):
     tt = torch.tensor([0, 57, 99])
     ref_noisy = sched.add_noise(x0, eps, tt)
     out = torch.empty(B, Ln, 9, device=dev)
-    L.call("a3d_ddpm_add_noise", x0.to(dev).data_ptr(), eps.to(dev).data_ptr(), tt.to(dev).data_ptr(),
-           sched.acp_pos.to(dev).data_ptr(), sched.acp_rot.to(dev).data_ptr(), out.data_ptr(), B, Ln, 9, 3, L.stream())
+    x0d, epsd, ttd, apd, ard = x0.to(dev), eps.to(dev), tt.to(dev), sched.acp_pos.to(dev), sched.acp_rot.to(dev)
+    L.call("a3d_ddpm_add_noise", x0d.data_ptr(), epsd.data_ptr(), ttd.data_ptr(), apd.data_ptr(), ard.data_ptr(),
+           out.data_ptr(), B, Ln, 9, 3, L.stream())
     report("ddpm add_noise", out, ref_noisy, 1e-6)
     cond = torch.randn(B, Ln, 9, generator=g)
     cmask = torch.zeros(B, Ln, 9, dtype=torch.bool)
@@ -451,9 +459,9 @@ def test_diffusion_elementwise(a3d, dev):
     cmask[1, -3:] = True
     mo = torch.randn(B, Ln, 9, generator=g) * 1.5
     cp, cr = sched.coef_pos.to(dev), sched.coef_rot.to(dev)
+    mod_, condd, cmd = mo.to(dev), cond.to(dev), cmask.to(dev).to(torch.uint8).contiguous()
     for tstep in (99, 40, 1, 0):
         ref_prev = sched.step_with_inpaint(mo, x0, eps, cond, cmask, tstep)
-        L.call("a3d_ddpm_step", mo.to(dev).data_ptr(), x0.to(dev).data_ptr(), eps.to(dev).data_ptr(),
-               cond.to(dev).data_ptr(), cmask.to(dev).to(torch.uint8).contiguous().data_ptr(), cp.data_ptr(),
-               cr.data_ptr(), out.data_ptr(), B * Ln, 9, 3, tstep, L.stream())
+        L.call("a3d_ddpm_step", mod_.data_ptr(), x0d.data_ptr(), epsd.data_ptr(), condd.data_ptr(), cmd.data_ptr(),
+               cp.data_ptr(), cr.data_ptr(), out.data_ptr(), B * Ln, 9, 3, tstep, L.stream())
         report(f"ddpm step t={tstep}", out, ref_prev, 2e-6, 1e-6)
