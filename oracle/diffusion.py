@@ -201,13 +201,13 @@ def head_forward(P, trajectory, traj_mask, timestep, ctx_feats, ctx_xyz, curr_gr
 
 
 def planner_loss(P, sched, gt_trajectory, traj_mask, ctx_feats, ctx_xyz_world, instruction, curr_gripper, goal_gripper,
-                 bounds, noise, timesteps, H):
+                 bounds, noise, timesteps, H, ctx_xyz_norm=None):
     """DiffusionPlanner.forward training branch (diffusion_model.py:253-324) with injected noise / timesteps.
     ctx_xyz_world: down-sampled point cloud in world metres (normalised here, which commutes with the bilinear
     down-sampling up to rounding)."""
     gt = gt_trajectory.clone()
     gt[..., :3] = normalize_pos(gt[..., :3], bounds)
-    cxyz = normalize_pos(ctx_xyz_world, bounds)
+    cxyz = ctx_xyz_norm if ctx_xyz_norm is not None else normalize_pos(ctx_xyz_world, bounds)
     cg, gg = curr_gripper.clone(), goal_gripper.clone()
     cg[:, :3] = normalize_pos(cg[:, :3], bounds)
     gg[:, :3] = normalize_pos(gg[:, :3], bounds)
@@ -234,11 +234,11 @@ def make_conditioning(traj_mask, curr_gripper9, goal_gripper9, use_goal_at_test=
 
 
 def compute_trajectory(P, sched, traj_mask, ctx_feats, ctx_xyz_world, instruction, curr_gripper, goal_gripper, bounds,
-                       init_noise, step_noise, H, n_steps=None):
+                       init_noise, step_noise, H, n_steps=None, ctx_xyz_norm=None):
     """DiffusionPlanner.compute_trajectory + conditional_sample (diffusion_model.py:86-185) with injected noise:
     init_noise (B, L, 9), step_noise (T, B, L, 9) indexed by t.  n_steps limits the loop for fixtures (the first
     n_steps timesteps T-1, T-2, ...; the final un-normalisation is applied to whatever state is reached)."""
-    cxyz = normalize_pos(ctx_xyz_world, bounds)
+    cxyz = ctx_xyz_norm if ctx_xyz_norm is not None else normalize_pos(ctx_xyz_world, bounds)
     cg, gg = curr_gripper.clone(), goal_gripper.clone()
     cg[:, :3] = normalize_pos(cg[:, :3], bounds)
     gg[:, :3] = normalize_pos(gg[:, :3], bounds)

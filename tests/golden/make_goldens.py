@@ -1,0 +1,374 @@
+"""Generates tests/golden/*.pt by running the REFERENCE (/root/reference, imported with stubs) on seeded inputs.
+
+Run in the build container only:   python tests/golden/make_goldens.py
+The fixtures hold seeds + the reference's outputs (small tensors); inputs/parameters are regenerated from the seeds
+by tests/golden/common.py.  Nothing of the reference's source is stored.
+"""
+import os
+import sys
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import common as C  # noqa: E402
+from refimport import import_reference  # noqa: E402
+
+torch.set_num_threads(8)
+R = import_reference()
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name)
+    torch.save(obj, path)
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------------------ G1-G3: blocks
+def golden_blocks():
+    out = {}
+    rs = np.random.RandomState(7)
+    # G1: RoPE-3D code, rotary application, sinusoidal embedding
+    for E in (60, 120):
+        xyz = C.rs_tensor(rs, (2, 9, 3), scale=1.5)
+        code = R.pe.RotaryPositionEncoding3D(E)(xyz)
+        x = C.rs_tensor(rs, (2, 9, E))
+        rot = R.pe.RotaryPositionEncoding.embed_rotary(x, code[..., 0], code[..., 1])
+        out[f"rope_{E}"] = dict(xyz=xyz, code=code, x=x, rotated=rot)
+    t = torch.tensor([0.0, 1.0, 17.0, 99.0])
+    out["sinusoidal_120"] = dict(t=t, emb=R.pe.SinusoidalPosEmb(120)(t))
+    # G2: MultiheadCustomAttention, the three projection paths, with / without RoPE and padding mask, fwd + grads
+    for tag, (Lq, S, E, H, rope, masked, mode) in {
+        "cross_rope": (37, 131, 60, 4, True, False, "kv"),
+        "self_mask": (16, 16, 120, 8, True, True, "qk"),
+        "cross_plain": (5, 53, 120, 8, False, False, "kv"),
+    }.items():
+        B = 2
+        m = R.mha.MultiheadCustomAttention(E, H)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = C.seeded_state_dict(shapes, seed=11 + E + Lq, gain=2.0)
+        m.load_state_dict(sd)
+        q = C.rs_tensor(rs, (B, Lq, E)).requires_grad_()
+        k = q if mode == "qk" else C.rs_tensor(rs, (B, S, E)).requires_grad_()
+        v = k if mode == "kv" else C.rs_tensor(rs, (B, S, E)).requires_grad_()
+        q_xyz = C.rs_tensor(rs, (B, Lq, 3)) if rope else None
+        k_xyz = (q_xyz if mode == "qk" else C.rs_tensor(rs, (B, S, 3))) if rope else None
+        kmask = None
+        if masked:
+            kmask = torch.zeros(B, S, dtype=torch.bool)
+            kmask[1, -5:] = True
+        pe = R.pe.RotaryPositionEncoding3D(E)
+        kw = {}
+        if rope:
+            kw["rotary_pe"] = (pe(q_xyz), pe(k_xyz))
+        if mode == "qk":
+            vv = v
+            o, w = m(query=q.transpose(0, 1), key=q.transpose(0, 1), value=vv.transpose(0, 1), key_padding_mask=kmask, **kw)
+        else:
+            o, w = m(query=q.transpose(0, 1), key=k.transpose(0, 1), value=v.transpose(0, 1), key_padding_mask=kmask, **kw)
+        o = o.transpose(0, 1)
+        dy = C.rs_tensor(rs, tuple(o.shape))
+        o.backward(dy)
+        out["mha_" + tag] = dict(cfg=(B, Lq, S, E, H, rope, masked, mode), seed=11 + E + Lq,
+                                 q=q.detach(), k=k.detach(), v=v.detach(), q_xyz=q_xyz, k_xyz=k_xyz, kmask=kmask, dy=dy,
+                                 out=o.detach(), weights_mean=w.detach().mean(1),
+                                 dq=q.grad.clone(), dk=None if mode == "qk" else k.grad.clone(),
+                                 dv=None if mode == "kv" else v.grad.clone(),
+                                 d_in_w=m.in_proj_weight.grad.clone(), d_in_b=m.in_proj_bias.grad.clone(),
+                                 d_out_w=m.out_proj.weight.grad.clone())
+    # G3: RelativeCrossAttentionModule (list outputs) and ParallelAttentionLayer with NON-zero AdaLN, eval mode
+    E, H, B, Lq, S = 60, 4, 2, 21, 77
+    mod = R.layers.RelativeCrossAttentionModule(E, H, 2)
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(C.seeded_state_dict(shapes, seed=31, gain=2.0))
+    q, v = C.rs_tensor(rs, (B, Lq, E)), C.rs_tensor(rs, (B, S, E))
+    q_xyz, v_xyz = C.rs_tensor(rs, (B, Lq, 3)), C.rs_tensor(rs, (B, S, 3))
+    pe = R.pe.RotaryPositionEncoding3D(E)
+    outs = mod(query=q.transpose(0, 1), value=v.transpose(0, 1), query_pos=pe(q_xyz), value_pos=pe(v_xyz))
+    out["rel_cross_attn_module"] = dict(seed=31, q=q, v=v, q_xyz=q_xyz, v_xyz=v_xyz,
+                                        outs=[o.detach().transpose(0, 1).contiguous() for o in outs])
+    E, H, B, Ln, S = 120, 8, 2, 16, 70
+    lay = R.layers.ParallelAttentionLayer(d_model=E, n_heads=H, self_attention1=True, self_attention2=False,
+                                          cross_attention1=True, cross_attention2=False, rotary_pe=True, use_adaln=True)
+    lay.eval()
+    shapes = {k: tuple(v.shape) for k, v in lay.state_dict().items()}
+    lay.load_state_dict(C.seeded_state_dict(shapes, seed=41, gain=1.5))
+    s1, s2 = C.rs_tensor(rs, (B, Ln, E)), C.rs_tensor(rs, (B, S, E))
+    x1, x2 = C.rs_tensor(rs, (B, Ln, 3)), C.rs_tensor(rs, (B, S, 3))
+    sem = R.pe.SinusoidalPosEmb(E)(torch.arange(Ln))[None].repeat(B, 1, 1)
+    ada = C.rs_tensor(rs, (B, E))
+    mask = torch.zeros(B, Ln, dtype=torch.bool)
+    mask[1, -4:] = True
+    pe = R.pe.RotaryPositionEncoding3D(E)
+    with torch.no_grad():
+        y, _ = lay(seq1=s1, seq1_key_padding_mask=mask, seq2=s2, seq2_key_padding_mask=None, seq1_pos=pe(x1),
+                   seq2_pos=pe(x2), seq1_sem_pos=sem, seq2_sem_pos=None, ada_sgnl=ada)
+    out["parallel_attention_layer"] = dict(seed=41, s1=s1, s2=s2, x1=x1, x2=x2, ada=ada, mask=mask, out=y)
+    save("blocks.pt", out)
+
+
+# ------------------------------------------------------------------------------------------------------ G4/G5: sampling
+def golden_sampling():
+    out = {}
+    np.random.seed(123)
+    b = C.PERACT_BOUNDS
+    out["cube"] = dict(seed=123, pts=R.utils.sample_ghost_points_uniform_cube(b, 50))
+    c = np.array([0.2, 0.0, 1.0])
+    bb = np.stack([np.clip(c - 0.08, b[0], b[1]), np.clip(c + 0.08, b[0], b[1])])
+    out["sphere"] = dict(center=c, radius=0.08, bounds=bb, pts=R.utils.sample_ghost_points_uniform_sphere(c, 0.08, bb, 50))
+    c2 = np.array([0.64, 0.5, 1.5])        # near the workspace corner: clipped box
+    bb2 = np.stack([np.clip(c2 - 0.02, b[0], b[1]), np.clip(c2 + 0.02, b[0], b[1])])
+    out["sphere_clipped"] = dict(center=c2, radius=0.02, bounds=bb2,
+                                 pts=R.utils.sample_ghost_points_uniform_sphere(c2, 0.02, bb2, 40))
+    rs = np.random.RandomState(5)
+    for f, H in ((2, 256), (8, 256), (4, 128), (2, 128)):
+        pcd = C.rs_tensor(rs, (1, 2, 3, H, H), kind="uniform")
+        ref = F.interpolate(pcd.view(2, 3, H, H), scale_factor=1.0 / f, mode="bilinear")
+        h = H // f
+        out[f"interp_{f}_{H}"] = dict(seed=5, sum=ref.double().sum().item(),
+                                      sample=ref.view(1, 2, 3, h, h).permute(0, 1, 3, 4, 2).reshape(1, 2 * h * h, 3)[:, ::97].clone())
+    save("sampling.pt", out)
+
+
+# ------------------------------------------------------------------------------------------------------ G6/G7: Act3D
+def build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain):
+    m = R.act3d.Act3D(backbone="clip", image_size=(256, 256), embedding_dim=E, num_attn_heads=4,
+                      gripper_loc_bounds=C.PERACT_BOUNDS, num_ghost_points=Ng * levels,
+                      num_ghost_points_val=Ng * levels * 2, num_sampling_level=levels, weight_tying=True,
+                      gp_emb_tying=True, use_instruction=use_instruction)
+    shapes, alias = C.unique_param_shapes(m)
+    sd = C.expand_aliases(C.seeded_state_dict(shapes, seed, gain), alias)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return m, sd
+
+
+def inject_features(m, inp, ncam):
+    """Replaces backbone+FPN by the seeded feature maps; everything downstream is the reference's own code."""
+    def fake(visible_rgb, visible_pcd, num_cameras):
+        import einops
+        pcd = einops.rearrange(visible_pcd, "bt ncam c h w -> (bt ncam) c h w")
+        feats, poss, pcds = [], [], []
+        for i in range(m.num_sampling_level):
+            p = F.interpolate(pcd, scale_factor=1. / m.downscaling_factor_pyramid[i], mode='bilinear')
+            p = einops.rearrange(p, "(bt ncam) c h w -> bt (ncam h w) c", ncam=num_cameras)
+            feats.append(inp["feats"][i])
+            poss.append(m.relative_pe_layer(p))
+            pcds.append(p)
+        return feats, poss, pcds
+    m._compute_visual_features = fake
+
+
+def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=1e-2):
+    for attempt in range(80):
+        seed, gain = 100 + attempt, 3.0
+        m, sd = build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain)
+        inp = C.keypose_inputs(seed, B, ncam, E, levels)
+        for f in inp["feats"]:
+            f.requires_grad_(train)
+        inject_features(m, inp, ncam)
+        m.train(train)
+        np.random.seed(seed)
+        rgb = torch.zeros(B, ncam, 3, 256, 256)
+        out = m(rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], gt_action=inp["action"] if train else None)
+        gaps = []
+        for masks in out["ghost_pcd_masks_pyramid"]:
+            top2 = masks[-1].topk(2, dim=-1).values
+            gaps.append((top2[:, 0] - top2[:, 1]).min().item())
+        if min(gaps) > min_gap:
+            break
+    else:
+        raise RuntimeError("no seed with a safe top-2 logit gap")
+    print(tag, "seed", seed, "min top-2 gaps per level", gaps)
+    rec = dict(cfg=dict(E=E, levels=levels, ncam=ncam, Ng=out["ghost_pcd_pyramid"][0].shape[-1],
+                        use_instruction=use_instruction, B=B, train=train),
+               seed=seed, gain=gain, gaps=gaps,
+               ghost=[g.detach().transpose(1, 2).contiguous() for g in out["ghost_pcd_pyramid"]],
+               masks=[[mm.detach() for mm in ms] for ms in out["ghost_pcd_masks_pyramid"]],
+               positions=[p.detach()[:, 0] for p in out["position_pyramid"]],
+               position=out["position"].detach(), rotation=out["rotation"].detach(), gripper=out["gripper"].detach(),
+               query_features=out["query_features"].detach()[0])
+    idxs = [None]
+    for i in range(1, levels):
+        l2 = ((out["position_pyramid"][i - 1] - out["visible_pcd_pyramid"][i]) ** 2).sum(-1).sqrt()
+        tk = l2.topk(k=32 * 32 * ncam, dim=-1, largest=False)
+        idxs.append(tk.indices)
+        rec.setdefault("topk_values", [None]).append(tk.values)
+    rec["topk"] = idxs
+    if train:
+        crit = R.main_keypose.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
+                                             ground_truth_gaussian_spread=0.01)
+        sample = {"action": inp["action"], "task": ["t"] * B}
+        losses = crit.compute_loss(out, sample)
+        total = sum(losses.values())
+        total.backward()
+        rec["losses"] = {k: v.detach() for k, v in losses.items()}
+        grads = {n: p.grad.clone() for n, p in m.named_parameters()
+                 if p.grad is not None and not n.startswith("backbone") and "feature_pyramid" not in n}
+        rec["grad_norms"] = {n: g.norm().item() for n, g in grads.items()}
+        keep = ["query_embed.weight", "curr_gripper_embed.weight", "ghost_points_embed_pyramid.0.weight",
+                "ghost_point_cross_attn_pyramid.0.attn_layers.0.multihead_attn.in_proj_weight",
+                "query_cross_attn_pyramid.0.attn_layers.1.multihead_attn.out_proj.weight",
+                "ghost_point_cross_attn_pyramid.0.ffw_layers.1.linear1.weight", "gripper_state_predictor.2.weight"]
+        rec["grads"] = {n: grads[n] for n in keep if n in grads}
+        rec["feat_grad_norms"] = [None if f.grad is None else f.grad.norm().item() for f in inp["feats"][:2]]
+        fg = inp["feats"][1].grad if levels > 1 else None
+        if fg is not None:
+            rec["feat1_grad_sample"] = C.tokens_from_maps(fg)[:, ::517].clone()
+        rec["metrics"] = {k: v.detach() for k, v in crit.compute_metrics(out, sample).items() if k.startswith("mean") or k == "gripper"}
+    return rec
+
+
+def golden_act3d():
+    out = {
+        "train_L3_C1_N64": run_act3d_case("train_L3_C1_N64", 60, 3, 1, 64, False, 2, True),
+        "eval_L3_C1_N128": run_act3d_case("eval_L3_C1_N128", 60, 3, 1, 64, False, 2, False),
+        "train_L2_C2_N64_instr": run_act3d_case("train_L2_C2_N64_instr", 60, 2, 2, 64, True, 2, True),
+        "train_L4_C1_N32": run_act3d_case("train_L4_C1_N32", 60, 4, 1, 32, False, 1, True, min_gap=2e-3),
+    }
+    save("act3d.pt", out)
+    # G12: parameter manifest of the default configuration
+    m, _ = build_ref_act3d(60, 3, 1, 333, False, 1, 1.0)
+    man = {n: tuple(p.shape) for n, p in m.named_parameters() if not n.startswith("backbone")}
+    m2, _ = build_ref_act3d(60, 3, 1, 333, True, 1, 1.0)
+    man2 = {n: tuple(p.shape) for n, p in m2.named_parameters() if not n.startswith("backbone")}
+    sdk = [k for k in m.state_dict().keys() if not k.startswith("backbone")]
+    save("act3d_manifest.pt", dict(named_parameters=man, named_parameters_instr=man2, state_dict_keys=sdk,
+                                   n_trainable=sum(int(np.prod(s)) for s in man.values()),
+                                   n_trainable_instr=sum(int(np.prod(s)) for s in man2.values())))
+
+
+# ------------------------------------------------------------------------------------------------------ G8/G9/G10: diffusion
+@contextmanager
+def patched_rng(randn_list, randint_value):
+    orig_randn, orig_randint = torch.randn, torch.randint
+    it = iter(randn_list)
+
+    def fake_randn(*a, **k):
+        return next(it).clone()
+
+    def fake_randint(*a, **k):
+        return randint_value.clone()
+
+    torch.randn, torch.randint = fake_randn, fake_randint
+    try:
+        yield
+    finally:
+        torch.randn, torch.randint = orig_randn, orig_randint
+
+
+def golden_diffusion():
+    E, B, Ln, ncam = 120, 2, 8, 1
+    m = R.dm.DiffusionPlanner(backbone="clip", image_size=(256, 256), embedding_dim=E, output_dim=7,
+                              num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6, use_instruction=True,
+                              use_goal=True, use_goal_at_test=True, feat_scales_to_use=1, attn_rounds=1,
+                              weight_tying=True, gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D",
+                              diffusion_timesteps=100)
+    shapes, alias = C.unique_param_shapes(m)
+    seed = 77
+    sd = C.expand_aliases(C.seeded_state_dict(shapes, seed, gain=1.5), alias)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    m.eval()                                   # dropout off (SURVEY §7 hard parts)
+    inp = C.trajectory_inputs(seed, B, Ln, ncam, E, pad_last=2)
+    head = m.prediction_head
+
+    def fake_encode_images(rgb, pcd):
+        import einops
+        p = einops.rearrange(pcd, "bt ncam c h w -> (bt ncam) c h w")
+        p = F.interpolate(p, scale_factor=1. / 8, mode='bilinear')
+        p = einops.rearrange(p, "(bt ncam) c h w -> bt (ncam h w) c", ncam=ncam)
+        return [inp["fmap"]], [p]
+    head.encode_images = fake_encode_images
+    rgb = torch.zeros(B, ncam, 3, 256, 256)
+    rec = dict(cfg=dict(E=E, B=B, L=Ln, ncam=ncam, pad_last=2), seed=seed, gain=1.5)
+    # G8: training loss with injected noise / timesteps (+ gradients)
+    with patched_rng([inp["noise"]], inp["timesteps"]):
+        loss = m(inp["trajectory"], inp["mask"], rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"])
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None and "feature_pyramid" not in n}
+    rec["train_loss"] = loss.detach()
+    rec["grad_norms"] = {n: g.norm().item() for n, g in grads.items()}
+    keep = ["prediction_head.traj_encoder.0.weight", "prediction_head.traj_attention.0.layers.0.adaln_12.modulation.1.weight",
+            "prediction_head.traj_attention.0.layers.3.sa1.in_proj_weight", "prediction_head.pos_regressor.0.3.weight",
+            "prediction_head.vl_attention.0.layers.1.cross_12.in_proj_weight", "prediction_head.goal_gripper_embed.weight"]
+    rec["grads"] = {n: grads[n].clone() for n in keep}
+    # head forward on a fixed noisy trajectory (eval)
+    with torch.no_grad():
+        tr9 = m.convert_rot(torch.cat([m.normalize_pos(inp["trajectory"][..., :3]), inp["trajectory"][..., 3:]], -1))
+        pcdn = torch.permute(m.normalize_pos(torch.permute(inp["pcd"], [0, 1, 3, 4, 2])), [0, 1, 4, 2, 3])
+        cg = inp["curr_gripper"].clone(); cg[:, :3] = m.normalize_pos(cg[:, :3]); cg = m.convert_rot(cg)
+        gg = inp["goal_gripper"].clone(); gg[:, :3] = m.normalize_pos(gg[:, :3]); gg = m.convert_rot(gg)
+        pred = head(tr9, inp["mask"], inp["timesteps"], rgb, pcdn, cg, gg, inp["instr"])[-1]
+    rec["head_in"] = tr9
+    rec["head_out"] = pred
+    rec["conv"] = dict(curr9=cg, goal9=gg)
+    # G9: the full 100-step sampling loop with injected noise
+    sn = inp["step_noise"]
+    m.position_noise_scheduler.injected_noise = {t: sn[t][..., :3] for t in range(100)}
+    m.rotation_noise_scheduler.injected_noise = {t: sn[t][..., 3:] for t in range(100)}
+    trace = {}
+    orig = m.policy_forward_pass
+
+    def spy(trajectory, timestep, fixed_inputs):
+        t = int(timestep[0])
+        if t in (99, 98, 60, 1, 0):
+            trace[t] = trajectory.detach().clone()
+        return orig(trajectory, timestep, fixed_inputs)
+    m.policy_forward_pass = spy
+    with torch.no_grad(), patched_rng([inp["init_noise"]], inp["timesteps"]):
+        final = m(inp["trajectory"], inp["mask"], rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+                  run_inference=True)
+    rec["sample_trace_inputs"] = trace
+    rec["sample_final"] = final
+    # G10: rotation conversions
+    rs = np.random.RandomState(3)
+    q = C.rs_tensor(rs, (6, 4))
+    qn = R.utils.normalise_quat(q)
+    mat = R.p3d.quaternion_to_matrix(qn)
+    o6 = R.utils.get_ortho6d_from_rotation_matrix(mat)
+    rec["rot"] = dict(q=q, qn=qn, mat=mat, o6=o6, mat_back=R.utils.compute_rotation_matrix_from_ortho6d(o6 * 1.7),
+                      q_back=R.p3d.matrix_to_quaternion(mat))
+    man = {n: tuple(p.shape) for n, p in m.named_parameters() if not n.startswith("prediction_head.backbone")}
+    rec["manifest"] = dict(named_parameters=man, n_trainable=sum(int(np.prod(s)) for s in man.values()),
+                           with_grad=sorted(grads.keys()))
+    save("diffusion.pt", rec)
+
+
+def golden_optimizer():
+    """G11: which names land in which AdamW group + one AdamW step on a toy module (engine.py:89-102)."""
+    import types
+    rs = np.random.RandomState(9)
+    mod = torch.nn.Sequential()
+    mod.add_module("lin", torch.nn.Linear(6, 4))
+    mod.add_module("norm", torch.nn.LayerNorm(4))
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(C.rs_tensor(rs, tuple(p.shape)))
+    no_decay = ["bias", "LayerNorm.weight", "LayerNorm.bias"]
+    groups = [{"params": [], "weight_decay": 0.0, "lr": 1e-4}, {"params": [], "weight_decay": 5e-4, "lr": 1e-4}]
+    names = [[], []]
+    for name, p in mod.named_parameters():
+        gi = 0 if any(nd in name for nd in no_decay) else 1
+        groups[gi]["params"].append(p)
+        names[gi].append(name)
+    opt = torch.optim.AdamW(groups)
+    before = {n: p.detach().clone() for n, p in mod.named_parameters()}
+    gr = {n: C.rs_tensor(rs, tuple(p.shape)) for n, p in mod.named_parameters()}
+    for it in range(2):
+        for n, p in mod.named_parameters():
+            p.grad = gr[n].clone() * (it + 1)
+        opt.step()
+    save("optimizer.pt", dict(groups=names, before=before, grads=gr, after={n: p.detach().clone() for n, p in mod.named_parameters()}))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "diffusion", "optimizer"]
+    for w in which:
+        globals()["golden_" + w]()

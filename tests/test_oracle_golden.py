@@ -1,0 +1,289 @@
+"""Pins the CPU oracle (oracle/) against golden outputs of the REFERENCE itself (tests/golden/*.pt, produced by
+tests/golden/make_goldens.py from /root/reference).  CPU only; runs everywhere."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import common as C  # noqa: E402
+from oracle import act3d as OA  # noqa: E402
+from oracle import blocks as OB  # noqa: E402
+from oracle import diffusion as OD  # noqa: E402
+from oracle import sampling as OS  # noqa: E402
+
+G = os.path.join(HERE, "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(G, name), weights_only=False)
+
+
+def close(name, got, ref, atol, rtol=0.0):
+    err = (got.detach() - ref).abs()
+    tol = atol + rtol * ref.abs()
+    assert got.shape == ref.shape, f"{name}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert (err <= tol).all(), f"{name}: max err {err.max().item():.3e} (ref absmax {ref.abs().max().item():.3e})"
+
+
+def test_rope_and_sinusoidal():
+    g = load("blocks.pt")
+    for E in (60, 120):
+        r = g[f"rope_{E}"]
+        cos, sin = OB.rope3d_code(r["xyz"], E)
+        assert torch.equal(cos, r["code"][..., 0]) and torch.equal(sin, r["code"][..., 1])
+        assert torch.equal(OB.rotary_apply(r["x"], cos, sin), r["rotated"])
+    s = g["sinusoidal_120"]
+    assert torch.equal(OB.sinusoidal(s["t"], 120), s["emb"])
+
+
+@pytest.mark.parametrize("tag", ["cross_rope", "self_mask", "cross_plain"])
+def test_mha_forward_and_grads(tag):
+    r = load("blocks.pt")["mha_" + tag]
+    B, Lq, S, E, H, rope, masked, mode = r["cfg"]
+    shapes = {"in_proj_weight": (3 * E, E), "in_proj_bias": (3 * E,), "out_proj.weight": (E, E), "out_proj.bias": (E,)}
+    sd = C.seeded_state_dict(shapes, r["seed"], gain=2.0)
+    P = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    q = r["q"].clone().requires_grad_()
+    k = q if mode == "qk" else r["k"].clone().requires_grad_()
+    v = k if mode == "kv" else r["v"].clone().requires_grad_()
+    o, w = OB.mha(q, k, v, P["in_proj_weight"], P["in_proj_bias"], P["out_proj.weight"], P["out_proj.bias"], H,
+                  r["q_xyz"], r["k_xyz"], r["kmask"], return_weights=True)
+    close("out", o, r["out"], 2e-5)
+    close("weights", w.mean(1), r["weights_mean"], 1e-6)
+    o.backward(r["dy"])
+    close("dq", q.grad, r["dq"], 5e-5)
+    if r["dk"] is not None:
+        close("dk", k.grad, r["dk"], 5e-5)
+    if r["dv"] is not None:
+        close("dv", v.grad, r["dv"], 5e-5)
+    close("d_in_w", P["in_proj_weight"].grad, r["d_in_w"], 2e-4)
+    close("d_in_b", P["in_proj_bias"].grad, r["d_in_b"], 2e-4)
+    close("d_out_w", P["out_proj.weight"].grad, r["d_out_w"], 2e-4)
+
+
+def test_rel_cross_attn_module_and_parallel_layer():
+    g = load("blocks.pt")
+    r = g["rel_cross_attn_module"]
+    E, H = 60, 4
+    shapes = {}
+    for i in range(2):
+        shapes.update({f"attn_layers.{i}.multihead_attn.in_proj_weight": (3 * E, E), f"attn_layers.{i}.multihead_attn.in_proj_bias": (3 * E,),
+                       f"attn_layers.{i}.multihead_attn.out_proj.weight": (E, E), f"attn_layers.{i}.multihead_attn.out_proj.bias": (E,),
+                       f"attn_layers.{i}.norm.weight": (E,), f"attn_layers.{i}.norm.bias": (E,),
+                       f"ffw_layers.{i}.linear1.weight": (E, E), f"ffw_layers.{i}.linear1.bias": (E,),
+                       f"ffw_layers.{i}.linear2.weight": (E, E), f"ffw_layers.{i}.linear2.bias": (E,),
+                       f"ffw_layers.{i}.norm.weight": (E,), f"ffw_layers.{i}.norm.bias": (E,)})
+    P = {"m." + k: v for k, v in C.seeded_state_dict(shapes, r["seed"], gain=2.0).items()}
+    outs = OB.rel_cross_attn_module(P, "m", 2, r["q"], r["v"], H, r["q_xyz"], r["v_xyz"])
+    for a, b in zip(outs, r["outs"]):
+        close("rel module", a, b, 3e-5)
+    r = g["parallel_attention_layer"]
+    E, H = 120, 8
+    shapes = {}
+    for nm in ("sa1", "cross_12"):
+        shapes.update({f"{nm}.in_proj_weight": (3 * E, E), f"{nm}.in_proj_bias": (3 * E,), f"{nm}.out_proj.weight": (E, E),
+                       f"{nm}.out_proj.bias": (E,)})
+    for nm in ("adaln_1", "adaln_12", "adaln_ff1"):
+        shapes.update({f"{nm}.modulation.1.weight": (2 * E, E), f"{nm}.modulation.1.bias": (2 * E,)})
+    for nm in ("norm_1", "norm_12", "norm_122"):
+        shapes.update({f"{nm}.weight": (E,), f"{nm}.bias": (E,)})
+    shapes.update({"ffn_12.0.weight": (4 * E, E), "ffn_12.0.bias": (4 * E,), "ffn_12.3.weight": (E, 4 * E), "ffn_12.3.bias": (E,)})
+    P = {"l." + k: v for k, v in C.seeded_state_dict(shapes, r["seed"], gain=1.5).items()}
+    sem = OB.sinusoidal(torch.arange(16, dtype=torch.float32), E)[None].expand(2, -1, -1)
+    y = OB.parallel_attention_layer(P, "l", r["s1"], r["mask"], r["s2"], H, seq1_xyz=r["x1"], seq2_xyz=r["x2"], seq1_sem=sem,
+                                    ada=r["ada"])
+    close("parallel layer", y, r["out"], 5e-5)
+
+
+def test_reference_numpy_samplers():
+    g = load("sampling.pt")
+    np.random.seed(g["cube"]["seed"])
+    assert np.array_equal(OS.ref_sample_cube(C.PERACT_BOUNDS, 50), g["cube"]["pts"])
+    s = g["sphere"]
+    assert np.array_equal(OS.ref_sample_sphere(s["center"], s["radius"], s["bounds"], 50), s["pts"])
+    s = g["sphere_clipped"]
+    assert np.array_equal(OS.ref_sample_sphere(s["center"], s["radius"], s["bounds"], 40), s["pts"])
+    with pytest.raises(RuntimeError):      # the reference never returns here; the oracle raises
+        OS.ref_sample_sphere(np.array([5.0, 5.0, 5.0]), 0.02, np.stack([C.PERACT_BOUNDS[1], C.PERACT_BOUNDS[1]]), 4,
+                             max_rounds=20)
+    rs = np.random.RandomState(5)
+    for f, H in ((2, 256), (8, 256), (4, 128), (2, 128)):
+        pcd = C.rs_tensor(rs, (1, 2, 3, H, H), kind="uniform")
+        r = g[f"interp_{f}_{H}"]
+        mine = torch.from_numpy(OS.pcd_downsample(pcd.numpy(), f))
+        assert torch.equal(mine[:, ::97], r["sample"]) and mine.double().sum().item() == r["sum"]
+
+
+def _act3d_case(tag):
+    r = load("act3d.pt")[tag]
+    cfg = r["cfg"]
+    man = load("act3d_manifest.pt")
+    names = man["named_parameters_instr"] if cfg["use_instruction"] else man["named_parameters"]
+    return r, cfg, names
+
+
+def act3d_params(cfg, seed, gain, names):
+    """Rebuilds the reference model's (tied) parameters from the seed, exactly as make_goldens.build_ref_act3d does."""
+    levels = cfg["levels"]
+    shapes = {n: s for n, s in names.items() if "feature_pyramid" not in n}
+    # named_parameters() lists tied tensors once, under their first alias (pyramid index 0); add the level aliases
+    canon = C.seeded_state_dict(shapes, seed, gain)
+    P = dict(canon)
+    for n, t in canon.items():
+        for pre in ("ghost_points_embed_pyramid", "ghost_point_cross_attn_pyramid", "query_cross_attn_pyramid", "vis_ins_attn_pyramid"):
+            if n.startswith(pre + ".0."):
+                for i in range(1, levels):
+                    P[n.replace(pre + ".0.", f"{pre}.{i}.", 1)] = t
+    return P
+
+
+@pytest.mark.parametrize("tag", ["train_L3_C1_N64", "eval_L3_C1_N128", "train_L2_C2_N64_instr", "train_L4_C1_N32"])
+def test_act3d_forward_trace(tag):
+    """Free-running oracle forward == the reference's forward: ghost points (numpy RNG), top-k indices, mask logits,
+    argmax cascade, action."""
+    r, cfg, names = _act3d_case(tag)
+    P = act3d_params(cfg, r["seed"], r["gain"], names)
+    inp = C.keypose_inputs(r["seed"], cfg["B"], cfg["ncam"], cfg["E"], cfg["levels"])
+    feats = [C.tokens_from_maps(f) for f in inp["feats"]]
+    pcds = [torch.from_numpy(OS.pcd_downsample(inp["pcd"].numpy(), 8 if i == 0 else 2)) for i in range(cfg["levels"])]
+    ocfg = OA.default_cfg(E=cfg["E"], levels=cfg["levels"], ncam=cfg["ncam"], use_instruction=cfg["use_instruction"])
+    np.random.seed(r["seed"])
+    with torch.no_grad():
+        out = OA.act3d_forward(P, ocfg, feats, pcds, inp["curr_gripper"], inp["instr"],
+                               gt_action=inp["action"] if cfg["train"] else None, num_ghost_points=cfg["Ng"])
+    for i in range(cfg["levels"]):
+        assert torch.equal(out["ghost_pcd_pyramid"][i].transpose(1, 2), r["ghost"][i]), f"ghost points level {i}"
+        if i > 0:
+            same = out["topk_indices"][i] == r["topk"][i]
+            # exact ties in distance may be ordered differently by torch.topk (see oracle/sampling.py)
+            assert same.float().mean() > 0.995, f"top-k level {i}"
+            assert torch.equal(out["topk_indices"][i].sort(-1).values, r["topk"][i].sort(-1).values)
+        for l in range(2):
+            close(f"mask level {i} layer {l}", out["ghost_pcd_masks_pyramid"][i][l], r["masks"][i][l], 2e-4, 1e-4)
+        assert torch.equal(out["position_pyramid"][i][:, 0], r["positions"][i]), f"argmax position level {i}"
+    close("rotation", out["rotation"], r["rotation"], 1e-4)
+    close("gripper", out["gripper"], r["gripper"], 1e-4)
+    close("query", out["query_features"][:, 0], r["query_features"], 5e-4)
+
+
+@pytest.mark.parametrize("tag", ["train_L3_C1_N64", "train_L2_C2_N64_instr"])
+def test_act3d_loss_and_grads(tag):
+    r, cfg, names = _act3d_case(tag)
+    Pc = act3d_params(cfg, r["seed"], r["gain"], names)
+    leaf = {}
+    P = {}
+    for n, t in Pc.items():
+        key = id(t)
+        if key not in leaf:
+            leaf[key] = t.clone().requires_grad_()
+        P[n] = leaf[key]
+    inp = C.keypose_inputs(r["seed"], cfg["B"], cfg["ncam"], cfg["E"], cfg["levels"])
+    fm = [inp["feats"][0].clone().requires_grad_(), inp["feats"][1].clone().requires_grad_()]
+    maps = [fm[0]] + [fm[1]] * (cfg["levels"] - 1)
+    feats = [C.tokens_from_maps(f) for f in maps]
+    pcds = [torch.from_numpy(OS.pcd_downsample(inp["pcd"].numpy(), 8 if i == 0 else 2)) for i in range(cfg["levels"])]
+    ocfg = OA.default_cfg(E=cfg["E"], levels=cfg["levels"], ncam=cfg["ncam"], use_instruction=cfg["use_instruction"])
+    out = OA.act3d_forward(P, ocfg, feats, pcds, inp["curr_gripper"], inp["instr"], gt_action=inp["action"],
+                           ghost_points=r["ghost"])
+    losses = OA.keypose_loss(out, inp["action"])
+    for k, v in r["losses"].items():
+        close("loss " + k, losses[k], v, 1e-4, 1e-4)
+    sum(losses.values()).backward()
+    for n, gref in r["grads"].items():
+        close("grad " + n, P[n].grad, gref, 3e-3, 3e-3)
+    for n, nr in r["grad_norms"].items():
+        if "feature_pyramid" in n or n not in P:
+            continue
+        assert abs(P[n].grad.norm().item() - nr) <= 3e-3 * nr + 1e-4, f"grad norm {n}"
+    for f, nr in zip(fm, r["feat_grad_norms"]):
+        if nr is not None:
+            assert abs(f.grad.norm().item() - nr) <= 2e-3 * nr + 1e-6
+    close("feat grad sample", C.tokens_from_maps(fm[1].grad)[:, ::517], r["feat1_grad_sample"], 1e-5, 1e-3)
+    m = OA.keypose_metrics(out, inp["action"])
+    for k, v in r["metrics"].items():
+        close("metric " + k, m[k], v, 1e-4)
+
+
+def test_act3d_manifest_counts():
+    man = load("act3d_manifest.pt")
+    assert man["n_trainable"] == 489785 and man["n_trainable_instr"] == 564965      # SURVEY G12 [probed]
+
+
+def _diffusion_params(r):
+    shapes = {n: s for n, s in r["manifest"]["named_parameters"].items() if "feature_pyramid" not in n}
+    return C.seeded_state_dict(shapes, r["seed"], r["gain"])
+
+
+def test_rotation_conversions():
+    r = load("diffusion.pt")["rot"]
+    assert torch.equal(OD.normalise_quat(r["q"]), r["qn"])
+    close("q2m", OD.quaternion_to_matrix(r["qn"]), r["mat"], 1e-6)
+    close("m26d", OD.ortho6d_from_matrix(r["mat"]), r["o6"], 1e-6)
+    close("6d2m", OD.matrix_from_ortho6d(r["o6"] * 1.7), r["mat_back"], 1e-6)
+    close("m2q", OD.matrix_to_quaternion(r["mat"]), r["q_back"], 1e-6)
+
+
+def test_diffusion_head_loss_and_sampling():
+    r = load("diffusion.pt")
+    cfg = r["cfg"]
+    inp = C.trajectory_inputs(r["seed"], cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"])
+    Pc = _diffusion_params(r)
+    P = {n: t.clone().requires_grad_() for n, t in Pc.items()}
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    sched = OD.DDPMSchedules(100)
+    ctx = C.tokens_from_maps(inp["fmap"])
+    # the reference normalises the cloud BEFORE the bilinear down-sampling (diffusion_model.py:257-259)
+    pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
+    H = 8
+    with torch.no_grad():
+        cg = inp["curr_gripper"].clone(); cg[:, :3] = OD.normalize_pos(cg[:, :3], bounds); cg = OD.convert_rot(cg)
+        gg = inp["goal_gripper"].clone(); gg[:, :3] = OD.normalize_pos(gg[:, :3], bounds); gg = OD.convert_rot(gg)
+        close("curr9", cg, r["conv"]["curr9"], 1e-6)
+        pred = OD.head_forward(P, r["head_in"], inp["mask"], inp["timesteps"], ctx, cxyz_n, cg, gg, inp["instr"], H)
+    close("head forward", pred, r["head_out"], 1e-4)
+    loss, _, _ = OD.planner_loss(P, sched, inp["trajectory"], inp["mask"], ctx, None, inp["instr"], inp["curr_gripper"],
+                                 inp["goal_gripper"], bounds, inp["noise"], inp["timesteps"], H, ctx_xyz_norm=cxyz_n)
+    close("train loss", loss, r["train_loss"], 1e-4, 1e-5)
+    loss.backward()
+    for n, gref in r["grads"].items():
+        close("grad " + n, P[n].grad, gref, 5e-4, 2e-3)
+    with_grad = set(r["manifest"]["with_grad"])
+    for n, p in P.items():
+        if n in r["grad_norms"]:
+            assert abs(p.grad.norm().item() - r["grad_norms"][n]) <= 3e-3 * r["grad_norms"][n] + 1e-5, n
+        else:
+            assert n not in with_grad
+    with torch.no_grad():
+        final, trace = OD.compute_trajectory(P, sched, inp["mask"], ctx, None, inp["instr"], inp["curr_gripper"],
+                                             inp["goal_gripper"], bounds, inp["init_noise"], inp["step_noise"], H,
+                                             ctx_xyz_norm=cxyz_n)
+    # trace[j] is the state AFTER step t = 99 - j, i.e. the network input at t = 98 - j
+    for t, ref in r["sample_trace_inputs"].items():
+        if t == 99:
+            continue
+        close(f"sampling state before t={t}", trace[98 - t], ref, 2e-3)
+    close("sampled trajectory xyz", final[..., :3], r["sample_final"][..., :3], 2e-3)
+    q, qr = final[..., 3:], r["sample_final"][..., 3:]
+    sign = torch.sign((q * qr).sum(-1, keepdim=True))
+    close("sampled trajectory quat", q * sign, qr, 5e-3)
+
+
+def test_optimizer_grouping_and_step():
+    r = load("optimizer.pt")
+    names = list(r["before"].keys())
+    g0, g1 = OA.optimizer_groups([(n, None) for n in names])
+    assert g0 == r["groups"][0] and g1 == r["groups"][1]
+    assert "norm.weight" in g1        # LayerNorm weights DO get weight decay in the reference (SURVEY a-14)
+    ps = {n: torch.nn.Parameter(t.clone()) for n, t in r["before"].items()}
+    opt = torch.optim.AdamW([{"params": [ps[n] for n in g0], "weight_decay": 0.0}, {"params": [ps[n] for n in g1], "weight_decay": 5e-4}], lr=1e-4)
+    for it in range(2):
+        for n in names:
+            ps[n].grad = r["grads"][n].clone() * (it + 1)
+        opt.step()
+    for n in names:
+        assert torch.equal(ps[n].detach(), r["after"][n])
