@@ -6,3 +6,7 @@ Nothing here computes on the CPU: every op needs libact3d_hip.so and a gfx950 de
 from . import lib  # noqa: F401
 from .build import build  # noqa: F401
 from . import ops  # noqa: F401,E402
+from . import nn, act3d, losses  # noqa: F401,E402
+from .act3d import Act3D  # noqa: F401,E402
+from .losses import LossAndMetrics, TrajectoryCriterion  # noqa: F401,E402
+from . import engine  # noqa: F401,E402

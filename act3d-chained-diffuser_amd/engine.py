@@ -1,0 +1,282 @@
+"""Training-step harness: flat parameter / gradient buffers, fused AdamW, data-parallel gradient all-reduce over
+RCCL, checkpoint format and whole-step hipGraph capture.
+
+Mirrors the hot-path-relevant surface of the reference's engine.BaseTrainTester (engine.py:18-230) and
+TrainTester.train_one_step (main_keypose.py:207-234, main_trajectory.py:177-204):
+  get_optimizer   -> FlatAdamW with the reference's two parameter groups (names containing "bias" -> no decay)
+  DDP wrap        -> FlatDataParallel: one flat fp32 gradient buffer, all-reduce(SUM) then 1/world folded into AdamW
+  save/load_checkpoint -> {"weight" (module.-prefixed), "optimizer", "iter", "best_loss"}
+The reference's CLI, data loaders, tensorboard and evaluation loop are out of scope.
+"""
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+NO_DECAY = ["bias", "LayerNorm.weight", "LayerNorm.bias"]       # engine.py:95 (the LayerNorm patterns never match)
+
+
+def _is_no_decay(name):
+    return any(nd in name for nd in NO_DECAY)
+
+
+def discover_active_parameters(model, run_fwd_bwd):
+    """Names of the parameters that receive a gradient in one forward/backward (the reference relies on
+    find_unused_parameters=True and AdamW skipping grad=None parameters, engine.py:121-124)."""
+    for p in model.parameters():
+        p.grad = None
+    run_fwd_bwd()
+    active = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    for p in model.parameters():
+        p.grad = None
+    return active
+
+
+class FlatParams:
+    """Re-homes the active parameters into ONE flat fp32 buffer and their .grad into one flat gradient buffer.
+
+    Layout: [ no-decay | decay ]; inside each, parameters of `late_prefixes` (the FPN, whose gradients are produced
+    last in backward) are placed at the inner edge so that they form one contiguous middle segment:
+        [ hot no-decay | late no-decay | late decay | hot decay ]
+    which lets the hot-path segments be all-reduced while the FPN backward is still running."""
+
+    def __init__(self, model, active_names=None, late_prefixes=("feature_pyramid",)):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if active_names is not None:
+            keep = set(active_names)
+            named = [(n, p) for n, p in named if n in keep]
+        is_late = lambda n: any(pre in n for pre in late_prefixes)
+        segs = [[], [], [], []]
+        for n, p in named:
+            nd, late = _is_no_decay(n), is_late(n)
+            segs[0 if (nd and not late) else 1 if (nd and late) else 2 if late else 3].append((n, p))
+        self.order = [x for s in segs for x in s]
+        sizes = [sum(p.numel() for _, p in s) for s in segs]
+        self.n = sum(sizes)
+        self.n_nodecay = sizes[0] + sizes[1]
+        self.late_range = (sizes[0], sizes[0] + sizes[1] + sizes[2])
+        dev = self.order[0][1].device
+        self.flat = torch.empty(self.n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.slices = {}
+        off = 0
+        with torch.no_grad():
+            for n, p in self.order:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                self.slices[n] = (off, off + k)
+                off += k
+
+    def rebind_grads(self):
+        """Re-attach .grad views (after something set p.grad = None)."""
+        for n, p in self.order:
+            a, b = self.slices[n]
+            p.grad = self.grad[a:b].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for n, p in self.order:
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + self.slices[n][0] * 4:
+                self.rebind_grads()
+                break
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (lr, betas, eps, two weight-decay groups) as one fused kernel over FlatParams."""
+
+    def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = torch.zeros(1, device=flat.flat.device, dtype=torch.float32)
+        self.param_groups = [{"lr": lr, "weight_decay": 0.0}, {"lr": lr, "weight_decay": weight_decay}]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        f = self.flat
+        L.call("a3d_adamw_step", f.flat.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), f.n, f.n_nodecay, float(self.param_groups[0]["lr"]),
+               self.betas[0], self.betas[1], self.eps, 0.0, float(self.weight_decay), float(grad_scale), L.stream())
+
+    def state_dict(self):
+        """Per-parameter state keyed by name (exp_avg / exp_avg_sq views) + the scalar step."""
+        st = {}
+        for n, _ in self.flat.order:
+            a, b = self.flat.slices[n]
+            st[n] = {"exp_avg": self.exp_avg[a:b].clone(), "exp_avg_sq": self.exp_avg_sq[a:b].clone()}
+        return {"state": st, "step": self.step_count.clone(), "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        for n, _ in self.flat.order:
+            if n in sd["state"]:
+                a, b = self.flat.slices[n]
+                self.exp_avg[a:b].copy_(sd["state"][n]["exp_avg"].reshape(-1))
+                self.exp_avg_sq[a:b].copy_(sd["state"][n]["exp_avg_sq"].reshape(-1))
+        self.step_count.copy_(sd["step"])
+
+
+def get_optimizer(model, lr=1e-4, active_names=None):
+    """engine.py:89-102 on the flat buffers.  Returns (FlatParams, FlatAdamW)."""
+    flat = FlatParams(model, active_names)
+    return flat, FlatAdamW(flat, lr=lr)
+
+
+class FlatDataParallel:
+    """Data parallelism over one flat gradient buffer (replaces DistributedDataParallel, engine.py:121-124).
+
+    broadcast_parameters(): rank 0 -> all (DDP's initial broadcast).
+    sync_gradients(): all-reduce(SUM); the 1/world_size averaging is returned as the grad_scale for FlatAdamW.step.
+    With `overlap=True` the hot-path segments are reduced on a side stream as soon as `hot_path_done()` is called
+    (from an autograd hook on the FPN output), while the FPN backward still runs; the FPN segment follows at the end.
+    Works with backend "nccl" (= RCCL on ROCm) on device buffers and with "gloo" on CPU buffers (tests)."""
+
+    def __init__(self, flat, process_group=None, overlap=True):
+        self.flat = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap and flat.flat.is_cuda
+        self._pending = []
+        self._side = torch.cuda.Stream() if self.overlap else None
+        self._early_done = False
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.flat.flat, src=src, group=self.pg)
+
+    def _segments(self):
+        a, b = self.flat.late_range
+        return [(0, a), (b, self.flat.n)], (a, b)
+
+    def hot_path_done(self):
+        """Call when every hot-path gradient has been produced (FPN backward not yet run)."""
+        if self.world == 1 or not self.overlap or self._early_done:
+            return
+        hot, _ = self._segments()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            for a, b in hot:
+                if b > a:
+                    self._pending.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg,
+                                                         async_op=True))
+        self._early_done = True
+
+    def sync_gradients(self):
+        """Returns the grad_scale (1/world) to pass to the optimizer."""
+        if self.world == 1:
+            return 1.0
+        hot, late = self._segments()
+        if self._early_done:
+            if late[1] > late[0]:
+                dist.all_reduce(self.flat.grad[late[0]:late[1]], op=dist.ReduceOp.SUM, group=self.pg)
+            for w in self._pending:
+                w.wait()
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._pending, self._early_done = [], False
+        else:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        return 1.0 / self.world
+
+
+def train_one_step(model, criterion, optimizer, step_id, sample, ddp=None, accumulate_grad_batches=1,
+                   use_ground_truth_position_for_sampling_train=True):
+    """TrainTester.train_one_step for the keypose model (main_keypose.py:207-234): zero_grad, forward, loss, backward,
+    (all-reduce), optimizer step.  Returns the detached total loss."""
+    if step_id % accumulate_grad_batches == 0:
+        optimizer.zero_grad()
+    out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"],
+                gt_action=sample["action"] if use_ground_truth_position_for_sampling_train else None)
+    loss = criterion.compute_loss(out, sample)
+    loss = sum(list(loss.values()))
+    loss.backward()
+    if step_id % accumulate_grad_batches == accumulate_grad_batches - 1:
+        scale = ddp.sync_gradients() if ddp is not None else 1.0
+        optimizer.step(grad_scale=scale) if isinstance(optimizer, FlatAdamW) else optimizer.step()
+    return loss.detach()
+
+
+def train_one_step_trajectory(model, criterion, optimizer, step_id, sample, ddp=None, accumulate_grad_batches=1):
+    """TrainTester.train_one_step for the trajectory model (main_trajectory.py:177-204)."""
+    if step_id % accumulate_grad_batches == 0:
+        optimizer.zero_grad()
+    out = model(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"], sample["instr"],
+                sample["curr_gripper"], sample["action"])
+    loss = criterion.compute_loss(out)
+    loss.backward()
+    if step_id % accumulate_grad_batches == accumulate_grad_batches - 1:
+        scale = ddp.sync_gradients() if ddp is not None else 1.0
+        optimizer.step(grad_scale=scale) if isinstance(optimizer, FlatAdamW) else optimizer.step()
+    return loss.detach()
+
+
+def save_checkpoint(path, model, optimizer, step_id, best_loss=None):
+    """engine.py:214-230 format; weights carry DDP's "module." prefix so that reference tooling can load them."""
+    weight = {"module." + k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.save({"weight": weight, "optimizer": optimizer.state_dict(), "iter": step_id + 1, "best_loss": best_loss}, path)
+
+
+def load_checkpoint(path, model, optimizer=None):
+    """engine.py:195-212 (+ online_evaluation/eval1.py:138-152 prefix stripping).  Returns (start_iter, best_loss)."""
+    d = torch.load(path, map_location="cpu", weights_only=False)
+    weight = {(k[7:] if k.startswith("module.") else k): v for k, v in d["weight"].items()}
+    with torch.no_grad():
+        own = model.state_dict()
+        for k, v in weight.items():
+            if k in own:
+                own[k].copy_(v)
+    if optimizer is not None and isinstance(d.get("optimizer"), dict) and "state" in d["optimizer"] and "step" in d["optimizer"]:
+        optimizer.load_state_dict(d["optimizer"])
+    return d.get("iter", 0), d.get("best_loss", None)
+
+
+class GraphedStep:
+    """Captures one full training step (zero_grad + forward + loss + backward + AdamW) into a hipGraph and replays it.
+
+    Every kernel of the hot path is enqueued on the caller's stream with static shapes and no host sync, the ghost
+    sampler and the AdamW step counter live on the device, so the step is capturable as is.  Inputs are copied into
+    static buffers before each replay.  For world_size > 1 the gradient all-reduce runs between the captured
+    forward/backward graph and the captured optimizer graph."""
+
+    def __init__(self, step_fwd_bwd, optimizer, static_inputs, ddp=None, warmup=3):
+        self.static_inputs = static_inputs
+        self.optimizer = optimizer
+        self.ddp = ddp
+        self.world = ddp.world if ddp is not None else 1
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                optimizer.zero_grad()
+                step_fwd_bwd(static_inputs)
+                scale = ddp.sync_gradients() if ddp is not None else 1.0
+                optimizer.step(grad_scale=scale)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            optimizer.zero_grad()
+            self.loss = step_fwd_bwd(static_inputs)
+            if self.world == 1:
+                optimizer.step(grad_scale=1.0)
+        self.g_opt = None
+        if self.world > 1:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                optimizer.step(grad_scale=1.0 / self.world)
+
+    def __call__(self, inputs=None):
+        if inputs is not None:
+            for k, v in inputs.items():
+                if torch.is_tensor(v) and k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
+                    self.static_inputs[k].copy_(v, non_blocking=True)
+        self.g_fb.replay()
+        if self.world > 1:
+            dist.all_reduce(self.optimizer.flat.grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
+            self.g_opt.replay()
+        return self.loss

@@ -1,0 +1,259 @@
+"""Parameter containers that mirror the reference's module tree (names, shapes, initialisation) so that state
+dicts are interchangeable, with forward passes that launch the HIP operators of ops.py.
+
+Reference classes mirrored: MultiheadCustomAttention (multihead_custom_attention.py:14-94), RelativeCrossAttentionLayer /
+FeedforwardLayer / RelativeCrossAttentionModule (layers.py:293-351), ParallelAttentionLayer / ParallelAttention / AdaLN
+(layers.py:7-290), torchvision's FeaturePyramidNetwork (third-party; restated) and a synthetic CLIP-RN50-shaped backbone.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops as O
+
+
+class MultiheadCustomAttention(nn.Module):
+    """Holds in_proj_weight (3E,E), in_proj_bias (3E), out_proj (Linear E->E); init as multihead_custom_attention.py:80-94."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim % num_heads == 0 and embed_dim // num_heads == 15, \
+            "the HIP attention kernels are specialised for head_dim 15 (60/4, 120/8), as in both reference models"
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class RelativeCrossAttentionLayer(nn.Module):
+    def __init__(self, embedding_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.multihead_attn = MultiheadCustomAttention(embedding_dim, num_heads, dropout=dropout)
+        self.norm = nn.LayerNorm(embedding_dim)
+        self.num_heads = num_heads
+
+    def forward(self, query, value, query_xyz=None, value_xyz=None, pad_mask=None):
+        """query (B, Lq, E), value (B, S, E) batch-first; xyz instead of materialised rotary codes."""
+        return O.attn_block(query, value, value, query, query_xyz, value_xyz, pad_mask, self.multihead_attn, self.norm,
+                            self.num_heads)
+
+
+class FeedforwardLayer(nn.Module):
+    def __init__(self, embedding_dim, hidden_dim, dropout=0.0):
+        super().__init__()
+        self.linear1 = nn.Linear(embedding_dim, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, embedding_dim)
+        self.norm = nn.LayerNorm(embedding_dim)
+        for p in self.parameters():                   # layers.py:323-326
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, x):
+        return O.mlp(x, self.linear1, self.linear2, self.norm)
+
+
+class RelativeCrossAttentionModule(nn.Module):
+    def __init__(self, embedding_dim, num_attn_heads, num_layers):
+        super().__init__()
+        self.attn_layers = nn.ModuleList(
+            [RelativeCrossAttentionLayer(embedding_dim, num_attn_heads) for _ in range(num_layers)])
+        self.ffw_layers = nn.ModuleList([FeedforwardLayer(embedding_dim, embedding_dim) for _ in range(num_layers)])
+
+    def forward(self, query, value, query_xyz=None, value_xyz=None):
+        """Returns the list of per-layer outputs (layers.py:345-351), batch-first."""
+        output = []
+        for attn, ffw in zip(self.attn_layers, self.ffw_layers):
+            query = ffw(attn(query, value, query_xyz, value_xyz))
+            output.append(query)
+        return output
+
+
+class AdaLN(nn.Module):
+    def __init__(self, embedding_dim):
+        super().__init__()
+        self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(embedding_dim, 2 * embedding_dim, bias=True))
+        nn.init.constant_(self.modulation[-1].weight, 0)
+        nn.init.constant_(self.modulation[-1].bias, 0)
+
+    def forward(self, x, silu_t):
+        """x (B, N, C); silu_t = SiLU(t) (B, C), computed once per forward and shared by every AdaLN."""
+        return O.AdaLNFn.apply(x, O.linear(silu_t, self.modulation[1]))
+
+
+class ParallelAttentionLayer(nn.Module):
+    """The seq1-only configuration the hot path uses (cross_attention1 [+ self_attention1] [+ ffn]); layers.py:7-218."""
+
+    def __init__(self, d_model=256, dropout=0.1, n_heads=8, pre_norm=False, self_attention1=True,
+                 self_attention2=False, cross_attention1=True, cross_attention2=False, apply_ffn=True,
+                 slot_attention12=False, slot_attention21=False, rotary_pe=False, use_adaln=False):
+        super().__init__()
+        if pre_norm or self_attention2 or cross_attention2 or slot_attention12 or slot_attention21 or not cross_attention1:
+            raise NotImplementedError("only the seq1 / post-norm configuration of ParallelAttentionLayer is on the hot "
+                                      "path (SURVEY §8a-12); other options are not implemented")
+        self.self_attention1, self.apply_ffn, self.rotary_pe = self_attention1, apply_ffn, rotary_pe
+        self.n_heads, self.dropout_p = n_heads, dropout
+        if self_attention1:
+            self.adaln_1 = AdaLN(d_model) if use_adaln else None
+            self.sa1 = MultiheadCustomAttention(d_model, n_heads, dropout=dropout)
+            self.norm_1 = nn.LayerNorm(d_model)
+        self.adaln_12 = AdaLN(d_model) if use_adaln else None
+        self.cross_12 = MultiheadCustomAttention(d_model, n_heads, dropout=dropout)
+        self.norm_12 = nn.LayerNorm(d_model)
+        # the reference builds FFN-1 whenever seq1 is updated, even if apply_ffn=False leaves it unused
+        self.adaln_ff1 = AdaLN(d_model) if use_adaln else None
+        self.ffn_12 = nn.Sequential(nn.Linear(d_model, 4 * d_model), nn.ReLU(), nn.Dropout(dropout),
+                                    nn.Linear(4 * d_model, d_model), nn.Dropout(dropout))
+        self.norm_122 = nn.LayerNorm(d_model)
+
+    def forward(self, seq1, seq1_key_padding_mask, seq2, seq1_xyz=None, seq2_xyz=None, seq1_sem_pos=None, silu_t=None):
+        if self.training and self.dropout_p > 0:
+            _dropout_unsupported()
+        rope = self.rotary_pe
+        q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
+        qa = self.adaln_12(q1, silu_t) if (self.adaln_12 is not None and silu_t is not None) else q1
+        seq1 = O.attn_block(qa, seq2, seq2, seq1, seq1_xyz if rope else None, seq2_xyz if rope else None, None,
+                            self.cross_12, self.norm_12, self.n_heads)
+        if self.self_attention1:
+            q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
+            if self.adaln_1 is not None and silu_t is not None:
+                qk, vv = self.adaln_1(q1, silu_t), self.adaln_1(seq1, silu_t)
+            else:
+                qk, vv = q1, seq1
+            seq1 = O.attn_block(qk, qk, vv, seq1, seq1_xyz if rope else None, seq1_xyz if rope else None,
+                                seq1_key_padding_mask, self.sa1, self.norm_1, self.n_heads)
+        if self.apply_ffn:
+            y = self.adaln_ff1(seq1, silu_t) if (self.adaln_ff1 is not None and silu_t is not None) else seq1
+            seq1 = O.mlp(y, self.ffn_12[0], self.ffn_12[3], self.norm_122)
+        return seq1
+
+
+def _dropout_unsupported():
+    raise NotImplementedError(
+        "training-mode dropout (p=0.1 in the diffusion transformer, layers.py:10) is not implemented in the HIP path "
+        "yet; construct the model with dropout=0.0 or call .eval() on the attention stack (documented in DESIGN.md)")
+
+
+class ParallelAttention(nn.Module):
+    def __init__(self, num_layers=1, **kw):
+        super().__init__()
+        self.layers = nn.ModuleList([ParallelAttentionLayer(**kw) for _ in range(num_layers)])
+
+    def forward(self, seq1, seq1_key_padding_mask, seq2, **kw):
+        for layer in self.layers:
+            seq1 = layer(seq1, seq1_key_padding_mask, seq2, **kw)
+        return seq1
+
+
+# ------------------------------------------------------------------------------------------------ adjacent: vision
+class FeaturePyramidNetwork(nn.Module):
+    """torchvision.ops.FeaturePyramidNetwork (0.14 naming: inner_blocks.i.0 / layer_blocks.i.0), restated: 1x1 lateral
+    convs, nearest top-down pathway, 3x3 output convs.  Runs on PyTorch-ROCm/MIOpen (adjacent to the hot path,
+    SURVEY §2a-8 / §8f-1).  `needed` restricts the 3x3 output convs to the maps the policy actually reads."""
+
+    def __init__(self, in_channels_list, out_channels):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(c, out_channels, 1)) for c in in_channels_list])
+        self.layer_blocks = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(out_channels, out_channels, 3, padding=1)) for _ in in_channels_list])
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, feats, needed=None):
+        names = list(feats.keys())
+        xs = list(feats.values())
+        last = self.inner_blocks[-1](xs[-1])
+        out = {}
+        lowest = min(names.index(n) for n in needed) if needed is not None else 0
+        if needed is None or names[-1] in needed:
+            out[names[-1]] = self.layer_blocks[-1](last)
+        for i in range(len(xs) - 2, lowest - 1, -1):
+            lat = self.inner_blocks[i](xs[i])
+            last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            if needed is None or names[i] in needed:
+                out[names[i]] = self.layer_blocks[i](last)
+        return out
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(nn.AvgPool2d(stride), nn.Conv2d(inplanes, planes * 4, 1, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(self.avgpool(out)))
+        return F.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+
+class SyntheticCLIPResNet50(nn.Module):
+    """Random-init network with the layer structure of CLIP's ModifiedResNet RN50 (3-conv stem, avg-pool
+    anti-aliased bottlenecks [3,4,6,3], width 64), returning res1..res5 with channels 64/256/512/1024/2048 at strides
+    2/4/8/16/32 like model/utils/clip.py:22-43.  The real weights (openai/CLIP) are not available offline; the
+    arithmetic cost and map shapes are the real ones.  Frozen; runs on MIOpen."""
+
+    def __init__(self, width=64, layers=(3, 4, 6, 3)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        self.avgpool = nn.AvgPool2d(2)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        layers = [_Bottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(_Bottleneck(self._inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x0 = F.relu(self.bn3(self.conv3(x)))
+        x1 = self.layer1(self.avgpool(x0))
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        x4 = self.layer4(x3)
+        return {"res1": x0, "res2": x1, "res3": x2, "res4": x3, "res5": x4}
+
+
+class ClipNormalize(nn.Module):
+    """CLIP's preprocessing normalisation (clip_transforms.transforms[-1], model/utils/clip.py:19)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1), persistent=False)
+
+    def forward(self, x):
+        return (x - self.mean) / self.std
+
+
+def load_synthetic_clip():
+    return SyntheticCLIPResNet50(), ClipNormalize()
