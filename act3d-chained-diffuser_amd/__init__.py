@@ -10,3 +10,5 @@ from . import nn, act3d, losses  # noqa: F401,E402
 from .act3d import Act3D  # noqa: F401,E402
 from .losses import LossAndMetrics, TrajectoryCriterion  # noqa: F401,E402
 from . import engine  # noqa: F401,E402
+from . import diffusion  # noqa: F401,E402
+from .diffusion import DiffusionPlanner, DiffusionHead  # noqa: F401,E402

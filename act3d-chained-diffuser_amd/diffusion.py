@@ -1,0 +1,434 @@
+"""ChainedDiffuser trajectory DDPM on the MI355X hot path.
+
+Drop-in for `model.DiffusionPlanner` (model/trajectory_optimization/diffusion_model.py:15-324) and its
+`DiffusionHead` (diffusion_head.py:10-363, on top of model/utils/encoder.py): same constructor keywords, same
+`forward(gt_trajectory, trajectory_mask, rgb_obs, pcd_obs, instruction, curr_gripper, goal_gripper, run_inference)`
+and `compute_trajectory(...)`, same parameter names (checkpoints interchange).
+
+What is restructured, with identical results:
+  * everything that does not depend on the denoising step -- image encoding, instruction encoding, vision->language
+    attention, gripper tokens and the K/V projections (+RoPE) of all cross-attention layers -- is computed ONCE per
+    trajectory batch (`encode_context`, `build_kv_cache`) instead of once per step;
+  * one denoise step is a fixed sequence of stream-ordered launches (no host sync: the boolean-mask scatter becomes a
+    masked select in the fused DDPM-step kernel, timestep tables live on the device), so the whole 100-step loop is
+    captured in a hipGraph and replayed (`compute_trajectory(..., use_graph=True)`).
+The DDPM schedules restate diffusers' DDPMScheduler (third-party, un-pinned -> parity unpinned).
+Additive keyword arguments: `noise`, `timesteps` (training) and `init_noise`, `step_noise` (sampling) inject the random
+draws; `visual_tokens` bypasses the backbone + FPN.  Training-mode dropout (p=0.1 in the reference) is NOT implemented:
+the constructor's additive `dropout` defaults to 0.0 and a positive value raises in train mode.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops as O
+from .act3d import broadcast_row
+from .nn import FeaturePyramidNetwork, ParallelAttention, load_synthetic_clip
+
+
+# ------------------------------------------------------------------------------------------------ DDPM tables
+class DDPMTables:
+    """alphas_cumprod and per-step posterior coefficients of the two schedulers the reference builds
+    (diffusion_model.py:51-60), as device tables.  Follows Ho et al. 2020 eq. 6-7 with diffusers' defaults
+    (beta_start 1e-4, beta_end 0.02, variance "fixed_small", clip_sample, prediction_type "sample")."""
+
+    def __init__(self, T, device):
+        self.T = T
+        betas_pos = torch.linspace(0.0001 ** 0.5, 0.02 ** 0.5, T, dtype=torch.float32) ** 2
+
+        def alpha_bar(s):
+            return math.cos((s + 0.008) / 1.008 * math.pi / 2) ** 2
+
+        betas_rot = torch.tensor([min(1 - alpha_bar((i + 1) / T) / alpha_bar(i / T), 0.999) for i in range(T)],
+                                 dtype=torch.float32)
+        acp_pos, acp_rot = torch.cumprod(1.0 - betas_pos, 0), torch.cumprod(1.0 - betas_rot, 0)
+        self.acp_pos, self.acp_rot = acp_pos.to(device), acp_rot.to(device)
+        self.coef_pos, self.coef_rot = self._coef(acp_pos).to(device), self._coef(acp_rot).to(device)
+
+    def _coef(self, acp):
+        one = torch.tensor(1.0)
+        rows = []
+        for t in range(self.T):
+            a_t, a_prev = acp[t], (acp[t - 1] if t > 0 else one)
+            b_t, b_prev = 1 - a_t, 1 - a_prev
+            cur_a = a_t / a_prev
+            cur_b = 1 - cur_a
+            var = torch.clamp(b_prev / b_t * cur_b, min=1e-20)
+            rows.append(torch.stack([(a_prev ** 0.5 * cur_b) / b_t, cur_a ** 0.5 * b_prev / b_t,
+                                     var ** 0.5 if t > 0 else torch.tensor(0.0)]))
+        return torch.stack(rows).float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ rotations (tiny, no grad)
+def normalise_quat(x):
+    return x / torch.clamp(x.square().sum(dim=-1).sqrt().unsqueeze(-1), min=1e-10)
+
+
+def quaternion_to_matrix(q):
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def matrix_to_quaternion(matrix):
+    bd = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(bd + (9,)), dim=-1)
+    x = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
+    q_abs = torch.sqrt(torch.clamp(x, min=0.0))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(dim=-1)                                      # gather instead of boolean indexing: no host sync
+    return torch.gather(cand, -2, best[..., None, None].expand(bd + (1, 4))).squeeze(-2)
+
+
+def ortho6d_from_matrix(m):
+    return m[..., :, :2].transpose(-1, -2).flatten(-2)
+
+
+def matrix_from_ortho6d(o):
+    def nrm(v):
+        return v / torch.clamp(v.pow(2).sum(-1, keepdim=True).sqrt(), min=1e-8)
+    x = nrm(o[..., 0:3])
+    z = nrm(torch.cross(x, o[..., 3:6], dim=-1))
+    y = torch.cross(z, x, dim=-1)
+    return torch.stack((x, y, z), dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ prediction head
+class DiffusionHead(nn.Module):
+
+    def __init__(self, backbone="clip", image_size=(256, 256), embedding_dim=60, output_dim=7, num_attn_heads=8,
+                 num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6, use_instruction=False, use_goal=False,
+                 use_sigma=False, feat_scales_to_use=1, attn_rounds=1, weight_tying=False,
+                 rotation_parametrization='quat', dropout=0.0):
+        super().__init__()
+        if feat_scales_to_use != 1 or attn_rounds != 1 or use_sigma:
+            raise NotImplementedError("only feat_scales_to_use=1, attn_rounds=1, use_sigma=False (the shipped "
+                                      "configuration, scripts/train_trajectory.sh) are implemented")
+        self.image_size = tuple(image_size)
+        self.use_instruction, self.use_goal = use_instruction, use_goal
+        self.rotation_parametrization = rotation_parametrization
+        self.num_attn_heads = num_attn_heads
+        self.dropout_p = dropout
+        if rotation_parametrization == '6D':
+            output_dim += 2
+        E = embedding_dim
+        # --- Encoder base (model/utils/encoder.py:14-73)
+        self.backbone, self.normalize = load_synthetic_clip()
+        for p in self.backbone.parameters():
+            p.requires_grad = False
+        self.backbone_dtype = torch.float32
+        self.feature_pyramid = FeaturePyramidNetwork([64, 256, 512, 1024, 2048], E)
+        self.feature_map_pyramid = ['res3', 'res1', 'res1', 'res1'] if self.image_size == (256, 256) else ['res2', 'res1', 'res1', 'res1']
+        self.downscaling_factor_pyramid = [8, 2, 2, 2] if self.image_size == (256, 256) else [4, 2, 2, 2]
+        self.curr_gripper_embed = nn.Embedding(1, E)
+        self.goal_gripper_embed = nn.Embedding(1, E)
+        self.instruction_encoder = nn.Linear(512, E)
+        # --- DiffusionHead (diffusion_head.py:41-199)
+        self.traj_encoder = nn.Sequential(nn.Linear(9, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, E))
+        self.curr_gripper_encoder = nn.Linear(output_dim, E)
+        if use_goal:
+            self.goal_gripper_encoder = nn.Linear(output_dim, E)
+        common = dict(d_model=E, n_heads=num_attn_heads, dropout=dropout, self_attention2=False, cross_attention1=True,
+                      cross_attention2=False)
+        if use_instruction:
+            self.vl_attention = nn.ModuleList([ParallelAttention(num_layers=num_vis_ins_attn_layers, self_attention1=False, **common)])
+        self.traj_lang_attention = nn.ModuleList([ParallelAttention(num_layers=1, self_attention1=False, rotary_pe=False,
+                                                                    apply_ffn=False, **common)])
+        self.traj_attention = nn.ModuleList([ParallelAttention(num_layers=num_query_cross_attn_layers - 2, self_attention1=True,
+                                                               rotary_pe=True, use_adaln=True, **common)])
+        self.pos_attention = nn.ModuleList([ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
+                                                              use_adaln=True, **common)])
+        self.rot_attention = nn.ModuleList([ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
+                                                              use_adaln=True, **common)])
+        self.pos_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, 3))])
+        self.rot_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, output_dim - 3))])
+        self._sem_cache = {}
+
+    # ---- vision (adjacent): one scale
+    def encode_images(self, rgb, pcd_norm):
+        """encoder.py:115-167 for one scale: tokens (B, ncam*h*w, E) and down-sampled (already normalised) coordinates."""
+        B, ncam = rgb.shape[:2]
+        x = rgb.flatten(0, 1)
+        with torch.no_grad():
+            x = self.normalize(x).contiguous(memory_format=torch.channels_last)
+            if self.backbone_dtype != torch.float32:
+                with torch.autocast("cuda", dtype=self.backbone_dtype):
+                    feats = self.backbone(x)
+                feats = {k: v.float() for k, v in feats.items()}
+            else:
+                feats = self.backbone(x)
+        name = self.feature_map_pyramid[0]
+        fm = self.feature_pyramid(feats, needed=[name])[name]
+        n, E, h, w = fm.shape
+        return fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+
+    def _sem(self, Ln, E, device):
+        key = (Ln, E, str(device))
+        if key not in self._sem_cache:
+            self._sem_cache[key] = O.sinusoidal_emb(torch.arange(Ln, device=device, dtype=torch.float32), E)
+        return self._sem_cache[key]
+
+    def encode_context(self, visual_tokens, ctx_xyz, instruction, curr_gripper, goal_gripper):
+        """Step-invariant context (diffusion_head.py:222-247, 290-323): returns (ctx (B,S,E), ctx_xyz (B,S,3), instr)."""
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("training-mode dropout is not implemented in the HIP path (DESIGN.md)")
+        B = visual_tokens.shape[0]
+        instr = O.linear(instruction.float(), self.instruction_encoder) if self.use_instruction else None
+        ctx = visual_tokens
+        if self.use_instruction:
+            ctx = self.vl_attention[0](ctx, None, instr)
+        cg = O.linear(curr_gripper, self.curr_gripper_encoder)[:, None] + broadcast_row(self.curr_gripper_embed.weight, B, 1)
+        extra, extra_xyz = [cg], [curr_gripper[:, None, :3]]
+        if self.use_goal:
+            gg = O.linear(goal_gripper, self.goal_gripper_encoder)[:, None] + broadcast_row(self.goal_gripper_embed.weight, B, 1)
+            extra.append(gg)
+            extra_xyz.append(goal_gripper[:, None, :3])
+        ctx = O.BuildContextFn.apply(ctx, None, torch.cat(extra, dim=1))
+        ctx_xyz = torch.cat([ctx_xyz] + extra_xyz, dim=1).contiguous()
+        return ctx, ctx_xyz, instr
+
+    def forward_tokens(self, trajectory, trajectory_mask, timestep, ctx, ctx_xyz, instr):
+        """The step-dependent part of DiffusionHead.forward (diffusion_head.py:214-219, 325-363) with autograd."""
+        B, Ln, _ = trajectory.shape
+        E = ctx.shape[-1]
+        trajectory = trajectory.contiguous()
+        traj_feats = O.mlp(trajectory, self.traj_encoder[0], self.traj_encoder[3])
+        traj_xyz = trajectory[..., :3].contiguous()
+        time_feats = O.sinusoidal_emb(timestep.float(), E)
+        silu_t = O.SiLUFn.apply(time_feats)
+        sem = self._sem(Ln, E, trajectory.device)
+        if self.use_instruction:
+            traj_feats = self.traj_lang_attention[0](traj_feats, trajectory_mask, instr, seq1_sem_pos=sem)
+        kw = dict(seq1_xyz=traj_xyz, seq2_xyz=ctx_xyz, seq1_sem_pos=sem, silu_t=silu_t)
+        traj_feats = self.traj_attention[0](traj_feats, trajectory_mask, ctx, **kw)
+        pos_feats = self.pos_attention[0](traj_feats, trajectory_mask, ctx, **kw)
+        rot_feats = self.rot_attention[0](traj_feats, trajectory_mask, ctx, **kw)
+        upd = torch.cat([O.mlp(pos_feats, self.pos_regressor[0][0], self.pos_regressor[0][3]),
+                         O.mlp(rot_feats, self.rot_regressor[0][0], self.rot_regressor[0][3])], dim=-1)
+        return O.TrajUpdateFn.apply(trajectory, upd)
+
+    # ---- inference with cached K/V
+    def _cross_layers(self):
+        out = []
+        for stack in (self.traj_attention[0], self.pos_attention[0], self.rot_attention[0]):
+            out.extend(stack.layers)
+        return out
+
+    @torch.no_grad()
+    def build_kv_cache(self, ctx, ctx_xyz, instr):
+        cache = {"ctx": [O.kv_cache_build(ctx, ctx_xyz, lay.cross_12, self.num_attn_heads) for lay in self._cross_layers()]}
+        if self.use_instruction:
+            cache["lang"] = O.kv_cache_build(instr, None, self.traj_lang_attention[0].layers[0].cross_12, self.num_attn_heads)
+        return cache
+
+    @torch.no_grad()
+    def denoise_tokens_cached(self, trajectory, trajectory_mask, t, cache, time_tables):
+        """One network evaluation at integer step t against the prebuilt K/V cache (no autograd, no host sync)."""
+        B, Ln, _ = trajectory.shape
+        H = self.num_attn_heads
+        E = self.curr_gripper_embed.weight.shape[1]
+        traj_feats = O.mlp(trajectory, self.traj_encoder[0], self.traj_encoder[3])
+        traj_xyz = trajectory[..., :3].contiguous()
+        silu_t = time_tables["silu"][t:t + 1].expand(B, E).contiguous()
+        sem = self._sem(Ln, E, trajectory.device)
+        if self.use_instruction:
+            lay = self.traj_lang_attention[0].layers[0]
+            q1 = O.AddRowsFn.apply(traj_feats, sem)
+            traj_feats = O.attn_block_cached(q1, traj_feats, None, cache["lang"], lay.cross_12, lay.norm_12, H)
+        li = 0
+
+        def run_stack(x, stack):
+            nonlocal li
+            for lay in stack.layers:
+                q1 = O.AddRowsFn.apply(x, sem)
+                x = O.attn_block_cached(lay.adaln_12(q1, silu_t), x, traj_xyz, cache["ctx"][li], lay.cross_12, lay.norm_12, H)
+                li += 1
+                q1 = O.AddRowsFn.apply(x, sem)
+                qk, vv = lay.adaln_1(q1, silu_t), lay.adaln_1(x, silu_t)
+                x = O.attn_block(qk, qk, vv, x, traj_xyz, traj_xyz, trajectory_mask, lay.sa1, lay.norm_1, H)
+                y = lay.adaln_ff1(x, silu_t)
+                x = O.mlp(y, lay.ffn_12[0], lay.ffn_12[3], lay.norm_122)
+            return x
+
+        traj_feats = run_stack(traj_feats, self.traj_attention[0])
+        keep = li
+        pos_feats = run_stack(traj_feats, self.pos_attention[0])
+        rot_feats = run_stack(traj_feats, self.rot_attention[0])
+        upd = torch.cat([O.mlp(pos_feats, self.pos_regressor[0][0], self.pos_regressor[0][3]),
+                         O.mlp(rot_feats, self.rot_regressor[0][0], self.rot_regressor[0][3])], dim=-1)
+        return O.TrajUpdateFn.apply(trajectory, upd)
+
+
+class DiffusionPlanner(nn.Module):
+
+    def __init__(self, backbone="clip", image_size=(256, 256), embedding_dim=60, output_dim=7,
+                 num_vis_ins_attn_layers=2, num_query_cross_attn_layers=8, use_instruction=False, use_goal=False,
+                 use_goal_at_test=True, feat_scales_to_use=1, attn_rounds=1, weight_tying=False,
+                 gripper_loc_bounds=None, rotation_parametrization='quat', diffusion_timesteps=100, num_attn_heads=8,
+                 dropout=0.0):
+        super().__init__()
+        if rotation_parametrization != '6D':
+            raise NotImplementedError("only rotation_parametrization='6D' (scripts/train_trajectory.sh) is implemented")
+        self._use_goal, self._use_goal_at_test = use_goal, use_goal_at_test
+        self._rotation_parametrization = rotation_parametrization
+        self.prediction_head = DiffusionHead(
+            backbone=backbone, image_size=image_size, embedding_dim=embedding_dim, output_dim=output_dim,
+            num_attn_heads=num_attn_heads, num_vis_ins_attn_layers=num_vis_ins_attn_layers,
+            num_query_cross_attn_layers=num_query_cross_attn_layers, use_instruction=use_instruction, use_goal=use_goal,
+            feat_scales_to_use=feat_scales_to_use, attn_rounds=attn_rounds, weight_tying=weight_tying,
+            rotation_parametrization=rotation_parametrization, dropout=dropout)
+        self.n_steps = diffusion_timesteps
+        self.register_buffer("gripper_loc_bounds", torch.tensor(gripper_loc_bounds, dtype=torch.float32), persistent=False)
+        self._tables = None
+        self._graph = None
+
+    # ---- helpers (diffusion_model.py:187-230)
+    def tables(self, device):
+        if self._tables is None or self._tables.acp_pos.device != device:
+            self._tables = DDPMTables(self.n_steps, device)
+            E = self.prediction_head.curr_gripper_embed.weight.shape[1]
+            sin = O.sinusoidal_emb(torch.arange(self.n_steps, device=device, dtype=torch.float32), E)
+            self._time_tables = {"sin": sin, "silu": F.silu(sin)}
+        return self._tables
+
+    def normalize_pos(self, pos):
+        lo, hi = self.gripper_loc_bounds[0], self.gripper_loc_bounds[1]
+        return (pos - lo) / (hi - lo) * 2.0 - 1.0
+
+    def unnormalize_pos(self, pos):
+        lo, hi = self.gripper_loc_bounds[0], self.gripper_loc_bounds[1]
+        return (pos + 1.0) / 2.0 * (hi - lo) + lo
+
+    def convert_rot(self, signal):
+        q = normalise_quat(signal[..., 3:7])
+        return torch.cat([signal[..., :3], ortho6d_from_matrix(quaternion_to_matrix(q)), signal[..., 7:]], dim=-1)
+
+    def unconvert_rot(self, signal):
+        return torch.cat([signal[..., :3], matrix_to_quaternion(matrix_from_ortho6d(signal[..., 3:9])), signal[..., 9:]], dim=-1)
+
+    def _prepare(self, rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens):
+        """Normalised, converted conditioning + visual tokens and their (normalised, down-sampled) coordinates."""
+        head = self.prediction_head
+        with torch.no_grad():
+            pcd_n = self.normalize_pos(pcd_obs.float().permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3).contiguous()
+            ctx_xyz = O.pcd_downsample(pcd_n, head.downscaling_factor_pyramid[0])
+            cg = curr_gripper.float().clone()
+            cg = self.convert_rot(torch.cat([self.normalize_pos(cg[:, :3]), cg[:, 3:]], dim=-1)).contiguous()
+            gg = goal_gripper.float().clone()
+            gg = self.convert_rot(torch.cat([self.normalize_pos(gg[:, :3]), gg[:, 3:]], dim=-1)).contiguous()
+        tokens = visual_tokens if visual_tokens is not None else head.encode_images(rgb_obs, pcd_n)
+        return tokens, ctx_xyz, cg, gg
+
+    # ---- training (diffusion_model.py:253-324)
+    def forward(self, gt_trajectory, trajectory_mask, rgb_obs, pcd_obs, instruction, curr_gripper, goal_gripper,
+                run_inference=False, *, noise=None, timesteps=None, visual_tokens=None, return_pred=False, **sample_kw):
+        if run_inference:
+            return self.compute_trajectory(trajectory_mask, rgb_obs, pcd_obs, instruction, curr_gripper, goal_gripper,
+                                           visual_tokens=visual_tokens, **sample_kw)
+        head = self.prediction_head
+        dev = pcd_obs.device
+        tb = self.tables(dev)
+        tokens, ctx_xyz, cg, gg = self._prepare(rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens)
+        with torch.no_grad():
+            gt = gt_trajectory.float()
+            gt = self.convert_rot(torch.cat([self.normalize_pos(gt[..., :3]), gt[..., 3:]], dim=-1)).contiguous()
+            if noise is None:
+                noise = torch.randn(gt.shape, device=dev)
+            if timesteps is None:
+                timesteps = torch.randint(0, self.n_steps, (gt.shape[0],), device=dev).long()
+            noisy = O.ddpm_add_noise(gt, noise.to(dev).float(), timesteps.to(dev), tb.acp_pos, tb.acp_rot)
+        ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
+        pred = head.forward_tokens(noisy, trajectory_mask, timesteps.to(dev), ctx, ctx_xyz, instr)
+        loss = O.ElemLossFn.apply(pred[..., :3], gt[..., :3], 1, 100.0) + O.ElemLossFn.apply(pred[..., 3:9], gt[..., 3:9], 1, 10.0)
+        return (loss, pred, gt) if return_pred else loss
+
+    # ---- sampling (diffusion_model.py:86-185)
+    @torch.no_grad()
+    def compute_trajectory(self, trajectory_mask, rgb_obs, pcd_obs, instruction, curr_gripper, goal_gripper, *,
+                           init_noise=None, step_noise=None, visual_tokens=None, use_graph=False, n_steps=None,
+                           return_trace=False):
+        head = self.prediction_head
+        dev = pcd_obs.device
+        tb = self.tables(dev)
+        B, Ln = trajectory_mask.shape
+        tokens, ctx_xyz, cg, gg = self._prepare(rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens)
+        ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
+        cache = head.build_kv_cache(ctx, ctx_xyz, instr)
+        # conditioning: start pose at index 0, goal at L - pad - 1 and after (no host sync: index arithmetic on device)
+        D = cg.shape[-1]
+        ar = torch.arange(Ln, device=dev)[None, :]
+        cond_mask = (ar == 0)
+        cond_data = torch.zeros((B, Ln, D), device=dev)
+        cond_data[:, 0] = cg
+        if self._use_goal_at_test:
+            gidx = (Ln - trajectory_mask.sum(1).long() - 1)[:, None]
+            cond_mask = cond_mask | (ar >= gidx)
+            cond_data = torch.where((ar == gidx)[..., None], gg[:, None, :], cond_data)
+        cond_mask_u8 = cond_mask[..., None].expand(B, Ln, D).to(torch.uint8).contiguous()
+        cond_data = cond_data.contiguous()
+        if init_noise is None:
+            init_noise = torch.randn((B, Ln, D), device=dev)
+        if step_noise is None:
+            step_noise = torch.randn((self.n_steps, B, Ln, D), device=dev)
+        step_noise = step_noise.to(dev).float().contiguous()
+        steps = list(range(self.n_steps - 1, -1, -1))
+        if n_steps is not None:
+            steps = steps[:n_steps]
+        traj = (init_noise.to(dev).float() + cond_data).contiguous()
+        kmask = trajectory_mask.to(torch.uint8).contiguous()
+        trace = []
+
+        def run_loop(x):
+            for t in steps:
+                out = head.denoise_tokens_cached(x, kmask, t, cache, self._time_tables)
+                x = O.ddpm_step(out, x, step_noise[t] if t > 0 else None, cond_data, cond_mask_u8, tb.coef_pos, tb.coef_rot, t)
+                if return_trace:
+                    trace.append(x)
+            return x
+
+        if use_graph and not return_trace:
+            key = (B, Ln, tuple(steps))
+            if self._graph is None or self._graph["key"] != key:
+                static_in = traj.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run_loop(static_in)                     # warm-up (allocator, lazy module state) outside capture
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                self._graph = {"key": key, "in": static_in, "cache": cache, "noise": step_noise, "cond": (cond_data, cond_mask_u8),
+                               "kmask": kmask}
+                with torch.cuda.graph(g):
+                    self._graph["out"] = run_loop(static_in)
+                self._graph["g"] = g
+            gr = self._graph
+            # refresh the captured buffers in place (same addresses)
+            gr["in"].copy_(traj)
+            for dst, src in zip(gr["cache"]["ctx"], cache["ctx"]):
+                if dst is not src:
+                    dst["Ks"].copy_(src["Ks"]); dst["Vt"].copy_(src["Vt"])
+            if "lang" in cache and gr["cache"]["lang"] is not cache["lang"]:
+                gr["cache"]["lang"]["Ks"].copy_(cache["lang"]["Ks"]); gr["cache"]["lang"]["Vt"].copy_(cache["lang"]["Vt"])
+            if gr["noise"] is not step_noise:
+                gr["noise"].copy_(step_noise)
+            if gr["cond"][0] is not cond_data:
+                gr["cond"][0].copy_(cond_data); gr["cond"][1].copy_(cond_mask_u8)
+            if gr["kmask"] is not kmask:
+                gr["kmask"].copy_(kmask)
+            gr["g"].replay()
+            traj = gr["out"]
+        else:
+            traj = run_loop(traj)
+        final = self.unconvert_rot(traj)
+        final = torch.cat([self.unnormalize_pos(final[..., :3]), final[..., 3:]], dim=-1)
+        return (final, trace) if return_trace else final

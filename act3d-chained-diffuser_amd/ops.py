@@ -633,3 +633,76 @@ class AddRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, None
+
+
+class TrajUpdateFn(torch.autograd.Function):
+    """cat(traj[..., :3] + upd[..., :3], upd[..., 3:])   (diffusion_head.py:268-272); gradient flows to `upd` only."""
+
+    @staticmethod
+    def forward(ctx, traj, upd):
+        traj, upd = _c(traj), _c(upd)
+        out = torch.empty_like(upd)
+        L.call("a3d_traj_update", traj.data_ptr(), upd.data_ptr(), out.data_ptr(), upd.numel() // upd.shape[-1],
+               upd.shape[-1], 3, L.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, dy
+
+
+def ddpm_add_noise(x0, noise, t, acp_pos, acp_rot):
+    x0, noise = _c(x0), _c(noise)
+    B, Ln, D = x0.shape
+    out = torch.empty_like(x0)
+    L.call("a3d_ddpm_add_noise", x0.data_ptr(), noise.data_ptr(), _c(t.long()).data_ptr(), acp_pos.data_ptr(),
+           acp_rot.data_ptr(), out.data_ptr(), B, Ln, D, 3, L.stream())
+    return out
+
+
+def ddpm_step(model_out, sample, noise, cond_data, cond_mask_u8, coef_pos, coef_rot, t, out=None):
+    out = torch.empty_like(sample) if out is None else out
+    L.call("a3d_ddpm_step", model_out.data_ptr(), sample.data_ptr(), None if noise is None else noise.data_ptr(),
+           cond_data.data_ptr(), cond_mask_u8.data_ptr(), coef_pos.data_ptr(), coef_rot.data_ptr(), out.data_ptr(),
+           sample.numel() // sample.shape[-1], sample.shape[-1], 3, int(t), L.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ inference K/V cache
+def kv_cache_build(k_in, k_xyz, mha, H):
+    """Step-invariant K/V operands of one cross-attention layer (context projected, rotated, split) -- computed once per
+    trajectory batch instead of once per denoise step (SURVEY §0 "re-encodes ... every step", §8f-2)."""
+    k_in = _c(k_in)
+    B, S, E = k_in.shape
+    dev = k_in.device
+    f4 = 4
+    kv_pre = linear_raw(k_in.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+                        mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
+    Sp = ceil_to(S, 64)
+    freq = rope_freq(E, dev)
+    Ks = torch.empty((B, H, Sp, 32), device=dev, dtype=torch.bfloat16)
+    Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.bfloat16)
+    st = L.stream()
+    L.call("a3d_rope_split_qk", kv_pre.data_ptr(), 2 * E, None if k_xyz is None else _c(k_xyz).data_ptr(), freq.data_ptr(),
+           1.0, Ks.data_ptr(), B, S, Sp, E, H, st)
+    L.call("a3d_split_vt", kv_pre.data_ptr() + E * f4, 2 * E, Vt.data_ptr(), B, S, Sp, E, H, st)
+    return {"Ks": Ks, "Vt": Vt, "S": S, "Sp": Sp}
+
+
+@torch.no_grad()
+def attn_block_cached(q_in, resid, q_xyz, cache, mha, norm, H):
+    """Inference-only cross-attention block against a prebuilt K/V cache: q-proj + RoPE + attention + out-proj + add&LN."""
+    q_in, resid = _c(q_in), _c(resid)
+    B, Lq, E = q_in.shape
+    dev = q_in.device
+    Lqp = ceil_to(Lq, 64)
+    q_pre = linear_raw(q_in.data_ptr(), E, mha.in_proj_weight.data_ptr(), E, mha.in_proj_bias.data_ptr(), B * Lq, E, E, dev)
+    Qs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
+    freq = rope_freq(E, dev)
+    L.call("a3d_rope_split_qk", q_pre.data_ptr(), E, None if q_xyz is None else _c(q_xyz).data_ptr(), freq.data_ptr(),
+           float(E // H) ** -0.5, Qs.data_ptr(), B, Lq, Lqp, E, H, L.stream())
+    nsplit = pick_nsplit(B, H, Lqp, cache["Sp"])
+    O_, _ = attn_core_fwd(Qs, cache["Ks"], cache["Vt"], None, B, H, Lq, Lqp, cache["S"], cache["Sp"], nsplit)
+    Y = linear2d(O_.view(B * Lq, E), mha.out_proj.weight, mha.out_proj.bias)
+    y, _, _ = add_layernorm(resid.view(B * Lq, E), Y, norm.weight, norm.bias)
+    return y.view(B, Lq, E)

@@ -1,0 +1,99 @@
+"""End-to-end parity of the HIP trajectory-diffusion path against golden outputs of the REFERENCE (tests/golden/diffusion.pt):
+denoiser forward, training loss + gradients with injected noise/timesteps, and the full 100-step sampling loop with
+injected noise (eager and hipGraph-captured).  The DDPM scheduler itself is third-party (parity unpinned)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import common as C  # noqa: E402
+from test_oracle_golden import _diffusion_params, load  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def scale_close(name, got, ref, tol=1e-3, floor=1.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = max(floor, ref.abs().max().item())
+    print(f"[parity] {name}: max_abs_err={err:.3e} ref_absmax={ref.abs().max().item():.3e} rel_to_scale={err / scale:.2e}")
+    assert torch.isfinite(got).all(), name
+    assert err <= tol * scale, f"{name}: max err {err:.3e} > {tol} * {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def setup(a3d, dev):
+    r = load("diffusion.pt")
+    cfg = r["cfg"]
+    m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+    res = m.load_state_dict(_diffusion_params(r), strict=False)
+    assert not res.unexpected_keys
+    assert all(".backbone." in k or "feature_pyramid" in k for k in res.missing_keys), res.missing_keys
+    m.to(dev)
+    inp = C.trajectory_inputs(r["seed"], cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"])
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    inp["tokens"] = C.tokens_from_maps(inp["fmap"])
+    return r, cfg, m, inp
+
+
+def test_denoiser_forward(setup, dev):
+    r, cfg, m, inp = setup
+    m.eval()
+    head = m.prediction_head
+    with torch.no_grad():
+        tokens, ctx_xyz, cg, gg = m._prepare(None, inp["pcd"], inp["curr_gripper"], inp["goal_gripper"], inp["tokens"])
+        scale_close("curr gripper 9d", cg, r["conv"]["curr9"], 1e-5)
+        ctx, cxyz, instr = head.encode_context(tokens, ctx_xyz, inp["instr"], cg, gg)
+        pred = head.forward_tokens(r["head_in"].to(dev), inp["mask"], inp["timesteps"], ctx, cxyz, instr)
+    scale_close("denoiser forward", pred, r["head_out"])
+
+
+def test_training_loss_and_grads(setup, dev):
+    r, cfg, m, inp = setup
+    m.train()
+    for p in m.parameters():
+        p.grad = None
+    loss = m(inp["trajectory"], inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+             noise=inp["noise"], timesteps=inp["timesteps"], visual_tokens=inp["tokens"])
+    scale_close("train loss", loss, r["train_loss"], 1e-3)
+    loss.backward()
+    named = dict(m.named_parameters())
+    for n, gref in r["grads"].items():
+        scale_close("grad " + n, named[n].grad, gref, 5e-3, floor=1e-3)
+    with_grad = set(r["manifest"]["with_grad"])
+    for n, p in named.items():
+        if ".backbone." in n or "feature_pyramid" in n:
+            continue
+        if n in with_grad:
+            assert p.grad is not None, f"{n} should receive a gradient"
+            nr = r["grad_norms"][n]
+            assert abs(p.grad.norm().item() - nr) <= 1e-2 * nr + 1e-4, f"grad norm {n}: {p.grad.norm().item()} vs {nr}"
+        else:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, f"{n} must not receive a gradient (SURVEY G12)"
+
+
+def test_sampling_loop_100_steps(setup, dev):
+    r, cfg, m, inp = setup
+    m.eval()
+    final, trace = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+                                        init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=inp["tokens"],
+                                        return_trace=True)
+    for t, ref in r["sample_trace_inputs"].items():
+        if t == 99:
+            continue
+        scale_close(f"state before t={t}", trace[98 - t], ref, 3e-3)
+    scale_close("sampled xyz", final[..., :3], r["sample_final"][..., :3], 3e-3)
+    q, qr = final[..., 3:].cpu(), r["sample_final"][..., 3:]
+    sign = torch.sign((q * qr).sum(-1, keepdim=True))
+    scale_close("sampled quaternion", q * sign, qr, 5e-3)
+    # hipGraph-captured loop == eager loop (same injected noise), twice (capture + replay)
+    for rep in range(2):
+        g_final = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+                                       init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=inp["tokens"],
+                                       use_graph=True)
+        assert torch.allclose(g_final, final, atol=1e-5), f"graph replay {rep} differs from the eager loop"
