@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops as O
-from .nn import FeaturePyramidNetwork, RelativeCrossAttentionModule, load_synthetic_clip
+from .nn import FeaturePyramidNetwork, RelativeCrossAttentionModule, load_synthetic_clip, run_frozen_backbone
 
 
 class _BroadcastRowFn(torch.autograd.Function):
@@ -91,7 +91,8 @@ class Act3D(nn.Module):
         self.backbone, self.normalize = load_synthetic_clip()
         for p in self.backbone.parameters():
             p.requires_grad = False
-        self.backbone_dtype = torch.float32
+        self.backbone_dtype = torch.float32      # set to torch.bfloat16 to run the frozen backbone under autocast
+        self.fpn_dtype = torch.float32           # set to torch.bfloat16 to run the FPN convolutions under autocast
 
         self.feature_pyramid = FeaturePyramidNetwork([64, 256, 512, 1024, 2048], embedding_dim)
         if self.image_size == (128, 128):
@@ -141,17 +142,16 @@ class Act3D(nn.Module):
         x = visible_rgb.flatten(0, 1)
         with torch.no_grad():
             x = self.normalize(x).contiguous(memory_format=torch.channels_last)
-            if self.backbone_dtype != torch.float32:
-                with torch.autocast("cuda", dtype=self.backbone_dtype):
-                    feats = self.backbone(x)
-                feats = {k: v.float() for k, v in feats.items()}
-            else:
-                feats = self.backbone(x)
-        pyr = self.feature_pyramid(feats, needed=self._needed_maps())
+            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32)
+        if self.fpn_dtype != torch.float32:
+            with torch.autocast("cuda", dtype=self.fpn_dtype):
+                pyr = self.feature_pyramid(feats, needed=self._needed_maps())
+        else:
+            pyr = self.feature_pyramid(feats, needed=self._needed_maps())
         tokens = {}
         for name, fm in pyr.items():
             n, E, h, w = fm.shape
-            tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+            tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E).float()
         return [tokens[self.feature_map_pyramid[i]] for i in range(self.num_sampling_level)]
 
     # ------------------------------------------------------------------------------------------------ ghost points

@@ -45,6 +45,16 @@ __global__ void dbg_mfma_f32_kernel(const float* A, const float* Bm, float* D) {
   for (int r = 0; r < 4; ++r) D[(g * 4 + r) * 16 + li] = acc[r];
 }
 
+// out[i] = packed {bf16(in[2i]) low, bf16(in[2i+1]) high} via v_cvt_pk_bf16_f32 (rounding-mode probe)
+__global__ void dbg_cvt_pk_kernel(const float* in, unsigned int* out, int npairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npairs) return;
+  unsigned int r;
+  const float a = in[2 * i], b = in[2 * i + 1];
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  out[i] = r;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -60,4 +70,8 @@ extern "C" int a3d_dbg_mfma_bf16(const void* A, const void* B, float* D, void* s
 extern "C" int a3d_dbg_mfma_f32(const float* A, const float* B, float* D, void* stream) {
   hipLaunchKernelGGL(dbg_mfma_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
   return check_launch("a3d_dbg_mfma_f32");
+}
+extern "C" int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream) {
+  hipLaunchKernelGGL(dbg_cvt_pk_kernel, dim3(cdiv(npairs, 256)), dim3(256), 0, (hipStream_t)stream, in, (unsigned int*)out, npairs);
+  return check_launch("a3d_dbg_cvt_pk_bf16");
 }

@@ -124,18 +124,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
       s16x8 phi[2], plo[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
+        unsigned int hw[4], lw[4];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __expf(s[hf][T][r] - m_use);
-            psum += p;
-            unsigned short ph, pl;
-            split_bf16(p, ph, pl);
-            phi[hf][T * 4 + r] = (short)ph;
-            plo[hf][T * 4 + r] = (short)pl;
+          for (int pr = 0; pr < 2; ++pr) {
+            const float p0 = __expf(s[hf][T][2 * pr] - m_use);
+            const float p1 = __expf(s[hf][T][2 * pr + 1] - m_use);
+            psum += p0 + p1;
+            // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
+            // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            const bf16x2 hb = __builtin_convertvector((f32x2){p0, p1}, bf16x2);
+            const unsigned int h2 = __builtin_bit_cast(unsigned int, hb);
+            const float r0 = p0 - __uint_as_float(h2 << 16);
+            const float r1 = p1 - __uint_as_float(h2 & 0xFFFF0000u);
+            const bf16x2 lb = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
+            const unsigned int l2 = __builtin_bit_cast(unsigned int, lb);
+            hw[T * 2 + pr] = h2;
+            lw[T * 2 + pr] = l2;
           }
         }
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        phi[hf] = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+        plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;

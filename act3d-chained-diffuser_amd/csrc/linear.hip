@@ -11,15 +11,28 @@
 //   a3d_add_layernorm_{fwd,bwd}  y = LN(a + r)      reference: layers.py:308-309, 329-331 (post-norm residual)
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
+#include <stdlib.h>
 
 namespace a3d {
 
 constexpr int LT_BM = 64;   // rows per workgroup
 constexpr int LT_BN = 64;   // cols per workgroup
-constexpr int LT_KC = 16;   // contraction chunk (one ds_read_b128 per lane)
-constexpr int LT_LD = 20;   // padded LDS row stride in floats (80 B: conflict-free b128 column reads)
+constexpr int LT_KC = 64;   // contraction chunk staged in LDS (K = 60 is ONE stage, K = 120 two)
+constexpr int LT_LD = 68;   // padded LDS row stride in floats (272 B: conflict-free b128 column reads)
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && k + 3 < K) return *reinterpret_cast<const float4*>(p);
+  if (k + 0 < K) v.x = p[0];
+  if (k + 1 < K) v.y = p[1];
+  if (k + 2 < K) v.z = p[2];
+  if (k + 3 < K) v.w = p[3];
+  return v;
+}
 
 // act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad]
+// One 64x64 output tile per workgroup; the next K-chunk is prefetched into registers while the current one is
+// multiplied, so a chunk costs one HBM round trip, not two barriers + a dependent load.
 template <bool WT>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
@@ -36,76 +49,62 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging assignment: thread -> (row, 4 consecutive k)
-  const int sr = t >> 2, sk = (t & 3) * 4;
   const bool x_vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
   const bool w_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  // staging roles: thread -> row sr (0..63), four float4 at columns sk + 16*i
+  const int sr = t >> 2, sk = (t & 3) * 4;
+  // transposed-W staging roles: thread -> k row (t >> 4) + 16*i, four consecutive n at (t & 15) * 4
+  const int tk = t >> 4, tn = (t & 15) * 4;
 
-  for (int k0 = 0; k0 < K; k0 += LT_KC) {
-    // ---- X tile [64][16]
-    {
-      const int m = m0 + sr, k = k0 + sk;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) {
-        const float* p = X + (size_t)m * ldx + k;
-        if (x_vec && k + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k + 0 < K) v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-          if (k + 3 < K) v.w = p[3];
-        }
-      }
-      *reinterpret_cast<float4*>(&Xs[sr * LT_LD + sk]) = v;
-    }
-    // ---- W tile -> Ws[n][k]
-    if (!WT) {
-      const int n = n0 + sr, k = k0 + sk;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) {
-        const float* p = W + (size_t)n * ldw + k;
-        if (w_vec && k + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k + 0 < K) v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-          if (k + 3 < K) v.w = p[3];
-        }
-      }
-      *reinterpret_cast<float4*>(&Ws[sr * LT_LD + sk]) = v;
-    } else {
-      // W stored [K][N] (dgrad): thread -> (k = t/16, 4 consecutive n)
-      const int kk = t >> 4, nn = (t & 15) * 4;
-      const int k = k0 + kk, n = n0 + nn;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        const float* p = W + (size_t)k * ldw + n;
-        if (w_vec && n + 3 < N) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (n + 0 < N) v.x = p[0];
-          if (n + 1 < N) v.y = p[1];
-          if (n + 2 < N) v.z = p[2];
-          if (n + 3 < N) v.w = p[3];
-        }
-      }
-      Ws[(nn + 0) * LT_LD + kk] = v.x;
-      Ws[(nn + 1) * LT_LD + kk] = v.y;
-      Ws[(nn + 2) * LT_LD + kk] = v.z;
-      Ws[(nn + 3) * LT_LD + kk] = v.w;
-    }
-    __syncthreads();
-    // contraction index of MFMA step j in lane group g is k = g*4 + j on both operands
-    const float4 a = *reinterpret_cast<const float4*>(&Xs[(wave * 16 + li) * LT_LD + g * 4]);
+  float4 xr[4], wr[4];
+  auto load_chunk = [&](int k0) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const float4 b = *reinterpret_cast<const float4*>(&Ws[(nt * 16 + li) * LT_LD + g * 4]);
-      acc[nt] = mfma_f32_16x16x4(a.x, b.x, acc[nt]);
-      acc[nt] = mfma_f32_16x16x4(a.y, b.y, acc[nt]);
-      acc[nt] = mfma_f32_16x16x4(a.z, b.z, acc[nt]);
-      acc[nt] = mfma_f32_16x16x4(a.w, b.w, acc[nt]);
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + sk + 16 * i;
+      const int m = m0 + sr;
+      xr[i] = (m < M && k < K) ? ld4_guard(X + (size_t)m * ldx + k, k, K, x_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!WT) {
+        const int n = n0 + sr;
+        wr[i] = (n < N && k < K) ? ld4_guard(W + (size_t)n * ldw + k, k, K, w_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int kk = k0 + tk + 16 * i, n = n0 + tn;
+        wr[i] = (kk < K && n < N) ? ld4_guard(W + (size_t)kk * ldw + n, n, N, w_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&Xs[sr * LT_LD + sk + 16 * i]) = xr[i];
+      if (!WT) {
+        *reinterpret_cast<float4*>(&Ws[sr * LT_LD + sk + 16 * i]) = wr[i];
+      } else {
+        const int kk = tk + 16 * i;
+        Ws[(tn + 0) * LT_LD + kk] = wr[i].x;
+        Ws[(tn + 1) * LT_LD + kk] = wr[i].y;
+        Ws[(tn + 2) * LT_LD + kk] = wr[i].z;
+        Ws[(tn + 3) * LT_LD + kk] = wr[i].w;
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += LT_KC) {
+    store_chunk();
+    __syncthreads();
+    if (k0 + LT_KC < K) load_chunk(k0 + LT_KC);
+    const int ksteps = min(4, (K - k0 + 15) >> 4);
+    for (int s4 = 0; s4 < ksteps; ++s4) {
+      // contraction index of MFMA step j in lane group g is k = s4*16 + g*4 + j on both operands
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[(wave * 16 + li) * LT_LD + s4 * 16 + g * 4]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float4 b = *reinterpret_cast<const float4*>(&Ws[(nt * 16 + li) * LT_LD + s4 * 16 + g * 4]);
+        acc[nt] = mfma_f32_16x16x4(a.x, b.x, acc[nt]);
+        acc[nt] = mfma_f32_16x16x4(a.y, b.y, acc[nt]);
+        acc[nt] = mfma_f32_16x16x4(a.z, b.z, acc[nt]);
+        acc[nt] = mfma_f32_16x16x4(a.w, b.w, acc[nt]);
+      }
     }
     __syncthreads();
   }
@@ -128,7 +127,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 }
 
 // dW[n][k] += sum_m dY[m][n] X[m][k];  column k == K of the virtual X is all ones -> db[n].
-constexpr int WG_MC = 16;    // rows of m staged per step
+// 64 (n) x 64 (k) outputs per workgroup, the m reduction split over blockIdx.z; 64 rows of m per LDS stage with the
+// next stage prefetched into registers.
+constexpr int WG_MC = 64;    // rows of m staged per step
 constexpr int WG_LD = 68;    // padded LDS row stride (floats)
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(
     const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx,
@@ -147,36 +148,52 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int sm = t >> 4, sc = (t & 15) * 4;   // thread -> (m row, 4 consecutive cols)
-  for (int mb = mbeg; mb < mend; mb += WG_MC) {
-    const int m = mb + sm;
-    float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < mend) {
-      const float* py = dY + (size_t)m * lddy + n0 + sc;
-      if (n0 + sc + 0 < N) vy.x = py[0];
-      if (n0 + sc + 1 < N) vy.y = py[1];
-      if (n0 + sc + 2 < N) vy.z = py[2];
-      if (n0 + sc + 3 < N) vy.w = py[3];
-      const float* px = X + (size_t)m * ldx + k0 + sc;
-      const int k = k0 + sc;
-      vx.x = (k + 0 < K) ? px[0] : ((k + 0 == K && db) ? 1.f : 0.f);
-      vx.y = (k + 1 < K) ? px[1] : ((k + 1 == K && db) ? 1.f : 0.f);
-      vx.z = (k + 2 < K) ? px[2] : ((k + 2 == K && db) ? 1.f : 0.f);
-      vx.w = (k + 3 < K) ? px[3] : ((k + 3 == K && db) ? 1.f : 0.f);
+  const bool y_vec = ((lddy & 3) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((n0 & 3) == 0);
+  const bool x_vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+  const int sm = t >> 4, sc = (t & 15) * 4;   // thread -> m rows sm + 16*i, 4 consecutive cols at sc
+  float4 yr[4], xr[4];
+  auto load_stage = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + sm + 16 * i;
+      float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
+      if (m < mend) {
+        vy = ld4_guard(dY + (size_t)m * lddy + n0 + sc, n0 + sc, N, y_vec);
+        const int k = k0 + sc;
+        vx = ld4_guard(X + (size_t)m * ldx + k, k, K, x_vec);
+        if (db) {
+          if (k + 0 == K) vx.x = 1.f;
+          if (k + 1 == K) vx.y = 1.f;
+          if (k + 2 == K) vx.z = 1.f;
+          if (k + 3 == K) vx.w = 1.f;
+        }
+      }
+      yr[i] = vy;
+      xr[i] = vx;
     }
-    *reinterpret_cast<float4*>(&Ys[sm * WG_LD + sc]) = vy;
-    *reinterpret_cast<float4*>(&Xs[sm * WG_LD + sc]) = vx;
+  };
+  load_stage(mbeg);
+  for (int mb = mbeg; mb < mend; mb += WG_MC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&Ys[(sm + 16 * i) * WG_LD + sc]) = yr[i];
+      *reinterpret_cast<float4*>(&Xs[(sm + 16 * i) * WG_LD + sc]) = xr[i];
+    }
     __syncthreads();
-    // wave -> n tile `wave`; contraction index of step j in group g is m = g*4 + j
-    float a[4];
+    if (mb + WG_MC < mend) load_stage(mb + WG_MC);
+    const int msteps = min(4, (mend - mb + 15) >> 4);
+    for (int mm = 0; mm < msteps; ++mm) {
+      // wave -> n tile `wave`; contraction index of step j in group g is m = mm*16 + g*4 + j
+      float a[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = Ys[(g * 4 + j) * WG_LD + wave * 16 + li];
+      for (int j = 0; j < 4; ++j) a[j] = Ys[(mm * 16 + g * 4 + j) * WG_LD + wave * 16 + li];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+      for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b = Xs[(g * 4 + j) * WG_LD + kt * 16 + li];
-        acc[kt] = mfma_f32_16x16x4(a[j], b, acc[kt]);
+        for (int j = 0; j < 4; ++j) {
+          const float b = Xs[(mm * 16 + g * 4 + j) * WG_LD + kt * 16 + li];
+          acc[kt] = mfma_f32_16x16x4(a[j], b, acc[kt]);
+        }
       }
     }
     __syncthreads();
@@ -324,9 +341,10 @@ extern "C" int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int l
   }
   if (M == 0) return A3D_OK;
   const int KE = db ? K + 1 : K;
-  // split the M reduction so that the launch has a few hundred workgroups
+  // split the M reduction: ~256-512 workgroups in flight, at least 256 rows (4 stages) per workgroup
   const int tiles = cdiv(N, 64) * cdiv(KE, 64);
-  int nsplit = max(1, min(cdiv(M, 256), cdiv(1024, tiles)));
+  static int target_wgs = getenv("A3D_WGRAD_WGS") ? atoi(getenv("A3D_WGRAD_WGS")) : 256;
+  int nsplit = max(1, min(cdiv(M, 256), cdiv(target_wgs, tiles)));
   int rows = cdiv(cdiv(M, nsplit), WG_MC) * WG_MC;
   nsplit = cdiv(M, rows);
   dim3 grid(cdiv(N, 64), cdiv(KE, 64), nsplit);

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import ops as O
 from .act3d import broadcast_row
-from .nn import FeaturePyramidNetwork, ParallelAttention, load_synthetic_clip
+from .nn import FeaturePyramidNetwork, ParallelAttention, load_synthetic_clip, run_frozen_backbone
 
 
 # ------------------------------------------------------------------------------------------------ DDPM tables
@@ -161,12 +161,7 @@ class DiffusionHead(nn.Module):
         x = rgb.flatten(0, 1)
         with torch.no_grad():
             x = self.normalize(x).contiguous(memory_format=torch.channels_last)
-            if self.backbone_dtype != torch.float32:
-                with torch.autocast("cuda", dtype=self.backbone_dtype):
-                    feats = self.backbone(x)
-                feats = {k: v.float() for k, v in feats.items()}
-            else:
-                feats = self.backbone(x)
+            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype)
         name = self.feature_map_pyramid[0]
         fm = self.feature_pyramid(feats, needed=[name])[name]
         n, E, h, w = fm.shape

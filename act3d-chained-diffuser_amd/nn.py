@@ -257,3 +257,18 @@ class ClipNormalize(nn.Module):
 
 def load_synthetic_clip():
     return SyntheticCLIPResNet50(), ClipNormalize()
+
+
+def run_frozen_backbone(backbone, x, dtype, keep_dtype=False):
+    """Forward of the frozen backbone under no_grad.  For a reduced dtype the convolution weights are converted ONCE
+    (the backbone is frozen, so there is no master copy to keep) instead of being re-cast by autocast at every step;
+    BatchNorm keeps fp32 parameters / running statistics and, as in the reference's train() mode, batch statistics."""
+    if dtype == torch.float32:
+        return backbone(x)
+    if getattr(backbone, "_conv_dtype", None) != dtype:
+        for m in backbone.modules():
+            if isinstance(m, nn.Conv2d):
+                m.to(dtype)
+        backbone._conv_dtype = dtype
+    feats = backbone(x.to(dtype))
+    return feats if keep_dtype else {k: v.float() for k, v in feats.items()}

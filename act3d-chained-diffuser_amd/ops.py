@@ -11,6 +11,7 @@ import torch
 from . import lib as L
 
 F32 = torch.float32
+LOG2E = 1.4426950408889634
 
 
 def ceil_to(x, m):

@@ -55,6 +55,7 @@ def build_model(a3d, device, backbone_dtype):
                   num_sampling_level=3, weight_tying=True, gp_emb_tying=True, use_instruction=False)
     m.to(device)
     m.backbone_dtype = backbone_dtype
+    m.fpn_dtype = backbone_dtype
     m.train()
     return m
 

@@ -142,6 +142,8 @@ int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, i
 /* ---- diagnostics ---------------------------------------------------------------------------------------------- */
 int a3d_dbg_mfma_bf16(const void* A16x32, const void* B32x16, float* D16x16, void* stream);
 int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void* stream);
+/* out[i] = v_cvt_pk_bf16_f32(in[2i], in[2i+1]) -- pins the rounding mode the attention kernel relies on (RNE). */
+int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -78,8 +78,8 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
         for l in range(2):
             scale_close(f"{tag} mask L{i} layer{l}", out["ghost_pcd_masks_pyramid"][i][l], r["masks"][i][l])
         assert torch.equal(out["position_pyramid"][i][:, 0].cpu(), r["positions"][i]), f"argmax position level {i}"
-    rel_close("rotation", out["rotation"], r["rotation"], 2e-3, 0)
-    rel_close("gripper", out["gripper"], r["gripper"], 2e-3, 0)
+    rel_close("rotation", out["rotation"], r["rotation"], 4e-3, 0)     # gain-3 fixtures: see the note on the query stream below
+    rel_close("gripper", out["gripper"], r["gripper"], 4e-3, 0)
     scale_close("query", out["query_features"][0], r["query_features"], 2e-3)   # Lq=1 stream, peaked softmax (see below)
     if not cfg["train"]:
         return

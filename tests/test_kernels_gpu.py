@@ -59,7 +59,8 @@ def test_mfma_layout_probes(a3d, dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 5, 60), (333, 60, 60), (1000, 120, 60), (70, 480, 120), (257, 120, 480),
-                                   (50, 60, 512), (33, 120, 9), (130, 3, 120)])
+                                   (50, 60, 512), (33, 120, 9), (130, 3, 120), (106, 240, 120), (2048, 120, 120),
+                                   (4098, 240, 120)])
 def test_linear_fwd_dgrad_wgrad(a3d, dev, M, N, K):
     O = a3d.ops
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -136,6 +137,8 @@ def _mk_modules(dev, in_w, in_b, out_w, out_b, ln_g, ln_b):
     (2, 333, 1025, 60, 4, True, False, "kv"),
     (2, 100, 53, 120, 8, False, False, "none"),
     (1, 130, 4097, 60, 4, True, False, "kv"),
+    (2, 1024, 53, 120, 8, False, False, "kv"),      # vision -> language attention of the diffusion head
+    (2, 8, 1026, 120, 8, True, False, "kv"),        # trajectory -> context cross-attention of the diffusion head
 ])
 def test_attn_block_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
     """AttnBlockFn (projections + RoPE + attention core + out-proj + residual LayerNorm) vs oracle.mha, incl. all grads."""
