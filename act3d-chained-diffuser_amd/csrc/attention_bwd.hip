@@ -1,0 +1,381 @@
+// Attention backward on split-bf16 MFMA (v_mfma_f32_16x16x32_bf16) -- same operand discipline as the forward.
+//
+// dQ, dK, dV of  O = softmax(Q K^T + mask) V  by recomputation from the saved log-sum-exp.  Every contraction has
+// both operands as bf16 hi+lo pairs (2^-17 operand precision, fp32 accumulate):
+//     S   = Q K^T          2 MFMAs / 16x16 tile     [x_hi | x_lo] . [y_hi | y_hi]  +  [x_hi | x_lo] . [y_lo | y_lo]
+//     dP  = dO V^T         2 MFMAs / 16x16 tile
+//     dQ += dS K, dK += dS^T Q, dV += P^T dO        3 MFMAs / (16 x 32-deep) block:  A_hi B_hi + A_hi B_lo + A_lo B_hi
+// against 4 f32 MFMAs (32 cycles each) per 16x16x16 block in the exact-f32 version it replaces (attention.hip,
+// kept as the A/B reference behind A3D_BWD_F32=1): 11-14 bf16 MFMAs x 16 cycles per 16x32 block instead of 24-32 x 32.
+// As in the forward, the score tiles are produced in the orientation (S^T for dQ, S for dK/dV) and with the row
+// interleave that leaves P / dS in B-operand order in registers: no score tile is staged through LDS.
+// Operand tensors (rope.hip / attn_bwd_prep): rows format [..][N][hi16|lo16] and planes format [..][2][16][N]
+// of q, k, v and dO.
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int BKC = 64;         // rows (keys or queries) per staged chunk
+constexpr int BVROW = 72;       // padded plane row (bf16 elements)
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// 8 floats -> hi and lo bf16x8 (round-to-nearest-even, x ~= hi + lo)
+__device__ __forceinline__ void split8(const float* x, s16x8& hi, s16x8& lo) {
+  unsigned int hw[4], lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2_t hb = __builtin_convertvector((f32x2_t){x[2 * i], x[2 * i + 1]}, bf16x2_t);
+    const unsigned int h2 = __builtin_bit_cast(unsigned int, hb);
+    const float r0 = x[2 * i] - __uint_as_float(h2 << 16);
+    const float r1 = x[2 * i + 1] - __uint_as_float(h2 & 0xFFFF0000u);
+    const bf16x2_t lb = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
+    hw[i] = h2;
+    lw[i] = __builtin_bit_cast(unsigned int, lb);
+  }
+  hi = __builtin_bit_cast(s16x8, (u32x4_t){hw[0], hw[1], hw[2], hw[3]});
+  lo = __builtin_bit_cast(s16x8, (u32x4_t){lw[0], lw[1], lw[2], lw[3]});
+}
+
+// swizzled 16-byte segment of a rows-format tile held in LDS as [64][32] bf16
+__device__ __forceinline__ int rows_off(int row, int seg) { return row * 32 + ((seg ^ ((row >> 3) & 3)) * 8); }
+
+// ------------------------------------------------------------------------------------------------ prep
+// dOs (rows format), dOt (planes format) of dO, and D[b][h][q] = sum_d dO * O.  grid (Lqp/64, B)
+__global__ __launch_bounds__(256) void attn_bwd_prep_bf16_kernel(
+    const float* __restrict__ dO, const float* __restrict__ O, unsigned short* __restrict__ dOs,
+    unsigned short* __restrict__ dOt, float* __restrict__ D, int B, int H, int Lq, int Lqp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int E = H * HD;
+  const int ldt = E + 1;
+  float* Td = smem;
+  float* To = smem + 64 * ldt;
+  const int b = blockIdx.y, q0 = blockIdx.x * 64;
+  for (int idx = threadIdx.x; idx < 64 * E; idx += blockDim.x) {
+    const int r = idx / E, c = idx - r * E;
+    const int q = q0 + r;
+    float a = 0.f, o = 0.f;
+    if (q < Lq) {
+      a = dO[((size_t)b * Lq + q) * E + c];
+      o = O[((size_t)b * Lq + q) * E + c];
+    }
+    Td[r * ldt + c] = a;
+    To[r * ldt + c] = o;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * H; idx += blockDim.x) {
+    const int r = idx & 63, h = idx >> 6;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s += Td[r * ldt + h * HD + d] * To[r * ldt + h * HD + d];
+    D[((size_t)b * H + h) * Lqp + q0 + r] = s;
+  }
+  for (int idx = threadIdx.x; idx < 64 * H * 4; idx += blockDim.x) {
+    const int seg = idx & 3;
+    const int r = (idx >> 2) & 63;
+    const int h = idx >> 8;
+    const int dbase = (seg & 1) * 8;
+    const bool want_lo = (seg >> 1) != 0;
+    s16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = dbase + j;
+      const float v = (d < HD) ? Td[r * ldt + h * HD + d] : 0.f;
+      unsigned short hi, lo;
+      split_bf16(v, hi, lo);
+      out[j] = (short)(want_lo ? lo : hi);
+    }
+    *reinterpret_cast<s16x8*>(dOs + (((size_t)b * H + h) * Lqp + q0 + r) * 32 + seg * 8) = out;
+  }
+  for (int idx = threadIdx.x; idx < H * 2 * 16 * 8; idx += blockDim.x) {
+    const int seg = idx & 7;
+    const int d = (idx >> 3) & 15;
+    const int plane = (idx >> 7) & 1;
+    const int h = idx >> 8;
+    s16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = seg * 8 + j;
+      const float v = (d < HD) ? Td[r * ldt + h * HD + d] : 0.f;
+      unsigned short hi, lo;
+      split_bf16(v, hi, lo);
+      out[j] = (short)(plane ? lo : hi);
+    }
+    *reinterpret_cast<s16x8*>(dOt + ((((size_t)b * H + h) * 2 + plane) * 16 + d) * Lqp + q0 + seg * 8) = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+struct DqStage {
+  s16x8 k, v, kt;
+  float bias;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
+    const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
+    const unsigned short* __restrict__ Kt, const unsigned short* __restrict__ Vs,
+    const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
+    const float* __restrict__ LSE, const float* __restrict__ D, float* __restrict__ dQp, int B, int H, int Lq,
+    int Lqp, int S, int Sp, int nsplit) {
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][BKC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][BKC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Ktm[2][2 * 16 * BVROW];
+  __shared__ __attribute__((aligned(16))) float biasS[2][BKC];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z / nsplit, sp = blockIdx.z - b * nsplit;
+  const int h = blockIdx.y;
+  const size_t bh = (size_t)b * H + h;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool active = q0 < Lqp;
+  const int q = q0 + li;
+
+  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = qhi, dohi = qhi, dolo = qhi;
+  float lse_q = INFINITY, d_q = 0.f;
+  if (active) {
+    const unsigned short* qp = Qs + (bh * Lqp + q) * 32;
+    qhi = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
+    qlo = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
+    const unsigned short* op = dOs + (bh * Lqp + q) * 32;
+    dohi = *reinterpret_cast<const s16x8*>(op + (g & 1) * 8);
+    dolo = *reinterpret_cast<const s16x8*>(op + 16 + (g & 1) * 8);
+    if (q < Lq) {
+      lse_q = LSE[bh * Lqp + q];
+      if (lse_q == -INFINITY) lse_q = INFINITY;
+      d_q = D[bh * Lqp + q];
+    }
+  }
+  const int nch = Sp / BKC;
+  const int cps = (nch + nsplit - 1) / nsplit;
+  const int c_beg = sp * cps, c_end = min(nch, c_beg + cps);
+  const int krow = t >> 2, kseg = t & 3;
+  const int vplane = t >> 7, vd = (t >> 3) & 15, vseg = t & 7;
+  auto stage_load = [&](int c) {
+    DqStage st;
+    st.k = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * BKC + krow) * 32 + kseg * 8);
+    st.v = *reinterpret_cast<const s16x8*>(Vs + (bh * Sp + (size_t)c * BKC + krow) * 32 + kseg * 8);
+    st.kt = *reinterpret_cast<const s16x8*>(Kt + ((bh * 2 + vplane) * 16 + vd) * Sp + (size_t)c * BKC + vseg * 8);
+    st.bias = 0.f;
+    if (t < BKC) {
+      const int key = c * BKC + t;
+      bool valid = key < S;
+      if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
+      st.bias = valid ? 0.f : -INFINITY;
+    }
+    return st;
+  };
+  auto stage_store = [&](const DqStage& st, int buf) {
+    *reinterpret_cast<s16x8*>(&Ksm[buf][rows_off(krow, kseg)]) = st.k;
+    *reinterpret_cast<s16x8*>(&Vsm[buf][rows_off(krow, kseg)]) = st.v;
+    *reinterpret_cast<s16x8*>(&Ktm[buf][(vplane * 16 + vd) * BVROW + vseg * 8]) = st.kt;
+    if (t < BKC) biasS[buf][t] = st.bias;
+  };
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c_beg < c_end) {
+    stage_store(stage_load(c_beg), 0);
+    __syncthreads();
+  }
+  for (int c = c_beg; c < c_end; ++c) {
+    const int buf = (c - c_beg) & 1;
+    DqStage nxt;
+    const bool has_next = (c + 1 < c_end);
+    if (has_next) nxt = stage_load(c + 1);
+    if (active) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float ds[8];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
+          const s16x8 kf = *reinterpret_cast<const s16x8*>(&Ksm[buf][rows_off(row, g)]);
+          const s16x8 vf = *reinterpret_cast<const s16x8*>(&Vsm[buf][rows_off(row, g)]);
+          f32x4 sT = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
+          sT = mfma_bf16_16x16x32(kf, qhi, sT);
+          sT = mfma_bf16_16x16x32(kf, qlo, sT);
+          f32x4 dpT = {0.f, 0.f, 0.f, 0.f};
+          dpT = mfma_bf16_16x16x32(vf, dohi, dpT);
+          dpT = mfma_bf16_16x16x32(vf, dolo, dpT);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(sT[r] - lse_q);
+            ds[T * 4 + r] = p * (dpT[r] - d_q);
+          }
+        }
+        s16x8 dhi, dlo;
+        split8(ds, dhi, dlo);
+        const s16x8 kth = *reinterpret_cast<const s16x8*>(&Ktm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
+        const s16x8 ktl = *reinterpret_cast<const s16x8*>(&Ktm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
+        acc = mfma_bf16_16x16x32(kth, dhi, acc);
+        acc = mfma_bf16_16x16x32(kth, dlo, acc);
+        acc = mfma_bf16_16x16x32(ktl, dhi, acc);
+      }
+    }
+    if (has_next) stage_store(nxt, buf ^ 1);
+    __syncthreads();
+  }
+  if (active) {
+    const size_t row = (((size_t)sp * B + b) * H + h) * Lqp + q;
+    *reinterpret_cast<f32x4*>(&dQp[row * HDP + g * 4]) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+struct DkvStage {
+  s16x8 q, o, qt, ot;
+  float lse, d;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
+    const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Qt,
+    const unsigned short* __restrict__ Ks, const unsigned short* __restrict__ Vs,
+    const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
+    const unsigned short* __restrict__ dOt, const float* __restrict__ LSE, const float* __restrict__ D,
+    float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp) {
+  __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][BKC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Osm[2][BKC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Qtm[2][2 * 16 * BVROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Otm[2][2 * 16 * BVROW];
+  __shared__ __attribute__((aligned(16))) float lseS[2][BKC];
+  __shared__ __attribute__((aligned(16))) float dS_[2][BKC];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const size_t bh = (size_t)b * H + h;
+  const int key = blockIdx.x * 64 + wave * 16 + li;   // < Sp always
+
+  const unsigned short* kp = Ks + (bh * Sp + key) * 32;
+  const unsigned short* vp = Vs + (bh * Sp + key) * 32;
+  const s16x8 khi = *reinterpret_cast<const s16x8*>(kp + (g & 1) * 8);
+  const s16x8 klo = *reinterpret_cast<const s16x8*>(kp + 16 + (g & 1) * 8);
+  const s16x8 vhi = *reinterpret_cast<const s16x8*>(vp + (g & 1) * 8);
+  const s16x8 vlo = *reinterpret_cast<const s16x8*>(vp + 16 + (g & 1) * 8);
+  bool valid = key < S;
+  if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
+  const float bias_k = valid ? 0.f : -INFINITY;
+
+  const int qrow = t >> 2, qseg = t & 3;
+  const int pplane = t >> 7, pd = (t >> 3) & 15, pseg = t & 7;
+  auto stage_load = [&](int c) {
+    DkvStage st;
+    const size_t base = (bh * Lqp + (size_t)c * BKC + qrow) * 32 + qseg * 8;
+    st.q = *reinterpret_cast<const s16x8*>(Qs + base);
+    st.o = *reinterpret_cast<const s16x8*>(dOs + base);
+    const size_t pb = ((bh * 2 + pplane) * 16 + pd) * Lqp + (size_t)c * BKC + pseg * 8;
+    st.qt = *reinterpret_cast<const s16x8*>(Qt + pb);
+    st.ot = *reinterpret_cast<const s16x8*>(dOt + pb);
+    st.lse = INFINITY;
+    st.d = 0.f;
+    if (t < BKC) {
+      const int qq = c * BKC + t;
+      if (qq < Lq) {
+        float l = LSE[bh * Lqp + qq];
+        st.lse = (l == -INFINITY) ? INFINITY : l;
+        st.d = D[bh * Lqp + qq];
+      }
+    }
+    return st;
+  };
+  auto stage_store = [&](const DkvStage& st, int buf) {
+    *reinterpret_cast<s16x8*>(&Qsm[buf][rows_off(qrow, qseg)]) = st.q;
+    *reinterpret_cast<s16x8*>(&Osm[buf][rows_off(qrow, qseg)]) = st.o;
+    *reinterpret_cast<s16x8*>(&Qtm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.qt;
+    *reinterpret_cast<s16x8*>(&Otm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.ot;
+    if (t < BKC) { lseS[buf][t] = st.lse; dS_[buf][t] = st.d; }
+  };
+
+  f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+  const int nch = Lqp / BKC;
+  stage_store(stage_load(0), 0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    DkvStage nxt;
+    const bool has_next = (c + 1 < nch);
+    if (has_next) nxt = stage_load(c + 1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float p8[8], ds8[8];
+#pragma unroll
+      for (int T = 0; T < 2; ++T) {
+        const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
+        const s16x8 qf = *reinterpret_cast<const s16x8*>(&Qsm[buf][rows_off(row, g)]);
+        const s16x8 of = *reinterpret_cast<const s16x8*>(&Osm[buf][rows_off(row, g)]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma_bf16_16x16x32(qf, khi, s);
+        s = mfma_bf16_16x16x32(qf, klo, s);
+        dp = mfma_bf16_16x16x32(of, vhi, dp);
+        dp = mfma_bf16_16x16x32(of, vlo, dp);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[r] + bias_k - l4[r]);
+          p8[T * 4 + r] = p;
+          ds8[T * 4 + r] = p * (dp[r] - d4[r]);
+        }
+      }
+      s16x8 phi, plo, dhi, dlo;
+      split8(p8, phi, plo);
+      split8(ds8, dhi, dlo);
+      const s16x8 oth = *reinterpret_cast<const s16x8*>(&Otm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
+      const s16x8 otl = *reinterpret_cast<const s16x8*>(&Otm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
+      dv = mfma_bf16_16x16x32(oth, phi, dv);
+      dv = mfma_bf16_16x16x32(oth, plo, dv);
+      dv = mfma_bf16_16x16x32(otl, phi, dv);
+      const s16x8 qth = *reinterpret_cast<const s16x8*>(&Qtm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
+      const s16x8 qtl = *reinterpret_cast<const s16x8*>(&Qtm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
+      dk = mfma_bf16_16x16x32(qth, dhi, dk);
+      dk = mfma_bf16_16x16x32(qth, dlo, dk);
+      dk = mfma_bf16_16x16x32(qtl, dhi, dk);
+    }
+    if (has_next) stage_store(nxt, buf ^ 1);
+    __syncthreads();
+  }
+  *reinterpret_cast<f32x4*>(&dK[(bh * Sp + key) * HDP + g * 4]) = dk;
+  *reinterpret_cast<f32x4*>(&dV[(bh * Sp + key) * HDP + g * 4]) = dv;
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                                 const unsigned char* kmask, const float* O, const float* dO, const float* LSE,
+                                 void* dOs, void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H,
+                                 int Lq, int Lqp, int S, int Sp, int nsplit, void* stream) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lqp < Lq || (Lqp % 64) != 0 || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 ||
+      nsplit > 64) {
+    set_error("a3d_attn_bwd_bf16: bad argument (B=%d H=%d Lq=%d Lqp=%d S=%d Sp=%d nsplit=%d; Lqp, Sp %% 64 == 0)", B, H, Lq,
+              Lqp, S, Sp, nsplit);
+    return A3D_ERR_ARG;
+  }
+  if (!Qs || !Qt || !Ks || !Kt || !Vs || !O || !dO || !LSE || !dOs || !dOt || !D || !dQp || !dK || !dV) {
+    set_error("a3d_attn_bwd_bf16: null pointer");
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int E = H * HD;
+  const size_t lds = (size_t)2 * 64 * (E + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_prep_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_prep_bf16_kernel, dim3(Lqp / 64, B), dim3(256), lds, s, dO, O, (unsigned short*)dOs,
+                     (unsigned short*)dOt, D, B, H, Lq, Lqp);
+  int rc = check_launch("a3d_attn_bwd_bf16(prep)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(Lqp / 64, H, B * nsplit), dim3(256), 0, s, (const unsigned short*)Qs,
+                     (const unsigned short*)Ks, (const unsigned short*)Kt, (const unsigned short*)Vs, kmask,
+                     (const unsigned short*)dOs, LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit);
+  rc = check_launch("a3d_attn_bwd_bf16(dq)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(Sp / 64, H, B), dim3(256), 0, s, (const unsigned short*)Qs,
+                     (const unsigned short*)Qt, (const unsigned short*)Ks, (const unsigned short*)Vs, kmask,
+                     (const unsigned short*)dOs, (const unsigned short*)dOt, LSE, D, dK, dV, B, H, Lq, Lqp, S, Sp);
+  return check_launch("a3d_attn_bwd_bf16(dkv)");
+}

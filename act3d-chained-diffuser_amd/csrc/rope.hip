@@ -51,58 +51,54 @@ __device__ __forceinline__ void rope_tile_to_lds(float* T, int ldt, const float*
   }
 }
 
-__global__ __launch_bounds__(256) void rope_split_qk_kernel(
+// Writes the rotated, scaled rows in QK format (rows_out) and / or VT format (planes_out); either may be null.
+__global__ __launch_bounds__(256) void rope_split_kernel(
     const float* __restrict__ Y, int ldy, const float* __restrict__ xyz, const float* __restrict__ freq,
-    float scale, unsigned short* __restrict__ dst, int B, int N, int Npad, int E, int H) {
+    float scale, unsigned short* __restrict__ rows_out, unsigned short* __restrict__ planes_out, int B, int N,
+    int Npad, int E, int H) {
   extern __shared__ __attribute__((aligned(16))) float T[];
   const int ldt = E + 1;
   const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
   rope_tile_to_lds(T, ldt, Y, ldy, xyz, freq, scale, b, n0, N, E);
   __syncthreads();
-  for (int idx = threadIdx.x; idx < RT_ROWS * H * 4; idx += blockDim.x) {
-    const int seg = idx & 3;
-    const int r = (idx >> 2) % RT_ROWS;
-    const int h = (idx >> 2) / RT_ROWS;
-    const int n = n0 + r;
-    if (n >= Npad) continue;
-    const int dbase = (seg & 1) * 8;
-    const bool want_lo = (seg >> 1) != 0;
-    s16x8 out;
+  if (rows_out) {
+    for (int idx = threadIdx.x; idx < RT_ROWS * H * 4; idx += blockDim.x) {
+      const int seg = idx & 3;
+      const int r = (idx >> 2) % RT_ROWS;
+      const int h = (idx >> 2) / RT_ROWS;
+      const int n = n0 + r;
+      if (n >= Npad) continue;
+      const int dbase = (seg & 1) * 8;
+      const bool want_lo = (seg >> 1) != 0;
+      s16x8 out;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int d = dbase + j;
-      const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
-      unsigned short hi, lo;
-      split_bf16(v, hi, lo);
-      out[j] = (short)(want_lo ? lo : hi);
+      for (int j = 0; j < 8; ++j) {
+        const int d = dbase + j;
+        const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
+        unsigned short hi, lo;
+        split_bf16(v, hi, lo);
+        out[j] = (short)(want_lo ? lo : hi);
+      }
+      *reinterpret_cast<s16x8*>(rows_out + (((size_t)b * H + h) * Npad + n) * 32 + seg * 8) = out;
     }
-    *reinterpret_cast<s16x8*>(dst + (((size_t)b * H + h) * Npad + n) * 32 + seg * 8) = out;
   }
-}
-
-__global__ __launch_bounds__(256) void split_vt_kernel(
-    const float* __restrict__ Y, int ldy, unsigned short* __restrict__ dst, int B, int N, int Npad, int E,
-    int H) {
-  extern __shared__ __attribute__((aligned(16))) float T[];
-  const int ldt = E + 1;
-  const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
-  rope_tile_to_lds(T, ldt, Y, ldy, nullptr, nullptr, 1.0f, b, n0, N, E);
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < H * 2 * 16 * 8; idx += blockDim.x) {
-    const int seg = idx & 7;
-    const int d = (idx >> 3) & 15;
-    const int plane = (idx >> 7) & 1;
-    const int h = idx >> 8;
-    s16x8 out;
+  if (planes_out) {
+    for (int idx = threadIdx.x; idx < H * 2 * 16 * 8; idx += blockDim.x) {
+      const int seg = idx & 7;
+      const int d = (idx >> 3) & 15;
+      const int plane = (idx >> 7) & 1;
+      const int h = idx >> 8;
+      s16x8 out;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = seg * 8 + j;
-      const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
-      unsigned short hi, lo;
-      split_bf16(v, hi, lo);
-      out[j] = (short)(plane ? lo : hi);
+      for (int j = 0; j < 8; ++j) {
+        const int r = seg * 8 + j;
+        const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
+        unsigned short hi, lo;
+        split_bf16(v, hi, lo);
+        out[j] = (short)(plane ? lo : hi);
+      }
+      *reinterpret_cast<s16x8*>(planes_out + ((((size_t)b * H + h) * 2 + plane) * 16 + d) * Npad + n0 + seg * 8) = out;
     }
-    *reinterpret_cast<s16x8*>(dst + ((((size_t)b * H + h) * 2 + plane) * 16 + d) * Npad + n0 + seg * 8) = out;
   }
 }
 
@@ -157,28 +153,26 @@ static int check_rope_args(const char* fn, int B, int N, int Npad, int E, int H)
   return A3D_OK;
 }
 
-extern "C" int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
-                                 void* dst, int B, int N, int Npad, int E, int H, void* stream) {
-  int rc = check_rope_args("a3d_rope_split_qk", B, N, Npad, E, H);
+extern "C" int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
+                              void* rows_out, void* planes_out, int B, int N, int Npad, int E, int H, void* stream) {
+  int rc = check_rope_args("a3d_rope_split", B, N, Npad, E, H);
   if (rc) return rc;
-  if (!Y || !dst || (xyz && !freq)) { set_error("a3d_rope_split_qk: null pointer"); return A3D_ERR_ARG; }
+  if (!Y || (!rows_out && !planes_out) || (xyz && !freq)) { set_error("a3d_rope_split: null pointer"); return A3D_ERR_ARG; }
   dim3 grid(Npad / RT_ROWS, B);
   const size_t lds = (size_t)RT_ROWS * (E + 1) * sizeof(float);
-  hipLaunchKernelGGL(rope_split_qk_kernel, grid, dim3(256), lds, (hipStream_t)stream, Y, ldy, xyz, freq, scale,
-                     (unsigned short*)dst, B, N, Npad, E, H);
-  return check_launch("a3d_rope_split_qk");
+  hipLaunchKernelGGL(rope_split_kernel, grid, dim3(256), lds, (hipStream_t)stream, Y, ldy, xyz, freq, scale,
+                     (unsigned short*)rows_out, (unsigned short*)planes_out, B, N, Npad, E, H);
+  return check_launch("a3d_rope_split");
+}
+
+extern "C" int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
+                                 void* dst, int B, int N, int Npad, int E, int H, void* stream) {
+  return a3d_rope_split(Y, ldy, xyz, freq, scale, dst, nullptr, B, N, Npad, E, H, stream);
 }
 
 extern "C" int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int E, int H,
                             void* stream) {
-  int rc = check_rope_args("a3d_split_vt", B, N, Npad, E, H);
-  if (rc) return rc;
-  if (!Y || !dst) { set_error("a3d_split_vt: null pointer"); return A3D_ERR_ARG; }
-  dim3 grid(Npad / RT_ROWS, B);
-  const size_t lds = (size_t)RT_ROWS * (E + 1) * sizeof(float);
-  hipLaunchKernelGGL(split_vt_kernel, grid, dim3(256), lds, (hipStream_t)stream, Y, ldy, (unsigned short*)dst,
-                     B, N, Npad, E, H);
-  return check_launch("a3d_split_vt");
+  return a3d_rope_split(Y, ldy, nullptr, nullptr, 1.0f, nullptr, dst, B, N, Npad, E, H, stream);
 }
 
 extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq,

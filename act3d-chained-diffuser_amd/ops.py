@@ -5,6 +5,7 @@ Parameter gradients are accumulated by the wgrad kernels straight into ``param.g
 when the model is wrapped by ``FlatParams``) instead of being returned through autograd; see DESIGN.md.
 """
 import math
+import os
 
 import torch
 
@@ -103,21 +104,30 @@ def pick_nsplit(B, H, Lqp, Sp):
     return ns
 
 
-def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device):
-    """rope + split the three projected row sets into the attention operand formats."""
+def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
+    """rope + split the three projected row sets into the attention operand formats.  The forward reads q and k in the
+    rows (QK) format and v in the planes (VT) format; the bf16 backward additionally needs the other format of each
+    (returned in `extra` = (Qt, Kt, Vs)), written by the same pass."""
     Lqp, Sp = ceil_to(Lq, 64), ceil_to(S, 64)
     scale = float(E // H) ** -0.5
     freq = rope_freq(E, device)
-    Qs = torch.empty((B, H, Lqp, 32), device=device, dtype=torch.bfloat16)
-    Ks = torch.empty((B, H, Sp, 32), device=device, dtype=torch.bfloat16)
-    Vt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=torch.bfloat16)
+    bf = torch.bfloat16
+    Qs = torch.empty((B, H, Lqp, 32), device=device, dtype=bf)
+    Ks = torch.empty((B, H, Sp, 32), device=device, dtype=bf)
+    Vt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=bf)
+    Qt = Kt = Vs = None
+    if need_bwd:
+        Qt = torch.empty((B, H, 2, 16, Lqp), device=device, dtype=bf)
+        Kt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=bf)
+        Vs = torch.empty((B, H, Sp, 32), device=device, dtype=bf)
     st = L.stream()
-    L.call("a3d_rope_split_qk", q_pre_ptr, ldq, None if q_xyz is None else q_xyz.data_ptr(), freq.data_ptr(), scale,
-           Qs.data_ptr(), B, Lq, Lqp, E, H, st)
-    L.call("a3d_rope_split_qk", k_pre_ptr, ldk, None if k_xyz is None else k_xyz.data_ptr(), freq.data_ptr(), 1.0,
-           Ks.data_ptr(), B, S, Sp, E, H, st)
-    L.call("a3d_split_vt", v_pre_ptr, ldv, Vt.data_ptr(), B, S, Sp, E, H, st)
-    return Qs, Ks, Vt, Lqp, Sp, scale, freq
+    qx = None if q_xyz is None else q_xyz.data_ptr()
+    kx = None if k_xyz is None else k_xyz.data_ptr()
+    nz = lambda t: None if t is None else t.data_ptr()
+    L.call("a3d_rope_split", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qs.data_ptr(), nz(Qt), B, Lq, Lqp, E, H, st)
+    L.call("a3d_rope_split", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Ks.data_ptr(), nz(Kt), B, S, Sp, E, H, st)
+    L.call("a3d_rope_split", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vs), Vt.data_ptr(), B, S, Sp, E, H, st)
+    return Qs, Ks, Vt, Lqp, Sp, scale, freq, (Qt, Kt, Vs)
 
 
 def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
@@ -134,16 +144,28 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
     return O, LSE
 
 
-def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit):
+BWD_F32 = os.environ.get("A3D_BWD_F32", "0") == "1"     # A/B switch: exact-f32 MFMA reference backward (attention.hip)
+
+
+def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, extra=None):
     dev = Qs.device
-    dOh = torch.empty((B, H, Lqp, 16), device=dev, dtype=F32)
     D = torch.empty((B, H, Lqp), device=dev, dtype=F32)
     dQp = torch.empty((nsplit, B, H, Lqp, 16), device=dev, dtype=F32)
     dK = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     dV = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
-    L.call("a3d_attn_bwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
-           O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOh.data_ptr(), D.data_ptr(), dQp.data_ptr(), dK.data_ptr(),
-           dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
+    km = None if kmask is None else kmask.data_ptr()
+    if extra is None or extra[0] is None or BWD_F32:
+        dOh = torch.empty((B, H, Lqp, 16), device=dev, dtype=F32)
+        L.call("a3d_attn_bwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), km, O.data_ptr(), dO.data_ptr(),
+               LSE.data_ptr(), dOh.data_ptr(), D.data_ptr(), dQp.data_ptr(), dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp,
+               S, Sp, nsplit, L.stream())
+    else:
+        Qt, Kt, Vs = extra
+        dOs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
+        dOt = torch.empty((B, H, 2, 16, Lqp), device=dev, dtype=torch.bfloat16)
+        L.call("a3d_attn_bwd_bf16", Qs.data_ptr(), Qt.data_ptr(), Ks.data_ptr(), Kt.data_ptr(), Vs.data_ptr(), km,
+               O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOs.data_ptr(), dOt.data_ptr(), D.data_ptr(), dQp.data_ptr(),
+               dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
     return dQp, dK, dV
 
 
@@ -197,8 +219,9 @@ class AttnBlockFn(torch.autograd.Function):
                 v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
                 k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
                 keep = (q_pre, k_pre, v_pre)
-        Qs, Ks, Vt, Lqp, Sp, scale, freq = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq, S,
-                                                         E, H, dev)
+        need_bwd = torch.is_grad_enabled()
+        Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
+                                                                S, E, H, dev, need_bwd=need_bwd)
         del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
         O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit)
@@ -209,6 +232,7 @@ class AttnBlockFn(torch.autograd.Function):
                               k_xyz if k_xyz is not None else torch.empty(0, device=dev),
                               kmask if kmask is not None else torch.empty(0, device=dev))
         ctx.params = (in_w, in_b, out_w, out_b, ln_g, ln_b)
+        ctx.extra = extra
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
         return y.view(B, Lq, E)
 
@@ -228,7 +252,8 @@ class AttnBlockFn(torch.autograd.Function):
         dS = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)      # = d resid = d Y
         dO = dgrad2d(dS, out_w)
         wgrad2d(dS, O.view(B * Lq, E), out_w, out_b)
-        dQp, dK, dV = attn_core_bwd(Qs, Ks, Vt, kmask, O, dO.view(B, Lq, E), LSE, B, H, Lq, Lqp, S, Sp, nsplit)
+        dQp, dK, dV = attn_core_bwd(Qs, Ks, Vt, kmask, O, dO.view(B, Lq, E), LSE, B, H, Lq, Lqp, S, Sp, nsplit,
+                                    extra=ctx.extra)
         gW, gb = grad_buf(in_w), grad_buf(in_b)
         st = L.stream()
         need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]

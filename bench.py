@@ -129,13 +129,14 @@ def kernel_rooflines(a3d, device, B):
     kv_pre = torch.randn(B * S, 2 * E, generator=g).to(device)
     q_xyz = torch.rand(B, Lq, 3, generator=g).to(device)
     k_xyz = torch.rand(B, S, 3, generator=g).to(device)
-    Qs, Ks, Vt, Lqp, Sp, scale, freq = O.attn_operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E, kv_pre.data_ptr() + E * 4,
-                                                        2 * E, q_xyz, k_xyz, B, Lq, S, E, H, device)
+    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O.attn_operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E,
+                                                               kv_pre.data_ptr() + E * 4, 2 * E, q_xyz, k_xyz, B, Lq, S, E, H,
+                                                               device, need_bwd=True)
     ns = O.pick_nsplit(B, H, Lqp, Sp)
     Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns)
     dO = torch.randn_like(Oo)
     t_fwd = time_kernel(lambda: O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns))
-    t_bwd = time_kernel(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Lq, Lqp, S, Sp, ns))
+    t_bwd = time_kernel(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Lq, Lqp, S, Sp, ns, extra=extra))
     f_fwd = 4.0 * Lq * S * E * B
     f_bwd = 10.0 * Lq * S * E * B
     x = torch.randn(B * S, E, generator=g).to(device)
@@ -146,8 +147,9 @@ def kernel_rooflines(a3d, device, B):
     return {
         "attn_fwd": {"bound": "mfma", "achieved": f_fwd / (t_fwd * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (hi+lo split operands)"},
-        "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                     "ms": t_bwd, "launches_per_step": 6, "dtype": "f32 MFMA"},
+        "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 157.3 if O.BWD_F32 else 2500.0,
+                     "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6,
+                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (hi+lo split operands)"},
         "kv_proj_linear": {"bound": "hbm", "achieved": bytes_lin / (t_lin * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                            "ms": t_lin, "launches_per_step": 12},
     }

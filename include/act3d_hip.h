@@ -57,6 +57,9 @@ int a3d_add_layernorm_bwd(const float* A, const float* R, const float* gamma, co
 int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* dst, int B,
                       int N, int Npad, int E, int H, void* stream);
 int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int E, int H, void* stream);
+/* Both formats of the same rotated rows in one pass (either output may be NULL); the backward needs q, k, v in both. */
+int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
+                   void* planes_out, int B, int N, int Npad, int E, int H, void* stream);
 /* dY[:, :E] = scale * R(xyz)^T * sum_s dR[s];  dR: [nsplit][B][H][Npad][16] fp32 (grad w.r.t. rotated rows). */
 int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq, float scale, float* dY,
                        int ldy, int B, int N, int Npad, int E, int H, void* stream);
@@ -73,6 +76,14 @@ size_t a3d_attn_fwd_ws_floats(int B, int H, int Lqp, int nsplit);
 int a3d_attn_bwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, const float* O,
                  const float* dO, const float* LSE, float* dOh, float* D, float* dQp, float* dK, float* dV, int B,
                  int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
+
+/* Same gradients on split-bf16 MFMA (default path).  Needs both formats of q, k, v: rows (QK) Qs, Ks, Vs and planes
+ * (VT) Qt, Kt (a3d_rope_split writes both).  Scratch: dOs [B][H][Lqp][32] bf16, dOt [B][H][2][16][Lqp] bf16,
+ * D [B][H][Lqp].  Lqp % 64 == 0. */
+int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                      const unsigned char* kmask, const float* O, const float* dO, const float* LSE, void* dOs,
+                      void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S,
+                      int Sp, int nsplit, void* stream);
 
 /* ---- scene tokens --------------------------------------------------------------------------------------- */
 /* out[b][(cam*h + y)*w + x][:] = bilinear(pcd[(b,cam)], 1/factor)  (act3d.py:379-383, encoder.py:147-158) */
