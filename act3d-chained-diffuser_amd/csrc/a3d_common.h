@@ -80,6 +80,19 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 }
 __device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }   // correctly rounded (HIP default)
 
+// XCD-aware workgroup decoding (MI355X: 8 XCDs with private 4 MiB L2s; workgroup i is dispatched to XCD i % 8).
+// All `per_group` workgroups that share one (sample, head)'s K/V or Q/dO tensors are placed on ONE XCD, so that
+// those tensors are fetched from HBM once and re-read from that XCD's L2.  Grid = xcd_grid(ngroups, per_group).
+// Placement only affects speed, never results.
+__device__ __forceinline__ bool xcd_decode(int per_group, int ngroups, int& group, int& within) {
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  group = (slot / per_group) * 8 + xcd;
+  within = slot % per_group;
+  return group < ngroups;
+}
+static inline int xcd_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace a3d

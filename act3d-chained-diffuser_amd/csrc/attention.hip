@@ -40,10 +40,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z / nsplit, sp = blockIdx.z - b * nsplit;
-  const int h = blockIdx.y;
+  const int tiles_x = (Lqp + 63) >> 6;
+  int group, within;
+  if (!xcd_decode(tiles_x * nsplit, B * H, group, within)) return;
+  const int b = group / H, h = group - b * H;
+  const int sp = within / tiles_x;
   const int E = H * HD;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = (within - sp * tiles_x) * 64 + wave * 16;
   const bool active = q0 < Lqp;
   const size_t bh = (size_t)b * H + h;
 
@@ -463,7 +466,7 @@ extern "C" int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, cons
   float* Op = ws;
   float* Mp = ws ? ws + (size_t)nsplit * rows * HDP : nullptr;
   float* Lp = ws ? Mp + (size_t)nsplit * rows : nullptr;
-  dim3 grid(cdiv(Lqp, 64), H, B * nsplit);
+  dim3 grid(xcd_grid(B * H, cdiv(Lqp, 64) * nsplit));
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, (const unsigned short*)Qs,
                      (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
                      Lqp, S, Sp, nsplit);

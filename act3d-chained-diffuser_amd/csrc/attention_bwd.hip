@@ -126,10 +126,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
   __shared__ __attribute__((aligned(16))) float biasS[2][BKC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z / nsplit, sp = blockIdx.z - b * nsplit;
-  const int h = blockIdx.y;
+  const int tiles_x = Lqp >> 6;
+  int group, within;
+  if (!xcd_decode(tiles_x * nsplit, B * H, group, within)) return;
+  const int b = group / H, h = group - b * H;
+  const int sp = within / tiles_x;
   const size_t bh = (size_t)b * H + h;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = (within - sp * tiles_x) * 64 + wave * 16;
   const bool active = q0 < Lqp;
   const int q = q0 + li;
 
@@ -243,9 +246,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
   __shared__ __attribute__((aligned(16))) float dS_[2][BKC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int group, within;
+  if (!xcd_decode(Sp >> 6, B * H, group, within)) return;
+  const int b = group / H, h = group - b * H;
   const size_t bh = (size_t)b * H + h;
-  const int key = blockIdx.x * 64 + wave * 16 + li;   // < Sp always
+  const int key = within * 64 + wave * 16 + li;   // < Sp always
 
   const unsigned short* kp = Ks + (bh * Sp + key) * 32;
   const unsigned short* vp = Vs + (bh * Sp + key) * 32;
@@ -369,12 +374,12 @@ extern "C" int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks,
                      (unsigned short*)dOt, D, B, H, Lq, Lqp);
   int rc = check_launch("a3d_attn_bwd_bf16(prep)");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(Lqp / 64, H, B * nsplit), dim3(256), 0, s, (const unsigned short*)Qs,
+  hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(xcd_grid(B * H, (Lqp / 64) * nsplit)), dim3(256), 0, s, (const unsigned short*)Qs,
                      (const unsigned short*)Ks, (const unsigned short*)Kt, (const unsigned short*)Vs, kmask,
                      (const unsigned short*)dOs, LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit);
   rc = check_launch("a3d_attn_bwd_bf16(dq)");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(Sp / 64, H, B), dim3(256), 0, s, (const unsigned short*)Qs,
+  hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(xcd_grid(B * H, Sp / 64)), dim3(256), 0, s, (const unsigned short*)Qs,
                      (const unsigned short*)Qt, (const unsigned short*)Ks, (const unsigned short*)Vs, kmask,
                      (const unsigned short*)dOs, (const unsigned short*)dOt, LSE, D, dK, dV, B, H, Lq, Lqp, S, Sp);
   return check_launch("a3d_attn_bwd_bf16(dkv)");

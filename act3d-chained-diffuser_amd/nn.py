@@ -6,6 +6,7 @@ FeedforwardLayer / RelativeCrossAttentionModule (layers.py:293-351), ParallelAtt
 (layers.py:7-290), torchvision's FeaturePyramidNetwork (third-party; restated) and a synthetic CLIP-RN50-shaped backbone.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -259,16 +260,81 @@ def load_synthetic_clip():
     return SyntheticCLIPResNet50(), ClipNormalize()
 
 
+def bn_act(x, bn, relu=True, residual=None):
+    """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
+    bf16 channels_last activation (vision.hip).  Three launches: stats, finalize, apply."""
+    N, C, H, W = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype and \
+            residual.is_contiguous(memory_format=torch.channels_last)
+    rows = N * H * W
+    dev = x.device
+    st = O.L.stream()
+    scale = torch.empty((2, C), device=dev, dtype=torch.float32)
+    train = 1 if bn.training else 0
+    partial, nslab = None, 1
+    if train:
+        nslab = O.L.load().a3d_bn_nslab(rows, C)
+        partial = torch.empty((nslab, 2, C), device=dev, dtype=torch.float32)
+        O.L.call("a3d_bn_stats", x.data_ptr(), partial.data_ptr(), rows, C, nslab, st)
+    O.L.call("a3d_bn_finalize", None if partial is None else partial.data_ptr(), nslab, rows, C, float(bn.eps),
+             float(bn.momentum if bn.momentum is not None else 0.1), bn.weight.data_ptr(), bn.bias.data_ptr(),
+             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale[0].data_ptr(), scale[1].data_ptr(), train, st)
+    y = torch.empty_like(x)
+    O.L.call("a3d_bn_apply", x.data_ptr(), None if residual is None else residual.data_ptr(), scale[0].data_ptr(),
+             scale[1].data_ptr(), y.data_ptr(), rows, C, 1 if relu else 0, st)
+    return y
+
+
+def fused_frozen_backbone_forward(bb, x):
+    """SyntheticCLIPResNet50.forward with MIOpen bf16 NHWC convolutions and the fused BatchNorm of vision.hip.
+    Same dataflow as the module's own forward (CLIP ModifiedResNet, model/utils/clip.py:28-43)."""
+    conv = lambda m, t: F.conv2d(t, m.weight, None, m.stride, m.padding)
+    x = bn_act(conv(bb.conv1, x), bb.bn1)
+    x = bn_act(conv(bb.conv2, x), bb.bn2)
+    x0 = bn_act(conv(bb.conv3, x), bb.bn3)
+    outs = [x0]
+    x = bb.avgpool(x0)
+    bns = [bb.bn1, bb.bn2, bb.bn3]
+    for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
+        for blk in layer:
+            out = bn_act(conv(blk.conv1, x), blk.bn1)
+            out = bn_act(conv(blk.conv2, out), blk.bn2)
+            out = blk.avgpool(out)
+            o3 = conv(blk.conv3, out)
+            if blk.downsample is not None:
+                idn = bn_act(conv(blk.downsample[1], blk.downsample[0](x)), blk.downsample[2], relu=False)
+                bns.append(blk.downsample[2])
+            else:
+                idn = x
+            x = bn_act(o3, blk.bn3, relu=True, residual=idn)
+            bns += [blk.bn1, blk.bn2, blk.bn3]
+        outs.append(x)
+    if bb.training:
+        torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+    return dict(zip(["res1", "res2", "res3", "res4", "res5"], outs))
+
+
+FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
+
+
 def run_frozen_backbone(backbone, x, dtype, keep_dtype=False):
     """Forward of the frozen backbone under no_grad.  For a reduced dtype the convolution weights are converted ONCE
     (the backbone is frozen, so there is no master copy to keep) instead of being re-cast by autocast at every step;
-    BatchNorm keeps fp32 parameters / running statistics and, as in the reference's train() mode, batch statistics."""
+    BatchNorm keeps fp32 parameters / running statistics and, as in the reference's train() mode, batch statistics.
+    On the GPU with bf16 the BatchNorm + ReLU + residual chain runs as the fused HIP kernels of vision.hip."""
     if dtype == torch.float32:
         return backbone(x)
     if getattr(backbone, "_conv_dtype", None) != dtype:
         for m in backbone.modules():
             if isinstance(m, nn.Conv2d):
                 m.to(dtype)
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         backbone._conv_dtype = dtype
-    feats = backbone(x.to(dtype))
+    xb = x.to(dtype)
+    if FUSED_BN and x.is_cuda and dtype == torch.bfloat16 and isinstance(backbone, SyntheticCLIPResNet50):
+        feats = fused_frozen_backbone_forward(backbone, xb.contiguous(memory_format=torch.channels_last))
+    else:
+        feats = backbone(xb)
     return feats if keep_dtype else {k: v.float() for k, v in feats.items()}

@@ -150,6 +150,19 @@ int a3d_add_rows(const float* x, const float* r, float* y, int B, int L, int E, 
 /* out = cat(traj[..., :npos] + upd[..., :npos], upd[..., npos:])  (diffusion_head.py:268-272) */
 int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, int D, int npos, void* stream);
 
+/* ---- frozen-backbone BatchNorm (train-mode statistics) + ReLU + residual, bf16 NHWC -------------- */
+/* x, residual, y: bf16, `rows` = N*H*W rows of C channels (torch channels_last storage).  C = 8 * divisor of 256. */
+int a3d_bn_nslab(size_t rows, int C);
+int a3d_bn_stats(const void* x, float* partial /* [nslab][2][C] */, size_t rows, int C, int nslab, void* stream);
+/* train: batch mean / biased variance from `partial`, running stats updated with `momentum` (unbiased variance), as
+ * nn.BatchNorm2d in train(); else the running statistics are used.  scale = gamma / sqrt(var + eps), shift = beta - mean*scale. */
+int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int C, float eps, float momentum, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float* scale, float* shift, int train,
+                    void* stream);
+/* y = relu?(x * scale[c] + shift[c] (+ residual)) */
+int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, size_t rows, int C,
+                 int relu, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------------- */
 int a3d_dbg_mfma_bf16(const void* A16x32, const void* B32x16, float* D16x16, void* stream);
 int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void* stream);

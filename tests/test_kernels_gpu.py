@@ -468,3 +468,53 @@ def test_diffusion_elementwise(a3d, dev):
         L.call("a3d_ddpm_step", mod_.data_ptr(), x0d.data_ptr(), epsd.data_ptr(), condd.data_ptr(), cmd.data_ptr(),
                cp.data_ptr(), cr.data_ptr(), out.data_ptr(), B * Ln, 9, 3, tstep, L.stream())
         report(f"ddpm step t={tstep}", out, ref_prev, 2e-6, 1e-6)
+
+
+@pytest.mark.parametrize("N,C,H", [(4, 32, 16), (3, 64, 24), (2, 256, 8), (2, 2048, 4)])
+def test_fused_batchnorm_train_relu_residual(a3d, dev, N, C, H):
+    """vision.hip BN (batch statistics + running-stat update) + residual + ReLU vs torch's fp32 batch_norm."""
+    g = torch.Generator().manual_seed(C + N)
+    x = (torch.randn(N, C, H, H, generator=g) * 1.7 + 0.3).to(torch.bfloat16)
+    res = torch.randn(N, C, H, H, generator=g).to(torch.bfloat16)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    ref_bn = torch.nn.BatchNorm2d(C)
+    ref_bn.load_state_dict(bn.state_dict())
+    ref = torch.relu(ref_bn(x.float()) + res.float())
+    bnd = bn.to(dev).train()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    rd = res.to(dev).contiguous(memory_format=torch.channels_last)
+    y = a3d.nn.bn_act(xd, bnd, relu=True, residual=rd)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    report("bn_act train", y.float(), ref, 2e-2, 8e-3)          # bf16 output rounding
+    report("bn running_mean", bnd.running_mean, ref_bn.running_mean, 1e-5, 1e-4)
+    report("bn running_var", bnd.running_var, ref_bn.running_var, 1e-5, 1e-4)
+    bnd.eval(); ref_bn.eval()
+    y2 = a3d.nn.bn_act(xd, bnd, relu=False)
+    report("bn_act eval", y2.float(), ref_bn(x.float()), 2e-2, 8e-3)
+
+
+def test_fused_frozen_backbone_matches_module(a3d, dev):
+    """Whole frozen backbone (train-mode BN): the fused-BN bf16 runner must be as close to the fp32 module as the plain
+    torch bf16 path (bf16 convs + torch BatchNorm) is -- both are bf16 activations through ~50 layers."""
+    import copy
+    torch.manual_seed(0)
+    bb32 = a3d.nn.SyntheticCLIPResNet50().to(dev).train()
+    bb, bb2 = copy.deepcopy(bb32), copy.deepcopy(bb32)
+    x = torch.rand(4, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = bb32(x)
+        a3d.nn.FUSED_BN = False
+        plain = a3d.nn.run_frozen_backbone(bb2, x, torch.bfloat16)
+        a3d.nn.FUSED_BN = True
+        got = a3d.nn.run_frozen_backbone(bb, x, torch.bfloat16)
+    rms = lambda t: t.float().pow(2).mean().sqrt().item()
+    for k in ref:
+        e_f, e_p, sc = rms(got[k] - ref[k]), rms(plain[k] - ref[k]), rms(ref[k])
+        print(f"[parity] backbone {k}: rms_err fused={e_f:.3e} torch_bf16={e_p:.3e} ref_rms={sc:.3e}")
+        assert got[k].shape == ref[k].shape and e_f <= 1.25 * e_p + 1e-3 * sc, k
+    report("backbone bn1.running_mean", bb.bn1.running_mean, bb32.bn1.running_mean, 1e-4, 1e-2)
+    report("backbone layer4 running_var", bb.layer4[2].bn3.running_var, bb32.layer4[2].bn3.running_var, 1e-3, 5e-2)
+    assert int(bb.layer3[0].bn2.num_batches_tracked) == 1
