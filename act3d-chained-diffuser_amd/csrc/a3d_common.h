@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int HD = 15;    // head dim of both models (60/4, 120/8)
+constexpr float LOG2E_F = 1.4426950408889634f;
 constexpr int HDP = 16;   // padded head dim
 
 // round-to-nearest-even fp32 -> bf16 bits (finite inputs)
@@ -36,6 +37,22 @@ __device__ __forceinline__ float bf2f(unsigned short h) {
 __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
   hi = f2bf(x);
   lo = f2bf(x - bf2f(hi));
+}
+
+// x ~= hi + lo + lo2 (24 mantissa bits: fp32-exact up to the last rounding).  The q / k score operands carry all three
+// parts: exp() turns an absolute score error into a relative weight error, and 2^-17 * |q||k| is ~1e-3 at |s| ~ 100.
+__device__ __forceinline__ void split_bf16_3(float x, unsigned short& hi, unsigned short& lo, unsigned short& lo2) {
+  hi = f2bf(x);
+  const float r1 = x - bf2f(hi);
+  lo = f2bf(r1);
+  lo2 = f2bf(r1 - bf2f(lo));
+}
+// row widths (bf16 elements) of the "rows" operand format: q / k rows are [hi16 | lo16 | lo2 16], v / dO rows [hi16 | lo16]
+constexpr int QKW = 48;
+constexpr int VRW = 32;
+// swizzled 16-byte slot of the [64][16] lo2 tile in LDS (conflict-free b128 reads by the 16 rows of one MFMA operand)
+__device__ __forceinline__ int lo2_off(int row, int seg) {
+  return (((row * 2 + seg) ^ (((row >> 3) & 1) << 3) ^ ((row >> 4) & 1)) * 8);
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(s16x8 a, s16x8 b, f32x4 c) {

@@ -5,9 +5,11 @@
 // (rope.hip).  The reference materialises the (B*H, Lq, S) score tensor three times; this file never does.
 //
 // Forward  (attn_fwd_kernel): flash-style online softmax on bf16 MFMA tiles (v_mfma_f32_16x16x32_bf16).
-//   Operands are split bf16 pairs x = hi + lo, so the K = 32 contraction of one MFMA carries
-//   [hi(16) | lo(16)] of the 16-padded head dim: two MFMAs give (k_hi + k_lo).(q_hi + q_lo), ~2^-17 relative
-//   -- what the 1e-3 parity bar against the fp32 reference needs; a single plain-bf16 MFMA does not meet it.
+//   Operands are split bf16 x = hi + lo (+ lo2), so the K = 32 contraction of one MFMA carries two 16-wide parts
+//   of the 16-padded head dim.  Scores use three parts per operand and three MFMAs ([k_hi|k_lo].[q_hi|q_hi] +
+//   [k_hi|k_lo].[q_lo|q_lo] + [k_hi|k_lo2].[q_lo2|q_hi]): fp32-grade logits, because exp() turns an absolute
+//   score error into a relative weight error and 2^-17 |q||k| (two parts) is ~1e-3 at |s| ~ 100 -- the parity
+//   bar against the fp32 reference.  A single plain-bf16 MFMA is off by 1e-1 there.
 //   The score tile is computed transposed (S^T = K Q^T) with the key rows of the two 16x16 tiles of a
 //   32-key half interleaved (tile T row i <-> key (i>>2)*8 + (i&3) + 4T) so that after exp() every lane
 //   already holds, in order, the 8 consecutive keys the P operand of the PV MFMA wants: P never touches LDS.
@@ -25,16 +27,18 @@ constexpr int VROW = 72;        // padded V^T row (bf16 elements): 144 B stride 
 constexpr int FLD = 20;         // padded fp32 row stride (80 B) for the backward's [64][16] tiles
 
 struct FwdStage {
-  s16x8 k, v;
+  s16x8 k, v, k2;
   float bias;
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(
+// __launch_bounds__(256, 2): <= 256 VGPRs, which lets the compiler keep MFMA results in VGPRs (no v_accvgpr_read copies)
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
     const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
     float* __restrict__ O, float* __restrict__ LSE, float* __restrict__ Op, float* __restrict__ Mp,
     float* __restrict__ Lp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit) {
   __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][KC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short K2sm[2][KC * 16];
   __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][2 * 16 * VROW];
   __shared__ __attribute__((aligned(16))) float biasS[2][KC];
 
@@ -50,11 +54,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
   const bool active = q0 < Lqp;
   const size_t bh = (size_t)b * H + h;
 
-  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = {0, 0, 0, 0, 0, 0, 0, 0};
+  // B operands of the three score MFMAs: [q_hi | q_hi], [q_lo | q_lo], [q_lo2 | q_hi]  (against A = [k_hi | k_lo],
+  // [k_hi | k_lo], [k_hi | k_lo2]): every product of (k_hi + k_lo + k_lo2)(q_hi + q_lo + q_lo2) above 2^-24
+  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = {0, 0, 0, 0, 0, 0, 0, 0}, q3 = {0, 0, 0, 0, 0, 0, 0, 0};
   if (active) {
-    const unsigned short* qp = Qs + (bh * Lqp + q0 + li) * 32;
+    const unsigned short* qp = Qs + (bh * Lqp + q0 + li) * QKW;
     qhi = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
     qlo = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
+    q3 = *reinterpret_cast<const s16x8*>(qp + ((g < 2) ? 32 + g * 8 : (g & 1) * 8));   // g < 2: q_lo2, else q_hi
   }
 
   const int nch = Sp / KC;
@@ -67,7 +74,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
   const int vplane = t >> 7, vd = (t >> 3) & 15, vseg = t & 7;
   auto stage_load = [&](int c) {
     FwdStage st;
-    st.k = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * KC + krow) * 32 + kseg * 8);
+    st.k = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * KC + krow) * QKW + kseg * 8);
+    if (t < 2 * KC) st.k2 = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * KC + (t >> 1)) * QKW + 32 + (t & 1) * 8);
     st.v = *reinterpret_cast<const s16x8*>(Vt + ((bh * 2 + vplane) * 16 + vd) * Sp + (size_t)c * KC + vseg * 8);
     st.bias = 0.f;
     if (t < KC) {
@@ -80,11 +88,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
   };
   auto stage_store = [&](const FwdStage& st, int buf) {
     *reinterpret_cast<s16x8*>(&Ksm[buf][krow * 32 + ((kseg ^ ((krow >> 3) & 3)) * 8)]) = st.k;
-    *reinterpret_cast<s16x8*>(&Vsm[buf][(vplane * 16 + vd) * VROW + vseg * 8]) = st.v;
+    if (t < 2 * KC) *reinterpret_cast<s16x8*>(&K2sm[buf][lo2_off(t >> 1, t & 1)]) = st.k2;
+    // padded channel 15 of V_hi := 1.0, so that acc[d = 15] accumulates the softmax denominator sum_k (p_hi + p_lo)
+    // on the MFMA pipe, from exactly the rounded P the numerator uses (no VALU row sums, self-consistent weights)
+    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    *reinterpret_cast<s16x8*>(&Vsm[buf][(vplane * 16 + vd) * VROW + vseg * 8]) = (vplane == 0 && vd == 15) ? ones : st.v;
     if (t < KC) biasS[buf][t] = st.bias;
   };
 
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
   if (c_beg < c_end) {
@@ -106,8 +118,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
           const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
           const s16x8 kf = *reinterpret_cast<const s16x8*>(&Ksm[buf][row * 32 + ((g ^ ((row >> 3) & 3)) * 8)]);
           f32x4 c4 = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
+          s16x8 k3 = kf;   // lanes g < 2 already hold k_hi; g >= 2 fetch k_lo2
+          if (g >= 2) k3 = *reinterpret_cast<const s16x8*>(&K2sm[buf][lo2_off(row, g - 2)]);
           c4 = mfma_bf16_16x16x32(kf, qhi, c4);
           c4 = mfma_bf16_16x16x32(kf, qlo, c4);
+          c4 = mfma_bf16_16x16x32(k3, q3, c4);
           s[hf][T] = c4;
         }
       }
@@ -122,8 +137,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
-      float psum = 0.f;
+      // p = exp(s - m) as exp2(fma(s, log2 e, -m log2 e)): one packed FMA per two scores + v_exp_f32
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const float nm = -m_use * LOG2E_F;
+      const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));   // m_run = -inf -> 0
+      const f32x2 c2 = {LOG2E_F, LOG2E_F}, nm2 = {nm, nm};
       s16x8 phi[2], plo[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -132,28 +151,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            const float p0 = __expf(s[hf][T][2 * pr] - m_use);
-            const float p1 = __expf(s[hf][T][2 * pr + 1] - m_use);
-            psum += p0 + p1;
+            const f32x2 arg = __builtin_elementwise_fma((f32x2){s[hf][T][2 * pr], s[hf][T][2 * pr + 1]}, c2, nm2);
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
             // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
             // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
-            typedef __attribute__((ext_vector_type(2))) float f32x2;
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-            const bf16x2 hb = __builtin_convertvector((f32x2){p0, p1}, bf16x2);
-            const unsigned int h2 = __builtin_bit_cast(unsigned int, hb);
-            const float r0 = p0 - __uint_as_float(h2 << 16);
-            const float r1 = p1 - __uint_as_float(h2 & 0xFFFF0000u);
-            const bf16x2 lb = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
-            const unsigned int l2 = __builtin_bit_cast(unsigned int, lb);
+            const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
+            const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
             hw[T * 2 + pr] = h2;
-            lw[T * 2 + pr] = l2;
+            lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
           }
         }
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         phi[hf] = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
         plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
       }
-      l_run = l_run * alpha + psum;
       m_run = m_new;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] *= alpha;
@@ -171,8 +182,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
   }
 
   if (!active) return;
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float l_tot = __shfl(acc[3], 48 + li, 64);   // channel 15 (lane group g = 3, register 3) holds sum_k p
   const int q = q0 + li;
   if (nsplit == 1) {
     const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
@@ -247,13 +257,15 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(
   }
 }
 
-__device__ __forceinline__ float4 load_split4(const unsigned short* p) {   // p -> 4 hi at p[0..3], 4 lo at p[16..19]
+// q / k rows: p -> 4 hi at p[0..3], 4 lo at p[16..19], 4 lo2 at p[32..35]; x = hi + (lo + lo2)
+__device__ __forceinline__ float4 load_split4(const unsigned short* p) {
   const s16x4 hi = *reinterpret_cast<const s16x4*>(p);
   const s16x4 lo = *reinterpret_cast<const s16x4*>(p + 16);
-  return make_float4(bf2f((unsigned short)hi[0]) + bf2f((unsigned short)lo[0]),
-                     bf2f((unsigned short)hi[1]) + bf2f((unsigned short)lo[1]),
-                     bf2f((unsigned short)hi[2]) + bf2f((unsigned short)lo[2]),
-                     bf2f((unsigned short)hi[3]) + bf2f((unsigned short)lo[3]));
+  const s16x4 l2 = *reinterpret_cast<const s16x4*>(p + 32);
+  return make_float4(bf2f((unsigned short)hi[0]) + (bf2f((unsigned short)lo[0]) + bf2f((unsigned short)l2[0])),
+                     bf2f((unsigned short)hi[1]) + (bf2f((unsigned short)lo[1]) + bf2f((unsigned short)l2[1])),
+                     bf2f((unsigned short)hi[2]) + (bf2f((unsigned short)lo[2]) + bf2f((unsigned short)l2[2])),
+                     bf2f((unsigned short)hi[3]) + (bf2f((unsigned short)lo[3]) + bf2f((unsigned short)l2[3])));
 }
 
 // stage 64 keys of K (from QK format) and V (from VT format) as fp32 [64][FLD]
@@ -265,7 +277,7 @@ __device__ __forceinline__ void stage_kv_f32(float* Kf, float* Vf, float* biasS,
   const int t = threadIdx.x;
   {
     const int row = t >> 2, qd = t & 3;
-    const float4 v = load_split4(Ks + (bh * Sp + (size_t)c * KC + row) * 32 + qd * 4);
+    const float4 v = load_split4(Ks + (bh * Sp + (size_t)c * KC + row) * QKW + qd * 4);
     *reinterpret_cast<float4*>(&Kf[row * FLD + qd * 4]) = v;
   }
   {
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), dof = qf;
   float lse_q = INFINITY, d_q = 0.f;
   if (active) {
-    qf = load_split4(Qs + (bh * Lqp + q) * 32 + g * 4);
+    qf = load_split4(Qs + (bh * Lqp + q) * QKW + g * 4);
     dof = *reinterpret_cast<const float4*>(&dOh[(bh * Lqp + q) * HDP + g * 4]);
     if (q < Lq) {
       lse_q = LSE[bh * Lqp + q];
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
   const size_t bh = (size_t)b * H + h;
   const int key = blockIdx.x * 64 + wave * 16 + li;   // < Sp always
 
-  const float4 kf = load_split4(Ks + (bh * Sp + key) * 32 + g * 4);
+  const float4 kf = load_split4(Ks + (bh * Sp + key) * QKW + g * 4);
   float4 vf;
   {
     float tmp[4];
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
       const int q = qc + row;
       float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ov = qv;
       if (q < Lqp) {
-        qv = load_split4(Qs + (bh * Lqp + q) * 32 + qd * 4);
+        qv = load_split4(Qs + (bh * Lqp + q) * QKW + qd * 4);
         ov = *reinterpret_cast<const float4*>(&dOh[(bh * Lqp + q) * HDP + qd * 4]);
       }
       *reinterpret_cast<float4*>(&Qf[row * FLD + qd * 4]) = qv;

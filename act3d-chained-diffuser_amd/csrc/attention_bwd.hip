@@ -2,7 +2,9 @@
 //
 // dQ, dK, dV of  O = softmax(Q K^T + mask) V  by recomputation from the saved log-sum-exp.  Every contraction has
 // both operands as bf16 hi+lo pairs (2^-17 operand precision, fp32 accumulate):
-//     S   = Q K^T          2 MFMAs / 16x16 tile     [x_hi | x_lo] . [y_hi | y_hi]  +  [x_hi | x_lo] . [y_lo | y_lo]
+//     S   = Q K^T          3 MFMAs / 16x16 tile     [x_hi | x_lo] . [y_hi | y_hi]  +  [x_hi | x_lo] . [y_lo | y_lo]
+//                                                   + [x_hi | x_lo2] . [y_lo2 | y_hi]   (three-part q, k: fp32-grade logits,
+//                                                   the same scores the forward saw -> P_bwd == P_fwd)
 //     dP  = dO V^T         2 MFMAs / 16x16 tile
 //     dQ += dS K, dK += dS^T Q, dV += P^T dO        3 MFMAs / (16 x 32-deep) block:  A_hi B_hi + A_hi B_lo + A_lo B_hi
 // against 4 f32 MFMAs (32 cycles each) per 16x16x16 block in the exact-f32 version it replaces (attention.hip,
@@ -110,11 +112,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_bf16_kernel(
 
 // ------------------------------------------------------------------------------------------------ dQ
 struct DqStage {
-  s16x8 k, v, kt;
+  s16x8 k, v, kt, k2;
   float bias;
 };
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
     const unsigned short* __restrict__ Kt, const unsigned short* __restrict__ Vs,
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
   __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][BKC * 32];
   __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][BKC * 32];
   __shared__ __attribute__((aligned(16))) unsigned short Ktm[2][2 * 16 * BVROW];
+  __shared__ __attribute__((aligned(16))) unsigned short K2sm[2][BKC * 16];
   __shared__ __attribute__((aligned(16))) float biasS[2][BKC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -136,13 +139,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
   const bool active = q0 < Lqp;
   const int q = q0 + li;
 
-  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = qhi, dohi = qhi, dolo = qhi;
+  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = qhi, q3 = qhi, dohi = qhi, dolo = qhi;
   float lse_q = INFINITY, d_q = 0.f;
   if (active) {
-    const unsigned short* qp = Qs + (bh * Lqp + q) * 32;
+    const unsigned short* qp = Qs + (bh * Lqp + q) * QKW;
     qhi = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
     qlo = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
-    const unsigned short* op = dOs + (bh * Lqp + q) * 32;
+    q3 = *reinterpret_cast<const s16x8*>(qp + ((g < 2) ? 32 + g * 8 : (g & 1) * 8));   // [q_lo2 | q_hi], as in the forward
+    const unsigned short* op = dOs + (bh * Lqp + q) * VRW;
     dohi = *reinterpret_cast<const s16x8*>(op + (g & 1) * 8);
     dolo = *reinterpret_cast<const s16x8*>(op + 16 + (g & 1) * 8);
     if (q < Lq) {
@@ -158,8 +162,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
   const int vplane = t >> 7, vd = (t >> 3) & 15, vseg = t & 7;
   auto stage_load = [&](int c) {
     DqStage st;
-    st.k = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * BKC + krow) * 32 + kseg * 8);
-    st.v = *reinterpret_cast<const s16x8*>(Vs + (bh * Sp + (size_t)c * BKC + krow) * 32 + kseg * 8);
+    st.k = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * BKC + krow) * QKW + kseg * 8);
+    if (t < 2 * BKC) st.k2 = *reinterpret_cast<const s16x8*>(Ks + (bh * Sp + (size_t)c * BKC + (t >> 1)) * QKW + 32 + (t & 1) * 8);
+    st.v = *reinterpret_cast<const s16x8*>(Vs + (bh * Sp + (size_t)c * BKC + krow) * VRW + kseg * 8);
     st.kt = *reinterpret_cast<const s16x8*>(Kt + ((bh * 2 + vplane) * 16 + vd) * Sp + (size_t)c * BKC + vseg * 8);
     st.bias = 0.f;
     if (t < BKC) {
@@ -172,12 +177,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
   };
   auto stage_store = [&](const DqStage& st, int buf) {
     *reinterpret_cast<s16x8*>(&Ksm[buf][rows_off(krow, kseg)]) = st.k;
+    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&K2sm[buf][lo2_off(t >> 1, t & 1)]) = st.k2;
     *reinterpret_cast<s16x8*>(&Vsm[buf][rows_off(krow, kseg)]) = st.v;
     *reinterpret_cast<s16x8*>(&Ktm[buf][(vplane * 16 + vd) * BVROW + vseg * 8]) = st.kt;
     if (t < BKC) biasS[buf][t] = st.bias;
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // P = exp(s - lse) = exp2(fma(s, log2 e, -lse log2 e)) (one packed FMA per two scores); -D rides in as the MFMA
+  // accumulator init of dP, so dS = P * (dP - D) is one packed multiply
+  const float nl = -lse_q * LOG2E_F;
+  const f32x2_t c2 = {LOG2E_F, LOG2E_F}, nl2 = {nl, nl};
+  const f32x4 nd4 = {-d_q, -d_q, -d_q, -d_q};
   if (c_beg < c_end) {
     stage_store(stage_load(c_beg), 0);
     __syncthreads();
@@ -197,15 +208,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
           const s16x8 kf = *reinterpret_cast<const s16x8*>(&Ksm[buf][rows_off(row, g)]);
           const s16x8 vf = *reinterpret_cast<const s16x8*>(&Vsm[buf][rows_off(row, g)]);
           f32x4 sT = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
+          s16x8 k3 = kf;
+          if (g >= 2) k3 = *reinterpret_cast<const s16x8*>(&K2sm[buf][lo2_off(row, g - 2)]);
           sT = mfma_bf16_16x16x32(kf, qhi, sT);
           sT = mfma_bf16_16x16x32(kf, qlo, sT);
-          f32x4 dpT = {0.f, 0.f, 0.f, 0.f};
+          sT = mfma_bf16_16x16x32(k3, q3, sT);
+          f32x4 dpT = nd4;
           dpT = mfma_bf16_16x16x32(vf, dohi, dpT);
           dpT = mfma_bf16_16x16x32(vf, dolo, dpT);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sT[r] - lse_q);
-            ds[T * 4 + r] = p * (dpT[r] - d_q);
+          for (int pr = 0; pr < 2; ++pr) {
+            const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){sT[2 * pr], sT[2 * pr + 1]}, c2, nl2);
+            const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            const f32x2_t d2 = p2 * (f32x2_t){dpT[2 * pr], dpT[2 * pr + 1]};
+            ds[T * 4 + 2 * pr] = d2.x;
+            ds[T * 4 + 2 * pr + 1] = d2.y;
           }
         }
         s16x8 dhi, dlo;
@@ -228,11 +245,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 struct DkvStage {
-  s16x8 q, o, qt, ot;
+  s16x8 q, o, qt, ot, q2;
   float lse, d;
 };
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Qt,
     const unsigned short* __restrict__ Ks, const unsigned short* __restrict__ Vs,
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
@@ -240,6 +257,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
     float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp) {
   __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][BKC * 32];
   __shared__ __attribute__((aligned(16))) unsigned short Osm[2][BKC * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Q2sm[2][BKC * 16];
   __shared__ __attribute__((aligned(16))) unsigned short Qtm[2][2 * 16 * BVROW];
   __shared__ __attribute__((aligned(16))) unsigned short Otm[2][2 * 16 * BVROW];
   __shared__ __attribute__((aligned(16))) float lseS[2][BKC];
@@ -252,23 +270,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
   const size_t bh = (size_t)b * H + h;
   const int key = within * 64 + wave * 16 + li;   // < Sp always
 
-  const unsigned short* kp = Ks + (bh * Sp + key) * 32;
-  const unsigned short* vp = Vs + (bh * Sp + key) * 32;
+  const unsigned short* kp = Ks + (bh * Sp + key) * QKW;
+  const unsigned short* vp = Vs + (bh * Sp + key) * VRW;
   const s16x8 khi = *reinterpret_cast<const s16x8*>(kp + (g & 1) * 8);
   const s16x8 klo = *reinterpret_cast<const s16x8*>(kp + 16 + (g & 1) * 8);
+  const s16x8 k3 = *reinterpret_cast<const s16x8*>(kp + ((g < 2) ? 32 + g * 8 : (g & 1) * 8));   // [k_lo2 | k_hi] vs A = [q_hi | q_lo2]
   const s16x8 vhi = *reinterpret_cast<const s16x8*>(vp + (g & 1) * 8);
   const s16x8 vlo = *reinterpret_cast<const s16x8*>(vp + 16 + (g & 1) * 8);
   bool valid = key < S;
   if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
   const float bias_k = valid ? 0.f : -INFINITY;
+  const f32x4 bias4 = {bias_k, bias_k, bias_k, bias_k};
+  const f32x2_t c2 = {LOG2E_F, LOG2E_F};
 
   const int qrow = t >> 2, qseg = t & 3;
   const int pplane = t >> 7, pd = (t >> 3) & 15, pseg = t & 7;
   auto stage_load = [&](int c) {
     DkvStage st;
-    const size_t base = (bh * Lqp + (size_t)c * BKC + qrow) * 32 + qseg * 8;
-    st.q = *reinterpret_cast<const s16x8*>(Qs + base);
-    st.o = *reinterpret_cast<const s16x8*>(dOs + base);
+    st.q = *reinterpret_cast<const s16x8*>(Qs + (bh * Lqp + (size_t)c * BKC + qrow) * QKW + qseg * 8);
+    if (t < 2 * BKC) st.q2 = *reinterpret_cast<const s16x8*>(Qs + (bh * Lqp + (size_t)c * BKC + (t >> 1)) * QKW + 32 + (t & 1) * 8);
+    st.o = *reinterpret_cast<const s16x8*>(dOs + (bh * Lqp + (size_t)c * BKC + qrow) * VRW + qseg * 8);
     const size_t pb = ((bh * 2 + pplane) * 16 + pd) * Lqp + (size_t)c * BKC + pseg * 8;
     st.qt = *reinterpret_cast<const s16x8*>(Qt + pb);
     st.ot = *reinterpret_cast<const s16x8*>(dOt + pb);
@@ -286,10 +307,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
   };
   auto stage_store = [&](const DkvStage& st, int buf) {
     *reinterpret_cast<s16x8*>(&Qsm[buf][rows_off(qrow, qseg)]) = st.q;
+    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&Q2sm[buf][lo2_off(t >> 1, t & 1)]) = st.q2;
     *reinterpret_cast<s16x8*>(&Osm[buf][rows_off(qrow, qseg)]) = st.o;
     *reinterpret_cast<s16x8*>(&Qtm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.qt;
     *reinterpret_cast<s16x8*>(&Otm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.ot;
-    if (t < BKC) { lseS[buf][t] = st.lse; dS_[buf][t] = st.d; }
+    if (t < BKC) { lseS[buf][t] = -st.lse * LOG2E_F; dS_[buf][t] = -st.d; }   // -lse log2 e (masked row: -inf), -D
   };
 
   f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
@@ -309,18 +331,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(
         const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
         const s16x8 qf = *reinterpret_cast<const s16x8*>(&Qsm[buf][rows_off(row, g)]);
         const s16x8 of = *reinterpret_cast<const s16x8*>(&Osm[buf][rows_off(row, g)]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        // the key mask (0 / -inf) and -D enter as MFMA accumulator inits; P = exp2(fma(s, log2 e, -lse log2 e))
+        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
+        f32x4 s = bias4, dp = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
+        s16x8 q3 = qf;
+        if (g >= 2) q3 = *reinterpret_cast<const s16x8*>(&Q2sm[buf][lo2_off(row, g - 2)]);
         s = mfma_bf16_16x16x32(qf, khi, s);
         s = mfma_bf16_16x16x32(qf, klo, s);
+        s = mfma_bf16_16x16x32(q3, k3, s);
         dp = mfma_bf16_16x16x32(of, vhi, dp);
         dp = mfma_bf16_16x16x32(of, vlo, dp);
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[r] + bias_k - l4[r]);
-          p8[T * 4 + r] = p;
-          ds8[T * 4 + r] = p * (dp[r] - d4[r]);
+        for (int pr = 0; pr < 2; ++pr) {
+          const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){s[2 * pr], s[2 * pr + 1]}, c2, (f32x2_t){nl4[2 * pr], nl4[2 * pr + 1]});
+          const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+          const f32x2_t d2 = p2 * (f32x2_t){dp[2 * pr], dp[2 * pr + 1]};
+          p8[T * 4 + 2 * pr] = p2.x;
+          p8[T * 4 + 2 * pr + 1] = p2.y;
+          ds8[T * 4 + 2 * pr] = d2.x;
+          ds8[T * 4 + 2 * pr + 1] = d2.y;
         }
       }
       s16x8 phi, plo, dhi, dlo;

@@ -133,7 +133,8 @@ constexpr int WG_MC = 64;    // rows of m staged per step
 constexpr int WG_LD = 68;    // padded LDS row stride (floats)
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(
     const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx,
-    float* __restrict__ dW, int lddw, float* __restrict__ db, int M, int N, int K, int rows_per_split) {
+    float* __restrict__ dW, int lddw, float* __restrict__ db, int M, int N, int K, int rows_per_split,
+    float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float Ys[WG_MC * WG_LD];
   __shared__ __attribute__((aligned(16))) float Xs[WG_MC * WG_LD];
   const int t = threadIdx.x;
@@ -207,10 +208,38 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(
       const int n = n0 + wave * 16 + g * 4 + r;
       if (n >= N) continue;
       const float v = acc[kt][r];
-      if (k < K) atomicAdd(&dW[(size_t)n * lddw + k], v);
+      if (partial) partial[((size_t)blockIdx.z * N + n) * KE + k] = v;   // two-stage: plain store, reduced below
+      else if (k < K) atomicAdd(&dW[(size_t)n * lddw + k], v);
       else atomicAdd(&db[n], v);
     }
   }
+}
+
+// second stage of the split-M weight gradient: dW[n][k] (+ db[n]) += sum_z partial[z][n][k], z in fixed order
+// (deterministic, and no memory-side float atomics: with >= 256 splits those serialise on the N*K addresses)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit,
+                                                           float* __restrict__ dW, int lddw, float* __restrict__ db,
+                                                           int N, int K, int KE) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const int total = N * KE;
+  float s0 = 0.f, s1 = 0.f;
+  if (idx < total) {
+    int z = zg;
+    for (; z + 4 < nsplit; z += 8) {
+      s0 += partial[(size_t)z * total + idx];
+      s1 += partial[(size_t)(z + 4) * total + idx];
+    }
+    if (z < nsplit) s0 += partial[(size_t)z * total + idx];
+  }
+  red[zg][lane] = s0 + s1;
+  __syncthreads();
+  if (zg != 0 || idx >= total) return;
+  const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int n = idx / KE, k = idx - n * KE;
+  if (k < K) dW[(size_t)n * lddw + k] += v;
+  else db[n] += v;
 }
 
 // ---------------------------------------------------------------- residual + LayerNorm
@@ -333,24 +362,60 @@ extern "C" int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
   return check_launch("a3d_linear_fwd");
 }
 
-extern "C" int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
-                                float* db, int M, int N, int K, void* stream) {
+// two-stage threshold: with more splits than this the atomics of the one-stage kernel dominate
+constexpr int WG_TWO_STAGE_MIN_SPLIT = 32;
+
+static void wgrad_plan(int M, int N, int KE, bool have_ws, int* nsplit_out, int* rows_out) {
+  const int tiles = cdiv(N, 64) * cdiv(KE, 64);
+  // one-stage: ~256 workgroups in flight, at least 256 rows (4 stages) per workgroup
+  static int target_wgs = getenv("A3D_WGRAD_WGS") ? atoi(getenv("A3D_WGRAD_WGS")) : 256;
+  int nsplit = max(1, min(cdiv(M, 256), cdiv(target_wgs, tiles)));
+  if (have_ws && nsplit >= WG_TWO_STAGE_MIN_SPLIT) {
+    // two-stage: no atomics, so oversubscribe (up to 4 workgroups per CU hide the stage latency), >= 256-row chunks
+    static int target2 = getenv("A3D_WGRAD_WGS2") ? atoi(getenv("A3D_WGRAD_WGS2")) : 1024;
+    nsplit = max(nsplit, min(cdiv(M, 256), cdiv(target2, tiles)));
+  }
+  int rows = cdiv(cdiv(M, nsplit), WG_MC) * WG_MC;
+  *nsplit_out = cdiv(M, rows);
+  *rows_out = rows;
+}
+
+extern "C" size_t a3d_linear_wgrad_ws_bytes(int M, int N, int K, int has_bias) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int KE = has_bias ? K + 1 : K;
+  int nsplit, rows;
+  wgrad_plan(M, N, KE, true, &nsplit, &rows);
+  return nsplit >= WG_TWO_STAGE_MIN_SPLIT ? (size_t)nsplit * N * KE * sizeof(float) : 0;
+}
+
+extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
+                                   float* db, int M, int N, int K, float* ws, size_t ws_bytes, void* stream) {
   if (!dY || !X || !dW || M < 0 || N <= 0 || K <= 0) {
     set_error("a3d_linear_wgrad: bad argument (M=%d N=%d K=%d)", M, N, K);
     return A3D_ERR_ARG;
   }
   if (M == 0) return A3D_OK;
   const int KE = db ? K + 1 : K;
-  // split the M reduction: ~256-512 workgroups in flight, at least 256 rows (4 stages) per workgroup
-  const int tiles = cdiv(N, 64) * cdiv(KE, 64);
-  static int target_wgs = getenv("A3D_WGRAD_WGS") ? atoi(getenv("A3D_WGRAD_WGS")) : 256;
-  int nsplit = max(1, min(cdiv(M, 256), cdiv(target_wgs, tiles)));
-  int rows = cdiv(cdiv(M, nsplit), WG_MC) * WG_MC;
-  nsplit = cdiv(M, rows);
+  int nsplit, rows;
+  wgrad_plan(M, N, KE, ws != nullptr, &nsplit, &rows);
+  const bool two_stage = ws && nsplit >= WG_TWO_STAGE_MIN_SPLIT;
+  if (two_stage && ws_bytes < (size_t)nsplit * N * KE * sizeof(float)) {
+    set_error("a3d_linear_wgrad_ws: workspace too small (%zu bytes, need %zu)", ws_bytes,
+              (size_t)nsplit * N * KE * sizeof(float));
+    return A3D_ERR_ARG;
+  }
   dim3 grid(cdiv(N, 64), cdiv(KE, 64), nsplit);
   hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dW,
-                     lddw, db, M, N, K, rows);
+                     lddw, db, M, N, K, rows, two_stage ? ws : nullptr);
+  if (two_stage)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * KE, 64)), dim3(256), 0, (hipStream_t)stream, ws, nsplit, dW,
+                       lddw, db, N, K, KE);
   return check_launch("a3d_linear_wgrad");
+}
+
+extern "C" int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
+                                float* db, int M, int N, int K, void* stream) {
+  return a3d_linear_wgrad_ws(dY, lddy, X, ldx, dW, lddw, db, M, N, K, nullptr, 0, stream);
 }
 
 extern "C" int a3d_add_layernorm_fwd(const float* A, const float* R, const float* gamma, const float* beta,

@@ -6,7 +6,8 @@
 // are recomputed from xyz in-kernel (12 B/token instead of 8E B/token) and the result is written straight
 // into the MFMA operand layouts used by attention.hip:
 //
-//   QK format  [B][H][Npad][32] bf16 : per row  hi(16) | lo(16)   (x = hi + lo, head dim 15 padded to 16)
+//   rows format [B][H][Npad][W] bf16 : per row  hi(16) | lo(16) [| lo2(16)]  (head dim 15 padded to 16); W = 48
+//              (x = hi + lo + lo2) for the q / k score operands, W = 32 (x = hi + lo) for v / dO rows
 //   VT format  [B][H][2][16][Npad] bf16 : plane 0 = hi, plane 1 = lo, transposed so that 8 consecutive
 //              keys of one channel are one 16-byte MFMA A-fragment.
 // Rows n >= N and slot d = 15 are written as zeros (finite padding is required by 0 * x in PV).
@@ -54,32 +55,33 @@ __device__ __forceinline__ void rope_tile_to_lds(float* T, int ldt, const float*
 // Writes the rotated, scaled rows in QK format (rows_out) and / or VT format (planes_out); either may be null.
 __global__ __launch_bounds__(256) void rope_split_kernel(
     const float* __restrict__ Y, int ldy, const float* __restrict__ xyz, const float* __restrict__ freq,
-    float scale, unsigned short* __restrict__ rows_out, unsigned short* __restrict__ planes_out, int B, int N,
-    int Npad, int E, int H) {
+    float scale, unsigned short* __restrict__ rows_out, int rows_width, unsigned short* __restrict__ planes_out, int B,
+    int N, int Npad, int E, int H) {
   extern __shared__ __attribute__((aligned(16))) float T[];
   const int ldt = E + 1;
   const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
   rope_tile_to_lds(T, ldt, Y, ldy, xyz, freq, scale, b, n0, N, E);
   __syncthreads();
   if (rows_out) {
-    for (int idx = threadIdx.x; idx < RT_ROWS * H * 4; idx += blockDim.x) {
-      const int seg = idx & 3;
-      const int r = (idx >> 2) % RT_ROWS;
-      const int h = (idx >> 2) / RT_ROWS;
+    const int nseg = rows_width >> 3;   // 4 (hi, lo) or 6 (hi, lo, lo2) 16-byte segments per row
+    for (int idx = threadIdx.x; idx < RT_ROWS * H * nseg; idx += blockDim.x) {
+      const int seg = idx % nseg;
+      const int r = (idx / nseg) % RT_ROWS;
+      const int h = (idx / nseg) / RT_ROWS;
       const int n = n0 + r;
       if (n >= Npad) continue;
       const int dbase = (seg & 1) * 8;
-      const bool want_lo = (seg >> 1) != 0;
+      const int part = seg >> 1;
       s16x8 out;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int d = dbase + j;
         const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
-        unsigned short hi, lo;
-        split_bf16(v, hi, lo);
-        out[j] = (short)(want_lo ? lo : hi);
+        unsigned short hi, lo, lo2;
+        split_bf16_3(v, hi, lo, lo2);
+        out[j] = (short)(part == 0 ? hi : (part == 1 ? lo : lo2));
       }
-      *reinterpret_cast<s16x8*>(rows_out + (((size_t)b * H + h) * Npad + n) * 32 + seg * 8) = out;
+      *reinterpret_cast<s16x8*>(rows_out + (((size_t)b * H + h) * Npad + n) * rows_width + seg * 8) = out;
     }
   }
   if (planes_out) {
@@ -154,25 +156,30 @@ static int check_rope_args(const char* fn, int B, int N, int Npad, int E, int H)
 }
 
 extern "C" int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
-                              void* rows_out, void* planes_out, int B, int N, int Npad, int E, int H, void* stream) {
+                              void* rows_out, int rows_width, void* planes_out, int B, int N, int Npad, int E, int H,
+                              void* stream) {
   int rc = check_rope_args("a3d_rope_split", B, N, Npad, E, H);
   if (rc) return rc;
+  if (rows_out && rows_width != VRW && rows_width != QKW) {
+    set_error("a3d_rope_split: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", rows_width);
+    return A3D_ERR_ARG;
+  }
   if (!Y || (!rows_out && !planes_out) || (xyz && !freq)) { set_error("a3d_rope_split: null pointer"); return A3D_ERR_ARG; }
   dim3 grid(Npad / RT_ROWS, B);
   const size_t lds = (size_t)RT_ROWS * (E + 1) * sizeof(float);
   hipLaunchKernelGGL(rope_split_kernel, grid, dim3(256), lds, (hipStream_t)stream, Y, ldy, xyz, freq, scale,
-                     (unsigned short*)rows_out, (unsigned short*)planes_out, B, N, Npad, E, H);
+                     (unsigned short*)rows_out, rows_width, (unsigned short*)planes_out, B, N, Npad, E, H);
   return check_launch("a3d_rope_split");
 }
 
 extern "C" int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
                                  void* dst, int B, int N, int Npad, int E, int H, void* stream) {
-  return a3d_rope_split(Y, ldy, xyz, freq, scale, dst, nullptr, B, N, Npad, E, H, stream);
+  return a3d_rope_split(Y, ldy, xyz, freq, scale, dst, QKW, nullptr, B, N, Npad, E, H, stream);
 }
 
 extern "C" int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int E, int H,
                             void* stream) {
-  return a3d_rope_split(Y, ldy, nullptr, nullptr, 1.0f, nullptr, dst, B, N, Npad, E, H, stream);
+  return a3d_rope_split(Y, ldy, nullptr, nullptr, 1.0f, nullptr, 0, dst, B, N, Npad, E, H, stream);
 }
 
 extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq,

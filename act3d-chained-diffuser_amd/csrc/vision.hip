@@ -30,8 +30,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (rsub < nsub) {
-    for (size_t r = r0 + rsub; r < r1; r += nsub) {
-      const uint4 v = x[r * tpr + cp];
+    auto accum = [&](const uint4& v) {
       const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -39,7 +38,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__
         s[2 * j] += a; q[2 * j] += a * a;
         s[2 * j + 1] += b; q[2 * j + 1] += b * b;
       }
+    };
+    size_t r = r0 + rsub;
+    const size_t step = (size_t)nsub;
+    // four independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+    for (; r + 3 * step < r1; r += 4 * step) {
+      const uint4 v0 = x[r * tpr + cp];
+      const uint4 v1 = x[(r + step) * tpr + cp];
+      const uint4 v2 = x[(r + 2 * step) * tpr + cp];
+      const uint4 v3 = x[(r + 3 * step) * tpr + cp];
+      accum(v0); accum(v1); accum(v2); accum(v3);
     }
+    for (; r < r1; r += step) accum(x[r * tpr + cp]);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s[j]; red[threadIdx.x * 16 + 8 + j] = q[j]; }
@@ -59,18 +69,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__
   }
 }
 
-// grid ceil(C / 64); 64 channels x 4 slab-groups per workgroup
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nslab, double rows, int C,
-                                                          float eps, float momentum, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ scale,
-                                                          float* __restrict__ shift, int train) {
-  __shared__ double rs[4][64], rq[4][64];
-  const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+// grid ceil(C / 16); 16 channels x 64 slab-groups per 1024-thread workgroup: the reduction over <= 1024 slabs is
+// <= 16 dependent-latency rounds (it was 128 with 4 slab-groups, 35 us per BatchNorm layer)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nslab, double rows, int C,
+                                                           float eps, float momentum, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ scale,
+                                                           float* __restrict__ shift, int train) {
+  __shared__ double rs[64][17], rq[64][17];
+  const int cx = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   double s = 0.0, q = 0.0;
   if (train && c < C) {
-    for (int i = sg; i < nslab; i += 4) {
+    for (int i = sg; i < nslab; i += 64) {
       s += (double)partial[(size_t)i * 2 * C + c];
       q += (double)partial[(size_t)i * 2 * C + C + c];
     }
@@ -81,8 +92,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   if (sg != 0 || c >= C) return;
   double mean, var;
   if (train) {
-    s = rs[0][cx] + rs[1][cx] + rs[2][cx] + rs[3][cx];
-    q = rq[0][cx] + rq[1][cx] + rq[2][cx] + rq[3][cx];
+    s = 0.0; q = 0.0;
+    for (int u = 0; u < 64; ++u) { s += rs[u][cx]; q += rq[u][cx]; }
     mean = s / rows;
     var = q / rows - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -139,8 +150,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
 using namespace a3d;
 
 extern "C" int a3d_bn_nslab(size_t rows, int C) {
-  // enough slabs to fill the chip (each workgroup covers 512 channels), at least 64 rows per slab
-  size_t n = 512;
+  // enough slabs to fill the chip with 4 workgroups per CU, at least 64 rows per slab
+  size_t n = 1024;
   if (n > rows / 64) n = rows / 64;
   if (n < 1) n = 1;
   return (int)n;
@@ -164,7 +175,7 @@ extern "C" int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int
     set_error("a3d_bn_finalize: bad argument");
     return A3D_ERR_ARG;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, nslab, (double)rows,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, partial, nslab, (double)rows,
                      C, eps, momentum, gamma, beta, running_mean, running_var, scale, shift, train);
   return check_launch("a3d_bn_finalize");
 }

@@ -22,11 +22,13 @@ SIGNATURES = {
     "a3d_last_error_string": (C.c_char_p, []),
     "a3d_linear_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_linear_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "a3d_linear_wgrad_ws": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _z, _p]),
+    "a3d_linear_wgrad_ws_bytes": (_z, [_i, _i, _i, _i]),
     "a3d_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "a3d_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "a3d_rope_split_qk": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_split_vt": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
-    "a3d_rope_split": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_rope_split": (_i, [_p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rope_merge_bwd": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_fwd_ws_floats": (_z, [_i, _i, _i, _i]),

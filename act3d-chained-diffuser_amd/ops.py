@@ -12,7 +12,7 @@ import torch
 from . import lib as L
 
 F32 = torch.float32
-LOG2E = 1.4426950408889634
+QKW = 48      # bf16 elements per q / k operand row: hi(16) | lo(16) | lo2(16)  (a3d_common.h)
 
 
 def ceil_to(x, m):
@@ -68,14 +68,23 @@ def dgrad2d(dy2d, W, mask=None):
                       ldm=K, transposed=True)
 
 
+def wgrad_raw(dy_ptr, lddy, x_ptr, ldx, gw_ptr, lddw, gb_ptr, M, N, K, device, st=None):
+    """dW += dY^T X, db += sum dY through a3d_linear_wgrad_ws: large-M reductions run two-stage (per-split partials in
+    a workspace + ordered reduce) instead of memory-side float atomics."""
+    nbytes = L.load().a3d_linear_wgrad_ws_bytes(M, N, K, 0 if gb_ptr is None else 1)
+    ws = torch.empty((nbytes // 4,), device=device, dtype=F32) if nbytes else None
+    L.call("a3d_linear_wgrad_ws", dy_ptr, lddy, x_ptr, ldx, gw_ptr, lddw, gb_ptr, M, N, K,
+           None if ws is None else ws.data_ptr(), nbytes, st if st is not None else L.stream())
+
+
 def wgrad2d(dy2d, x2d, W, b):
     """W.grad += dy^T x ; b.grad += sum dy   (W, b are Parameters or None)"""
     M, N = dy2d.shape
     K = x2d.shape[1]
     gW = grad_buf(W)
     gb = grad_buf(b) if b is not None else None
-    L.call("a3d_linear_wgrad", dy2d.data_ptr(), N, x2d.data_ptr(), K, gW.data_ptr(), gW.shape[1],
-           None if gb is None else gb.data_ptr(), M, N, K, L.stream())
+    wgrad_raw(dy2d.data_ptr(), N, x2d.data_ptr(), K, gW.data_ptr(), gW.shape[1],
+              None if gb is None else gb.data_ptr(), M, N, K, dy2d.device)
 
 
 def add_layernorm(a2d, r2d, g, b, eps=1e-5):
@@ -112,8 +121,8 @@ def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, 
     scale = float(E // H) ** -0.5
     freq = rope_freq(E, device)
     bf = torch.bfloat16
-    Qs = torch.empty((B, H, Lqp, 32), device=device, dtype=bf)
-    Ks = torch.empty((B, H, Sp, 32), device=device, dtype=bf)
+    Qs = torch.empty((B, H, Lqp, QKW), device=device, dtype=bf)     # q, k rows: hi | lo | lo2
+    Ks = torch.empty((B, H, Sp, QKW), device=device, dtype=bf)
     Vt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=bf)
     Qt = Kt = Vs = None
     if need_bwd:
@@ -124,9 +133,9 @@ def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, 
     qx = None if q_xyz is None else q_xyz.data_ptr()
     kx = None if k_xyz is None else k_xyz.data_ptr()
     nz = lambda t: None if t is None else t.data_ptr()
-    L.call("a3d_rope_split", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qs.data_ptr(), nz(Qt), B, Lq, Lqp, E, H, st)
-    L.call("a3d_rope_split", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Ks.data_ptr(), nz(Kt), B, S, Sp, E, H, st)
-    L.call("a3d_rope_split", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vs), Vt.data_ptr(), B, S, Sp, E, H, st)
+    L.call("a3d_rope_split", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qs.data_ptr(), QKW, nz(Qt), B, Lq, Lqp, E, H, st)
+    L.call("a3d_rope_split", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Ks.data_ptr(), QKW, nz(Kt), B, S, Sp, E, H, st)
+    L.call("a3d_rope_split", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vs), 32, Vt.data_ptr(), B, S, Sp, E, H, st)
     return Qs, Ks, Vt, Lqp, Sp, scale, freq, (Qt, Kt, Vs)
 
 
@@ -264,10 +273,10 @@ class AttnBlockFn(torch.autograd.Function):
             rope_merge(dK, 1, k_xyz, freq, 1.0, dqk.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
             dv_pre = torch.empty((B * S, E), device=dev, dtype=F32)
             rope_merge(dV, 1, None, freq, 1.0, dv_pre.data_ptr(), E, B, S, Sp, E, H)
-            L.call("a3d_linear_wgrad", dqk.data_ptr(), 2 * E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
-                   B * Lq, 2 * E, E, st)
-            L.call("a3d_linear_wgrad", dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4, E,
-                   gb.data_ptr() + 2 * E * f4, B * S, E, E, st)
+            wgrad_raw(dqk.data_ptr(), 2 * E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
+                   B * Lq, 2 * E, E, dev, st)
+            wgrad_raw(dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4, E,
+                   gb.data_ptr() + 2 * E * f4, B * S, E, E, dev, st)
             if need_q or need_k:
                 d_q_in = linear_raw(dqk.data_ptr(), 2 * E, in_w.data_ptr(), E, None, B * Lq, E, 2 * E, dev,
                                     transposed=True).view(B, Lq, E)
@@ -277,16 +286,16 @@ class AttnBlockFn(torch.autograd.Function):
         else:
             dq_pre = torch.empty((B * Lq, E), device=dev, dtype=F32)
             rope_merge(dQp, nsplit, q_xyz, freq, scale, dq_pre.data_ptr(), E, B, Lq, Lqp, E, H)
-            L.call("a3d_linear_wgrad", dq_pre.data_ptr(), E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
-                   B * Lq, E, E, st)
+            wgrad_raw(dq_pre.data_ptr(), E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
+                   B * Lq, E, E, dev, st)
             if need_q:
                 d_q_in = dgrad2d(dq_pre, in_w[:E]).view(B, Lq, E)
             if mode == "kv":
                 dkv = torch.empty((B * S, 2 * E), device=dev, dtype=F32)
                 rope_merge(dK, 1, k_xyz, freq, 1.0, dkv.data_ptr(), 2 * E, B, S, Sp, E, H)
                 rope_merge(dV, 1, None, freq, 1.0, dkv.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
-                L.call("a3d_linear_wgrad", dkv.data_ptr(), 2 * E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
-                       gb.data_ptr() + E * f4, B * S, 2 * E, E, st)
+                wgrad_raw(dkv.data_ptr(), 2 * E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
+                       gb.data_ptr() + E * f4, B * S, 2 * E, E, dev, st)
                 if need_k or need_v:
                     d_k_in = linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E,
                                         dev, transposed=True).view(B, S, E)
@@ -295,10 +304,10 @@ class AttnBlockFn(torch.autograd.Function):
                 dv_pre = torch.empty((B * S, E), device=dev, dtype=F32)
                 rope_merge(dK, 1, k_xyz, freq, 1.0, dk_pre.data_ptr(), E, B, S, Sp, E, H)
                 rope_merge(dV, 1, None, freq, 1.0, dv_pre.data_ptr(), E, B, S, Sp, E, H)
-                L.call("a3d_linear_wgrad", dk_pre.data_ptr(), E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
-                       gb.data_ptr() + E * f4, B * S, E, E, st)
-                L.call("a3d_linear_wgrad", dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4,
-                       E, gb.data_ptr() + 2 * E * f4, B * S, E, E, st)
+                wgrad_raw(dk_pre.data_ptr(), E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
+                       gb.data_ptr() + E * f4, B * S, E, E, dev, st)
+                wgrad_raw(dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4,
+                       E, gb.data_ptr() + 2 * E * f4, B * S, E, E, dev, st)
                 if need_k:
                     d_k_in = dgrad2d(dk_pre, in_w[E:2 * E]).view(B, S, E)
                 if need_v:
@@ -706,7 +715,7 @@ def kv_cache_build(k_in, k_xyz, mha, H):
                         mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
     Sp = ceil_to(S, 64)
     freq = rope_freq(E, dev)
-    Ks = torch.empty((B, H, Sp, 32), device=dev, dtype=torch.bfloat16)
+    Ks = torch.empty((B, H, Sp, QKW), device=dev, dtype=torch.bfloat16)
     Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.bfloat16)
     st = L.stream()
     L.call("a3d_rope_split_qk", kv_pre.data_ptr(), 2 * E, None if k_xyz is None else _c(k_xyz).data_ptr(), freq.data_ptr(),
@@ -723,7 +732,7 @@ def attn_block_cached(q_in, resid, q_xyz, cache, mha, norm, H):
     dev = q_in.device
     Lqp = ceil_to(Lq, 64)
     q_pre = linear_raw(q_in.data_ptr(), E, mha.in_proj_weight.data_ptr(), E, mha.in_proj_bias.data_ptr(), B * Lq, E, E, dev)
-    Qs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
+    Qs = torch.empty((B, H, Lqp, QKW), device=dev, dtype=torch.bfloat16)
     freq = rope_freq(E, dev)
     L.call("a3d_rope_split_qk", q_pre.data_ptr(), E, None if q_xyz is None else _c(q_xyz).data_ptr(), freq.data_ptr(),
            float(E // H) ** -0.5, Qs.data_ptr(), B, Lq, Lqp, E, H, L.stream())

@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backbone-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="only the dominant-kernel micro-benchmarks (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -182,6 +184,9 @@ def main():
     E = a3d.engine
 
     B = args.batch
+    if args.kernels_only:
+        print(json.dumps({"kernels": kernel_rooflines(a3d, device, B), "per_gpu_batch_keyframes": B}))
+        return
     model = build_model(a3d, device, torch.bfloat16 if args.backbone_dtype == "bf16" else torch.float32)
     crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
     batch = synthetic_batch(B, 4, device, seed=1000 + rank)

@@ -17,8 +17,10 @@
  *   - indices are int64 (long long) at the API, as torch.topk / torch.max return them.
  *
  * Attention operand formats (written by a3d_rope_split_qk / a3d_split_vt, read by a3d_attn_*):
- *   QK : [B][H][Npad][32] bf16, row = hi(16) | lo(16), x ~= hi + lo, head dim 15 padded to 16 with zero
- *   VT : [B][H][2][16][Npad] bf16, plane 0 = hi, plane 1 = lo (transposed: keys contiguous)
+ *   rows  : [B][H][Npad][W] bf16, head dim 15 padded to 16 with zero;
+ *             W = 48 for q and k ("QK"): row = hi(16) | lo(16) | lo2(16), x ~= hi + lo + lo2 (fp32-grade logits),
+ *             W = 32 for v and dO rows (backward only): row = hi(16) | lo(16), x ~= hi + lo
+ *   planes: [B][H][2][16][Npad] bf16 ("VT"), plane 0 = hi, plane 1 = lo (transposed: keys contiguous)
  *   Npad % 64 == 0 for keys/values, Npad % 16 == 0 suffices for queries when written by a3d_rope_split_qk with
  *   Npad % 64 == 0 (callers simply use a multiple of 64 everywhere).
  */
@@ -42,6 +44,13 @@ int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float
 /* dW[n*lddw+k] += sum_m dY[m,n] X[m,k];  db[n] += sum_m dY[m,n] (db may be NULL).  Accumulates atomically. */
 int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db, int M,
                      int N, int K, void* stream);
+/* Same, with a caller-provided workspace: when the M reduction is split over many workgroups (large M: the scene-token
+ * K/V projections, M = B*4097) the per-split partial sums go to `ws` and a second kernel adds them into dW/db in a
+ * fixed order -- deterministic and free of memory-side atomics.  a3d_linear_wgrad_ws_bytes returns the size needed
+ * (0 = the one-stage atomic kernel is used and ws may be NULL). */
+size_t a3d_linear_wgrad_ws_bytes(int M, int N, int K, int has_bias);
+int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db, int M,
+                        int N, int K, float* ws, size_t ws_bytes, void* stream);
 /* Y = LayerNorm(A + R) * gamma + beta over the last dim (R may be NULL); saves mean/rstd per row.
  * Replaces `output = self.norm(query + dropout(attn_output))` layers.py:308-309, 329-331, 158-159. */
 int a3d_add_layernorm_fwd(const float* A, const float* R, const float* gamma, const float* beta, float* Y,
@@ -57,9 +66,10 @@ int a3d_add_layernorm_bwd(const float* A, const float* R, const float* gamma, co
 int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* dst, int B,
                       int N, int Npad, int E, int H, void* stream);
 int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int E, int H, void* stream);
-/* Both formats of the same rotated rows in one pass (either output may be NULL); the backward needs q, k, v in both. */
+/* Both formats of the same rotated rows in one pass (either output may be NULL); the backward needs q, k, v in both.
+ * rows_width: 48 (q, k: hi|lo|lo2) or 32 (v: hi|lo); a3d_rope_split_qk writes 48-wide rows. */
 int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
-                   void* planes_out, int B, int N, int Npad, int E, int H, void* stream);
+                   int rows_width, void* planes_out, int B, int N, int Npad, int E, int H, void* stream);
 /* dY[:, :E] = scale * R(xyz)^T * sum_s dR[s];  dR: [nsplit][B][H][Npad][16] fp32 (grad w.r.t. rotated rows). */
 int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq, float scale, float* dY,
                        int ldy, int B, int N, int Npad, int E, int H, void* stream);
@@ -77,8 +87,8 @@ int a3d_attn_bwd(const void* Qs, const void* Ks, const void* Vt, const unsigned 
                  const float* dO, const float* LSE, float* dOh, float* D, float* dQp, float* dK, float* dV, int B,
                  int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
 
-/* Same gradients on split-bf16 MFMA (default path).  Needs both formats of q, k, v: rows (QK) Qs, Ks, Vs and planes
- * (VT) Qt, Kt (a3d_rope_split writes both).  Scratch: dOs [B][H][Lqp][32] bf16, dOt [B][H][2][16][Lqp] bf16,
+/* Same gradients on split-bf16 MFMA (default path).  Needs both formats of q, k, v: rows Qs, Ks (48-wide), Vs (32-wide)
+ * and planes Qt, Kt (a3d_rope_split writes both).  Scratch: dOs [B][H][Lqp][32] bf16, dOt [B][H][2][16][Lqp] bf16,
  * D [B][H][Lqp].  Lqp % 64 == 0. */
 int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
                       const unsigned char* kmask, const float* O, const float* dO, const float* LSE, void* dOs,

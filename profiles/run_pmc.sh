@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 counter passes over the dominant-kernel micro-benchmarks (bench.py --kernels-only), one --pmc set per pass
+# as the MI355X guide prescribes (TCC has 4 slots: FETCH_SIZE and WRITE_SIZE cannot share a pass).  No sys/hip/hsa
+# trace domains are combined with --pmc.   usage: profiles/run_pmc.sh <out-dir> [batch]
+set -u
+OUT=${1:-gpurun_out/pmc}
+B=${2:-16}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+case "$OUT" in /*) ;; *) OUT="$R/$OUT";; esac
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
+pass() {
+  name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
+      python "$R/bench.py" --kernels-only --batch "$B" > "$OUT/$name.log" 2>&1
+  echo "pass $name rc=$?" >> "$OUT/passes.txt"
+  python "$R/profiles/pmc_summary.py" "$OUT/$name" attn_ linear_ bn_ > "$OUT/$name.summary.txt" 2>&1
+  find "$OUT/$name" -name '*.csv' -size +8M -delete
+}
+: > "$OUT/passes.txt"
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+pass derived MfmaUtil VALUBusy
+cat "$OUT/passes.txt"

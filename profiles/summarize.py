@@ -23,7 +23,8 @@ def main():
     agg = collections.defaultdict(lambda: [0, 0.0])
     shapes = collections.defaultdict(lambda: [0, 0.0])
     for name, s, e, gx, gy, gz, wx in win:
-        k = name.split("(")[0][:100]
+        k = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        k = k.split("<")[0] if k.startswith("at::native::") and "elementwise" not in k else k[:110]
         agg[k][0] += 1
         agg[k][1] += e - s
         if "a3d::" in k:

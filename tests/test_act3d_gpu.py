@@ -78,9 +78,9 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
         for l in range(2):
             scale_close(f"{tag} mask L{i} layer{l}", out["ghost_pcd_masks_pyramid"][i][l], r["masks"][i][l])
         assert torch.equal(out["position_pyramid"][i][:, 0].cpu(), r["positions"][i]), f"argmax position level {i}"
-    rel_close("rotation", out["rotation"], r["rotation"], 4e-3, 0)     # gain-3 fixtures: see the note on the query stream below
-    rel_close("gripper", out["gripper"], r["gripper"], 4e-3, 0)
-    scale_close("query", out["query_features"][0], r["query_features"], 2e-3)   # Lq=1 stream, peaked softmax (see below)
+    rel_close("rotation", out["rotation"], r["rotation"], 1e-3, 0)
+    rel_close("gripper", out["gripper"], r["gripper"], 1e-3, 0)
+    scale_close("query", out["query_features"][0], r["query_features"], 1e-3)
     if not cfg["train"]:
         return
     crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
@@ -92,17 +92,16 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
     sum(losses.values()).backward()
     named = dict(m.named_parameters())
     for n, gref in r["grads"].items():
-        # The Lq=1 query stream attends ~1000-4000 keys with a (deliberately) sharply peaked softmax in these gain-3
-        # fixtures; dS = P (dP - D) then cancels to ~1e-3 of its operands and amplifies the 2^-17 operand precision
-        # of the split-bf16 forward (DESIGN.md "numerics").  3e-3 elsewhere.
-        scale_close("grad " + n, named[n].grad, gref, 3e-2 if n.startswith("query_") else 3e-3)
+        # gain-3 fixtures: sharply peaked softmax over ~1000-4000 keys, |logit| ~ 100.  With the three-part (fp32-grade)
+        # q / k score operands every gradient, the Lq=1 query stream included, is within 3e-3 of the reference's
+        # (observed <= 1.1e-3; with two-part operands the query stream was off by 1.5e-2 -- DESIGN.md "numerics").
+        scale_close("grad " + n, named[n].grad, gref, 3e-3)
     for n, nr in r["grad_norms"].items():
         if "feature_pyramid" in n or n not in named:
             continue
         g = named[n].grad
         assert g is not None, n
-        tol = 3e-2 if n.startswith("query_") else 5e-3
-        assert abs(g.norm().item() - nr) <= tol * nr + 2e-4, f"grad norm {n}: {g.norm().item()} vs {nr}"
+        assert abs(g.norm().item() - nr) <= 5e-3 * nr + 2e-4, f"grad norm {n}: {g.norm().item()} vs {nr}"
     for f, nr in zip(fmaps, r["feat_grad_norms"]):
         if nr is not None:
             assert abs(f.grad.norm().item() - nr) <= 5e-3 * nr + 1e-5
@@ -177,7 +176,6 @@ def test_act3d_cfg2_shapes_vs_oracle_teacher_forced(a3d, dev):
             denom = ref.abs().max().item() + 1e-6
             err = (g.cpu() - ref).abs().max().item()
             print(f"[parity] cfg2 grad {n}: max_abs_err={err:.3e} ref_absmax={denom:.3e}")
-            tol = 1e-2 if n.startswith("query_") else 3e-3
-            assert err <= tol * denom + 1e-4, f"grad {n}: err {err:.3e} vs absmax {denom:.3e}"
-    scale_close("cfg2 d feat level0", d0.grad, f0.grad, 2e-2, floor=0.0)
-    scale_close("cfg2 d feat fine", d1.grad, f1.grad, 2e-2, floor=0.0)
+            assert err <= 3e-3 * denom + 1e-4, f"grad {n}: err {err:.3e} vs absmax {denom:.3e}"
+    scale_close("cfg2 d feat level0", d0.grad, f0.grad, 3e-3, floor=0.0)
+    scale_close("cfg2 d feat fine", d1.grad, f1.grad, 3e-3, floor=0.0)

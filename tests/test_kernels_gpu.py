@@ -60,7 +60,7 @@ def test_mfma_layout_probes(a3d, dev):
 
 @pytest.mark.parametrize("M,N,K", [(1, 5, 60), (333, 60, 60), (1000, 120, 60), (70, 480, 120), (257, 120, 480),
                                    (50, 60, 512), (33, 120, 9), (130, 3, 120), (106, 240, 120), (2048, 120, 120),
-                                   (4098, 240, 120)])
+                                   (4098, 240, 120), (65552, 120, 60), (20011, 60, 60)])
 def test_linear_fwd_dgrad_wgrad(a3d, dev, M, N, K):
     O = a3d.ops
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -83,6 +83,14 @@ def test_linear_fwd_dgrad_wgrad(a3d, dev, M, N, K):
     O.wgrad2d(dy.to(dev), x.to(dev), W, Bp)   # accumulates
     report("linear_wgrad dW", W.grad, 2 * (dy.t() @ x), 1e-4 * max(1.0, math.sqrt(M) / 4), 1e-5)
     report("linear_wgrad db", Bp.grad, 2 * dy.sum(0), 1e-4 * max(1.0, math.sqrt(M) / 4), 1e-5)
+    two_stage = a3d.lib.load().a3d_linear_wgrad_ws_bytes(M, N, K, 1) > 0
+    assert two_stage == (M >= 20000)        # the large-M (scene-token) reductions take the atomics-free path
+    if two_stage:                           # ... which is run-to-run deterministic
+        W2 = torch.nn.Parameter(w.to(dev))
+        B2 = torch.nn.Parameter(b.to(dev))
+        O.wgrad2d(dy.to(dev), x.to(dev), W2, B2)
+        O.wgrad2d(dy.to(dev), x.to(dev), W2, B2)
+        assert torch.equal(W2.grad, W.grad) and torch.equal(B2.grad, Bp.grad)
 
 
 @pytest.mark.parametrize("M,E", [(5, 60), (1333, 60), (700, 120), (9, 480)])
@@ -178,9 +186,9 @@ def test_attn_block_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
     dr = resid.to(dev).requires_grad_()
     y = O.attn_block(dq, dk, dv, dr, None if q_xyz is None else q_xyz.to(dev), None if k_xyz is None else k_xyz.to(dev),
                      None if kmask is None else kmask.to(dev), mha, norm, H)
-    report(f"attn_block[{mode}] fwd", y, ref, 1e-3)
+    report(f"attn_block[{mode}] fwd", y, ref, 1e-4)      # observed ~1e-5: fp32-grade logits (three-part q, k operands)
     y.backward(dy.to(dev))
-    gtol = 2e-3
+    gtol = 5e-4
     report("attn_block d q_in", dq.grad, cq.grad, gtol, 1e-3)
     if mode == "none" or mode == "kv":
         report("attn_block d k_in", dk.grad, ck.grad, gtol, 1e-3)
