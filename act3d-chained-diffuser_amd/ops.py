@@ -228,7 +228,9 @@ class AttnBlockFn(torch.autograd.Function):
                 v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
                 k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
                 keep = (q_pre, k_pre, v_pre)
-        need_bwd = torch.is_grad_enabled()
+        # grad mode is always off inside Function.forward: ask the ctx whether a backward can follow (the in-projection
+        # parameters count -- they get .grad through wgrad even when no input needs a gradient)
+        need_bwd = any(ctx.needs_input_grad) or in_w.requires_grad
         Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
                                                                 S, E, H, dev, need_bwd=need_bwd)
         del keep
