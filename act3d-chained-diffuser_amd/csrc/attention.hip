@@ -23,7 +23,6 @@
 namespace a3d {
 
 constexpr int KC = 64;          // keys per staged chunk
-constexpr int VROW = 72;        // padded V^T row (bf16 elements): 144 B stride -> conflict-free b128 column reads
 constexpr int FLD = 20;         // padded fp32 row stride (80 B) for the backward's [64][16] tiles
 
 struct FwdStage {
@@ -37,9 +36,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
     float* __restrict__ O, float* __restrict__ LSE, float* __restrict__ Op, float* __restrict__ Mp,
     float* __restrict__ Lp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit) {
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][KC * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short K2sm[2][KC * 16];
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][2 * 16 * VROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][KC * 32];    // [k_hi | k_lo]  rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short K3sm[2][KC * 32];   // [k_hi | k_lo2] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][4 * 16 * 32];   // [plane][32-key half][16 ch][32 keys]
   __shared__ __attribute__((aligned(16))) float biasS[2][KC];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -87,17 +86,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     return st;
   };
   auto stage_store = [&](const FwdStage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Ksm[buf][krow * 32 + ((kseg ^ ((krow >> 3) & 3)) * 8)]) = st.k;
-    if (t < 2 * KC) *reinterpret_cast<s16x8*>(&K2sm[buf][lo2_off(t >> 1, t & 1)]) = st.k2;
+    *reinterpret_cast<s16x8*>(&Ksm[buf][tile_off(krow, kseg)]) = st.k;
+    if (kseg < 2) *reinterpret_cast<s16x8*>(&K3sm[buf][tile_off(krow, kseg)]) = st.k;           // k_hi
+    if (t < 2 * KC) *reinterpret_cast<s16x8*>(&K3sm[buf][tile_off(t >> 1, 2 + (t & 1))]) = st.k2;   // k_lo2
     // padded channel 15 of V_hi := 1.0, so that acc[d = 15] accumulates the softmax denominator sum_k (p_hi + p_lo)
     // on the MFMA pipe, from exactly the rounded P the numerator uses (no VALU row sums, self-consistent weights)
     const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-    *reinterpret_cast<s16x8*>(&Vsm[buf][(vplane * 16 + vd) * VROW + vseg * 8]) = (vplane == 0 && vd == 15) ? ones : st.v;
+    *reinterpret_cast<s16x8*>(&Vsm[buf][((vplane * 2 + (vseg >> 2)) * 16) * 32 + plane_off(vd, vseg & 3)]) =
+        (vplane == 0 && vd == 15) ? ones : st.v;
     if (t < KC) biasS[buf][t] = st.bias;
   };
 
+  // per-lane fragment offsets (constant over the key loop): score tile j = hf * 2 + T covers keys
+  // hf * 32 + (i >> 2) * 8 + (i & 3) + 4 T, i = 0..15 (the interleave that leaves P in B-operand order)
+  int koff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) koff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
+  const int voff = plane_off(li, g);
+
   float m_run = -INFINITY;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // one accumulator per 32-key half: two PV chains
 
   if (c_beg < c_end) {
     stage_store(stage_load(c_beg), 0);
@@ -110,36 +118,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     if (has_next) nxt = stage_load(c + 1);
 
     if (active) {
-      f32x4 s[2][2];
+      // ---- all LDS fragment reads of the chunk up front, then the MFMAs as four independent chains
+      s16x8 kf[4], k3[4], vh[2], vl[2];
+      f32x4 s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kf[j] = *reinterpret_cast<const s16x8*>(&Ksm[buf][koff[j]]);
+        k3[j] = *reinterpret_cast<const s16x8*>(&K3sm[buf][koff[j]]);
+        s[j] = *reinterpret_cast<const f32x4*>(&biasS[buf][(j >> 1) * 32 + g * 8 + (j & 1) * 4]);
+      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-          const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
-          const s16x8 kf = *reinterpret_cast<const s16x8*>(&Ksm[buf][row * 32 + ((g ^ ((row >> 3) & 3)) * 8)]);
-          f32x4 c4 = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
-          s16x8 k3 = kf;   // lanes g < 2 already hold k_hi; g >= 2 fetch k_lo2
-          if (g >= 2) k3 = *reinterpret_cast<const s16x8*>(&K2sm[buf][lo2_off(row, g - 2)]);
-          c4 = mfma_bf16_16x16x32(kf, qhi, c4);
-          c4 = mfma_bf16_16x16x32(kf, qlo, c4);
-          c4 = mfma_bf16_16x16x32(k3, q3, c4);
-          s[hf][T] = c4;
-        }
+        vh[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((0 * 2 + hf) * 16) * 32 + voff]);
+        vl[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((1 * 2 + hf) * 16) * 32 + voff]);
       }
-      float mx = -INFINITY;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
+      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(kf[j], qhi, s[j]);
 #pragma unroll
-        for (int T = 0; T < 2; ++T)
+      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(kf[j], qlo, s[j]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[hf][T][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(k3[j], q3, s[j]);
+
+      // running max: a depth-3 tree over the lane's 16 scores, then across the column's four lanes
+      float mt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mt[j] = fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3]));
+      const float mx = colmax4(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
       const float m_new = fmaxf(m_run, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       // p = exp(s - m) as exp2(fma(s, log2 e, -m log2 e)): one packed FMA per two scores + v_exp_f32
       typedef __attribute__((ext_vector_type(2))) float f32x2;
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
       const float nm = -m_use * LOG2E_F;
       const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));   // m_run = -inf -> 0
       const f32x2 c2 = {LOG2E_F, LOG2E_F}, nm2 = {nm, nm};
@@ -151,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            const f32x2 arg = __builtin_elementwise_fma((f32x2){s[hf][T][2 * pr], s[hf][T][2 * pr + 1]}, c2, nm2);
+            const f32x4& sj = s[hf * 2 + T];
+            const f32x2 arg = __builtin_elementwise_fma((f32x2){sj[2 * pr], sj[2 * pr + 1]}, c2, nm2);
             const f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
             // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
             // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
@@ -161,27 +172,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
             lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
           }
         }
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         phi[hf] = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
         plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
       }
       m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const s16x8 vh = *reinterpret_cast<const s16x8*>(&Vsm[buf][(0 * 16 + li) * VROW + hf * 32 + g * 8]);
-        const s16x8 vl = *reinterpret_cast<const s16x8*>(&Vsm[buf][(1 * 16 + li) * VROW + hf * 32 + g * 8]);
-        acc = mfma_bf16_16x16x32(vh, phi[hf], acc);
-        acc = mfma_bf16_16x16x32(vh, plo[hf], acc);
-        acc = mfma_bf16_16x16x32(vl, phi[hf], acc);
-      }
+      for (int r = 0; r < 4; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+      acc0 = mfma_bf16_16x16x32(vh[0], phi[0], acc0);
+      acc1 = mfma_bf16_16x16x32(vh[1], phi[1], acc1);
+      acc0 = mfma_bf16_16x16x32(vh[0], plo[0], acc0);
+      acc1 = mfma_bf16_16x16x32(vh[1], plo[1], acc1);
+      acc0 = mfma_bf16_16x16x32(vl[0], phi[0], acc0);
+      acc1 = mfma_bf16_16x16x32(vl[1], phi[1], acc1);
     }
     if (has_next) stage_store(nxt, buf ^ 1);
     __syncthreads();
   }
 
   if (!active) return;
+  f32x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
   const float l_tot = __shfl(acc[3], 48 + li, 64);   // channel 15 (lane group g = 3, register 3) holds sum_k p
   const int q = q0 + li;
   if (nsplit == 1) {

@@ -19,7 +19,6 @@
 namespace a3d {
 
 constexpr int BKC = 64;         // rows (keys or queries) per staged chunk
-constexpr int BVROW = 72;       // padded plane row (bf16 elements)
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -41,9 +40,6 @@ __device__ __forceinline__ void split8(const float* x, s16x8& hi, s16x8& lo) {
   hi = __builtin_bit_cast(s16x8, (u32x4_t){hw[0], hw[1], hw[2], hw[3]});
   lo = __builtin_bit_cast(s16x8, (u32x4_t){lw[0], lw[1], lw[2], lw[3]});
 }
-
-// swizzled 16-byte segment of a rows-format tile held in LDS as [64][32] bf16
-__device__ __forceinline__ int rows_off(int row, int seg) { return row * 32 + ((seg ^ ((row >> 3) & 3)) * 8); }
 
 // ------------------------------------------------------------------------------------------------ prep
 // dOs (rows format), dOt (planes format) of dO, and D[b][h][q] = sum_d dO * O.  grid (Lqp/64, B)
@@ -122,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
     const float* __restrict__ LSE, const float* __restrict__ D, float* __restrict__ dQp, int B, int H, int Lq,
     int Lqp, int S, int Sp, int nsplit) {
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][BKC * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][BKC * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short Ktm[2][2 * 16 * BVROW];
-  __shared__ __attribute__((aligned(16))) unsigned short K2sm[2][BKC * 16];
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][BKC * 32];    // [k_hi | k_lo]  rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short K3sm[2][BKC * 32];   // [k_hi | k_lo2] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][BKC * 32];    // [v_hi | v_lo]  rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Ktm[2][4 * 16 * 32]; // K planes [plane][32-key half][16][32]
   __shared__ __attribute__((aligned(16))) float biasS[2][BKC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -176,14 +172,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
     return st;
   };
   auto stage_store = [&](const DqStage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Ksm[buf][rows_off(krow, kseg)]) = st.k;
-    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&K2sm[buf][lo2_off(t >> 1, t & 1)]) = st.k2;
-    *reinterpret_cast<s16x8*>(&Vsm[buf][rows_off(krow, kseg)]) = st.v;
-    *reinterpret_cast<s16x8*>(&Ktm[buf][(vplane * 16 + vd) * BVROW + vseg * 8]) = st.kt;
+    *reinterpret_cast<s16x8*>(&Ksm[buf][tile_off(krow, kseg)]) = st.k;
+    if (kseg < 2) *reinterpret_cast<s16x8*>(&K3sm[buf][tile_off(krow, kseg)]) = st.k;
+    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&K3sm[buf][tile_off(t >> 1, 2 + (t & 1))]) = st.k2;
+    *reinterpret_cast<s16x8*>(&Vsm[buf][tile_off(krow, kseg)]) = st.v;
+    *reinterpret_cast<s16x8*>(&Ktm[buf][((vplane * 2 + (vseg >> 2)) * 16) * 32 + plane_off(vd, vseg & 3)]) = st.kt;
     if (t < BKC) biasS[buf][t] = st.bias;
   };
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int koff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) koff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
+  const int poff = plane_off(li, g);
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   // P = exp(s - lse) = exp2(fma(s, log2 e, -lse log2 e)) (one packed FMA per two scores); -D rides in as the MFMA
   // accumulator init of dP, so dS = P * (dP - D) is one packed multiply
   const float nl = -lse_q * LOG2E_F;
@@ -199,36 +201,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
     const bool has_next = (c + 1 < c_end);
     if (has_next) nxt = stage_load(c + 1);
     if (active) {
+      // per 32-key half: the fragment reads first, then four independent MFMA chains (two score tiles, two dP tiles)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
+        s16x8 kf[2], k3[2], vf[2];
+        f32x4 sT[2], dpT[2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          kf[T] = *reinterpret_cast<const s16x8*>(&Ksm[buf][koff[hf * 2 + T]]);
+          k3[T] = *reinterpret_cast<const s16x8*>(&K3sm[buf][koff[hf * 2 + T]]);
+          vf[T] = *reinterpret_cast<const s16x8*>(&Vsm[buf][koff[hf * 2 + T]]);
+          sT[T] = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
+          dpT[T] = nd4;
+        }
+        const s16x8 kth = *reinterpret_cast<const s16x8*>(&Ktm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
+        const s16x8 ktl = *reinterpret_cast<const s16x8*>(&Ktm[buf][((1 * 2 + hf) * 16) * 32 + poff]);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) { sT[T] = mfma_bf16_16x16x32(kf[T], qhi, sT[T]); dpT[T] = mfma_bf16_16x16x32(vf[T], dohi, dpT[T]); }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) { sT[T] = mfma_bf16_16x16x32(kf[T], qlo, sT[T]); dpT[T] = mfma_bf16_16x16x32(vf[T], dolo, dpT[T]); }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) sT[T] = mfma_bf16_16x16x32(k3[T], q3, sT[T]);
         float ds[8];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
-          const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
-          const s16x8 kf = *reinterpret_cast<const s16x8*>(&Ksm[buf][rows_off(row, g)]);
-          const s16x8 vf = *reinterpret_cast<const s16x8*>(&Vsm[buf][rows_off(row, g)]);
-          f32x4 sT = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
-          s16x8 k3 = kf;
-          if (g >= 2) k3 = *reinterpret_cast<const s16x8*>(&K2sm[buf][lo2_off(row, g - 2)]);
-          sT = mfma_bf16_16x16x32(kf, qhi, sT);
-          sT = mfma_bf16_16x16x32(kf, qlo, sT);
-          sT = mfma_bf16_16x16x32(k3, q3, sT);
-          f32x4 dpT = nd4;
-          dpT = mfma_bf16_16x16x32(vf, dohi, dpT);
-          dpT = mfma_bf16_16x16x32(vf, dolo, dpT);
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){sT[2 * pr], sT[2 * pr + 1]}, c2, nl2);
+            const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){sT[T][2 * pr], sT[T][2 * pr + 1]}, c2, nl2);
             const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-            const f32x2_t d2 = p2 * (f32x2_t){dpT[2 * pr], dpT[2 * pr + 1]};
+            const f32x2_t d2 = p2 * (f32x2_t){dpT[T][2 * pr], dpT[T][2 * pr + 1]};
             ds[T * 4 + 2 * pr] = d2.x;
             ds[T * 4 + 2 * pr + 1] = d2.y;
           }
         }
         s16x8 dhi, dlo;
         split8(ds, dhi, dlo);
-        const s16x8 kth = *reinterpret_cast<const s16x8*>(&Ktm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
-        const s16x8 ktl = *reinterpret_cast<const s16x8*>(&Ktm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
+        f32x4& acc = hf ? acc1 : acc0;
         acc = mfma_bf16_16x16x32(kth, dhi, acc);
         acc = mfma_bf16_16x16x32(kth, dlo, acc);
         acc = mfma_bf16_16x16x32(ktl, dhi, acc);
@@ -239,6 +247,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
   }
   if (active) {
     const size_t row = (((size_t)sp * B + b) * H + h) * Lqp + q;
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
     *reinterpret_cast<f32x4*>(&dQp[row * HDP + g * 4]) = acc;
   }
 }
@@ -255,11 +266,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
     const unsigned short* __restrict__ dOt, const float* __restrict__ LSE, const float* __restrict__ D,
     float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp) {
-  __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][BKC * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short Osm[2][BKC * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short Q2sm[2][BKC * 16];
-  __shared__ __attribute__((aligned(16))) unsigned short Qtm[2][2 * 16 * BVROW];
-  __shared__ __attribute__((aligned(16))) unsigned short Otm[2][2 * 16 * BVROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][BKC * 32];    // [q_hi | q_lo]  rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Q3sm[2][BKC * 32];   // [q_hi | q_lo2] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Osm[2][BKC * 32];    // [dO_hi | dO_lo] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Qtm[2][4 * 16 * 32]; // planes [plane][32-query half][16][32]
+  __shared__ __attribute__((aligned(16))) unsigned short Otm[2][4 * 16 * 32];
   __shared__ __attribute__((aligned(16))) float lseS[2][BKC];
   __shared__ __attribute__((aligned(16))) float dS_[2][BKC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -306,15 +317,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     return st;
   };
   auto stage_store = [&](const DkvStage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Qsm[buf][rows_off(qrow, qseg)]) = st.q;
-    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&Q2sm[buf][lo2_off(t >> 1, t & 1)]) = st.q2;
-    *reinterpret_cast<s16x8*>(&Osm[buf][rows_off(qrow, qseg)]) = st.o;
-    *reinterpret_cast<s16x8*>(&Qtm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.qt;
-    *reinterpret_cast<s16x8*>(&Otm[buf][(pplane * 16 + pd) * BVROW + pseg * 8]) = st.ot;
+    *reinterpret_cast<s16x8*>(&Qsm[buf][tile_off(qrow, qseg)]) = st.q;
+    if (qseg < 2) *reinterpret_cast<s16x8*>(&Q3sm[buf][tile_off(qrow, qseg)]) = st.q;
+    if (t < 2 * BKC) *reinterpret_cast<s16x8*>(&Q3sm[buf][tile_off(t >> 1, 2 + (t & 1))]) = st.q2;
+    *reinterpret_cast<s16x8*>(&Osm[buf][tile_off(qrow, qseg)]) = st.o;
+    const int po = ((pplane * 2 + (pseg >> 2)) * 16) * 32 + plane_off(pd, pseg & 3);
+    *reinterpret_cast<s16x8*>(&Qtm[buf][po]) = st.qt;
+    *reinterpret_cast<s16x8*>(&Otm[buf][po]) = st.ot;
     if (t < BKC) { lseS[buf][t] = -st.lse * LOG2E_F; dS_[buf][t] = -st.d; }   // -lse log2 e (masked row: -inf), -D
   };
 
-  f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+  int qoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qoff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
+  const int poff = plane_off(li, g);
+
+  f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
   const int nch = Lqp / BKC;
   stage_store(stage_load(0), 0);
   __syncthreads();
@@ -323,29 +341,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     DkvStage nxt;
     const bool has_next = (c + 1 < nch);
     if (has_next) nxt = stage_load(c + 1);
+    // per 32-query half: fragment reads first; the key mask (0 / -inf) and -D enter as MFMA accumulator inits
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      s16x8 qf[2], q3[2], of[2];
+      f32x4 s[2], dp[2], nl4[2];
+#pragma unroll
+      for (int T = 0; T < 2; ++T) {
+        qf[T] = *reinterpret_cast<const s16x8*>(&Qsm[buf][qoff[hf * 2 + T]]);
+        q3[T] = *reinterpret_cast<const s16x8*>(&Q3sm[buf][qoff[hf * 2 + T]]);
+        of[T] = *reinterpret_cast<const s16x8*>(&Osm[buf][qoff[hf * 2 + T]]);
+        nl4[T] = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
+        dp[T] = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
+        s[T] = bias4;
+      }
+      const s16x8 oth = *reinterpret_cast<const s16x8*>(&Otm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
+      const s16x8 otl = *reinterpret_cast<const s16x8*>(&Otm[buf][((1 * 2 + hf) * 16) * 32 + poff]);
+      const s16x8 qth = *reinterpret_cast<const s16x8*>(&Qtm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
+      const s16x8 qtl = *reinterpret_cast<const s16x8*>(&Qtm[buf][((1 * 2 + hf) * 16) * 32 + poff]);
+#pragma unroll
+      for (int T = 0; T < 2; ++T) { s[T] = mfma_bf16_16x16x32(qf[T], khi, s[T]); dp[T] = mfma_bf16_16x16x32(of[T], vhi, dp[T]); }
+#pragma unroll
+      for (int T = 0; T < 2; ++T) { s[T] = mfma_bf16_16x16x32(qf[T], klo, s[T]); dp[T] = mfma_bf16_16x16x32(of[T], vlo, dp[T]); }
+#pragma unroll
+      for (int T = 0; T < 2; ++T) s[T] = mfma_bf16_16x16x32(q3[T], k3, s[T]);
       float p8[8], ds8[8];
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
-        const int row = hf * 32 + (li >> 2) * 8 + (li & 3) + T * 4;
-        const s16x8 qf = *reinterpret_cast<const s16x8*>(&Qsm[buf][rows_off(row, g)]);
-        const s16x8 of = *reinterpret_cast<const s16x8*>(&Osm[buf][rows_off(row, g)]);
-        // the key mask (0 / -inf) and -D enter as MFMA accumulator inits; P = exp2(fma(s, log2 e, -lse log2 e))
-        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
-        f32x4 s = bias4, dp = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
-        s16x8 q3 = qf;
-        if (g >= 2) q3 = *reinterpret_cast<const s16x8*>(&Q2sm[buf][lo2_off(row, g - 2)]);
-        s = mfma_bf16_16x16x32(qf, khi, s);
-        s = mfma_bf16_16x16x32(qf, klo, s);
-        s = mfma_bf16_16x16x32(q3, k3, s);
-        dp = mfma_bf16_16x16x32(of, vhi, dp);
-        dp = mfma_bf16_16x16x32(of, vlo, dp);
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){s[2 * pr], s[2 * pr + 1]}, c2, (f32x2_t){nl4[2 * pr], nl4[2 * pr + 1]});
+          // P = exp2(fma(s, log2 e, -lse log2 e)); dS = P * (dP - D)
+          const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){s[T][2 * pr], s[T][2 * pr + 1]}, c2,
+                                                        (f32x2_t){nl4[T][2 * pr], nl4[T][2 * pr + 1]});
           const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-          const f32x2_t d2 = p2 * (f32x2_t){dp[2 * pr], dp[2 * pr + 1]};
+          const f32x2_t d2 = p2 * (f32x2_t){dp[T][2 * pr], dp[T][2 * pr + 1]};
           p8[T * 4 + 2 * pr] = p2.x;
           p8[T * 4 + 2 * pr + 1] = p2.y;
           ds8[T * 4 + 2 * pr] = d2.x;
@@ -355,20 +384,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
       s16x8 phi, plo, dhi, dlo;
       split8(p8, phi, plo);
       split8(ds8, dhi, dlo);
-      const s16x8 oth = *reinterpret_cast<const s16x8*>(&Otm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
-      const s16x8 otl = *reinterpret_cast<const s16x8*>(&Otm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
+      f32x4& dv = hf ? dv1 : dv0;
+      f32x4& dk = hf ? dk1 : dk0;
       dv = mfma_bf16_16x16x32(oth, phi, dv);
-      dv = mfma_bf16_16x16x32(oth, plo, dv);
-      dv = mfma_bf16_16x16x32(otl, phi, dv);
-      const s16x8 qth = *reinterpret_cast<const s16x8*>(&Qtm[buf][(0 * 16 + li) * BVROW + hf * 32 + g * 8]);
-      const s16x8 qtl = *reinterpret_cast<const s16x8*>(&Qtm[buf][(1 * 16 + li) * BVROW + hf * 32 + g * 8]);
       dk = mfma_bf16_16x16x32(qth, dhi, dk);
+      dv = mfma_bf16_16x16x32(oth, plo, dv);
       dk = mfma_bf16_16x16x32(qth, dlo, dk);
+      dv = mfma_bf16_16x16x32(otl, phi, dv);
       dk = mfma_bf16_16x16x32(qtl, dhi, dk);
     }
     if (has_next) stage_store(nxt, buf ^ 1);
     __syncthreads();
   }
+  f32x4 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { dk[r] = dk0[r] + dk1[r]; dv[r] = dv0[r] + dv1[r]; }
   *reinterpret_cast<f32x4*>(&dK[(bh * Sp + key) * HDP + g * 4]) = dk;
   *reinterpret_cast<f32x4*>(&dV[(bh * Sp + key) * HDP + g * 4]) = dv;
 }

@@ -145,6 +145,113 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
   }
 }
 
+// y = relu?(x * scale + shift (+ residual)) as bn_apply_kernel, plus the 2x2 average pool of y that follows the
+// activation in the CLIP bottlenecks (AvgPool2d(stride) after bn2 / in the downsample branch) and the stem: each thread
+// owns 8 channels of one POOLED pixel, evaluates its four source pixels, optionally writes them (y_full) and writes their
+// mean.  scale == NULL means identity (plain average pool of x).  Saves the pool kernel's re-read of the full activation.
+__global__ __launch_bounds__(256) void bn_apply_pool2_kernel(const uint4* __restrict__ x, const uint4* __restrict__ res,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             uint4* __restrict__ y_full, uint4* __restrict__ y_pool, int N,
+                                                             int H, int W, int C8, int relu) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t nout = (size_t)N * Ho * Wo * C8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    size_t pix = i / C8;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = c8 * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale ? scale[c + j] : 1.f; sh[j] = scale ? shift[c + j] : 0.f; }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const size_t src = (((size_t)n * H + 2 * ho + dy) * W + 2 * wo + dx) * C8 + c8;
+        const uint4 v = x[src];
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (res) rv = res[src];
+        const unsigned int vw[4] = {v.x, v.y, v.z, v.w};
+        const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+        unsigned int ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = __uint_as_float(vw[j] << 16) * sc[2 * j] + sh[2 * j];
+          float b = __uint_as_float(vw[j] & 0xFFFF0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+          if (res) {
+            a += __uint_as_float(rw[j] << 16);
+            b += __uint_as_float(rw[j] & 0xFFFF0000u);
+          }
+          if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+          ow[j] = pack2(a, b);
+          // pool what the next layer would have read: the bf16-rounded activation
+          acc[2 * j] += __uint_as_float(ow[j] << 16);
+          acc[2 * j + 1] += __uint_as_float(ow[j] & 0xFFFF0000u);
+        }
+        if (y_full) y_full[src] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      }
+    }
+    y_pool[i] = make_uint4(pack2(acc[0] * 0.25f, acc[1] * 0.25f), pack2(acc[2] * 0.25f, acc[3] * 0.25f),
+                           pack2(acc[4] * 0.25f, acc[5] * 0.25f), pack2(acc[6] * 0.25f, acc[7] * 0.25f));
+  }
+}
+
+// FPN top-down step (torchvision FeaturePyramidNetwork: inner_lateral + F.interpolate(last_inner, nearest)) for an exact
+// 2x upsampling, bf16 NHWC, C % 4 == 0 (8-byte vectors; the policy's C = 60 is not a multiple of 8):
+//   fwd  y[n][h][w][:]  = lat[n][h][w][:] + top[n][h/2][w/2][:]
+//   bwd  dtop[n][i][j][:] = sum of the 2x2 dy block (the lateral branch's gradient is dy itself)
+__device__ __forceinline__ uint2 add_bf16x4(uint2 a, uint2 b) {
+  return make_uint2(pack2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16),
+                          __uint_as_float(a.x & 0xFFFF0000u) + __uint_as_float(b.x & 0xFFFF0000u)),
+                    pack2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16),
+                          __uint_as_float(a.y & 0xFFFF0000u) + __uint_as_float(b.y & 0xFFFF0000u)));
+}
+__global__ __launch_bounds__(256) void upsample2_add_fwd_kernel(const uint2* __restrict__ lat, const uint2* __restrict__ top,
+                                                                uint2* __restrict__ y, int N, int H, int W, int C4) {
+  const size_t total = (size_t)N * H * W * C4;
+  const int Ht = H >> 1, Wt = W >> 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    size_t pix = i / C4;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    y[i] = add_bf16x4(lat[i], top[(((size_t)n * Ht + (h >> 1)) * Wt + (w >> 1)) * C4 + c]);
+  }
+}
+__global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __restrict__ dy, uint2* __restrict__ dtop, int N,
+                                                                int H, int W, int C4) {
+  const int Ht = H >> 1, Wt = W >> 1;
+  const size_t total = (size_t)N * Ht * Wt * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    size_t pix = i / C4;
+    const int wt = (int)(pix % Wt);
+    pix /= Wt;
+    const int ht = (int)(pix % Ht);
+    const int n = (int)(pix / Ht);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const uint2 v = dy[(((size_t)n * H + 2 * ht + dyy) * W + 2 * wt + dx) * C4 + c];
+        acc[0] += __uint_as_float(v.x << 16);
+        acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
+        acc[2] += __uint_as_float(v.y << 16);
+        acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+      }
+    dtop[i] = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
+  }
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -192,4 +299,48 @@ extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* sc
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
                      scale, shift, (uint4*)y, nvec, C / 8, relu);
   return check_launch("a3d_bn_apply");
+}
+
+extern "C" int a3d_bn_apply_pool2(const void* x, const void* residual, const float* scale, const float* shift, void* y_full,
+                                  void* y_pool, int N, int H, int W, int C, int relu, void* stream) {
+  if (!x || !y_pool || (scale && !shift) || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) != 0 ||
+      ((((uintptr_t)x) | ((uintptr_t)y_pool) | ((uintptr_t)y_full) | ((uintptr_t)residual)) & 15)) {
+    set_error("a3d_bn_apply_pool2: bad argument (H=%d W=%d must be even, C=%d a multiple of 8, pointers 16-byte aligned)", H,
+              W, C);
+    return A3D_ERR_ARG;
+  }
+  const size_t nout = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+  const int grid = (int)std::min<size_t>((nout + 255) / 256, 16384);
+  hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
+                     (const uint4*)residual, scale, shift, (uint4*)y_full, (uint4*)y_pool, N, H, W, C / 8, relu);
+  return check_launch("a3d_bn_apply_pool2");
+}
+
+static int check_up2(const char* fn, const void* a, const void* b, const void* c, int N, int H, int W, int C) {
+  if (!a || !b || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 4) != 0 ||
+      ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 7)) {
+    set_error("%s: bad argument (H=%d W=%d must be even, C=%d a multiple of 4, pointers 8-byte aligned)", fn, H, W, C);
+    return A3D_ERR_ARG;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_upsample2_add_fwd(const void* lat, const void* top, void* y, int N, int H, int W, int C, void* stream) {
+  int rc = check_up2("a3d_upsample2_add_fwd", lat, top, y, N, H, W, C);
+  if (rc || !y) { if (!rc) set_error("a3d_upsample2_add_fwd: null output"); return A3D_ERR_ARG; }
+  const size_t total = (size_t)N * H * W * (C / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(upsample2_add_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint2*)lat,
+                     (const uint2*)top, (uint2*)y, N, H, W, C / 4);
+  return check_launch("a3d_upsample2_add_fwd");
+}
+
+extern "C" int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, int W, int C, void* stream) {
+  int rc = check_up2("a3d_upsample2_add_bwd", dy, dtop, nullptr, N, H, W, C);
+  if (rc) return rc;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(upsample2_add_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint2*)dy, (uint2*)dtop,
+                     N, H, W, C / 4);
+  return check_launch("a3d_upsample2_add_bwd");
 }

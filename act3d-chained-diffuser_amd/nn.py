@@ -150,6 +150,37 @@ class ParallelAttention(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ adjacent: vision
+class _Upsample2AddFn(torch.autograd.Function):
+    """lat + F.interpolate(top, 2x, nearest) for bf16 channels_last maps in one kernel; backward: dtop = 2x2 sums."""
+
+    @staticmethod
+    def forward(ctx, lat, top):
+        N, C, H, W = lat.shape
+        y = torch.empty_like(lat)
+        O.L.call("a3d_upsample2_add_fwd", lat.data_ptr(), top.data_ptr(), y.data_ptr(), N, H, W, C, O.L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = dy.shape
+        dtop = None
+        if ctx.needs_input_grad[1]:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dtop = torch.empty((N, C, H // 2, W // 2), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
+            O.L.call("a3d_upsample2_add_bwd", dy.data_ptr(), dtop.data_ptr(), N, H, W, C, O.L.stream())
+        return (dy if ctx.needs_input_grad[0] else None), dtop
+
+
+def fpn_top_down(lat, last):
+    """inner_lateral + nearest-upsampled last_inner (torchvision FPN); fused HIP kernel for the exact-2x bf16 NHWC case."""
+    cl = torch.channels_last
+    if (lat.is_cuda and lat.dtype == torch.bfloat16 and last.dtype == torch.bfloat16 and lat.shape[1] % 4 == 0
+            and lat.shape[-2] == 2 * last.shape[-2] and lat.shape[-1] == 2 * last.shape[-1]
+            and lat.is_contiguous(memory_format=cl) and last.is_contiguous(memory_format=cl)):
+        return _Upsample2AddFn.apply(lat, last)
+    return lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+
+
 class FeaturePyramidNetwork(nn.Module):
     """torchvision.ops.FeaturePyramidNetwork (0.14 naming: inner_blocks.i.0 / layer_blocks.i.0), restated: 1x1 lateral
     convs, nearest top-down pathway, 3x3 output convs.  Runs on PyTorch-ROCm/MIOpen (adjacent to the hot path,
@@ -175,7 +206,7 @@ class FeaturePyramidNetwork(nn.Module):
             out[names[-1]] = self.layer_blocks[-1](last)
         for i in range(len(xs) - 2, lowest - 1, -1):
             lat = self.inner_blocks[i](xs[i])
-            last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            last = fpn_top_down(lat, last)
             if needed is None or names[i] in needed:
                 out[names[i]] = self.layer_blocks[i](last)
         return out
@@ -260,9 +291,11 @@ def load_synthetic_clip():
     return SyntheticCLIPResNet50(), ClipNormalize()
 
 
-def bn_act(x, bn, relu=True, residual=None):
+def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
-    bf16 channels_last activation (vision.hip).  Three launches: stats, finalize, apply."""
+    bf16 channels_last activation (vision.hip).  Three launches: stats, finalize, apply.  pool=True also applies the
+    nn.AvgPool2d(2) that follows in the CLIP ResNet inside the apply kernel and returns (full, pooled); full is None
+    when keep_full=False.  bn=None: no normalisation (plain 2x2 average pool of x)."""
     N, C, H, W = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
     if residual is not None:
@@ -271,46 +304,86 @@ def bn_act(x, bn, relu=True, residual=None):
     rows = N * H * W
     dev = x.device
     st = O.L.stream()
-    scale = torch.empty((2, C), device=dev, dtype=torch.float32)
-    train = 1 if bn.training else 0
-    partial, nslab = None, 1
-    if train:
-        nslab = O.L.load().a3d_bn_nslab(rows, C)
-        partial = torch.empty((nslab, 2, C), device=dev, dtype=torch.float32)
-        O.L.call("a3d_bn_stats", x.data_ptr(), partial.data_ptr(), rows, C, nslab, st)
-    O.L.call("a3d_bn_finalize", None if partial is None else partial.data_ptr(), nslab, rows, C, float(bn.eps),
-             float(bn.momentum if bn.momentum is not None else 0.1), bn.weight.data_ptr(), bn.bias.data_ptr(),
-             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale[0].data_ptr(), scale[1].data_ptr(), train, st)
-    y = torch.empty_like(x)
-    O.L.call("a3d_bn_apply", x.data_ptr(), None if residual is None else residual.data_ptr(), scale[0].data_ptr(),
-             scale[1].data_ptr(), y.data_ptr(), rows, C, 1 if relu else 0, st)
-    return y
+    sc_ptr = sh_ptr = None
+    if bn is not None:
+        scale = torch.empty((2, C), device=dev, dtype=torch.float32)
+        train = 1 if bn.training else 0
+        partial, nslab = None, 1
+        if train:
+            nslab = O.L.load().a3d_bn_nslab(rows, C)
+            partial = torch.empty((nslab, 2, C), device=dev, dtype=torch.float32)
+            O.L.call("a3d_bn_stats", x.data_ptr(), partial.data_ptr(), rows, C, nslab, st)
+        O.L.call("a3d_bn_finalize", None if partial is None else partial.data_ptr(), nslab, rows, C, float(bn.eps),
+                 float(bn.momentum if bn.momentum is not None else 0.1), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale[0].data_ptr(), scale[1].data_ptr(), train, st)
+        sc_ptr, sh_ptr = scale[0].data_ptr(), scale[1].data_ptr()
+    res_ptr = None if residual is None else residual.data_ptr()
+    if not pool:
+        y = torch.empty_like(x)
+        O.L.call("a3d_bn_apply", x.data_ptr(), res_ptr, sc_ptr, sh_ptr, y.data_ptr(), rows, C, 1 if relu else 0, st)
+        return y
+    y = torch.empty_like(x) if keep_full else None
+    yp = torch.empty((N, C, H // 2, W // 2), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
+    O.L.call("a3d_bn_apply_pool2", x.data_ptr(), res_ptr, sc_ptr, sh_ptr, None if y is None else y.data_ptr(), yp.data_ptr(),
+             N, H, W, C, 1 if relu else 0, st)
+    return y, yp
+
+
+def _pool2_ok(m, t):
+    """m is the nn.AvgPool2d(2) of a stride-2 CLIP bottleneck and t has even spatial size (else: torch's pool)."""
+    return isinstance(m, nn.AvgPool2d) and m.kernel_size in (2, (2, 2)) and t.shape[-1] % 2 == 0 and t.shape[-2] % 2 == 0
 
 
 def fused_frozen_backbone_forward(bb, x):
     """SyntheticCLIPResNet50.forward with MIOpen bf16 NHWC convolutions and the fused BatchNorm of vision.hip.
-    Same dataflow as the module's own forward (CLIP ModifiedResNet, model/utils/clip.py:28-43)."""
+    Same dataflow as the module's own forward (CLIP ModifiedResNet, model/utils/clip.py:28-43); every AvgPool2d(2) is
+    folded into the BatchNorm-apply kernel that produces its input (the block output also feeds the next block's
+    downsample branch pooled, so that kernel emits both)."""
     conv = lambda m, t: F.conv2d(t, m.weight, None, m.stride, m.padding)
     x = bn_act(conv(bb.conv1, x), bb.bn1)
     x = bn_act(conv(bb.conv2, x), bb.bn2)
-    x0 = bn_act(conv(bb.conv3, x), bb.bn3)
+    c3 = conv(bb.conv3, x)
+    if _pool2_ok(bb.avgpool, c3):
+        x0, x = bn_act(c3, bb.bn3, pool=True)
+    else:
+        x0 = bn_act(c3, bb.bn3)
+        x = bb.avgpool(x0)
     outs = [x0]
-    x = bb.avgpool(x0)
     bns = [bb.bn1, bb.bn2, bb.bn3]
-    for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
-        for blk in layer:
-            out = bn_act(conv(blk.conv1, x), blk.bn1)
-            out = bn_act(conv(blk.conv2, out), blk.bn2)
-            out = blk.avgpool(out)
-            o3 = conv(blk.conv3, out)
-            if blk.downsample is not None:
-                idn = bn_act(conv(blk.downsample[1], blk.downsample[0](x)), blk.downsample[2], relu=False)
-                bns.append(blk.downsample[2])
+    blocks = [blk for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for blk in layer]
+    last_of_layer = {id(layer[-1]) for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4)}
+    x_pooled = None                                    # AvgPool2d(2)(x), when the producer of x already emitted it
+    for bi, blk in enumerate(blocks):
+        out = bn_act(conv(blk.conv1, x), blk.bn1)
+        c2 = conv(blk.conv2, out)
+        if _pool2_ok(blk.avgpool, c2):
+            out = bn_act(c2, blk.bn2, pool=True, keep_full=False)[1]
+        else:
+            out = blk.avgpool(bn_act(c2, blk.bn2))
+        o3 = conv(blk.conv3, out)
+        if blk.downsample is not None:
+            dpool = blk.downsample[0]
+            if x_pooled is not None:
+                xin = x_pooled
+            elif _pool2_ok(dpool, x):
+                xin = bn_act(x, None, relu=False, pool=True, keep_full=False)[1]
+            elif isinstance(dpool, nn.AvgPool2d) and dpool.kernel_size in (1, (1, 1)):
+                xin = x                                # AvgPool2d(1) is the identity
             else:
-                idn = x
-            x = bn_act(o3, blk.bn3, relu=True, residual=idn)
-            bns += [blk.bn1, blk.bn2, blk.bn3]
-        outs.append(x)
+                xin = dpool(x)
+            idn = bn_act(conv(blk.downsample[1], xin), blk.downsample[2], relu=False)
+            bns.append(blk.downsample[2])
+        else:
+            idn = x
+        nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+        want_pooled = nxt is not None and nxt.downsample is not None and _pool2_ok(nxt.downsample[0], o3)
+        if want_pooled:
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True)
+        else:
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn), None
+        bns += [blk.bn1, blk.bn2, blk.bn3]
+        if id(blk) in last_of_layer:
+            outs.append(x)
     if bb.training:
         torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
     return dict(zip(["res1", "res2", "res3", "res4", "res5"], outs))

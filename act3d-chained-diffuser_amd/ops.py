@@ -107,9 +107,13 @@ def add_layernorm_bwd(a2d, r2d, g, b, mean, rstd, dy2d):
     return ds
 
 
+ATTN_TARGET_WGS = int(os.environ.get("A3D_ATTN_WGS", "768"))
+
+
 def pick_nsplit(B, H, Lqp, Sp):
+    """Key-range splits of the forward / dQ kernels: enough workgroups for several waves per SIMD on 256 CUs."""
     wgs = B * H * ((Lqp + 63) // 64)
-    ns = max(1, min(16, Sp // 64, -(-768 // wgs)))
+    ns = max(1, min(16, Sp // 64, -(-ATTN_TARGET_WGS // wgs)))
     return ns
 
 

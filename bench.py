@@ -179,6 +179,8 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    if os.environ.get("A3D_CUDNN_BENCHMARK", "1") == "1":
+        torch.backends.cudnn.benchmark = True        # MIOpen find mode for the frozen backbone / FPN convolutions
     a3d = importlib.import_module("act3d-chained-diffuser_amd")
     a3d.lib.load()                                    # fails loudly if the HIP library is missing
     E = a3d.engine

@@ -172,6 +172,15 @@ int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int C, float e
 /* y = relu?(x * scale[c] + shift[c] (+ residual)) */
 int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, size_t rows, int C,
                  int relu, void* stream);
+/* Same, followed by the nn.AvgPool2d(2) that the CLIP bottleneck / stem applies to the activation (model/utils/clip.py
+ * Bottleneck.avgpool, downsample[0], ModifiedResNet.avgpool): y_pool [N][H/2][W/2][C] = mean of the 2x2 bf16 activations;
+ * y_full [N][H][W][C] is also written unless NULL.  scale == NULL: identity (plain average pool of x).  H, W even. */
+int a3d_bn_apply_pool2(const void* x, const void* residual, const float* scale, const float* shift, void* y_full,
+                       void* y_pool, int N, int H, int W, int C, int relu, void* stream);
+/* FPN top-down step, bf16 NHWC, exact 2x: y = lat + nearest_up2(top)  (torchvision FeaturePyramidNetwork.forward as the
+ * reference instantiates it, act3d.py:60-66); backward: dtop = 2x2 block sums of dy (dlat = dy).  H, W: the fine size. */
+int a3d_upsample2_add_fwd(const void* lat, const void* top, void* y, int N, int H, int W, int C, void* stream);
+int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, int W, int C, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------------- */
 int a3d_dbg_mfma_bf16(const void* A16x32, const void* B32x16, float* D16x16, void* stream);

@@ -502,6 +502,15 @@ def test_fused_batchnorm_train_relu_residual(a3d, dev, N, C, H):
     bnd.eval(); ref_bn.eval()
     y2 = a3d.nn.bn_act(xd, bnd, relu=False)
     report("bn_act eval", y2.float(), ref_bn(x.float()), 2e-2, 8e-3)
+    # fused AvgPool2d(2): the pooled output is the mean of the bf16 activations the un-pooled kernel writes
+    yf, yp = a3d.nn.bn_act(xd, bnd, relu=True, residual=rd, pool=True)
+    assert torch.equal(yf, a3d.nn.bn_act(xd, bnd, relu=True, residual=rd))
+    assert yp.is_contiguous(memory_format=torch.channels_last)
+    report("bn_act pooled", yp.float(), F.avg_pool2d(yf.float(), 2), 1e-6, 8e-3)     # one bf16 rounding
+    _, yp2 = a3d.nn.bn_act(xd, bnd, relu=True, residual=rd, pool=True, keep_full=False)
+    assert torch.equal(yp2, yp)
+    report("plain pool2", a3d.nn.bn_act(xd, None, relu=False, pool=True, keep_full=False)[1].float(),
+           F.avg_pool2d(x.float(), 2), 1e-6, 8e-3)
 
 
 def test_fused_frozen_backbone_matches_module(a3d, dev):
@@ -526,3 +535,23 @@ def test_fused_frozen_backbone_matches_module(a3d, dev):
     report("backbone bn1.running_mean", bb.bn1.running_mean, bb32.bn1.running_mean, 1e-4, 1e-2)
     report("backbone layer4 running_var", bb.layer4[2].bn3.running_var, bb32.layer4[2].bn3.running_var, 1e-3, 5e-2)
     assert int(bb.layer3[0].bn2.num_batches_tracked) == 1
+
+
+def test_fpn_top_down_fused(a3d, dev):
+    """lat + nearest_up2(top), bf16 NHWC, C = 60: forward bit-exact vs torch, backward = 2x2 block sums (one bf16 rounding)."""
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(3, 60, 16, 24, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    top = torch.randn(3, 60, 8, 12, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    l1, t1 = lat.clone().requires_grad_(), top.clone().requires_grad_()
+    l2, t2 = lat.clone().requires_grad_(), top.clone().requires_grad_()
+    y = a3d.nn.fpn_top_down(l1, t1)
+    ref = l2 + F.interpolate(t2, size=l2.shape[-2:], mode="nearest")
+    assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, ref)
+    dy = torch.randn(3, 60, 16, 24, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    ref.backward(dy)
+    assert torch.equal(l1.grad, l2.grad)
+    report("fpn top-down dtop", t1.grad.float(), t2.grad.float(), 1e-6, 8e-3)
+    # shapes the fused kernel does not cover fall back to torch
+    odd = torch.randn(1, 60, 5, 7, generator=g).to(torch.bfloat16).to(dev)
+    assert a3d.nn.fpn_top_down(odd, top[:1, :, :3, :4].contiguous()).shape == odd.shape
