@@ -71,6 +71,20 @@ __device__ __forceinline__ float colmax4(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 of a double (two 32-bit row swaps per step)
+__device__ __forceinline__ double colsum4(double v) {
+  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+  unsigned int lo = (unsigned int)(__double_as_longlong(v) & 0xFFFFFFFFll), hi = (unsigned int)(__double_as_longlong(v) >> 32);
+  u32x2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u32x2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __longlong_as_double(((long long)b[0] << 32) | a[0]) + __longlong_as_double(((long long)b[1] << 32) | a[1]);
+  lo = (unsigned int)(__double_as_longlong(v) & 0xFFFFFFFFll);
+  hi = (unsigned int)(__double_as_longlong(v) >> 32);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)b[0] << 32) | a[0]) + __longlong_as_double(((long long)b[1] << 32) | a[1]);
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);

@@ -48,31 +48,39 @@ __global__ __launch_bounds__(256) void mask_logits_fwd_kernel(
 }
 
 // dF[b][n][c] (+)= dlog[b][n] q[b][c];  dq[b][c] = sum_n dlog[b][n] F[b][n][c]
-__global__ __launch_bounds__(256) void mask_logits_bwd_kernel(
+// one 1024-thread workgroup per sample: 16 row-groups x 64 channels (x2 for E > 64), rows summed in a fixed order
+__global__ __launch_bounds__(1024) void mask_logits_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ F, const float* __restrict__ dlog,
     float* __restrict__ dF, float* __restrict__ dq, int B, int Ng, int E, int accumulate_dF) {
-  __shared__ float part[4][128];
+  __shared__ float part[16][128];
   const int b = blockIdx.x, t = threadIdx.x;
   const int c = t & 63, pr = t >> 6;
+  const float q0 = (c < E) ? q[(size_t)b * E + c] : 0.f;
+  const float q1 = (c + 64 < E) ? q[(size_t)b * E + c + 64] : 0.f;
   float a0 = 0.f, a1 = 0.f;
-  for (int n = pr; n < Ng; n += 4) {
+  for (int n = pr; n < Ng; n += 16) {
     const float d = dlog[(size_t)b * Ng + n];
     const size_t base = ((size_t)b * Ng + n) * E;
     if (c < E) {
       a0 += d * F[base + c];
-      const float v = d * q[(size_t)b * E + c];
+      const float v = d * q0;
       if (accumulate_dF) dF[base + c] += v; else dF[base + c] = v;
     }
     if (c + 64 < E) {
       a1 += d * F[base + c + 64];
-      const float v = d * q[(size_t)b * E + c + 64];
+      const float v = d * q1;
       if (accumulate_dF) dF[base + c + 64] += v; else dF[base + c + 64] = v;
     }
   }
   part[pr][c] = a0;
   part[pr][c + 64] = a1;
   __syncthreads();
-  if (t < E) dq[(size_t)b * E + t] = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+  if (t < E) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += part[u][t];
+    dq[(size_t)b * E + t] = s;
+  }
 }
 
 __global__ __launch_bounds__(256) void argmax_gather_kernel(
@@ -307,7 +315,7 @@ extern "C" int a3d_mask_logits_fwd(const float* q, const float* F, float* out, i
 extern "C" int a3d_mask_logits_bwd(const float* q, const float* F, const float* dlog, float* dF, float* dq, int B,
                                    int Ng, int E, int accumulate_dF, void* stream) {
   if (!q || !F || !dlog || !dF || !dq || B <= 0 || Ng <= 0 || E <= 0 || E > 128) { set_error("a3d_mask_logits_bwd: bad argument (E=%d)", E); return A3D_ERR_ARG; }
-  hipLaunchKernelGGL(mask_logits_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, F, dlog, dF, dq, B, Ng, E, accumulate_dF);
+  hipLaunchKernelGGL(mask_logits_bwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, q, F, dlog, dF, dq, B, Ng, E, accumulate_dF);
   return check_launch("a3d_mask_logits_bwd");
 }
 extern "C" int a3d_argmax_gather(const float* logits, const float* ghost, long long* top_idx, float* pos, int B, int Ng,

@@ -216,27 +216,30 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(
 }
 
 // second stage of the split-M weight gradient: dW[n][k] (+ db[n]) += sum_z partial[z][n][k], z in fixed order
-// (deterministic, and no memory-side float atomics: with >= 256 splits those serialise on the N*K addresses)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit,
-                                                           float* __restrict__ dW, int lddw, float* __restrict__ db,
-                                                           int N, int K, int KE) {
-  __shared__ float red[4][64];
+// (deterministic, and no memory-side float atomics: those serialise on the N*K addresses, ~10 G atomics/s)
+// 1024 threads = 64 outputs x 16 split-groups: <= nsplit/16 dependent loads per thread.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit,
+                                                            float* __restrict__ dW, int lddw, float* __restrict__ db,
+                                                            int N, int K, int KE) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   const int total = N * KE;
   float s0 = 0.f, s1 = 0.f;
   if (idx < total) {
     int z = zg;
-    for (; z + 4 < nsplit; z += 8) {
+    for (; z + 16 < nsplit; z += 32) {
       s0 += partial[(size_t)z * total + idx];
-      s1 += partial[(size_t)(z + 4) * total + idx];
+      s1 += partial[(size_t)(z + 16) * total + idx];
     }
     if (z < nsplit) s0 += partial[(size_t)z * total + idx];
   }
   red[zg][lane] = s0 + s1;
   __syncthreads();
   if (zg != 0 || idx >= total) return;
-  const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  float v = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v += red[u][lane];
   const int n = idx / KE, k = idx - n * KE;
   if (k < K) dW[(size_t)n * lddw + k] += v;
   else db[n] += v;
@@ -362,18 +365,23 @@ extern "C" int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
   return check_launch("a3d_linear_fwd");
 }
 
-// two-stage threshold: with more splits than this the atomics of the one-stage kernel dominate
-constexpr int WG_TWO_STAGE_MIN_SPLIT = 32;
+// With a workspace the M reduction is split into single-stage (64-row) .. 256-row chunks whose partial tiles a second
+// kernel adds in order; without one (or for M < 1024) the one-stage kernel accumulates with float atomics.
+constexpr int WG_TWO_STAGE_MIN_ROWS = 1024;
 
-static void wgrad_plan(int M, int N, int KE, bool have_ws, int* nsplit_out, int* rows_out) {
+static void wgrad_plan(int M, int N, int KE, bool have_ws, int* nsplit_out, int* rows_out, bool* two_stage) {
   const int tiles = cdiv(N, 64) * cdiv(KE, 64);
-  // one-stage: ~256 workgroups in flight, at least 256 rows (4 stages) per workgroup
-  static int target_wgs = getenv("A3D_WGRAD_WGS") ? atoi(getenv("A3D_WGRAD_WGS")) : 256;
-  int nsplit = max(1, min(cdiv(M, 256), cdiv(target_wgs, tiles)));
-  if (have_ws && nsplit >= WG_TWO_STAGE_MIN_SPLIT) {
-    // two-stage: no atomics, so oversubscribe (up to 4 workgroups per CU hide the stage latency), >= 256-row chunks
+  int nsplit;
+  *two_stage = have_ws && M >= WG_TWO_STAGE_MIN_ROWS;
+  if (*two_stage) {
+    // no atomics: oversubscribe (up to ~4 workgroups per CU hide the stage latency); short chunks for mid-size M
     static int target2 = getenv("A3D_WGRAD_WGS2") ? atoi(getenv("A3D_WGRAD_WGS2")) : 1024;
-    nsplit = max(nsplit, min(cdiv(M, 256), cdiv(target2, tiles)));
+    nsplit = max(1, min(cdiv(M, WG_MC), cdiv(target2, tiles)));
+    if (cdiv(M, nsplit) > 256) nsplit = max(nsplit, min(cdiv(M, 256), 4 * cdiv(target2, tiles)));
+  } else {
+    // one-stage: ~256 workgroups in flight, at least 256 rows (4 stages) per workgroup
+    static int target_wgs = getenv("A3D_WGRAD_WGS") ? atoi(getenv("A3D_WGRAD_WGS")) : 256;
+    nsplit = max(1, min(cdiv(M, 256), cdiv(target_wgs, tiles)));
   }
   int rows = cdiv(cdiv(M, nsplit), WG_MC) * WG_MC;
   *nsplit_out = cdiv(M, rows);
@@ -384,8 +392,9 @@ extern "C" size_t a3d_linear_wgrad_ws_bytes(int M, int N, int K, int has_bias) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int KE = has_bias ? K + 1 : K;
   int nsplit, rows;
-  wgrad_plan(M, N, KE, true, &nsplit, &rows);
-  return nsplit >= WG_TWO_STAGE_MIN_SPLIT ? (size_t)nsplit * N * KE * sizeof(float) : 0;
+  bool two;
+  wgrad_plan(M, N, KE, true, &nsplit, &rows, &two);
+  return two ? (size_t)nsplit * N * KE * sizeof(float) : 0;
 }
 
 extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
@@ -397,8 +406,8 @@ extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, in
   if (M == 0) return A3D_OK;
   const int KE = db ? K + 1 : K;
   int nsplit, rows;
-  wgrad_plan(M, N, KE, ws != nullptr, &nsplit, &rows);
-  const bool two_stage = ws && nsplit >= WG_TWO_STAGE_MIN_SPLIT;
+  bool two_stage;
+  wgrad_plan(M, N, KE, ws != nullptr, &nsplit, &rows, &two_stage);
   if (two_stage && ws_bytes < (size_t)nsplit * N * KE * sizeof(float)) {
     set_error("a3d_linear_wgrad_ws: workspace too small (%zu bytes, need %zu)", ws_bytes,
               (size_t)nsplit * N * KE * sizeof(float));
@@ -408,7 +417,7 @@ extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, in
   hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dW,
                      lddw, db, M, N, K, rows, two_stage ? ws : nullptr);
   if (two_stage)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * KE, 64)), dim3(256), 0, (hipStream_t)stream, ws, nsplit, dW,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * KE, 64)), dim3(1024), 0, (hipStream_t)stream, ws, nsplit, dW,
                        lddw, db, N, K, KE);
   return check_launch("a3d_linear_wgrad");
 }

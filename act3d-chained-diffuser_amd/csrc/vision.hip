@@ -76,24 +76,37 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ scale,
                                                            float* __restrict__ shift, int train) {
-  __shared__ double rs[64][17], rq[64][17];
-  const int cx = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  __shared__ double rs[16][16], rq[16][16];
+  const int cx = threadIdx.x & 15, sg = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 16 + cx;
   double s = 0.0, q = 0.0;
   if (train && c < C) {
-    for (int i = sg; i < nslab; i += 64) {
+    int i = sg;
+    double s1 = 0.0, q1 = 0.0;
+    for (; i + 64 < nslab; i += 128) {      // two independent load pairs in flight
+      s += (double)partial[(size_t)i * 2 * C + c];
+      q += (double)partial[(size_t)i * 2 * C + C + c];
+      s1 += (double)partial[(size_t)(i + 64) * 2 * C + c];
+      q1 += (double)partial[(size_t)(i + 64) * 2 * C + C + c];
+    }
+    if (i < nslab) {
       s += (double)partial[(size_t)i * 2 * C + c];
       q += (double)partial[(size_t)i * 2 * C + C + c];
     }
+    s += s1;
+    q += q1;
   }
-  rs[sg][cx] = s;
-  rq[sg][cx] = q;
+  // the wave's four slab-groups live in lanes cx, cx + 16, cx + 32, cx + 48: row-swap sums, then 16 waves through LDS
+  s = colsum4(s);
+  q = colsum4(q);
+  if ((threadIdx.x & 63) < 16) { rs[wave][cx] = s; rq[wave][cx] = q; }
   __syncthreads();
   if (sg != 0 || c >= C) return;
   double mean, var;
   if (train) {
     s = 0.0; q = 0.0;
-    for (int u = 0; u < 64; ++u) { s += rs[u][cx]; q += rq[u][cx]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { s += rs[u][cx]; q += rq[u][cx]; }
     mean = s / rows;
     var = q / rows - mean * mean;
     if (var < 0.0) var = 0.0;
