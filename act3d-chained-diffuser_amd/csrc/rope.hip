@@ -52,16 +52,10 @@ __device__ __forceinline__ void rope_tile_to_lds(float* T, int ldt, const float*
   }
 }
 
-// Writes the rotated, scaled rows in QK format (rows_out) and / or VT format (planes_out); either may be null.
-__global__ __launch_bounds__(256) void rope_split_kernel(
-    const float* __restrict__ Y, int ldy, const float* __restrict__ xyz, const float* __restrict__ freq,
-    float scale, unsigned short* __restrict__ rows_out, int rows_width, unsigned short* __restrict__ planes_out, int B,
-    int N, int Npad, int E, int H) {
-  extern __shared__ __attribute__((aligned(16))) float T[];
-  const int ldt = E + 1;
-  const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
-  rope_tile_to_lds(T, ldt, Y, ldy, xyz, freq, scale, b, n0, N, E);
-  __syncthreads();
+// T[r][c] (64 rows x E, rotated, scaled, rows >= N zero) -> rows format (width 32 / 48) and / or planes format
+__device__ __forceinline__ void write_operand_formats(const float* T, int ldt, unsigned short* __restrict__ rows_out,
+                                                      int rows_width, unsigned short* __restrict__ planes_out, int b, int n0,
+                                                      int Npad, int H) {
   if (rows_out) {
     const int nseg = rows_width >> 3;   // 4 (hi, lo) or 6 (hi, lo, lo2) 16-byte segments per row
     for (int idx = threadIdx.x; idx < RT_ROWS * H * nseg; idx += blockDim.x) {
@@ -102,6 +96,122 @@ __global__ __launch_bounds__(256) void rope_split_kernel(
       *reinterpret_cast<s16x8*>(planes_out + ((((size_t)b * H + h) * 2 + plane) * 16 + d) * Npad + n0 + seg * 8) = out;
     }
   }
+}
+
+// Writes the rotated, scaled rows in rows format (rows_out) and / or planes format (planes_out); either may be null.
+__global__ __launch_bounds__(256) void rope_split_kernel(
+    const float* __restrict__ Y, int ldy, const float* __restrict__ xyz, const float* __restrict__ freq,
+    float scale, unsigned short* __restrict__ rows_out, int rows_width, unsigned short* __restrict__ planes_out, int B,
+    int N, int Npad, int E, int H) {
+  extern __shared__ __attribute__((aligned(16))) float T[];
+  const int ldt = E + 1;
+  const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
+  rope_tile_to_lds(T, ldt, Y, ldy, xyz, freq, scale, b, n0, N, E);
+  __syncthreads();
+  write_operand_formats(T, ldt, rows_out, rows_width, planes_out, b, n0, Npad, H);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Projection + RoPE + operand formatting in one kernel: the projected rows never go to HBM.
+//   Y[64 rows][E] = X[64][K] W_blk[E][K]^T + bias_blk  (exact fp32 MFMA 16x16x4, as linear.hip)
+//   -> scale, rotate by xyz (in LDS) -> rows / planes operand formats.
+// blockIdx.y selects the output block (0: W rows [0, E), 1: W rows [E, 2E)) -- q | k of a packed q,k projection or
+// k | v of a packed k,v projection (multihead_custom_attention.py:251-303), each with its own rotation / scale / formats.
+struct ProjBlock {
+  const float* xyz;        // [B][N][3] or null (no rotation)
+  float scale;
+  unsigned short* rows;    // rows format or null
+  int rows_width;          // 32 or 48
+  unsigned short* planes;  // planes format or null
+};
+constexpr int PR_KC = 64;    // K chunk
+constexpr int PR_LD = 68;    // padded LDS row stride (floats)
+
+template <int NT>   // 16-column output tiles: 4 (E <= 64) or 8 (E <= 128)
+__global__ __launch_bounds__(256) void proj_rope_split_kernel(
+    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ bias, int K,
+    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                          // [64][PR_LD]
+  float* Ws = smem + RT_ROWS * PR_LD;        // [NT * 16][PR_LD]
+  float* T = smem;                           // [64][E + 1], aliases Xs / Ws after the contraction
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, n0 = blockIdx.x * RT_ROWS;
+  const ProjBlock blk = blockIdx.y ? blk1 : blk0;
+  const float* Wb = W + (size_t)blockIdx.y * E * ldw;
+  const float* bb = bias ? bias + blockIdx.y * E : nullptr;
+  const bool w_vec = ((((uintptr_t)Wb) & 15) == 0) && ((ldw & 3) == 0);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += PR_KC) {
+    // stage X[64][64] and W_blk[NT*16][64] (zero beyond N / E / K)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + i * 256;
+      const int r = idx >> 4, c = (idx & 15) * 4;
+      const int n = n0 + r, k = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N && k < K) v = *reinterpret_cast<const float4*>(X + ((size_t)b * N + n) * ldx + k);
+      *reinterpret_cast<float4*>(&Xs[r * PR_LD + c]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int idx = t + i * 256;
+      const int j = idx >> 4, c = (idx & 15) * 4;
+      const int k = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < E && k < K) {
+        const float* wp = Wb + (size_t)j * ldw + k;
+        // parameters living in a flat optimizer buffer are only 4-byte aligned
+        v = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
+      }
+      *reinterpret_cast<float4*>(&Ws[j * PR_LD + c]) = v;
+    }
+    __syncthreads();
+    const int ksteps = min(16, (K - k0 + 3) >> 2);
+    for (int kk = 0; kk < ksteps; ++kk) {
+      const float a = Xs[(wave * 16 + li) * PR_LD + kk * 4 + g];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f32_16x16x4(a, Ws[(nt * 16 + li) * PR_LD + kk * 4 + g], acc[nt]);
+    }
+    __syncthreads();
+  }
+  // Y tile (+ bias, * scale) -> T; rows n >= N stay zero (finite padding)
+  const int ldt = E + 1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = nt * 16 + li;
+    if (c >= E) continue;
+    const float bv = bb ? bb[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + g * 4 + r;
+      T[row * ldt + c] = (n0 + row < N) ? (acc[nt][r] + bv) * blk.scale : 0.f;
+    }
+  }
+  __syncthreads();
+  if (blk.xyz) {
+    const int half = E >> 1, third = E / 3;
+    for (int idx = t; idx < RT_ROWS * half; idx += 256) {
+      const int r = idx / half, p = idx - r * half;
+      const int n = n0 + r;
+      if (n >= N) continue;
+      const int c = 2 * p;
+      const int axis = c / third;
+      const int kf = (c - axis * third) >> 1;
+      const float th = blk.xyz[((size_t)b * N + n) * 3 + axis] * freq[kf];
+      float sn, cs;
+      sincosf(th, &sn, &cs);
+      const float y0 = T[r * ldt + c], y1 = T[r * ldt + c + 1];
+      T[r * ldt + c] = y0 * cs - y1 * sn;
+      T[r * ldt + c + 1] = y1 * cs + y0 * sn;
+    }
+    __syncthreads();
+  }
+  write_operand_formats(T, ldt, blk.rows, blk.rows_width, blk.planes, b, n0, Npad, H);
 }
 
 // dY[m][c] = scale * R(xyz)^T * sum_s dR[s][b][h][n][d]   (R^T = inverse rotation; identity when xyz == null)
@@ -195,4 +305,37 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
   hipLaunchKernelGGL(rope_merge_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz,
                      freq, scale, dY, ldy, B, N, Npad, E, H);
   return check_launch("a3d_rope_merge_bwd");
+}
+
+extern "C" int a3d_proj_rope_split(const float* X, int ldx, const float* W, int ldw, const float* bias, int K,
+                                   const float* xyz0, float scale0, void* rows0, int rows0_width, void* planes0,
+                                   const float* xyz1, float scale1, void* rows1, int rows1_width, void* planes1,
+                                   const float* freq, int B, int N, int Npad, int E, int H, void* stream) {
+  int rc = check_rope_args("a3d_proj_rope_split", B, N, Npad, E, H);
+  if (rc) return rc;
+  const bool two = rows1 || planes1;
+  if (!X || !W || K <= 0 || (K & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || E > 128 ||
+      (!rows0 && !planes0) || ((xyz0 || xyz1) && !freq) || (rows0 && rows0_width != VRW && rows0_width != QKW) ||
+      (rows1 && rows1_width != VRW && rows1_width != QKW)) {
+    set_error("a3d_proj_rope_split: bad argument (K=%d ldx=%d must be multiples of 4, X 16-byte aligned, E=%d <= 128, "
+              "rows widths 32 or 48)", K, ldx, E);
+    return A3D_ERR_ARG;
+  }
+  ProjBlock b0{xyz0, scale0, (unsigned short*)rows0, rows0_width, (unsigned short*)planes0};
+  ProjBlock b1{xyz1, scale1, (unsigned short*)rows1, rows1_width, (unsigned short*)planes1};
+  dim3 grid(Npad / RT_ROWS, two ? 2 : 1, B);
+  const int NT = E <= 64 ? 4 : 8;
+  const size_t lds = std::max((size_t)(RT_ROWS + NT * 16) * PR_LD, (size_t)RT_ROWS * (E + 1)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)proj_rope_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  if (NT == 4)
+    hipLaunchKernelGGL(proj_rope_split_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
+                       freq, B, N, Npad, E, H);
+  else
+    hipLaunchKernelGGL(proj_rope_split_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
+                       freq, B, N, Npad, E, H);
+  return check_launch("a3d_proj_rope_split");
 }

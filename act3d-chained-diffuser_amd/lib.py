@@ -28,6 +28,7 @@ SIGNATURES = {
     "a3d_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "a3d_rope_split_qk": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_split_vt": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_proj_rope_split": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rope_split": (_i, [_p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rope_merge_bwd": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -143,6 +143,48 @@ def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, 
     return Qs, Ks, Vt, Lqp, Sp, scale, freq, (Qt, Kt, Vs)
 
 
+FUSED_PROJ = os.environ.get("A3D_FUSED_PROJ", "1") == "1"
+
+
+def attn_operands_fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
+    """attn_operands with the in-projections folded in (a3d_proj_rope_split): q | k | v = x W^T + b computed per 64-row
+    tile and written straight in the operand formats.  wp / bp: device pointers of in_proj_weight [3E][E] / bias [3E]."""
+    Lqp, Sp = ceil_to(Lq, 64), ceil_to(S, 64)
+    scale = float(E // H) ** -0.5
+    freq = rope_freq(E, device)
+    bf = torch.bfloat16
+    Qs = torch.empty((B, H, Lqp, QKW), device=device, dtype=bf)
+    Ks = torch.empty((B, H, Sp, QKW), device=device, dtype=bf)
+    Vt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=bf)
+    Qt = Kt = Vs = None
+    if need_bwd:
+        Qt = torch.empty((B, H, 2, 16, Lqp), device=device, dtype=bf)
+        Kt = torch.empty((B, H, 2, 16, Sp), device=device, dtype=bf)
+        Vs = torch.empty((B, H, Sp, 32), device=device, dtype=bf)
+    st = L.stream()
+    f4 = 4
+    qx = None if q_xyz is None else q_xyz.data_ptr()
+    kx = None if k_xyz is None else k_xyz.data_ptr()
+    nz = lambda t: None if t is None else t.data_ptr()
+    fp = freq.data_ptr()
+
+    def proj(x, w_off, blk0, blk1, N, Npad):
+        L.call("a3d_proj_rope_split", x.data_ptr(), E, wp + w_off * E * f4, E, bp + w_off * f4, E,
+               *blk0, *(blk1 if blk1 is not None else (None, 1.0, None, 32, None)), fp, B, N, Npad, E, H, st)
+
+    if mode == "qk":        # q and k from the same rows (packed q,k projection), v separately
+        proj(q_in, 0, (qx, scale, Qs.data_ptr(), QKW, nz(Qt)), (kx, 1.0, Ks.data_ptr(), QKW, nz(Kt)), Lq, Lqp)
+        proj(v_in, 2 * E, (None, 1.0, nz(Vs), 32, Vt.data_ptr()), None, S, Sp)
+    else:
+        proj(q_in, 0, (qx, scale, Qs.data_ptr(), QKW, nz(Qt)), None, Lq, Lqp)
+        if mode == "kv":    # packed k,v projection of the shared key/value rows
+            proj(k_in, E, (kx, 1.0, Ks.data_ptr(), QKW, nz(Kt)), (None, 1.0, nz(Vs), 32, Vt.data_ptr()), S, Sp)
+        else:
+            proj(k_in, E, (kx, 1.0, Ks.data_ptr(), QKW, nz(Kt)), None, S, Sp)
+            proj(v_in, 2 * E, (None, 1.0, nz(Vs), 32, Vt.data_ptr()), None, S, Sp)
+    return Qs, Ks, Vt, Lqp, Sp, scale, freq, (Qt, Kt, Vs)
+
+
 def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
     dev = Qs.device
     E = H * 15
@@ -211,33 +253,38 @@ class AttnBlockFn(torch.autograd.Function):
             kmask = _c(kmask.to(torch.uint8))
         wp, bp = in_w.data_ptr(), in_b.data_ptr()
         f4 = 4
-        # ---- projections
-        if mode == "qk":
-            qk_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, 2 * E, E, dev)            # [B*Lq, 2E]
-            q_ptr, ldq = qk_pre.data_ptr(), 2 * E
-            k_ptr, ldk = qk_pre.data_ptr() + E * f4, 2 * E
-            v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
-            v_ptr, ldv = v_pre.data_ptr(), E
-            keep = (qk_pre, v_pre)
-        else:
-            q_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, E, E, dev)
-            q_ptr, ldq = q_pre.data_ptr(), E
-            if mode == "kv":
-                kv_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, 2 * E, E, dev)
-                k_ptr, ldk = kv_pre.data_ptr(), 2 * E
-                v_ptr, ldv = kv_pre.data_ptr() + E * f4, 2 * E
-                keep = (q_pre, kv_pre)
-            else:
-                k_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, E, E, dev)
-                v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
-                k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
-                keep = (q_pre, k_pre, v_pre)
         # grad mode is always off inside Function.forward: ask the ctx whether a backward can follow (the in-projection
         # parameters count -- they get .grad through wgrad even when no input needs a gradient)
         need_bwd = any(ctx.needs_input_grad) or in_w.requires_grad
-        Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
-                                                                S, E, H, dev, need_bwd=need_bwd)
-        del keep
+        if FUSED_PROJ and E % 4 == 0 and E <= 128:
+            # ---- projections fused with RoPE + operand formatting: the projected rows never reach HBM
+            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands_fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B,
+                                                                          Lq, S, E, H, dev, need_bwd)
+        else:
+            # ---- projections, then RoPE + operand formatting
+            if mode == "qk":
+                qk_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, 2 * E, E, dev)            # [B*Lq, 2E]
+                q_ptr, ldq = qk_pre.data_ptr(), 2 * E
+                k_ptr, ldk = qk_pre.data_ptr() + E * f4, 2 * E
+                v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
+                v_ptr, ldv = v_pre.data_ptr(), E
+                keep = (qk_pre, v_pre)
+            else:
+                q_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B * Lq, E, E, dev)
+                q_ptr, ldq = q_pre.data_ptr(), E
+                if mode == "kv":
+                    kv_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, 2 * E, E, dev)
+                    k_ptr, ldk = kv_pre.data_ptr(), 2 * E
+                    v_ptr, ldv = kv_pre.data_ptr() + E * f4, 2 * E
+                    keep = (q_pre, kv_pre)
+                else:
+                    k_pre = linear_raw(k_in.data_ptr(), E, wp + E * E * f4, E, bp + E * f4, B * S, E, E, dev)
+                    v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
+                    k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
+                    keep = (q_pre, k_pre, v_pre)
+            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
+                                                                    S, E, H, dev, need_bwd=need_bwd)
+            del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
         O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit)
         Y = linear2d(O.view(B * Lq, E), out_w, out_b)

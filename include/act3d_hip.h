@@ -70,6 +70,15 @@ int a3d_split_vt(const float* Y, int ldy, void* dst, int B, int N, int Npad, int
  * rows_width: 48 (q, k: hi|lo|lo2) or 32 (v: hi|lo); a3d_rope_split_qk writes 48-wide rows. */
 int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
                    int rows_width, void* planes_out, int B, int N, int Npad, int E, int H, void* stream);
+/* In-projection + RoPE + operand formatting in one pass: for output block j in {0, 1} (block 1 optional: rows1 and
+ * planes1 both NULL), Y_j = (X W[jE:(j+1)E, :K]^T + bias[jE:(j+1)E]) * scale_j, rotated by xyz_j (NULL: none), written as
+ * rows (width 32 | 48, may be NULL) and planes (may be NULL).  X: [B*N][ldx] fp32; the projected rows never reach HBM.
+ * Replaces the F.linear in-projections (multihead_custom_attention.py:246-303) feeding a3d_rope_split.
+ * K, ldx multiples of 4, X 16-byte aligned (W may be 4-byte aligned: flat parameter buffers); E <= 128. */
+int a3d_proj_rope_split(const float* X, int ldx, const float* W, int ldw, const float* bias, int K, const float* xyz0,
+                        float scale0, void* rows0, int rows0_width, void* planes0, const float* xyz1, float scale1,
+                        void* rows1, int rows1_width, void* planes1, const float* freq, int B, int N, int Npad, int E,
+                        int H, void* stream);
 /* dY[:, :E] = scale * R(xyz)^T * sum_s dR[s];  dR: [nsplit][B][H][Npad][16] fp32 (grad w.r.t. rotated rows). */
 int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const float* freq, float scale, float* dY,
                        int ldy, int B, int N, int Npad, int E, int H, void* stream);

@@ -127,7 +127,15 @@ class _Mod:
 
 def _mk_modules(dev, in_w, in_b, out_w, out_b, ln_g, ln_b):
     mha = _Mod()
-    mha.in_proj_weight = torch.nn.Parameter(in_w.to(dev))
+    if in_w.shape[1] == 60:
+        # as inside engine.FlatParams: a 4-byte-aligned view into a larger buffer (exercises the unaligned-W path of the
+        # fused projection kernel); the E = 120 cases keep a 16-byte-aligned weight
+        buf = torch.zeros(in_w.numel() + 1, device=dev)
+        buf[1:].copy_(in_w.reshape(-1))
+        mha.in_proj_weight = torch.nn.Parameter(buf[1:].view(in_w.shape))
+        assert mha.in_proj_weight.data_ptr() % 16 == 4
+    else:
+        mha.in_proj_weight = torch.nn.Parameter(in_w.to(dev))
     mha.in_proj_bias = torch.nn.Parameter(in_b.to(dev))
     mha.out_proj = _Mod()
     mha.out_proj.weight = torch.nn.Parameter(out_w.to(dev))
