@@ -645,8 +645,10 @@ class QuatSigmoidFn(torch.autograd.Function):
     def backward(ctx, drot, dgrip):
         (pred,) = ctx.saved_tensors
         dp = torch.empty_like(pred)
-        L.call("a3d_quat_sigmoid_bwd", pred.data_ptr(), None if drot is None else _c(drot).data_ptr(),
-               None if dgrip is None else _c(dgrip).data_ptr(), dp.data_ptr(), pred.shape[0], L.stream())
+        drot = None if drot is None else _c(drot)        # bound to locals: both stay alive until the launch is enqueued
+        dgrip = None if dgrip is None else _c(dgrip)
+        L.call("a3d_quat_sigmoid_bwd", pred.data_ptr(), None if drot is None else drot.data_ptr(),
+               None if dgrip is None else dgrip.data_ptr(), dp.data_ptr(), pred.shape[0], L.stream())
         return dp
 
 
@@ -764,16 +766,22 @@ def kv_cache_build(k_in, k_xyz, mha, H):
     B, S, E = k_in.shape
     dev = k_in.device
     f4 = 4
-    kv_pre = linear_raw(k_in.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
-                        mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
     Sp = ceil_to(S, 64)
     freq = rope_freq(E, dev)
     Ks = torch.empty((B, H, Sp, QKW), device=dev, dtype=torch.bfloat16)
     Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.bfloat16)
     st = L.stream()
-    L.call("a3d_rope_split_qk", kv_pre.data_ptr(), 2 * E, None if k_xyz is None else _c(k_xyz).data_ptr(), freq.data_ptr(),
-           1.0, Ks.data_ptr(), B, S, Sp, E, H, st)
-    L.call("a3d_split_vt", kv_pre.data_ptr() + E * f4, 2 * E, Vt.data_ptr(), B, S, Sp, E, H, st)
+    k_xyz = None if k_xyz is None else _c(k_xyz.to(F32))      # keep the (possibly converted) tensor alive
+    kx = None if k_xyz is None else k_xyz.data_ptr()
+    if FUSED_PROJ and E % 4 == 0 and E <= 128:
+        L.call("a3d_proj_rope_split", k_in.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+               mha.in_proj_bias.data_ptr() + E * f4, E, kx, 1.0, Ks.data_ptr(), QKW, None, None, 1.0, None, 32, Vt.data_ptr(),
+               freq.data_ptr(), B, S, Sp, E, H, st)
+    else:
+        kv_pre = linear_raw(k_in.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+                            mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
+        L.call("a3d_rope_split_qk", kv_pre.data_ptr(), 2 * E, kx, freq.data_ptr(), 1.0, Ks.data_ptr(), B, S, Sp, E, H, st)
+        L.call("a3d_split_vt", kv_pre.data_ptr() + E * f4, 2 * E, Vt.data_ptr(), B, S, Sp, E, H, st)
     return {"Ks": Ks, "Vt": Vt, "S": S, "Sp": Sp}
 
 
@@ -784,11 +792,18 @@ def attn_block_cached(q_in, resid, q_xyz, cache, mha, norm, H):
     B, Lq, E = q_in.shape
     dev = q_in.device
     Lqp = ceil_to(Lq, 64)
-    q_pre = linear_raw(q_in.data_ptr(), E, mha.in_proj_weight.data_ptr(), E, mha.in_proj_bias.data_ptr(), B * Lq, E, E, dev)
     Qs = torch.empty((B, H, Lqp, QKW), device=dev, dtype=torch.bfloat16)
     freq = rope_freq(E, dev)
-    L.call("a3d_rope_split_qk", q_pre.data_ptr(), E, None if q_xyz is None else _c(q_xyz).data_ptr(), freq.data_ptr(),
-           float(E // H) ** -0.5, Qs.data_ptr(), B, Lq, Lqp, E, H, L.stream())
+    q_xyz = None if q_xyz is None else _c(q_xyz.to(F32))      # keep the (possibly converted) tensor alive
+    qx = None if q_xyz is None else q_xyz.data_ptr()
+    if FUSED_PROJ and E % 4 == 0 and E <= 128:
+        L.call("a3d_proj_rope_split", q_in.data_ptr(), E, mha.in_proj_weight.data_ptr(), E, mha.in_proj_bias.data_ptr(), E,
+               qx, float(E // H) ** -0.5, Qs.data_ptr(), QKW, None, None, 1.0, None, 32, None, freq.data_ptr(), B, Lq, Lqp, E,
+               H, L.stream())
+    else:
+        q_pre = linear_raw(q_in.data_ptr(), E, mha.in_proj_weight.data_ptr(), E, mha.in_proj_bias.data_ptr(), B * Lq, E, E, dev)
+        L.call("a3d_rope_split_qk", q_pre.data_ptr(), E, qx, freq.data_ptr(), float(E // H) ** -0.5, Qs.data_ptr(), B, Lq, Lqp,
+               E, H, L.stream())
     nsplit = pick_nsplit(B, H, Lqp, cache["Sp"])
     O_, _ = attn_core_fwd(Qs, cache["Ks"], cache["Vt"], None, B, H, Lq, Lqp, cache["S"], cache["Sp"], nsplit)
     Y = linear2d(O_.view(B * Lq, E), mha.out_proj.weight, mha.out_proj.bias)

@@ -121,7 +121,8 @@ def time_kernel(fn, iters=20):
 def kernel_rooflines(a3d, device, B):
     """Live timing of the dominant hand-written kernels at the workload's shapes (ghost attention: Lq=333, S=4097,
     E=60, H=4) against their rooflines.  Algorithmic FLOPs per launch: forward 4*Lq*S*E*B (QK^T + PV), backward
-    10*Lq*S*E*B (five contractions); see DESIGN.md §kernels."""
+    10*Lq*S*E*B (five contractions); the fused k,v in-projection + RoPE + operand-format kernel is HBM-bound:
+    algorithmic bytes = the fp32 input rows + the bf16 operand tensors it writes.  See DESIGN.md, kernels."""
     O = a3d.ops
     H, E, Lq, S = 4, 60, 333, 4097
     g = torch.Generator().manual_seed(1)
@@ -139,20 +140,40 @@ def kernel_rooflines(a3d, device, B):
     t_bwd = time_kernel(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Lq, Lqp, S, Sp, ns, extra=extra))
     f_fwd = 4.0 * Lq * S * E * B
     f_bwd = 10.0 * Lq * S * E * B
-    x = torch.randn(B * S, E, generator=g).to(device)
-    w = torch.randn(2 * E, E, generator=g).to(device)
-    bb = torch.zeros(2 * E, device=device)
-    t_lin = time_kernel(lambda: O.linear2d(x, w, bb))
-    bytes_lin = 4.0 * (B * S * E + B * S * 2 * E)
+    x = torch.randn(B, S, E, generator=g).to(device)
+    w = torch.randn(3 * E, E, generator=g).to(device)
+    bb = torch.zeros(3 * E, device=device)
+    Spad = (S + 63) // 64 * 64
+    bf = torch.bfloat16
+    Kr = torch.empty((B, H, Spad, O.QKW), device=device, dtype=bf)
+    Kp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
+    Vr = torch.empty((B, H, Spad, 32), device=device, dtype=bf)
+    Vp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
+    t_proj = time_kernel(lambda: O.L.call(
+        "a3d_proj_rope_split", x.data_ptr(), E, w.data_ptr() + E * E * 4, E, bb.data_ptr() + E * 4, E,
+        k_xyz.data_ptr(), 1.0, Kr.data_ptr(), O.QKW, Kp.data_ptr(), None, 1.0, Vr.data_ptr(), 32, Vp.data_ptr(),
+        freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
+    bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (O.QKW + 32 + 32 + 32))      # x rows + K rows/planes + V rows/planes
     return {
         "attn_fwd": {"bound": "mfma", "achieved": f_fwd / (t_fwd * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (hi+lo split operands)"},
+                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (split operands)"},
         "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 157.3 if O.BWD_F32 else 2500.0,
                      "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6,
-                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (hi+lo split operands)"},
-        "kv_proj_linear": {"bound": "hbm", "achieved": bytes_lin / (t_lin * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                           "ms": t_lin, "launches_per_step": 12},
+                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (split operands)"},
+        "kv_proj_rope": {"bound": "hbm", "achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "ms": t_proj, "launches_per_step": 6},
     }
+
+
+def pmc_record(B):
+    """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
+    counters cannot be read from inside this process).  None when no record exists for this batch size."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_B{B}.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["kernels"]
+    except Exception:
+        return None
 
 
 def main():
@@ -250,8 +271,8 @@ def main():
             "metric": "train samples/sec (Act3D keypose fwd+bwd+AdamW step)", "value": world * B * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA (split hi+lo operands, fp32 accumulate) attention; fp32 elsewhere; bf16 frozen backbone"
-                     if args.backbone_dtype == "bf16" else "bf16 MFMA attention; fp32 elsewhere",
+            "dtype": "bf16 MFMA on split operands (q,k = hi+lo+lo2, p,v = hi+lo; fp32 accumulate) in attention; fp32 MFMA "
+                     "linears; " + ("bf16 frozen backbone + FPN" if args.backbone_dtype == "bf16" else "fp32 backbone + FPN"),
             "data": "synthetic",
             "config": {"workload": "Act3D keypose training step, 18-PerAct-task shapes: 4 cameras 256x256, 3 ghost-point "
                                    "levels, 1000 ghost points (333/level), E=60, frozen synthetic CLIP-RN50-shaped backbone "
@@ -288,7 +309,11 @@ def main():
             r = dict(ks[dom])
             r["kernel"] = dom
             r["frac"] = r["achieved"] / r["peak"]
-            r["traffic"] = None
+            pmc = pmc_record(B) or {}
+            r["traffic"] = pmc.get(dom, {}).get("hbm_bytes")
+            if dom in pmc:
+                r["traffic_source"] = f"profiles/r01_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
+                r["pmc"] = pmc[dom].get("pmc")
             res["roofline"] = r
             res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"]}
                               for k, v in ks.items()}

@@ -72,14 +72,15 @@ def main():
     assert torch.isfinite(out).all()
     S = C * 1024 + 2
     Sp = (S + 63) // 64 * 64
-    # K/V cache actually streamed per denoise step: 8 cross-attention layers x (K: 64 B + V: 64 B per key and head)
-    bytes_step = 8 * B * H * Sp * 128
+    # K/V cache actually streamed per denoise step: 8 cross-attention layers x (K: 96 B (hi|lo|lo2) + V: 64 B per key and head)
+    KV_BYTES = 2 * a3d.ops.QKW + 64
+    bytes_step = 8 * B * H * Sp * KV_BYTES
     flops_step = 8 * 4.0 * Ln * S * E * B                  # QK^T + PV of the 8 cross-attention layers
     # live timing of one cross-attention core launch at these shapes
     O = a3d.ops
     Lqp = 64
-    Qs = torch.randn(B, H, Lqp, 32, device=dev).to(torch.bfloat16)
-    Ks = torch.randn(B, H, Sp, 32, device=dev).to(torch.bfloat16)
+    Qs = torch.randn(B, H, Lqp, O.QKW, device=dev).to(torch.bfloat16)
+    Ks = torch.randn(B, H, Sp, O.QKW, device=dev).to(torch.bfloat16)
     Vt = torch.randn(B, H, 2, 16, Sp, device=dev).to(torch.bfloat16)
     ns = O.pick_nsplit(B, H, Lqp, Sp)
     for _ in range(3):
@@ -92,11 +93,11 @@ def main():
     en.record()
     torch.cuda.synchronize()
     t_attn = st.elapsed_time(en) / 20 * 1e-3
-    kv_bytes_launch = B * H * Sp * 128
+    kv_bytes_launch = B * H * Sp * KV_BYTES
     res = {
         "metric": "DDPM trajectory sampling, 100 denoise steps (trajectories/s)", "value": B / dt, "unit": "trajectories/s",
         "n_gpus": 1, "ms_per_100_step_batch": dt * 1e3, "ms_per_denoise_step": dt * 10, "higher_is_better": True,
-        "dtype": "bf16 MFMA (split hi+lo) attention, fp32 elsewhere", "data": "synthetic",
+        "dtype": "bf16 MFMA on split operands (q,k hi+lo+lo2; p,v hi+lo) attention, fp32 elsewhere", "data": "synthetic",
         "config": {"workload": f"ChainedDiffuser compute_trajectory: B={B}, horizon={Ln}, {C} cameras (S={S} context tokens), "
                                "E=120, H=8, 100 steps, context + K/V cache built once, loop hipGraph-captured"
                                if not args.no_graph else "eager loop", "hipgraph": not args.no_graph},

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Folds the rocprofv3 --pmc passes of profiles/run_pmc.sh into one JSON keyed by bench.py's kernel names.
+
+usage: python profiles/pmc_to_json.py <pmc-dir> <batch> > profiles/rNN_pmc_B<batch>.json
+HBM traffic per launch = FETCH_SIZE * 1024 * 2 (gfx950 under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md
+"HBM") + WRITE_SIZE * 1024, summed over the kernels that make up one bench.py "launch" (attn_bwd = prep + dq + dkv)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+GROUPS = {
+    "attn_fwd": ["attn_fwd_kernel", "attn_combine_kernel"],
+    "attn_bwd": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel"],
+    "kv_proj_rope": ["proj_rope_split_kernel"],
+}
+
+
+def means(pmc_dir, name):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(pmc_dir, name, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = row.get("Kernel_Name", "")
+                agg[(k, row["Counter_Name"])][0] += 1
+                agg[(k, row["Counter_Name"])][1] += float(row["Counter_Value"])
+    return {k: v[1] / v[0] for k, v in agg.items()}
+
+
+def main():
+    pmc_dir, batch = sys.argv[1], int(sys.argv[2])
+    fetch, write, derived = means(pmc_dir, "fetch"), means(pmc_dir, "write"), means(pmc_dir, "derived")
+    out = {"batch": batch, "source": "rocprofv3 --pmc passes of profiles/run_pmc.sh (FETCH_SIZE, WRITE_SIZE, MfmaUtil/VALUBusy), "
+                                     "bench.py --kernels-only", "kernels": {}}
+    for key, kernels in GROUPS.items():
+        fb = wb = 0.0
+        util = {}
+        found = False
+        for kn in kernels:
+            for (name, ctr), v in fetch.items():
+                if kn in name and ctr == "FETCH_SIZE":
+                    fb += v * 1024 * 2
+                    found = True
+            for (name, ctr), v in write.items():
+                if kn in name and ctr == "WRITE_SIZE":
+                    wb += v * 1024
+            for (name, ctr), v in derived.items():
+                if kn in name and ctr in ("MfmaUtil", "VALUBusy"):
+                    util.setdefault(kn, {})[ctr] = round(v, 1)
+        if found:
+            out["kernels"][key] = {"hbm_read_bytes": fb, "hbm_write_bytes": wb, "hbm_bytes": fb + wb, "pmc": util}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
