@@ -166,6 +166,147 @@ __global__ __launch_bounds__(TK_THREADS) void knn_topk_kernel(
   }
 }
 
+// hist[bin] += 1 for every lane with pred, with the wave's most common case -- many lanes in the same bin (distances
+// share their exponent bits) -- folded into one LDS atomic: up to two rounds of "leader's bin" peeling, then plain atomics.
+__device__ __forceinline__ void hist_add_wave(unsigned int* hist, unsigned int bin, bool pred, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const unsigned long long act = __ballot(pred);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const unsigned int lb = __builtin_amdgcn_readlane(bin, leader);
+    const unsigned long long same = __ballot(pred && bin == lb);
+    if (lane == leader) atomicAdd(&hist[lb], (unsigned int)__popcll(same));
+    pred = pred && (bin != lb);
+  }
+  if (pred) atomicAdd(&hist[bin], 1u);
+}
+
+// Same selection as knn_topk_kernel with each thread's ITEMS distances held in registers (N <= 1024 * ITEMS): no scratch
+// round trips through L2 in the seven passes, wave-aggregated histogram atomics.
+template <int ITEMS>
+__global__ __launch_bounds__(TK_THREADS) void knn_topk_reg_kernel(
+    const float* __restrict__ pos, const float* __restrict__ xyz, long long* __restrict__ idx_out,
+    float* __restrict__ dist_out, int N, int k, int kpad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_prefix, sh_krem, sh_count, sh_neq;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const float px = pos[b * 3 + 0], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  const float* pts = xyz + (size_t)b * N * 3;
+
+  unsigned int dv[ITEMS];     // element i of this thread is point t + i * 1024 (0xFFFFFFFF beyond N: never selected, k <= N)
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int n = t + i * TK_THREADS;
+    dv[i] = (n < N) ? __float_as_uint(l2_dist(px, py, pz, pts + (size_t)n * 3)) : 0xFFFFFFFFu;
+  }
+  if (t == 0) { sh_prefix = 0; sh_krem = (unsigned int)k; }
+  __syncthreads();
+
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const unsigned int prefix = sh_prefix;
+    const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const bool in = (t + i * TK_THREADS < N) && ((dv[i] & himask) == prefix);
+      hist_add_wave(hist, (dv[i] >> shift) & 255u, in, lane);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned int krem = sh_krem, cum = 0;
+      int bin = 0;
+      for (; bin < 256; ++bin) {
+        if (cum + hist[bin] >= krem) break;
+        cum += hist[bin];
+      }
+      if (bin > 255) bin = 255;
+      sh_krem = krem - cum;
+      sh_prefix = prefix | ((unsigned int)bin << shift);
+      sh_neq = hist[bin];
+    }
+    __syncthreads();
+  }
+  const unsigned int T = sh_prefix;       // k-th smallest value
+  unsigned int need = sh_krem;            // how many elements == T are wanted
+  unsigned int idx_thr = 0xFFFFFFFFu;     // elements == T with idx <= idx_thr are taken
+  if (sh_neq != need) {
+    __syncthreads();
+    if (t == 0) { sh_prefix = 0; sh_krem = need; }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 16 - 8 * pass;
+      if (t < 256) hist[t] = 0;
+      __syncthreads();
+      const unsigned int prefix = sh_prefix;
+      const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        const unsigned int n = (unsigned int)(t + i * TK_THREADS);
+        const bool in = (n < (unsigned int)N) && dv[i] == T && ((n & himask) == prefix);
+        hist_add_wave(hist, (n >> shift) & 255u, in, lane);
+      }
+      __syncthreads();
+      if (t == 0) {
+        unsigned int krem = sh_krem, cum = 0;
+        int bin = 0;
+        for (; bin < 256; ++bin) {
+          if (cum + hist[bin] >= krem) break;
+          cum += hist[bin];
+        }
+        if (bin > 255) bin = 255;
+        sh_krem = krem - cum;
+        sh_prefix = prefix | ((unsigned int)bin << shift);
+      }
+      __syncthreads();
+    }
+    idx_thr = sh_prefix;
+  }
+  // ---- collect survivors (one LDS atomic per wave-instruction: lanes take consecutive slots)
+  if (t == 0) sh_count = 0;
+  for (int i = t; i < kpad; i += TK_THREADS) keys[i] = 0xFFFFFFFFFFFFFFFFull;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const unsigned int n = (unsigned int)(t + i * TK_THREADS);
+    const unsigned int v = dv[i];
+    const bool take = (n < (unsigned int)N) && (v < T || (v == T && n <= idx_thr));
+    const unsigned long long m = __ballot(take);
+    if (m != 0ull) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(&sh_count, (unsigned int)__popcll(m));
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (take) {
+        const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned int)kpad) keys[slot] = ((unsigned long long)v << 32) | n;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort of kpad 64-bit keys (value major, index minor)
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (kpad >> 1); i += TK_THREADS) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < k; i += TK_THREADS) {
+    const unsigned long long kk = keys[i];
+    idx_out[(size_t)b * k + i] = (long long)(kk & 0xFFFFFFFFull);
+    if (dist_out) dist_out[(size_t)b * k + i] = __uint_as_float((unsigned int)(kk >> 32));
+  }
+}
+
 // ctx[b][s][:] = s < k ? feat[b][idx ? idx[b][s] : s][:] : extra[b][s-k][:]   (rows of E floats, E % 4 == 0)
 __global__ __launch_bounds__(256) void build_context_kernel(
     const float* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
@@ -269,8 +410,22 @@ extern "C" int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long l
     (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz,
-                     (unsigned int*)ws, idx_out, dist_out, N, k, kpad);
+  static bool attr2_set = false;
+  if (!attr2_set) {
+    (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr2_set = true;
+  }
+  static const bool use_ws = getenv("A3D_KNN_WS") && atoi(getenv("A3D_KNN_WS")) != 0;   // A/B switch: scratch-based kernel
+  if (!use_ws && N <= 16 * TK_THREADS)
+    hipLaunchKernelGGL(knn_topk_reg_kernel<16>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
+                       dist_out, N, k, kpad);
+  else if (!use_ws && N <= 64 * TK_THREADS)
+    hipLaunchKernelGGL(knn_topk_reg_kernel<64>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
+                       dist_out, N, k, kpad);
+  else
+    hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz,
+                       (unsigned int*)ws, idx_out, dist_out, N, k, kpad);
   return check_launch("a3d_knn_topk");
 }
 
