@@ -15,7 +15,7 @@ pass() {
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
       python "$R/bench.py" --kernels-only --batch "$B" > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?" >> "$OUT/passes.txt"
-  python "$R/profiles/pmc_summary.py" "$OUT/$name" attn_ linear_ bn_ > "$OUT/$name.summary.txt" 2>&1
+  python "$R/profiles/pmc_summary.py" "$OUT/$name" attn_ linear_ bn_ proj_rope > "$OUT/$name.summary.txt" 2>&1
   find "$OUT/$name" -name '*.csv' -size +8M -delete
 }
 : > "$OUT/passes.txt"
