@@ -52,48 +52,54 @@ __device__ __forceinline__ void rope_tile_to_lds(float* T, int ldt, const float*
   }
 }
 
-// T[r][c] (64 rows x E, rotated, scaled, rows >= N zero) -> rows format (width 32 / 48) and / or planes format
+// T[r][c] (64 rows x E, rotated, scaled, rows >= N zero) -> rows format (width 32 / 48) and / or planes format.
+// Each work item splits its 8 values once and stores every part it yields (2-3 row segments, 2 plane segments).
 __device__ __forceinline__ void write_operand_formats(const float* T, int ldt, unsigned short* __restrict__ rows_out,
                                                       int rows_width, unsigned short* __restrict__ planes_out, int b, int n0,
                                                       int Npad, int H) {
   if (rows_out) {
-    const int nseg = rows_width >> 3;   // 4 (hi, lo) or 6 (hi, lo, lo2) 16-byte segments per row
-    for (int idx = threadIdx.x; idx < RT_ROWS * H * nseg; idx += blockDim.x) {
-      const int seg = idx % nseg;
-      const int r = (idx / nseg) % RT_ROWS;
-      const int h = (idx / nseg) / RT_ROWS;
+    const bool three = rows_width == QKW;
+    for (int idx = threadIdx.x; idx < RT_ROWS * H * 2; idx += blockDim.x) {
+      const int half = idx & 1;                 // head-dim elements 0-7 / 8-15
+      const int r = (idx >> 1) % RT_ROWS;
+      const int h = (idx >> 1) / RT_ROWS;
       const int n = n0 + r;
       if (n >= Npad) continue;
-      const int dbase = (seg & 1) * 8;
-      const int part = seg >> 1;
-      s16x8 out;
+      s16x8 ohi, olo, olo2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int d = dbase + j;
+        const int d = half * 8 + j;
         const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
         unsigned short hi, lo, lo2;
         split_bf16_3(v, hi, lo, lo2);
-        out[j] = (short)(part == 0 ? hi : (part == 1 ? lo : lo2));
+        ohi[j] = (short)hi;
+        olo[j] = (short)lo;
+        olo2[j] = (short)lo2;
       }
-      *reinterpret_cast<s16x8*>(rows_out + (((size_t)b * H + h) * Npad + n) * rows_width + seg * 8) = out;
+      unsigned short* dst = rows_out + (((size_t)b * H + h) * Npad + n) * rows_width + half * 8;
+      *reinterpret_cast<s16x8*>(dst) = ohi;
+      *reinterpret_cast<s16x8*>(dst + 16) = olo;
+      if (three) *reinterpret_cast<s16x8*>(dst + 32) = olo2;
     }
   }
   if (planes_out) {
-    for (int idx = threadIdx.x; idx < H * 2 * 16 * 8; idx += blockDim.x) {
-      const int seg = idx & 7;
+    for (int idx = threadIdx.x; idx < H * 16 * 8; idx += blockDim.x) {
+      const int seg = idx & 7;                  // 8 consecutive rows (keys)
       const int d = (idx >> 3) & 15;
-      const int plane = (idx >> 7) & 1;
-      const int h = idx >> 8;
-      s16x8 out;
+      const int h = idx >> 7;
+      s16x8 ohi, olo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = seg * 8 + j;
         const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
         unsigned short hi, lo;
         split_bf16(v, hi, lo);
-        out[j] = (short)(plane ? lo : hi);
+        ohi[j] = (short)hi;
+        olo[j] = (short)lo;
       }
-      *reinterpret_cast<s16x8*>(planes_out + ((((size_t)b * H + h) * 2 + plane) * 16 + d) * Npad + n0 + seg * 8) = out;
+      unsigned short* dst = planes_out + ((((size_t)b * H + h) * 2 + 0) * 16 + d) * Npad + n0 + seg * 8;
+      *reinterpret_cast<s16x8*>(dst) = ohi;
+      *reinterpret_cast<s16x8*>(dst + (size_t)16 * Npad) = olo;
     }
   }
 }

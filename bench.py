@@ -168,7 +168,7 @@ def kernel_rooflines(a3d, device, B):
 def pmc_record(B):
     """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
     counters cannot be read from inside this process).  None when no record exists for this batch size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_B{B}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_B{B}.json")   # B = 16, 64
     try:
         with open(path) as fh:
             return json.load(fh)["kernels"]
@@ -181,7 +181,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="keyframe rows per GPU (16 = cfg-4's per-GPU batch)")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="keyframe rows per GPU; 64 = the reference's default step: batch_size 16 episodes "
+                         "(main_keypose.py:49) x ~4 keyframes per episode (<= 5, datasets/dataset_engine.py chunking)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backbone-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -278,6 +280,7 @@ def main():
                                    "levels, 1000 ghost points (333/level), E=60, frozen synthetic CLIP-RN50-shaped backbone "
                                    "+ trainable FPN included in the step",
                        "per_gpu_batch_keyframes": B, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "batch_note": "keyframe rows; reference default = 16 episodes x <=5 keyframes per step",
                        "hipgraph": graphed is not None, "final_loss": loss_val},
         }
         if graph_err:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over the dominant-kernel micro-benchmarks (bench.py --kernels-only), one --pmc set per pass
 # as the MI355X guide prescribes (TCC has 4 slots: FETCH_SIZE and WRITE_SIZE cannot share a pass).  No sys/hip/hsa
-# trace domains are combined with --pmc.   usage: profiles/run_pmc.sh <out-dir> [batch]
+# trace domains are combined with --pmc.   usage: [PASSES="fetch write derived"] profiles/run_pmc.sh <out-dir> [batch]
 set -u
 OUT=${1:-gpurun_out/pmc}
 B=${2:-16}
@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 pass() {
   name=$1; shift
+  case " ${PASSES:-fetch write sq stall insts derived} " in *" $name "*) ;; *) return;; esac
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
       python "$R/bench.py" --kernels-only --batch "$B" > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?" >> "$OUT/passes.txt"
