@@ -154,12 +154,20 @@ def kernel_rooflines(a3d, device, B):
         k_xyz.data_ptr(), 1.0, Kr.data_ptr(), O.QKW, Kp.data_ptr(), None, 1.0, Vr.data_ptr(), 32, Vp.data_ptr(),
         freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
     bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (O.QKW + 32 + 32 + 32))      # x rows + K rows/planes + V rows/planes
+    # MFMA FLOPs actually executed (SURVEY 8d's "MFMA utilisation"): v_mfma_f32_16x16x32_bf16 = 16384 FLOP each; per
+    # (64 keys x 16 queries) tile the forward issues 12 score + 6 PV, dQ 20 + 6, dK/dV 20 + 12 (split operands, d 15 -> 16)
+    tiles = B * H * (Lqp // 16) * (Sp // 64)
+    x_fwd = tiles * 18 * 16384.0
+    x_bwd = tiles * (26 + 32) * 16384.0
     return {
         "attn_fwd": {"bound": "mfma", "achieved": f_fwd / (t_fwd * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (split operands)"},
+                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (split operands)",
+                     "executed_tflops": x_fwd / (t_fwd * 1e-3) / 1e12, "mfma_util_executed": x_fwd / (t_fwd * 1e-3) / 2.5e15},
         "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 157.3 if O.BWD_F32 else 2500.0,
                      "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6,
-                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (split operands)"},
+                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (split operands)",
+                     **({} if O.BWD_F32 else {"executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12,
+                                              "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15})},
         "kv_proj_rope": {"bound": "hbm", "achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "ms": t_proj, "launches_per_step": 6},
     }
@@ -318,7 +326,8 @@ def main():
                 r["traffic_source"] = f"profiles/r01_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
                 r["pmc"] = pmc[dom].get("pmc")
             res["roofline"] = r
-            res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"]}
+            res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
+                                  **({"mfma_util_executed": v["mfma_util_executed"]} if "mfma_util_executed" in v else {})}
                               for k, v in ks.items()}
         except Exception as e:
             res["roofline"] = {"error": repr(e)[:300]}
