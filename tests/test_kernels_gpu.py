@@ -563,3 +563,67 @@ def test_fpn_top_down_fused(a3d, dev):
     # shapes the fused kernel does not cover fall back to torch
     odd = torch.randn(1, 60, 5, 7, generator=g).to(torch.bfloat16).to(dev)
     assert a3d.nn.fpn_top_down(odd, top[:1, :, :3, :4].contiguous()).shape == odd.shape
+
+
+@pytest.mark.parametrize("mode,B,Lq,S,E,H", [("kv", 2, 37, 131, 60, 4), ("qk", 2, 70, 70, 120, 8), ("none", 1, 5, 64, 60, 4),
+                                             ("kv", 1, 1, 1, 60, 4)])
+def test_fused_projection_equals_unfused_operands(a3d, dev, mode, B, Lq, S, E, H):
+    """a3d_proj_rope_split (projection + RoPE + operand formats in one kernel) writes exactly the operand tensors of the
+    unfused path (a3d_linear_fwd + a3d_rope_split): same fp32 MFMA order, same rotation, same bf16 splits."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(E + Lq)
+    in_w, in_b, _, _ = _mha_params(E, g, scale=2.0)
+    in_w, in_b = in_w.to(dev), in_b.to(dev)
+    xq = torch.randn(B, Lq, E, generator=g).to(dev)
+    xk = xq if mode == "qk" else torch.randn(B, S, E, generator=g).to(dev)
+    xv = xk if mode == "kv" else torch.randn(B, S, E, generator=g).to(dev)
+    q_xyz = (torch.rand(B, Lq, 3, generator=g) * 2 - 0.5).to(dev)
+    k_xyz = q_xyz if mode == "qk" else (torch.rand(B, S, 3, generator=g) * 2 - 0.5).to(dev)
+    fused = O.attn_operands_fused(mode, xq, xk, xv, in_w.data_ptr(), in_b.data_ptr(), q_xyz, k_xyz, B, Lq, S, E, H, dev,
+                                  need_bwd=True)
+    y = O.linear2d(torch.cat([xq.reshape(-1, E)]), in_w[:E], in_b[:E])
+    yk = O.linear2d(xk.reshape(-1, E), in_w[E:2 * E], in_b[E:2 * E])
+    yv = O.linear2d(xv.reshape(-1, E), in_w[2 * E:], in_b[2 * E:])
+    ref = O.attn_operands(y.data_ptr(), E, yk.data_ptr(), E, yv.data_ptr(), E, q_xyz, k_xyz, B, Lq, S, E, H, dev, need_bwd=True)
+    def value(t, rows):
+        """fp32 value carried by an operand tensor: sum of its bf16 parts (rows: 16-wide column groups; planes: dim 2)."""
+        t = t.float()
+        return t.view(*t.shape[:-1], t.shape[-1] // 16, 16).sum(-2) if rows else t.sum(2)
+
+    # same fp32 MFMA order, same angles; the two kernels may contract the rotation's multiply-adds differently, so the
+    # carried values agree to an fp32 ulp of the tensor scale (the hi / lo parts then agree exactly almost everywhere)
+    # three-part rows carry 24 bits (tolerance: an fp32 ulp of the scale); two-part tensors 16 bits (their last part
+    # may round the other way when the fp32 input moves by an ulp: 2^-16 of the scale)
+    for n, a, b, rows, tol in [("Qs", fused[0], ref[0], True, 4e-7), ("Ks", fused[1], ref[1], True, 4e-7),
+                               ("Vt", fused[2], ref[2], False, 2e-5), ("Qt", fused[7][0], ref[7][0], False, 2e-5),
+                               ("Kt", fused[7][1], ref[7][1], False, 2e-5), ("Vs", fused[7][2], ref[7][2], True, 2e-5)]:
+        assert a.shape == b.shape, f"{mode}: {n} shape"
+        va, vb = value(a, rows), value(b, rows)
+        err = (va - vb).abs().max().item()
+        assert err <= tol * max(vb.abs().max().item(), 1e-30), f"{mode}: {n} differs by {err:.3e}"
+        if rows:
+            same_hi = (a[..., :16].view(torch.int16) == b[..., :16].view(torch.int16)).float().mean().item()
+            assert same_hi > 0.999, f"{mode}: {n} hi parts agree only {same_hi:.4f}"
+    assert fused[3:6] == ref[3:6]
+
+
+def test_attention_edge_shapes(a3d, dev):
+    """One query / one key, a key count that is an exact multiple of the 64-key chunk, and a sample whose keys are all
+    padding except one (the softmax collapses onto it) -- against the oracle."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(11)
+    E, H = 60, 4
+    in_w, in_b, out_w, out_b = _mha_params(E, g, scale=1.5)
+    ln_g, ln_b = torch.ones(E), torch.zeros(E)
+    for B, Lq, S, keep in [(1, 1, 1, None), (2, 3, 64, None), (2, 17, 128, 1), (1, 64, 65, 3)]:
+        xq = torch.randn(B, Lq, E, generator=g)
+        xk = torch.randn(B, S, E, generator=g)
+        kmask = None
+        if keep is not None:
+            kmask = torch.ones(B, S, dtype=torch.bool)
+            kmask[:, :keep] = False
+        ref = OB.layer_norm(xq + OB.mha(xq, xk, xk, in_w, in_b, out_w, out_b, H, None, None, kmask), ln_g, ln_b)
+        mha, norm = _mk_modules(dev, in_w, in_b, out_w, out_b, ln_g, ln_b)
+        kd = xk.to(dev)
+        y = O.attn_block(xq.to(dev), kd, kd, xq.to(dev), None, None, None if kmask is None else kmask.to(dev), mha, norm, H)
+        report(f"attn edge B={B} Lq={Lq} S={S} keep={keep}", y, ref, 1e-4)
