@@ -39,6 +39,44 @@ def test_c_abi_argument_validation_without_gpu():
     assert rc == -22
     rc = lib.a3d_rope_split_qk(None, 0, None, None, 1.0, None, 1, 10, 64, 61, 4, None)                 # E != 15 * H
     assert rc == -22
+    # entry points added for the fused projection, the frozen-backbone BatchNorm path and the FPN top-down step
+    dummy = ctypes.c_void_p(64)                                                      # aligned, never dereferenced
+    rc = lib.a3d_proj_rope_split(dummy, 60, dummy, 60, None, 62, None, 1.0, dummy, 48, None, None, 1.0, None, 32, None,
+                                 None, 1, 10, 64, 60, 4, None)                                          # K % 4 != 0
+    assert rc == -22 and b"a3d_proj_rope_split" in lib.a3d_last_error_string()
+    rc = lib.a3d_proj_rope_split(dummy, 60, dummy, 60, None, 60, None, 1.0, dummy, 40, None, None, 1.0, None, 32, None,
+                                 None, 1, 10, 64, 60, 4, None)                                          # rows width 40
+    assert rc == -22
+    rc = lib.a3d_rope_split(dummy, 60, None, None, 1.0, dummy, 24, None, 1, 10, 64, 60, 4, None)      # rows width 24
+    assert rc == -22 and b"rows_width" in lib.a3d_last_error_string()
+    assert lib.a3d_bn_stats(dummy, dummy, 1024, 24, 4, None) == -22                                   # C/8 must divide 256
+    assert lib.a3d_bn_apply(dummy, None, dummy, dummy, dummy, 1024, 60, 1, None) == -22               # C % 8
+    assert lib.a3d_bn_apply_pool2(dummy, None, None, None, None, dummy, 1, 7, 8, 64, 1, None) == -22  # odd H
+    assert lib.a3d_upsample2_add_fwd(dummy, dummy, dummy, 1, 8, 8, 62, None) == -22                   # C % 4
+    assert lib.a3d_upsample2_add_bwd(dummy, dummy, 1, 8, 9, 60, None) == -22                          # odd W
+    assert lib.a3d_linear_wgrad_ws(None, 0, None, 0, None, 0, None, 4, 4, 4, None, 0, None) == -22
+
+
+def test_c_abi_host_side_planning_functions():
+    """Workspace / launch planning entry points are pure host code: callable without a GPU, and consistent."""
+    a3d = load_pkg()
+    lib = a3d.lib.load()
+    # weight-gradient reduction: atomics for tiny M, ordered two-stage (workspace = nsplit partial tiles) from 1024 rows on
+    assert lib.a3d_linear_wgrad_ws_bytes(1000, 120, 60, 1) == 0
+    for M, N, K, bias in [(1024, 60, 60, 1), (5328, 120, 60, 1), (65552, 120, 60, 1), (262208, 120, 60, 0), (4098, 240, 120, 1)]:
+        nbytes = lib.a3d_linear_wgrad_ws_bytes(M, N, K, bias)
+        tile = N * (K + bias) * 4
+        assert nbytes > 0 and nbytes % tile == 0
+        nsplit = nbytes // tile
+        assert 1 <= nsplit <= (M + 63) // 64 and nsplit * 64 >= M / 8        # 64 .. 512-row chunks
+    assert lib.a3d_linear_wgrad_ws_bytes(0, 60, 60, 1) == 0
+    # BatchNorm statistics slabs: >= 64 rows per slab, at most 1024 slabs
+    assert lib.a3d_bn_nslab(10, 64) == 1
+    assert lib.a3d_bn_nslab(64 * 100, 64) == 100
+    assert lib.a3d_bn_nslab(1 << 22, 32) == 1024
+    # attention split-K workspace and k-NN scratch grow linearly
+    assert lib.a3d_attn_fwd_ws_floats(2, 4, 64, 4) == 2 * lib.a3d_attn_fwd_ws_floats(1, 4, 64, 4)
+    assert lib.a3d_knn_topk_ws_bytes(3, 1000) == 3 * 1000 * 4
 
 
 def test_product_ops_refuse_cpu_tensors():
