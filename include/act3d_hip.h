@@ -16,7 +16,7 @@
  *     reference's sequence-first (N, B, E) is a view concern of the Python shim;
  *   - indices are int64 (long long) at the API, as torch.topk / torch.max return them.
  *
- * Attention operand formats (written by a3d_rope_split_qk / a3d_split_vt, read by a3d_attn_*):
+ * Attention operand formats (written by a3d_proj_rope_split / a3d_rope_split*, read by a3d_attn_*):
  *   rows  : [B][H][Npad][W] bf16, head dim 15 padded to 16 with zero;
  *             W = 48 for q and k ("QK"): row = hi(16) | lo(16) | lo2(16), x ~= hi + lo + lo2 (fp32-grade logits),
  *             W = 32 for v and dO rows (backward only): row = hi(16) | lo(16), x ~= hi + lo
@@ -44,10 +44,10 @@ int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float
 /* dW[n*lddw+k] += sum_m dY[m,n] X[m,k];  db[n] += sum_m dY[m,n] (db may be NULL).  Accumulates atomically. */
 int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db, int M,
                      int N, int K, void* stream);
-/* Same, with a caller-provided workspace: when the M reduction is split over many workgroups (large M: the scene-token
- * K/V projections, M = B*4097) the per-split partial sums go to `ws` and a second kernel adds them into dW/db in a
- * fixed order -- deterministic and free of memory-side atomics.  a3d_linear_wgrad_ws_bytes returns the size needed
- * (0 = the one-stage atomic kernel is used and ws may be NULL). */
+/* Same, with a caller-provided workspace: for M >= 1024 the M reduction is split into 64..256-row chunks whose partial
+ * tiles go to `ws`, and a second kernel adds them into dW/db in a fixed order -- deterministic and free of memory-side
+ * float atomics.  a3d_linear_wgrad_ws_bytes returns the size needed (0 = the one-stage atomic kernel is used and ws
+ * may be NULL). */
 size_t a3d_linear_wgrad_ws_bytes(int M, int N, int K, int has_bias);
 int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db, int M,
                         int N, int K, float* ws, size_t ws_bytes, void* stream);
