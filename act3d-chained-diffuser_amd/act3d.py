@@ -25,7 +25,9 @@ class _BroadcastRowFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, B, N):
         ctx.weight = weight
-        return weight.detach().view(1, 1, -1).expand(B, N, -1).contiguous()
+        # a real copy even for B * N == 1 (expand().contiguous() would alias the parameter, whose storage inside the flat
+        # parameter buffer is only 4-byte aligned and is updated in place by the optimizer)
+        return weight.detach().view(1, 1, -1).expand(B, N, -1).clone(memory_format=torch.contiguous_format)
 
     @staticmethod
     def backward(ctx, dy):

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 PERACT_BOUNDS = np.array([[-0.1101, -0.5558, 0.7129], [0.6481, 0.5184, 1.5116]])
+HIVEFORMER_BOUNDS = np.array([[-0.9439, -0.5644, 0.7106], [0.7039, 0.5821, 1.5122]])       # 74 tasks, SURVEY §8d
 DIFFUSION_BOUNDS = np.array([[-0.7342, -0.7915, 0.7098], [0.6944, 0.8437, 1.8645]])
 
 
@@ -68,7 +69,7 @@ def keypose_inputs(seed, B, ncam, E, levels, image=256, bounds=PERACT_BOUNDS):
     lo, hi = bounds[0], bounds[1]
     feats = []
     for i in range(levels):
-        f = 8 if i == 0 else 2
+        f = (8 if image == 256 else 4) if i == 0 else 2       # act3d.py:78-87: 128x128 images use res2 @ 1/4
         feats.append(rs_tensor(rs, (B, ncam, E, image // f, image // f)))
         if i >= 1:
             feats[-1] = feats[1]            # levels >= 1 share the res1 map (act3d.py:86)

@@ -137,11 +137,15 @@ def golden_sampling():
 
 
 # ------------------------------------------------------------------------------------------------------ G6/G7: Act3D
-def build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain):
-    m = R.act3d.Act3D(backbone="clip", image_size=(256, 256), embedding_dim=E, num_attn_heads=4,
+def build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=256, Ng_val=None):
+    m = R.act3d.Act3D(backbone="clip", image_size=(image, image), embedding_dim=E, num_attn_heads=4,
                       gripper_loc_bounds=C.PERACT_BOUNDS, num_ghost_points=Ng * levels,
-                      num_ghost_points_val=Ng * levels * 2, num_sampling_level=levels, weight_tying=True,
-                      gp_emb_tying=True, use_instruction=use_instruction)
+                      num_ghost_points_val=(Ng * 2 if Ng_val is None else Ng_val) * levels, num_sampling_level=levels,
+                      weight_tying=True, gp_emb_tying=True, use_instruction=use_instruction)
+    if image == 128:
+        # the reference's constructor names the attribute `coarse_feature_map` for 128x128 images but forward reads
+        # `feature_map_pyramid` (act3d.py:81 vs :378); patch the instance as SURVEY App. B-5 does
+        m.feature_map_pyramid = m.coarse_feature_map
     shapes, alias = C.unique_param_shapes(m)
     sd = C.expand_aliases(C.seeded_state_dict(shapes, seed, gain), alias)
     missing = m.load_state_dict(sd, strict=False)
@@ -165,17 +169,17 @@ def inject_features(m, inp, ncam):
     m._compute_visual_features = fake
 
 
-def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=1e-2):
+def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=1e-2, image=256, Ng_val=None):
     for attempt in range(80):
         seed, gain = 100 + attempt, 3.0
-        m, sd = build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain)
-        inp = C.keypose_inputs(seed, B, ncam, E, levels)
+        m, sd = build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=image, Ng_val=Ng_val)
+        inp = C.keypose_inputs(seed, B, ncam, E, levels, image=image)
         for f in inp["feats"]:
             f.requires_grad_(train)
         inject_features(m, inp, ncam)
         m.train(train)
         np.random.seed(seed)
-        rgb = torch.zeros(B, ncam, 3, 256, 256)
+        rgb = torch.zeros(B, ncam, 3, image, image)
         out = m(rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], gt_action=inp["action"] if train else None)
         gaps = []
         for masks in out["ghost_pcd_masks_pyramid"]:
@@ -187,7 +191,7 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
         raise RuntimeError("no seed with a safe top-2 logit gap")
     print(tag, "seed", seed, "min top-2 gaps per level", gaps)
     rec = dict(cfg=dict(E=E, levels=levels, ncam=ncam, Ng=out["ghost_pcd_pyramid"][0].shape[-1],
-                        use_instruction=use_instruction, B=B, train=train),
+                        use_instruction=use_instruction, B=B, train=train, image=image),
                seed=seed, gain=gain, gaps=gaps,
                ghost=[g.detach().transpose(1, 2).contiguous() for g in out["ghost_pcd_pyramid"]],
                masks=[[mm.detach() for mm in ms] for ms in out["ghost_pcd_masks_pyramid"]],
@@ -218,6 +222,8 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
                 "ghost_point_cross_attn_pyramid.0.ffw_layers.1.linear1.weight", "gripper_state_predictor.2.weight"]
         rec["grads"] = {n: grads[n] for n in keep if n in grads}
         rec["feat_grad_norms"] = [None if f.grad is None else f.grad.norm().item() for f in inp["feats"][:2]]
+        if levels == 1:
+            rec["feat0_grad_sample"] = C.tokens_from_maps(inp["feats"][0].grad)[:, ::37].clone()
         fg = inp["feats"][1].grad if levels > 1 else None
         if fg is not None:
             rec["feat1_grad_sample"] = C.tokens_from_maps(fg)[:, ::517].clone()
@@ -242,6 +248,18 @@ def golden_act3d():
     save("act3d_manifest.pt", dict(named_parameters=man, named_parameters_instr=man2, state_dict_keys=sdk,
                                    n_trainable=sum(int(np.prod(s)) for s in man.values()),
                                    n_trainable_instr=sum(int(np.prod(s)) for s in man2.values())))
+
+
+def golden_act3d_cfg1():
+    """BASELINE.json configs[0]: single-task keypose, batch 1, one 128x128 camera, ONE ghost-point level
+    (num_ghost_points 1000 in training, 10000 at evaluation).  Free-running (numpy-seeded ghost points)."""
+    out = {
+        "train_128_L1_C1_N1000": run_act3d_case("train_128_L1_C1_N1000", 60, 1, 1, 1000, False, 1, True, min_gap=2e-3,
+                                                image=128, Ng_val=10000),
+        "eval_128_L1_C1_N10000": run_act3d_case("eval_128_L1_C1_N10000", 60, 1, 1, 1000, False, 1, False, min_gap=2e-3,
+                                                image=128, Ng_val=10000),
+    }
+    save("act3d_cfg1.pt", out)
 
 
 # ------------------------------------------------------------------------------------------------------ G8/G9/G10: diffusion

@@ -64,7 +64,7 @@ def test_training_loss_and_grads(setup, dev):
     loss.backward()
     named = dict(m.named_parameters())
     for n, gref in r["grads"].items():
-        scale_close("grad " + n, named[n].grad, gref, 5e-3, floor=1e-3)
+        scale_close("grad " + n, named[n].grad, gref, 1.5e-3, floor=1e-3)      # observed <= 1.1e-3 of scale
     with_grad = set(r["manifest"]["with_grad"])
     for n, p in named.items():
         if ".backbone." in n or "feature_pyramid" in n:
@@ -72,7 +72,7 @@ def test_training_loss_and_grads(setup, dev):
         if n in with_grad:
             assert p.grad is not None, f"{n} should receive a gradient"
             nr = r["grad_norms"][n]
-            assert abs(p.grad.norm().item() - nr) <= 1e-2 * nr + 1e-4, f"grad norm {n}: {p.grad.norm().item()} vs {nr}"
+            assert abs(p.grad.norm().item() - nr) <= 3e-3 * nr + 1e-4, f"grad norm {n}: {p.grad.norm().item()} vs {nr}"
         else:
             assert p.grad is None or p.grad.abs().max().item() == 0.0, f"{n} must not receive a gradient (SURVEY G12)"
 
@@ -86,14 +86,56 @@ def test_sampling_loop_100_steps(setup, dev):
     for t, ref in r["sample_trace_inputs"].items():
         if t == 99:
             continue
-        scale_close(f"state before t={t}", trace[98 - t], ref, 3e-3)
-    scale_close("sampled xyz", final[..., :3], r["sample_final"][..., :3], 3e-3)
+        scale_close(f"state before t={t}", trace[98 - t], ref, 2e-4)           # observed 1e-5 after 100 steps
+    scale_close("sampled xyz", final[..., :3], r["sample_final"][..., :3], 2e-4)
     q, qr = final[..., 3:].cpu(), r["sample_final"][..., 3:]
     sign = torch.sign((q * qr).sum(-1, keepdim=True))
-    scale_close("sampled quaternion", q * sign, qr, 5e-3)
+    scale_close("sampled quaternion", q * sign, qr, 2e-4)
     # hipGraph-captured loop == eager loop (same injected noise), twice (capture + replay)
     for rep in range(2):
         g_final = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
                                        init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=inp["tokens"],
                                        use_graph=True)
         assert torch.allclose(g_final, final, atol=1e-5), f"graph replay {rep} differs from the eager loop"
+
+
+def test_cfg3_full_shape_graph_vs_oracle(a3d, dev):
+    """BASELINE.json configs[2] at its full shape: batch 64, horizon 16, 3 cameras (S = 3 * 1024 + 2 context tokens),
+    100 denoise steps, hipGraph-captured -- against the CPU oracle's 100-step loop on a sub-batch (the samples of a
+    trajectory batch never interact, so two of the 64 rows pin the whole batch's arithmetic)."""
+    import numpy as np
+    from oracle import diffusion as OD
+    from oracle import sampling as OS
+    r = load("diffusion.pt")
+    E, B, Ln, ncam, H = 120, 64, 16, 3, 8
+    m = a3d.DiffusionPlanner(embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+    P = _diffusion_params(r)
+    m.load_state_dict(P, strict=False)
+    m.to(dev).eval()
+    inp = C.trajectory_inputs(91, B, Ln, ncam, E, pad_last=3)
+    tokens = C.tokens_from_maps(inp["fmap"])
+    d = {k: v.to(dev) for k, v in inp.items()}
+    outs = []
+    for rep in range(2):                                   # capture + replay
+        outs.append(m.compute_trajectory(d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
+                                         init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=tokens.to(dev),
+                                         use_graph=True).cpu())
+    assert torch.equal(outs[0], outs[1]), "graph replay differs from the captured run"
+    eager = m.compute_trajectory(d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
+                                 init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=tokens.to(dev)).cpu()
+    assert torch.allclose(outs[0], eager, atol=1e-5), "graph differs from the eager loop"
+    assert torch.isfinite(outs[0]).all()
+    sub = [3, 40]                                          # one unpadded and one padded trajectory
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    pcdn = OD.normalize_pos(inp["pcd"][sub].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
+    with torch.no_grad():
+        ofinal, _ = OD.compute_trajectory(P, OD.DDPMSchedules(100), inp["mask"][sub], tokens[sub], None, inp["instr"][sub],
+                                          inp["curr_gripper"][sub], inp["goal_gripper"][sub], bounds, inp["init_noise"][sub],
+                                          inp["step_noise"][:, sub], H, ctx_xyz_norm=cxyz_n)
+    got = outs[0][sub]
+    scale_close("cfg3 sampled xyz", got[..., :3], ofinal[..., :3], 3e-4)
+    sign = torch.sign((got[..., 3:] * ofinal[..., 3:]).sum(-1, keepdim=True))
+    scale_close("cfg3 sampled quaternion", got[..., 3:] * sign, ofinal[..., 3:], 3e-4)

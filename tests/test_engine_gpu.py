@@ -1,0 +1,144 @@
+"""GPU tests of the training-step harness (engine.py) and of the full model path including the frozen backbone + FPN:
+  * BASELINE.json configs[0] end to end -- one 128x128 camera, one ghost-point level, batch 1, RGB in -> action out,
+    free-running device sampler -- against the CPU oracle fed with the same FPN tokens and ghost points;
+  * engine.GraphedStep (the thing bench.py times) replays == eager engine.train_one_step, step for step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import common as C  # noqa: E402
+from oracle import act3d as OA  # noqa: E402
+from oracle import sampling as OS  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(B, ncam, image, dev, seed):
+    inp = C.keypose_inputs(seed, B, ncam, 60, 1, image=image)
+    rs = np.random.RandomState(seed + 1)
+    rgb = torch.from_numpy(rs.uniform(0, 1, size=(B, ncam, 3, image, image)).astype(np.float32))
+    s = {"rgbs": rgb, "pcds": inp["pcd"], "instr": inp["instr"], "curr_gripper": inp["curr_gripper"], "action": inp["action"]}
+    s = {k: v.to(dev) for k, v in s.items()}
+    s["task"] = ["t"] * B
+    return s
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_cfg1_end_to_end_128px_one_level(a3d, dev, train):
+    torch.manual_seed(0)
+    Ng = 1000 if train else 10000
+    m = a3d.Act3D(image_size=(128, 128), embedding_dim=60, num_attn_heads=4, gripper_loc_bounds=C.PERACT_BOUNDS,
+                  num_ghost_points=1000, num_ghost_points_val=10000, num_sampling_level=1, sampler_seed=11).to(dev)
+    assert m.feature_map_pyramid[0] == "res2" and m.downscaling_factor_pyramid[0] == 4        # act3d.py:78-82
+    m.train(train)
+    s = _sample(1, 1, 128, dev, 21)
+    with torch.set_grad_enabled(train):
+        out = m(s["rgbs"], s["pcds"], s["instr"], s["curr_gripper"], gt_action=s["action"] if train else None)
+    feats = out["visible_rgb_features_pyramid"][0]
+    assert feats.shape == (1, 32 * 32, 60)                                                   # res2 map at 1/4 resolution
+    ghost = out["ghost_pcd_pyramid"][0].transpose(1, 2).contiguous()
+    assert ghost.shape == (1, Ng, 3)
+    lo, hi = torch.tensor(C.PERACT_BOUNDS[0], device=dev), torch.tensor(C.PERACT_BOUNDS[1], device=dev)
+    assert ((ghost >= lo) & (ghost <= hi)).all(), "ghost points outside the workspace"
+    if train:
+        feats.retain_grad()
+    # oracle on the same tokens / points
+    P = {}
+    for k, v in m.state_dict().items():
+        if not k.startswith("backbone") and "feature_pyramid" not in k:
+            P[k] = v.detach().cpu().clone().requires_grad_(train)
+    of = feats.detach().cpu().clone().requires_grad_(train)
+    pcds = [torch.from_numpy(OS.pcd_downsample(s["pcds"].cpu().numpy(), 4))]
+    cfg = OA.default_cfg(E=60, levels=1, ncam=1)
+    with torch.set_grad_enabled(train):
+        oout = OA.act3d_forward(P, cfg, [of], pcds, s["curr_gripper"].cpu(), None,
+                                gt_action=s["action"].cpu() if train else None, ghost_points=[ghost.cpu()])
+    for l in range(2):
+        got, ref = out["ghost_pcd_masks_pyramid"][0][l].detach().cpu(), oout["ghost_pcd_masks_pyramid"][0][l].detach()
+        err = (got - ref).abs().max().item()
+        print(f"[parity] cfg1 e2e mask layer{l}: max_abs_err={err:.3e} ref_absmax={ref.abs().max().item():.3e}")
+        assert err <= 1e-3 * max(1.0, ref.abs().max().item())
+    top2 = oout["ghost_pcd_masks_pyramid"][0][-1].detach().topk(2, -1).values
+    if (top2[:, 0] - top2[:, 1]).min() > 1e-3:
+        assert torch.equal(out["position"].cpu(), oout["position"].detach()), "argmax ghost point"
+    assert (out["rotation"].detach().cpu() - oout["rotation"].detach()).abs().max() < 1e-3
+    assert (out["gripper"].detach().cpu() - oout["gripper"].detach()).abs().max() < 1e-3
+    if not train:
+        return
+    crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    loss = sum(crit.compute_loss(out, s).values())
+    oloss = sum(OA.keypose_loss(oout, s["action"].cpu()).values())
+    assert abs(loss.item() - oloss.item()) <= 1e-3 * max(1.0, abs(oloss.item()))
+    loss.backward()
+    oloss.backward()
+    named = dict(m.named_parameters())
+    for n, p in P.items():
+        if p.grad is None or n not in named:
+            continue
+        ref = p.grad
+        err = (named[n].grad.cpu() - ref).abs().max().item()
+        assert err <= 1.5e-3 * ref.abs().max().item() + 1e-5, f"grad {n}: {err:.3e} vs absmax {ref.abs().max().item():.3e}"
+    err = (feats.grad.cpu() - of.grad).abs().max().item()
+    assert err <= 1.5e-3 * of.grad.abs().max().item() + 1e-7, f"d tokens: {err:.3e}"
+    # the FPN (trainable, adjacent) received gradients through the token view
+    g = m.feature_pyramid.layer_blocks[1][0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_graphed_step_equals_eager_train_one_step(a3d, dev):
+    """GraphedStep (capture of zero_grad + forward + loss + backward + AdamW, what bench.py replays) against the eager
+    engine.train_one_step on an identically initialised model: same losses and parameters after every step.  The device
+    Philox sampler state, the AdamW step counter and the BatchNorm running statistics all advance inside the graph."""
+    E = a3d.engine
+
+    def make():
+        torch.manual_seed(0)
+        m = a3d.Act3D(image_size=(128, 128), embedding_dim=60, num_attn_heads=4, gripper_loc_bounds=C.PERACT_BOUNDS,
+                      num_ghost_points=128, num_ghost_points_val=128, num_sampling_level=2, sampler_seed=5).to(dev)
+        return m.train()
+
+    s = _sample(2, 2, 128, dev, 33)
+    crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    mA, mB = make(), make()
+    flatA, optA = E.get_optimizer(mA, lr=1e-4)
+    flatB, optB = E.get_optimizer(mB, lr=1e-4)
+    assert torch.equal(flatA.flat, flatB.flat)
+    warm, replays = 2, 3
+    lossesA = [E.train_one_step(mA, crit, optA, i, s) for i in range(warm + replays)]
+
+    def fwd_bwd(sample):
+        out = mB(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"], gt_action=sample["action"])
+        loss = sum(crit.compute_loss(out, sample).values())
+        loss.backward()
+        return loss.detach()
+
+    graphed = E.GraphedStep(fwd_bwd, optB, s, warmup=warm)          # `warm` eager steps, then the capture
+    for i in range(replays):
+        lossB = graphed(s).clone()
+        ref = lossesA[warm + i]
+        assert abs(lossB.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item())), (i, lossB.item(), ref.item())
+    torch.cuda.synchronize()
+    # last step's gradients agree to accumulation-order noise ...
+    gA, gB = flatA.grad, flatB.grad
+    gscale = gA.abs().max().item()
+    gdiff = (gA - gB).abs().max().item()
+    print(f"[parity] graphed vs eager gradients at step {warm + replays}: max abs diff {gdiff:.3e} (scale {gscale:.3e})")
+    assert gdiff <= 2e-5 * gscale, (gdiff, gscale)
+    # ... and so do the parameters wherever the gradient is above that noise.  (AdamW normalises every element by its own
+    # magnitude, so an element whose gradient is mathematically zero -- e.g. the last ghost LayerNorm's bias, whose
+    # gradient is q * sum_n (softmax - label)_n = 0 -- takes +-lr steps of accumulation-order noise in ANY two runs.)
+    solid = gA.abs() > 1e-3 * gscale
+    diff = (flatA.flat - flatB.flat).abs()
+    print(f"[parity] graphed vs eager parameters after {warm + replays} steps: max abs diff {diff[solid].max().item():.3e} "
+          f"on {int(solid.sum())} of {solid.numel()} elements; {diff.max().item():.3e} overall")
+    assert diff[solid].max().item() <= 1e-6
+    assert diff.max().item() <= 2.5e-4 * (warm + replays)      # never more than opposite +-lr steps
+    assert torch.equal(optA.step_count, optB.step_count)
+    assert torch.equal(mA._rng_state, mB._rng_state)
+    for (n, a), (_, b) in zip(mA.backbone.named_buffers(), mB.backbone.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), n
