@@ -127,6 +127,53 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 }
 __device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }   // correctly rounded (HIP default)
 
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. 2011)
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------- dropout masks (training-mode nn.Dropout / F.dropout)
+// One Philox call yields the keep flags of a block of 8 elements: element j of the block is KEPT iff the j-th 16-bit
+// field of the 128 output bits is >= thr16 = round(p * 65536); kept elements are scaled by 1 / (1 - p).
+//   counter = (c0, c1, c2, site), key = (seed_lo ^ offset_lo, seed_hi ^ offset_hi)
+//   attention weights (multihead_custom_attention.py:413): c0 = key >> 3, c1 = query, c2 = b * H + h
+//   elementwise sites  (layers.py:82-84,146,181; diffusion_head.py:46,183,193): c0, c1 = lo / hi of (index >> 3),
+//                      c2 = 0xFFFFFFFF
+// `site` identifies the nn.Dropout module instance; {seed, offset} is a device-resident uint64[2] snapshot taken at the
+// start of the forward pass, so forward and backward of one step regenerate the same masks and the step stays capturable.
+struct DropKey { uint32_t k0, k1; };
+__device__ __forceinline__ DropKey drop_key(const unsigned long long* state) {
+  const unsigned long long seed = state[0], offs = state[1];
+  DropKey k;
+  k.k0 = (uint32_t)seed ^ (uint32_t)offs;
+  k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offs >> 32);
+  return k;
+}
+// bit j of the result = keep flag of element j of the 8-element block
+__device__ __forceinline__ uint32_t drop_keep8(DropKey k, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t site,
+                                               uint32_t thr16) {
+  uint32_t r[4];
+  philox4x32_10(c0, c1, c2, site, k.k0, k.k1, r);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    bits |= ((r[w] & 0xFFFFu) >= thr16 ? 1u : 0u) << (2 * w);
+    bits |= ((r[w] >> 16) >= thr16 ? 1u : 0u) << (2 * w + 1);
+  }
+  return bits;
+}
+
 // XCD-aware workgroup decoding (MI355X: 8 XCDs with private 4 MiB L2s; workgroup i is dispatched to XCD i % 8).
 // All `per_group` workgroups that share one (sample, head)'s K/V or Q/dO tensors are placed on ONE XCD, so that
 // those tensors are fetched from HBM once and re-read from that XCD's L2.  Grid = xcd_grid(ngroups, per_group).

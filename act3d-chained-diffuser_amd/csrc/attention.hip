@@ -31,11 +31,17 @@ struct FwdStage {
 };
 
 // __launch_bounds__(256, 2): <= 256 VGPRs, which lets the compiler keep MFMA results in VGPRs (no v_accvgpr_read copies)
+// DROP: training-mode dropout of the attention weights (multihead_custom_attention.py:413): A = softmax(..) is
+// normalised by the UN-dropped row sum, then every weight is kept with probability 1 - p and scaled by 1 / (1 - p).  The
+// keep flags of a lane's 8 consecutive keys come from one Philox call (a3d_common.h); the denominator is a per-lane f32
+// sum (the ones-channel of V would see the dropped weights).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
     const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
     float* __restrict__ O, float* __restrict__ LSE, float* __restrict__ Op, float* __restrict__ Mp,
-    float* __restrict__ Lp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit) {
+    float* __restrict__ Lp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
+    const unsigned long long* __restrict__ drop_state, unsigned int drop_site, unsigned int drop_thr, float drop_scale) {
   __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][KC * 32];    // [k_hi | k_lo]  rows tile
   __shared__ __attribute__((aligned(16))) unsigned short K3sm[2][KC * 32];   // [k_hi | k_lo2] rows tile
   __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][4 * 16 * 32];   // [plane][32-key half][16 ch][32 keys]
@@ -106,6 +112,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 
   float m_run = -INFINITY;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // one accumulator per 32-key half: two PV chains
+  float l_run = 0.f;                                                  // DROP: this lane's share of sum_k p (un-dropped)
+  DropKey dkey = {0u, 0u};
+  if (DROP) dkey = drop_key(drop_state);
 
   if (c_beg < c_end) {
     stage_store(stage_load(c_beg), 0);
@@ -154,16 +163,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
       const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));   // m_run = -inf -> 0
       const f32x2 c2 = {LOG2E_F, LOG2E_F}, nm2 = {nm, nm};
       s16x8 phi[2], plo[2];
+      float l_tile = 0.f;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         unsigned int hw[4], lw[4];
+        unsigned int keep = 0xFFu;
+        if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (KC / 8) + hf * 4 + g), (uint32_t)(q0 + li), (uint32_t)bh, drop_site, drop_thr);
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
             const f32x4& sj = s[hf * 2 + T];
             const f32x2 arg = __builtin_elementwise_fma((f32x2){sj[2 * pr], sj[2 * pr + 1]}, c2, nm2);
-            const f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            if (DROP) {
+              l_tile += p2.x + p2.y;
+              const int j = T * 4 + 2 * pr;          // this lane's keys of the half: g * 8 + j, g * 8 + j + 1
+              p2.x = ((keep >> j) & 1u) ? p2.x * drop_scale : 0.f;
+              p2.y = ((keep >> (j + 1)) & 1u) ? p2.y * drop_scale : 0.f;
+            }
             // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
             // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
             const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
       }
       m_run = m_new;
+      if (DROP) l_run = l_run * alpha + l_tile;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
       acc0 = mfma_bf16_16x16x32(vh[0], phi[0], acc0);
@@ -193,7 +212,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   f32x4 acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
-  const float l_tot = __shfl(acc[3], 48 + li, 64);   // channel 15 (lane group g = 3, register 3) holds sum_k p
+  float l_tot;
+  if (DROP) {
+    l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);              // the four lane groups hold disjoint key subsets of column li
+  } else {
+    l_tot = __shfl(acc[3], 48 + li, 64);             // channel 15 (lane group g = 3, register 3) holds sum_k p
+  }
   const int q = q0 + li;
   if (nsplit == 1) {
     const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
@@ -475,24 +500,37 @@ static int check_attn_args(const char* fn, int B, int H, int Lq, int Lqp, int S,
   return A3D_OK;
 }
 
-extern "C" int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask,
-                            float* O, float* LSE, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp,
-                            int nsplit, void* stream) {
+static int attn_fwd_launch(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask,
+                           float* O, float* LSE, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp,
+                           int nsplit, const unsigned long long* drop_state, unsigned int drop_site, float drop_p,
+                           void* stream) {
   int rc = check_attn_args("a3d_attn_fwd", B, H, Lq, Lqp, S, Sp, nsplit);
   if (rc) return rc;
   if (!Qs || !Ks || !Vt || !O || !LSE || (nsplit > 1 && !ws)) {
     set_error("a3d_attn_fwd: null pointer");
     return A3D_ERR_ARG;
   }
+  const bool drop = drop_state != nullptr && drop_p > 0.f;
+  if (drop_state && !(drop_p >= 0.f && drop_p < 1.f)) {
+    set_error("a3d_attn_fwd_dropout: dropout probability %g outside [0, 1)", (double)drop_p);
+    return A3D_ERR_ARG;
+  }
+  const unsigned int thr = drop ? (unsigned int)lrintf(drop_p * 65536.0f) : 0u;
+  const float dscale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
   const size_t rows = (size_t)B * H * Lqp;
   float* Op = ws;
   float* Mp = ws ? ws + (size_t)nsplit * rows * HDP : nullptr;
   float* Lp = ws ? Mp + (size_t)nsplit * rows : nullptr;
   dim3 grid(xcd_grid(B * H, cdiv(Lqp, 64) * nsplit));
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, (const unsigned short*)Qs,
-                     (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
-                     Lqp, S, Sp, nsplit);
+  if (drop)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
+                       Lqp, S, Sp, nsplit, drop_state, drop_site, thr, dscale);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
+                       Lqp, S, Sp, nsplit, (const unsigned long long*)nullptr, 0u, 0u, 1.0f);
   rc = check_launch("a3d_attn_fwd");
   if (rc) return rc;
   if (nsplit > 1) {
@@ -501,6 +539,20 @@ extern "C" int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, cons
     rc = check_launch("a3d_attn_fwd(combine)");
   }
   return rc;
+}
+
+extern "C" int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask,
+                            float* O, float* LSE, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp,
+                            int nsplit, void* stream) {
+  return attn_fwd_launch(Qs, Ks, Vt, kmask, O, LSE, ws, B, H, Lq, Lqp, S, Sp, nsplit, nullptr, 0u, 0.f, stream);
+}
+
+extern "C" int a3d_attn_fwd_dropout(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask,
+                                    float* O, float* LSE, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp,
+                                    int nsplit, const unsigned long long* drop_state, unsigned int drop_site,
+                                    float drop_p, void* stream) {
+  if (!drop_state) { set_error("a3d_attn_fwd_dropout: null dropout state"); return A3D_ERR_ARG; }
+  return attn_fwd_launch(Qs, Ks, Vt, kmask, O, LSE, ws, B, H, Lq, Lqp, S, Sp, nsplit, drop_state, drop_site, drop_p, stream);
 }
 
 extern "C" size_t a3d_attn_fwd_ws_floats(int B, int H, int Lqp, int nsplit) {

@@ -112,12 +112,16 @@ struct DqStage {
   float bias;
 };
 
+// DROP (both kernels): O = (M o P) V with M = keep / (1 - p) regenerated from the Philox counters the forward used, so
+// dV += (M o P)^T dO, dP = M o (dO V^T), dS = P o (dP - D) with D = rowsum(dO o O) as without dropout.
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
     const unsigned short* __restrict__ Kt, const unsigned short* __restrict__ Vs,
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
     const float* __restrict__ LSE, const float* __restrict__ D, float* __restrict__ dQp, int B, int H, int Lq,
-    int Lqp, int S, int Sp, int nsplit) {
+    int Lqp, int S, int Sp, int nsplit, const unsigned long long* __restrict__ drop_state, unsigned int drop_site,
+    unsigned int drop_thr, float drop_scale) {
   __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][BKC * 32];    // [k_hi | k_lo]  rows tile
   __shared__ __attribute__((aligned(16))) unsigned short K3sm[2][BKC * 32];   // [k_hi | k_lo2] rows tile
   __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][BKC * 32];    // [v_hi | v_lo]  rows tile
@@ -191,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
   const float nl = -lse_q * LOG2E_F;
   const f32x2_t c2 = {LOG2E_F, LOG2E_F}, nl2 = {nl, nl};
   const f32x4 nd4 = {-d_q, -d_q, -d_q, -d_q};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  DropKey dkey = {0u, 0u};
+  if (DROP) dkey = drop_key(drop_state);
   if (c_beg < c_end) {
     stage_store(stage_load(c_beg), 0);
     __syncthreads();
@@ -212,8 +219,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
           k3[T] = *reinterpret_cast<const s16x8*>(&K3sm[buf][koff[hf * 2 + T]]);
           vf[T] = *reinterpret_cast<const s16x8*>(&Vsm[buf][koff[hf * 2 + T]]);
           sT[T] = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
-          dpT[T] = nd4;
+          dpT[T] = DROP ? zero4 : nd4;
         }
+        unsigned int keep = 0xFFu;
+        if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (BKC / 8) + hf * 4 + g), (uint32_t)q, (uint32_t)bh, drop_site, drop_thr);
         const s16x8 kth = *reinterpret_cast<const s16x8*>(&Ktm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
         const s16x8 ktl = *reinterpret_cast<const s16x8*>(&Ktm[buf][((1 * 2 + hf) * 16) * 32 + poff]);
 #pragma unroll
@@ -229,7 +238,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
           for (int pr = 0; pr < 2; ++pr) {
             const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){sT[T][2 * pr], sT[T][2 * pr + 1]}, c2, nl2);
             const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-            const f32x2_t d2 = p2 * (f32x2_t){dpT[T][2 * pr], dpT[T][2 * pr + 1]};
+            f32x2_t d2;
+            if (DROP) {
+              const int j = T * 4 + 2 * pr;
+              const float m0 = ((keep >> j) & 1u) ? drop_scale : 0.f, m1 = ((keep >> (j + 1)) & 1u) ? drop_scale : 0.f;
+              d2 = p2 * (f32x2_t){__builtin_fmaf(m0, dpT[T][2 * pr], -d_q), __builtin_fmaf(m1, dpT[T][2 * pr + 1], -d_q)};
+            } else {
+              d2 = p2 * (f32x2_t){dpT[T][2 * pr], dpT[T][2 * pr + 1]};
+            }
             ds[T * 4 + 2 * pr] = d2.x;
             ds[T * 4 + 2 * pr + 1] = d2.y;
           }
@@ -258,14 +274,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(
 struct DkvStage {
   s16x8 q, o, qt, ot, q2;
   float lse, d;
+  unsigned char mb[2];
 };
 
+// DROP: a lane of this kernel holds ONE key and 8 consecutive queries, the transpose of the (query, 8-key block) unit
+// the Philox counters are defined on; the workgroup therefore generates the 64 query x 64 key keep tile of a chunk
+// cooperatively (512 calls, 2 per thread, during staging) into LDS as maskS[key block][query] bytes and every lane reads
+// its 8 queries' bytes with one ds_read_b64.
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Qt,
     const unsigned short* __restrict__ Ks, const unsigned short* __restrict__ Vs,
     const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOs,
     const unsigned short* __restrict__ dOt, const float* __restrict__ LSE, const float* __restrict__ D,
-    float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp) {
+    float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp,
+    const unsigned long long* __restrict__ drop_state, unsigned int drop_site, unsigned int drop_thr, float drop_scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char maskS[2][DROP ? 8 * BKC : 16];
   __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][BKC * 32];    // [q_hi | q_lo]  rows tile
   __shared__ __attribute__((aligned(16))) unsigned short Q3sm[2][BKC * 32];   // [q_hi | q_lo2] rows tile
   __shared__ __attribute__((aligned(16))) unsigned short Osm[2][BKC * 32];    // [dO_hi | dO_lo] rows tile
@@ -296,8 +320,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
 
   const int qrow = t >> 2, qseg = t & 3;
   const int pplane = t >> 7, pd = (t >> 3) & 15, pseg = t & 7;
+  DropKey dkey = {0u, 0u};
+  if (DROP) dkey = drop_key(drop_state);
   auto stage_load = [&](int c) {
     DkvStage st;
+    if (DROP) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        st.mb[i] = (unsigned char)drop_keep8(dkey, (uint32_t)(within * 8 + (t >> 6) + 4 * i), (uint32_t)(c * BKC + (t & 63)),
+                                             (uint32_t)bh, drop_site, drop_thr);
+    }
     st.q = *reinterpret_cast<const s16x8*>(Qs + (bh * Lqp + (size_t)c * BKC + qrow) * QKW + qseg * 8);
     if (t < 2 * BKC) st.q2 = *reinterpret_cast<const s16x8*>(Qs + (bh * Lqp + (size_t)c * BKC + (t >> 1)) * QKW + 32 + (t & 1) * 8);
     st.o = *reinterpret_cast<const s16x8*>(dOs + (bh * Lqp + (size_t)c * BKC + qrow) * VRW + qseg * 8);
@@ -325,6 +357,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
     *reinterpret_cast<s16x8*>(&Qtm[buf][po]) = st.qt;
     *reinterpret_cast<s16x8*>(&Otm[buf][po]) = st.ot;
     if (t < BKC) { lseS[buf][t] = -st.lse * LOG2E_F; dS_[buf][t] = -st.d; }   // -lse log2 e (masked row: -inf), -D
+    if (DROP) {
+      maskS[buf][((t >> 6)) * BKC + (t & 63)] = st.mb[0];
+      maskS[buf][((t >> 6) + 4) * BKC + (t & 63)] = st.mb[1];
+    }
   };
 
   int qoff[4];
@@ -345,16 +381,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       s16x8 qf[2], q3[2], of[2];
-      f32x4 s[2], dp[2], nl4[2];
+      f32x4 s[2], dp[2], nl4[2], nd[2];
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
         qf[T] = *reinterpret_cast<const s16x8*>(&Qsm[buf][qoff[hf * 2 + T]]);
         q3[T] = *reinterpret_cast<const s16x8*>(&Q3sm[buf][qoff[hf * 2 + T]]);
         of[T] = *reinterpret_cast<const s16x8*>(&Osm[buf][qoff[hf * 2 + T]]);
         nl4[T] = *reinterpret_cast<const f32x4*>(&lseS[buf][hf * 32 + g * 8 + T * 4]);
-        dp[T] = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
+        nd[T] = *reinterpret_cast<const f32x4*>(&dS_[buf][hf * 32 + g * 8 + T * 4]);
+        dp[T] = DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : nd[T];
         s[T] = bias4;
       }
+      unsigned long long keep8 = 0;      // byte j: keep flags of query hf * 32 + g * 8 + j for this wave's key blocks
+      if (DROP) keep8 = *reinterpret_cast<const unsigned long long*>(&maskS[buf][(wave * 2 + (li >> 3)) * BKC + hf * 32 + g * 8]);
       const s16x8 oth = *reinterpret_cast<const s16x8*>(&Otm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
       const s16x8 otl = *reinterpret_cast<const s16x8*>(&Otm[buf][((1 * 2 + hf) * 16) * 32 + poff]);
       const s16x8 qth = *reinterpret_cast<const s16x8*>(&Qtm[buf][((0 * 2 + hf) * 16) * 32 + poff]);
@@ -373,8 +412,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
           // P = exp2(fma(s, log2 e, -lse log2 e)); dS = P * (dP - D)
           const f32x2_t arg = __builtin_elementwise_fma((f32x2_t){s[T][2 * pr], s[T][2 * pr + 1]}, c2,
                                                         (f32x2_t){nl4[T][2 * pr], nl4[T][2 * pr + 1]});
-          const f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-          const f32x2_t d2 = p2 * (f32x2_t){dp[T][2 * pr], dp[T][2 * pr + 1]};
+          f32x2_t p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+          f32x2_t d2;
+          if (DROP) {
+            const int j = T * 4 + 2 * pr;
+            const float m0 = ((keep8 >> (8 * j + (li & 7))) & 1ull) ? drop_scale : 0.f;
+            const float m1 = ((keep8 >> (8 * (j + 1) + (li & 7))) & 1ull) ? drop_scale : 0.f;
+            d2 = p2 * (f32x2_t){__builtin_fmaf(m0, dp[T][2 * pr], nd[T][2 * pr]), __builtin_fmaf(m1, dp[T][2 * pr + 1], nd[T][2 * pr + 1])};
+            p2 = p2 * (f32x2_t){m0, m1};             // dV sees the dropped weights
+          } else {
+            d2 = p2 * (f32x2_t){dp[T][2 * pr], dp[T][2 * pr + 1]};
+          }
           p8[T * 4 + 2 * pr] = p2.x;
           p8[T * 4 + 2 * pr + 1] = p2.y;
           ds8[T * 4 + 2 * pr] = d2.x;
@@ -407,10 +455,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(
 
 using namespace a3d;
 
-extern "C" int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
-                                 const unsigned char* kmask, const float* O, const float* dO, const float* LSE,
-                                 void* dOs, void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H,
-                                 int Lq, int Lqp, int S, int Sp, int nsplit, void* stream) {
+static int attn_bwd_bf16_launch(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                                const unsigned char* kmask, const float* O, const float* dO, const float* LSE,
+                                void* dOs, void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H,
+                                int Lq, int Lqp, int S, int Sp, int nsplit, const unsigned long long* drop_state,
+                                unsigned int drop_site, float drop_p, void* stream) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lqp < Lq || (Lqp % 64) != 0 || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 ||
       nsplit > 64) {
     set_error("a3d_attn_bwd_bf16: bad argument (B=%d H=%d Lq=%d Lqp=%d S=%d Sp=%d nsplit=%d; Lqp, Sp %% 64 == 0)", B, H, Lq,
@@ -433,13 +482,52 @@ extern "C" int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks,
                      (unsigned short*)dOt, D, B, H, Lq, Lqp);
   int rc = check_launch("a3d_attn_bwd_bf16(prep)");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(xcd_grid(B * H, (Lqp / 64) * nsplit)), dim3(256), 0, s, (const unsigned short*)Qs,
-                     (const unsigned short*)Ks, (const unsigned short*)Kt, (const unsigned short*)Vs, kmask,
-                     (const unsigned short*)dOs, LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit);
+  const bool drop = drop_state != nullptr && drop_p > 0.f;
+  if (drop_state && !(drop_p >= 0.f && drop_p < 1.f)) {
+    set_error("a3d_attn_bwd_bf16_dropout: dropout probability %g outside [0, 1)", (double)drop_p);
+    return A3D_ERR_ARG;
+  }
+  const unsigned int thr = drop ? (unsigned int)lrintf(drop_p * 65536.0f) : 0u;
+  const float dscale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const dim3 gq(xcd_grid(B * H, (Lqp / 64) * nsplit)), gk(xcd_grid(B * H, Sp / 64));
+  const unsigned long long* nostate = nullptr;
+  if (drop)
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<true>, gq, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Ks, (const unsigned short*)Kt, (const unsigned short*)Vs, kmask,
+                       (const unsigned short*)dOs, LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit, drop_state, drop_site, thr, dscale);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<false>, gq, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Ks, (const unsigned short*)Kt, (const unsigned short*)Vs, kmask,
+                       (const unsigned short*)dOs, LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit, nostate, 0u, 0u, 1.0f);
   rc = check_launch("a3d_attn_bwd_bf16(dq)");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(xcd_grid(B * H, Sp / 64)), dim3(256), 0, s, (const unsigned short*)Qs,
-                     (const unsigned short*)Qt, (const unsigned short*)Ks, (const unsigned short*)Vs, kmask,
-                     (const unsigned short*)dOs, (const unsigned short*)dOt, LSE, D, dK, dV, B, H, Lq, Lqp, S, Sp);
+  if (drop)
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<true>, gk, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Qt, (const unsigned short*)Ks, (const unsigned short*)Vs, kmask,
+                       (const unsigned short*)dOs, (const unsigned short*)dOt, LSE, D, dK, dV, B, H, Lq, Lqp, S, Sp,
+                       drop_state, drop_site, thr, dscale);
+  else
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<false>, gk, dim3(256), 0, s, (const unsigned short*)Qs,
+                       (const unsigned short*)Qt, (const unsigned short*)Ks, (const unsigned short*)Vs, kmask,
+                       (const unsigned short*)dOs, (const unsigned short*)dOt, LSE, D, dK, dV, B, H, Lq, Lqp, S, Sp,
+                       nostate, 0u, 0u, 1.0f);
   return check_launch("a3d_attn_bwd_bf16(dkv)");
+}
+
+extern "C" int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                                 const unsigned char* kmask, const float* O, const float* dO, const float* LSE,
+                                 void* dOs, void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H,
+                                 int Lq, int Lqp, int S, int Sp, int nsplit, void* stream) {
+  return attn_bwd_bf16_launch(Qs, Qt, Ks, Kt, Vs, kmask, O, dO, LSE, dOs, dOt, D, dQp, dK, dV, B, H, Lq, Lqp, S, Sp, nsplit,
+                              nullptr, 0u, 0.f, stream);
+}
+
+extern "C" int a3d_attn_bwd_bf16_dropout(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                                         const unsigned char* kmask, const float* O, const float* dO, const float* LSE,
+                                         void* dOs, void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H,
+                                         int Lq, int Lqp, int S, int Sp, int nsplit, const unsigned long long* drop_state,
+                                         unsigned int drop_site, float drop_p, void* stream) {
+  if (!drop_state) { set_error("a3d_attn_bwd_bf16_dropout: null dropout state"); return A3D_ERR_ARG; }
+  return attn_bwd_bf16_launch(Qs, Qt, Ks, Kt, Vs, kmask, O, dO, LSE, dOs, dOt, D, dQp, dK, dV, B, H, Lq, Lqp, S, Sp, nsplit,
+                              drop_state, drop_site, drop_p, stream);
 }

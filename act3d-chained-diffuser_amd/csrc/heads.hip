@@ -220,21 +220,7 @@ __global__ void quat_sigmoid_bwd_kernel(const float* __restrict__ pred, const fl
   dpred[b * 5 + 4] = (dgrip ? dgrip[b] : 0.f) * sg * (1.f - sg);
 }
 
-// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. 2011)
-__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+// Philox4x32-10 lives in a3d_common.h (shared with the dropout masks of attention.hip / dropout.hip)
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 // state[0] = seed, state[1] = call offset (uint64 each).  anchor == null: uniform in [lo, hi].

@@ -14,8 +14,11 @@ What is restructured, with identical results:
     captured in a hipGraph and replayed (`compute_trajectory(..., use_graph=True)`).
 The DDPM schedules restate diffusers' DDPMScheduler (third-party, un-pinned -> parity unpinned).
 Additive keyword arguments: `noise`, `timesteps` (training) and `init_noise`, `step_noise` (sampling) inject the random
-draws; `visual_tokens` bypasses the backbone + FPN.  Training-mode dropout (p=0.1 in the reference) is NOT implemented:
-the constructor's additive `dropout` defaults to 0.0 and a positive value raises in train mode.
+draws; `visual_tokens` bypasses the backbone + FPN.  Training-mode dropout (p = 0.1 in every ParallelAttentionLayer --
+attention weights, residual branches, FFN -- and in the traj_encoder / regressor MLPs: layers.py:10,
+diffusion_head.py:46,183,193) runs on a device-resident Philox stream (csrc/dropout.hip, attention kernels): same
+distribution as the reference's torch generator, not the same draws.  The additive constructor keyword `dropout`
+(default 0.1 = the reference) sets that probability; 0.0 disables it.
 """
 import math
 
@@ -109,7 +112,7 @@ class DiffusionHead(nn.Module):
     def __init__(self, backbone="clip", image_size=(256, 256), embedding_dim=60, output_dim=7, num_attn_heads=8,
                  num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6, use_instruction=False, use_goal=False,
                  use_sigma=False, feat_scales_to_use=1, attn_rounds=1, weight_tying=False,
-                 rotation_parametrization='quat', dropout=0.0):
+                 rotation_parametrization='quat', dropout=0.1, dropout_seed=0):
         super().__init__()
         if feat_scales_to_use != 1 or attn_rounds != 1 or use_sigma:
             raise NotImplementedError("only feat_scales_to_use=1, attn_rounds=1, use_sigma=False (the shipped "
@@ -134,7 +137,7 @@ class DiffusionHead(nn.Module):
         self.goal_gripper_embed = nn.Embedding(1, E)
         self.instruction_encoder = nn.Linear(512, E)
         # --- DiffusionHead (diffusion_head.py:41-199)
-        self.traj_encoder = nn.Sequential(nn.Linear(9, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, E))
+        self.traj_encoder = nn.Sequential(nn.Linear(9, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, E))
         self.curr_gripper_encoder = nn.Linear(output_dim, E)
         if use_goal:
             self.goal_gripper_encoder = nn.Linear(output_dim, E)
@@ -150,9 +153,24 @@ class DiffusionHead(nn.Module):
                                                               use_adaln=True, **common)])
         self.rot_attention = nn.ModuleList([ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
                                                               use_adaln=True, **common)])
-        self.pos_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, 3))])
-        self.rot_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(0.1), nn.Linear(E, output_dim - 3))])
+        self.pos_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, 3))])
+        self.rot_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, output_dim - 3))])
         self._sem_cache = {}
+        # dropout sites are named after the modules (ops.site_id); generator state {seed, forward-pass counter} on the device
+        for name, mod in self.named_modules():
+            if hasattr(mod, "site_base"):
+                mod.site_base = O.site_id(name)
+        self._mlp_sites = {n: O.site_id(n, 4) for n in ("traj_encoder", "pos_regressor.0", "rot_regressor.0")}
+        self.register_buffer("_drop_state", torch.tensor([dropout_seed, 0], dtype=torch.int64), persistent=False)
+
+    def begin_dropout(self):
+        """DropCtx of one training forward pass (None in eval mode or with dropout=0): snapshots the device generator
+        state and advances it by one, both as stream-ordered kernels (capturable)."""
+        if not self.training or self.dropout_p <= 0:
+            return None
+        snap = self._drop_state.clone()
+        O.L.call("a3d_rng_advance", self._drop_state.data_ptr(), 1, O.L.stream())
+        return O.DropCtx(snap, self.dropout_p)
 
     # ---- vision (adjacent): one scale
     def encode_images(self, rgb, pcd_norm):
@@ -173,15 +191,13 @@ class DiffusionHead(nn.Module):
             self._sem_cache[key] = O.sinusoidal_emb(torch.arange(Ln, device=device, dtype=torch.float32), E)
         return self._sem_cache[key]
 
-    def encode_context(self, visual_tokens, ctx_xyz, instruction, curr_gripper, goal_gripper):
+    def encode_context(self, visual_tokens, ctx_xyz, instruction, curr_gripper, goal_gripper, drop=None):
         """Step-invariant context (diffusion_head.py:222-247, 290-323): returns (ctx (B,S,E), ctx_xyz (B,S,3), instr)."""
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("training-mode dropout is not implemented in the HIP path (DESIGN.md)")
         B = visual_tokens.shape[0]
         instr = O.linear(instruction.float(), self.instruction_encoder) if self.use_instruction else None
         ctx = visual_tokens
         if self.use_instruction:
-            ctx = self.vl_attention[0](ctx, None, instr)
+            ctx = self.vl_attention[0](ctx, None, instr, drop=drop)
         cg = O.linear(curr_gripper, self.curr_gripper_encoder)[:, None] + broadcast_row(self.curr_gripper_embed.weight, B, 1)
         extra, extra_xyz = [cg], [curr_gripper[:, None, :3]]
         if self.use_goal:
@@ -192,24 +208,27 @@ class DiffusionHead(nn.Module):
         ctx_xyz = torch.cat([ctx_xyz] + extra_xyz, dim=1).contiguous()
         return ctx, ctx_xyz, instr
 
-    def forward_tokens(self, trajectory, trajectory_mask, timestep, ctx, ctx_xyz, instr):
+    def forward_tokens(self, trajectory, trajectory_mask, timestep, ctx, ctx_xyz, instr, drop=None):
         """The step-dependent part of DiffusionHead.forward (diffusion_head.py:214-219, 325-363) with autograd."""
         B, Ln, _ = trajectory.shape
         E = ctx.shape[-1]
         trajectory = trajectory.contiguous()
-        traj_feats = O.mlp(trajectory, self.traj_encoder[0], self.traj_encoder[3])
+        ms = self._mlp_sites
+        traj_feats = O.mlp(trajectory, self.traj_encoder[0], self.traj_encoder[3], drop=drop, site_hidden=ms["traj_encoder"])
         traj_xyz = trajectory[..., :3].contiguous()
         time_feats = O.sinusoidal_emb(timestep.float(), E)
         silu_t = O.SiLUFn.apply(time_feats)
         sem = self._sem(Ln, E, trajectory.device)
         if self.use_instruction:
-            traj_feats = self.traj_lang_attention[0](traj_feats, trajectory_mask, instr, seq1_sem_pos=sem)
-        kw = dict(seq1_xyz=traj_xyz, seq2_xyz=ctx_xyz, seq1_sem_pos=sem, silu_t=silu_t)
+            traj_feats = self.traj_lang_attention[0](traj_feats, trajectory_mask, instr, seq1_sem_pos=sem, drop=drop)
+        kw = dict(seq1_xyz=traj_xyz, seq2_xyz=ctx_xyz, seq1_sem_pos=sem, silu_t=silu_t, drop=drop)
         traj_feats = self.traj_attention[0](traj_feats, trajectory_mask, ctx, **kw)
         pos_feats = self.pos_attention[0](traj_feats, trajectory_mask, ctx, **kw)
         rot_feats = self.rot_attention[0](traj_feats, trajectory_mask, ctx, **kw)
-        upd = torch.cat([O.mlp(pos_feats, self.pos_regressor[0][0], self.pos_regressor[0][3]),
-                         O.mlp(rot_feats, self.rot_regressor[0][0], self.rot_regressor[0][3])], dim=-1)
+        upd = torch.cat([O.mlp(pos_feats, self.pos_regressor[0][0], self.pos_regressor[0][3], drop=drop,
+                               site_hidden=ms["pos_regressor.0"]),
+                         O.mlp(rot_feats, self.rot_regressor[0][0], self.rot_regressor[0][3], drop=drop,
+                               site_hidden=ms["rot_regressor.0"])], dim=-1)
         return O.TrajUpdateFn.apply(trajectory, upd)
 
     # ---- inference with cached K/V
@@ -270,7 +289,7 @@ class DiffusionPlanner(nn.Module):
                  num_vis_ins_attn_layers=2, num_query_cross_attn_layers=8, use_instruction=False, use_goal=False,
                  use_goal_at_test=True, feat_scales_to_use=1, attn_rounds=1, weight_tying=False,
                  gripper_loc_bounds=None, rotation_parametrization='quat', diffusion_timesteps=100, num_attn_heads=8,
-                 dropout=0.0):
+                 dropout=0.1, dropout_seed=0):
         super().__init__()
         if rotation_parametrization != '6D':
             raise NotImplementedError("only rotation_parametrization='6D' (scripts/train_trajectory.sh) is implemented")
@@ -281,7 +300,7 @@ class DiffusionPlanner(nn.Module):
             num_attn_heads=num_attn_heads, num_vis_ins_attn_layers=num_vis_ins_attn_layers,
             num_query_cross_attn_layers=num_query_cross_attn_layers, use_instruction=use_instruction, use_goal=use_goal,
             feat_scales_to_use=feat_scales_to_use, attn_rounds=attn_rounds, weight_tying=weight_tying,
-            rotation_parametrization=rotation_parametrization, dropout=dropout)
+            rotation_parametrization=rotation_parametrization, dropout=dropout, dropout_seed=dropout_seed)
         self.n_steps = diffusion_timesteps
         self.register_buffer("gripper_loc_bounds", torch.tensor(gripper_loc_bounds, dtype=torch.float32), persistent=False)
         self._tables = None
@@ -341,9 +360,11 @@ class DiffusionPlanner(nn.Module):
                 noise = torch.randn(gt.shape, device=dev)
             if timesteps is None:
                 timesteps = torch.randint(0, self.n_steps, (gt.shape[0],), device=dev).long()
-            noisy = O.ddpm_add_noise(gt, noise.to(dev).float(), timesteps.to(dev), tb.acp_pos, tb.acp_rot)
-        ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
-        pred = head.forward_tokens(noisy, trajectory_mask, timesteps.to(dev), ctx, ctx_xyz, instr)
+            gt = gt[..., :9].contiguous()               # the reference rebuilds the 9 pose channels (diffusion_model.py:296-305)
+            noisy = O.ddpm_add_noise(gt, noise.to(dev).float()[..., :9].contiguous(), timesteps.to(dev), tb.acp_pos, tb.acp_rot)
+        drop = head.begin_dropout()
+        ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg, drop=drop)
+        pred = head.forward_tokens(noisy, trajectory_mask, timesteps.to(dev), ctx, ctx_xyz, instr, drop=drop)
         loss = O.ElemLossFn.apply(pred[..., :3], gt[..., :3], 1, 100.0) + O.ElemLossFn.apply(pred[..., 3:9], gt[..., 3:9], 1, 10.0)
         return (loss, pred, gt) if return_pred else loss
 

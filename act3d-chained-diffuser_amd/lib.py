@@ -35,6 +35,10 @@ SIGNATURES = {
     "a3d_attn_fwd_ws_floats": (_z, [_i, _i, _i, _i]),
     "a3d_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_bwd_bf16": (_i, [_p] * 15 + [_i] * 7 + [_p]),
+    "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
+    "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),
+    "a3d_attn_fwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_uint, _f, _p]),
+    "a3d_attn_bwd_bf16_dropout": (_i, [_p] * 15 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
     "a3d_pcd_downsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_knn_topk_ws_bytes": (_z, [_i, _i]),
     "a3d_knn_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),

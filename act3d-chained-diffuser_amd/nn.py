@@ -97,6 +97,7 @@ class ParallelAttentionLayer(nn.Module):
                                       "path (SURVEY §8a-12); other options are not implemented")
         self.self_attention1, self.apply_ffn, self.rotary_pe = self_attention1, apply_ffn, rotary_pe
         self.n_heads, self.dropout_p = n_heads, dropout
+        self.site_base = O.site_id("parallel_attention_layer")     # re-assigned from the module's name by its owner
         if self_attention1:
             self.adaln_1 = AdaLN(d_model) if use_adaln else None
             self.sa1 = MultiheadCustomAttention(d_model, n_heads, dropout=dropout)
@@ -110,14 +111,21 @@ class ParallelAttentionLayer(nn.Module):
                                     nn.Linear(4 * d_model, d_model), nn.Dropout(dropout))
         self.norm_122 = nn.LayerNorm(d_model)
 
-    def forward(self, seq1, seq1_key_padding_mask, seq2, seq1_xyz=None, seq2_xyz=None, seq1_sem_pos=None, silu_t=None):
-        if self.training and self.dropout_p > 0:
-            _dropout_unsupported()
+    def forward(self, seq1, seq1_key_padding_mask, seq2, seq1_xyz=None, seq2_xyz=None, seq1_sem_pos=None, silu_t=None,
+                drop=None):
+        """drop: ops.DropCtx of this forward pass (None: no dropout).  Training with dropout_p > 0 needs one -- the owner
+        (DiffusionHead.begin_dropout) creates it; there is no silent un-regularised path."""
+        if self.training and self.dropout_p > 0 and drop is None:
+            raise RuntimeError("ParallelAttentionLayer in training mode with dropout=%g needs the forward pass's DropCtx "
+                               "(DiffusionHead.begin_dropout())" % self.dropout_p)
+        if drop is not None and (not self.training or self.dropout_p <= 0):
+            drop = None
+        sb = self.site_base
         rope = self.rotary_pe
         q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
         qa = self.adaln_12(q1, silu_t) if (self.adaln_12 is not None and silu_t is not None) else q1
         seq1 = O.attn_block(qa, seq2, seq2, seq1, seq1_xyz if rope else None, seq2_xyz if rope else None, None,
-                            self.cross_12, self.norm_12, self.n_heads)
+                            self.cross_12, self.norm_12, self.n_heads, drop=drop, site=sb)
         if self.self_attention1:
             q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
             if self.adaln_1 is not None and silu_t is not None:
@@ -125,17 +133,11 @@ class ParallelAttentionLayer(nn.Module):
             else:
                 qk, vv = q1, seq1
             seq1 = O.attn_block(qk, qk, vv, seq1, seq1_xyz if rope else None, seq1_xyz if rope else None,
-                                seq1_key_padding_mask, self.sa1, self.norm_1, self.n_heads)
+                                seq1_key_padding_mask, self.sa1, self.norm_1, self.n_heads, drop=drop, site=sb + 2)
         if self.apply_ffn:
             y = self.adaln_ff1(seq1, silu_t) if (self.adaln_ff1 is not None and silu_t is not None) else seq1
-            seq1 = O.mlp(y, self.ffn_12[0], self.ffn_12[3], self.norm_122)
+            seq1 = O.mlp(y, self.ffn_12[0], self.ffn_12[3], self.norm_122, drop=drop, site_hidden=sb + 4, site_out=sb + 5)
         return seq1
-
-
-def _dropout_unsupported():
-    raise NotImplementedError(
-        "training-mode dropout (p=0.1 in the diffusion transformer, layers.py:10) is not implemented in the HIP path "
-        "yet; construct the model with dropout=0.0 or call .eval() on the attention stack (documented in DESIGN.md)")
 
 
 class ParallelAttention(nn.Module):

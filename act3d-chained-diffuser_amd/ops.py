@@ -55,6 +55,9 @@ def linear2d(x2d, W, b, act=0):
     """y = act(x W^T + b) for contiguous x2d [M,K], W [N,K]."""
     M, K = x2d.shape
     N = W.shape[0]
+    if W.shape[1] != K or (b is not None and b.numel() != N):
+        raise ValueError("linear: activation rows of %d features against a weight of shape %s / bias of %s" %
+                         (K, tuple(W.shape), None if b is None else tuple(b.shape)))
     return linear_raw(x2d.data_ptr(), K, W.data_ptr(), W.shape[1], None if b is None else b.data_ptr(), M, N, K,
                       x2d.device, act=act)
 
@@ -185,7 +188,53 @@ def attn_operands_fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, 
     return Qs, Ks, Vt, Lqp, Sp, scale, freq, (Qt, Kt, Vs)
 
 
-def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
+class DropCtx:
+    """Dropout context of ONE forward pass: `state` is a device uint64[2] snapshot {seed, offset} of the model's dropout
+    generator (taken before it was advanced), `p` the probability.  Forward and backward kernels of the pass regenerate
+    their masks from (state, site, element index) -- nothing is stored, no host RNG, capturable."""
+
+    def __init__(self, state, p):
+        self.state, self.p = state, float(p)
+
+
+def site_id(name, sub=0):
+    """Dropout site of module `name` (e.g. "traj_attention.0.layers.2"): CRC-32 of the name with the low 3 bits
+    replaced by the sub-site (0 cross-attention weights, 1 cross residual, 2 self-attention weights, 3 self residual,
+    4 FFN / MLP hidden, 5 FFN output).  The CPU twin (oracle/blocks.py) derives the same ids from parameter prefixes."""
+    import zlib
+    return ((zlib.crc32(name.encode()) & 0xFFFFFFF8) | sub) & 0xFFFFFFFF
+
+
+def dropout_raw(x, drop, site, out=None):
+    """y = x o keep / (1 - p) (its own backward).  x contiguous fp32; out may be x (in place)."""
+    y = torch.empty_like(x) if out is None else out
+    L.call("a3d_dropout", x.data_ptr(), y.data_ptr(), x.numel(), drop.state.data_ptr(), int(site), drop.p, L.stream())
+    return y
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode on the device Philox stream (layers.py:34,58,82-84; diffusion_head.py:46,183,193)."""
+
+    @staticmethod
+    def forward(ctx, x, drop, site):
+        L.require_gpu(x)
+        ctx.drop, ctx.site = drop, site
+        return dropout_raw(_c(x), drop, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout_raw(_c(dy), ctx.drop, ctx.site), None, None
+
+
+def dropout_mask(drop, site, n, bh=None, q=None):
+    """Keep flags (uint8) the kernels use: flat elementwise indexing (bh None) or attention-weight row (bh, q)."""
+    out = torch.empty((n,), device=drop.state.device, dtype=torch.uint8)
+    L.call("a3d_dropout_mask", out.data_ptr(), n, drop.state.data_ptr(), 0xFFFFFFFF if bh is None else int(bh),
+           0 if q is None else int(q), int(site), drop.p, L.stream())
+    return out
+
+
+def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0):
     dev = Qs.device
     E = H * 15
     O = torch.empty((B, Lq, E), device=dev, dtype=F32)
@@ -193,23 +242,29 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit):
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit * B * H * Lqp * 18,), device=dev, dtype=F32)
-    L.call("a3d_attn_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
-           O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
-           L.stream())
+    args = (Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
+            O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit)
+    if drop is not None and drop.p > 0:
+        L.call("a3d_attn_fwd_dropout", *args, drop.state.data_ptr(), int(site), drop.p, L.stream())
+    else:
+        L.call("a3d_attn_fwd", *args, L.stream())
     return O, LSE
 
 
 BWD_F32 = os.environ.get("A3D_BWD_F32", "0") == "1"     # A/B switch: exact-f32 MFMA reference backward (attention.hip)
 
 
-def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, extra=None):
+def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, extra=None, drop=None, site=0):
     dev = Qs.device
+    dropping = drop is not None and drop.p > 0
     D = torch.empty((B, H, Lqp), device=dev, dtype=F32)
     dQp = torch.empty((nsplit, B, H, Lqp, 16), device=dev, dtype=F32)
     dK = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     dV = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     km = None if kmask is None else kmask.data_ptr()
     if extra is None or extra[0] is None or BWD_F32:
+        if dropping:
+            raise NotImplementedError("attention-weight dropout is implemented in the split-bf16 backward only")
         dOh = torch.empty((B, H, Lqp, 16), device=dev, dtype=F32)
         L.call("a3d_attn_bwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), km, O.data_ptr(), dO.data_ptr(),
                LSE.data_ptr(), dOh.data_ptr(), D.data_ptr(), dQp.data_ptr(), dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp,
@@ -218,9 +273,13 @@ def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, e
         Qt, Kt, Vs = extra
         dOs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
         dOt = torch.empty((B, H, 2, 16, Lqp), device=dev, dtype=torch.bfloat16)
-        L.call("a3d_attn_bwd_bf16", Qs.data_ptr(), Qt.data_ptr(), Ks.data_ptr(), Kt.data_ptr(), Vs.data_ptr(), km,
-               O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOs.data_ptr(), dOt.data_ptr(), D.data_ptr(), dQp.data_ptr(),
-               dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
+        args = (Qs.data_ptr(), Qt.data_ptr(), Ks.data_ptr(), Kt.data_ptr(), Vs.data_ptr(), km,
+                O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOs.data_ptr(), dOt.data_ptr(), D.data_ptr(), dQp.data_ptr(),
+                dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit)
+        if dropping:
+            L.call("a3d_attn_bwd_bf16_dropout", *args, drop.state.data_ptr(), int(site), drop.p, L.stream())
+        else:
+            L.call("a3d_attn_bwd_bf16", *args, L.stream())
     return dQp, dK, dV
 
 
@@ -241,8 +300,13 @@ class AttnBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode):
+    def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode,
+                drop=None, site=0):
+        """drop / site: DropCtx of the pass and this block's site id (attention weights: site, residual branch: site + 1;
+        multihead_custom_attention.py:413, layers.py:146,181)."""
         L.require_gpu(q_in, k_in, v_in, resid)
+        if drop is not None and drop.p <= 0:
+            drop = None
         q_in, k_in, v_in, resid = _c(q_in), _c(k_in), _c(v_in), _c(resid)
         B, Lq, E = q_in.shape
         S = k_in.shape[1]
@@ -286,8 +350,10 @@ class AttnBlockFn(torch.autograd.Function):
                                                                     S, E, H, dev, need_bwd=need_bwd)
             del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
-        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit)
+        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site)
         Y = linear2d(O.view(B * Lq, E), out_w, out_b)
+        if drop is not None:
+            dropout_raw(Y, drop, site + 1, out=Y)          # seq1 + dropout(attn_out): Y now holds the dropped branch
         y, mean, rstd = add_layernorm(resid.view(B * Lq, E), Y, ln_g, ln_b)
         ctx.save_for_backward(q_in, k_in, v_in, resid, Y, mean, rstd, Qs, Ks, Vt, O, LSE,
                               q_xyz if q_xyz is not None else torch.empty(0, device=dev),
@@ -295,6 +361,7 @@ class AttnBlockFn(torch.autograd.Function):
                               kmask if kmask is not None else torch.empty(0, device=dev))
         ctx.params = (in_w, in_b, out_w, out_b, ln_g, ln_b)
         ctx.extra = extra
+        ctx.drop, ctx.site = drop, site
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
         return y.view(B, Lq, E)
 
@@ -311,11 +378,12 @@ class AttnBlockFn(torch.autograd.Function):
         freq = rope_freq(E, dev)
         dy = _c(dy).view(B * Lq, E)
         f4 = 4
-        dS = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)      # = d resid = d Y
-        dO = dgrad2d(dS, out_w)
-        wgrad2d(dS, O.view(B * Lq, E), out_w, out_b)
+        dS = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)      # = d resid = d (dropped) Y
+        dYo = dS if ctx.drop is None else dropout_raw(dS, ctx.drop, ctx.site + 1)         # through the residual dropout
+        dO = dgrad2d(dYo, out_w)
+        wgrad2d(dYo, O.view(B * Lq, E), out_w, out_b)
         dQp, dK, dV = attn_core_bwd(Qs, Ks, Vt, kmask, O, dO.view(B, Lq, E), LSE, B, H, Lq, Lqp, S, Sp, nsplit,
-                                    extra=ctx.extra)
+                                    extra=ctx.extra, drop=ctx.drop, site=ctx.site)
         gW, gb = grad_buf(in_w), grad_buf(in_b)
         st = L.stream()
         need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
@@ -366,10 +434,10 @@ class AttnBlockFn(torch.autograd.Function):
                 if need_v:
                     d_v_in = dgrad2d(dv_pre, in_w[2 * E:]).view(B, S, E)
         d_resid = dS.view(B, Lq, E) if ctx.needs_input_grad[3] else None
-        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 11
+        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 13
 
 
-def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H):
+def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=None, site=0):
     """mha: module with in_proj_weight/in_proj_bias/out_proj; norm: LayerNorm-like with weight/bias.
 
     The projection path is chosen structurally (which inputs are the same tensor), replacing the reference's
@@ -381,7 +449,7 @@ def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H):
     else:
         mode = "none"
     return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
-                             mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode)
+                             mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site)
 
 
 class MLPFn(torch.autograd.Function):
@@ -389,14 +457,23 @@ class MLPFn(torch.autograd.Function):
     ffn_12 + norm_122 layers.py:205-209; plain MLP heads act3d.py:151-166, diffusion_head.py:41-49,177-199)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b):
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, drop=None, site_hidden=0, site_out=None):
+        """drop: DropCtx; site_hidden: the nn.Dropout between ReLU and the second Linear (layers.py:82, diffusion_head.py:46);
+        site_out: the one after it (layers.py:84), None if the module has none."""
         L.require_gpu(x)
         x = _c(x)
         shp = x.shape
         K = shp[-1]
         x2 = x.view(-1, K)
+        if drop is not None and drop.p <= 0:
+            drop = None
         h = linear2d(x2, w1, b1, act=1)
+        if drop is not None:
+            dropout_raw(h, drop, site_hidden, out=h)       # h > 0 <=> relu active AND kept: still the ReLU mask of dgrad
         o = linear2d(h, w2, b2)
+        if drop is not None and site_out is not None:
+            dropout_raw(o, drop, site_out, out=o)
+        ctx.drop, ctx.sites = drop, (site_hidden, site_out)
         if ln_g is not None:
             y, mean, rstd = add_layernorm(x2, o, ln_g, ln_b)
             ctx.save_for_backward(x2, h, o, mean, rstd)
@@ -418,8 +495,13 @@ class MLPFn(torch.autograd.Function):
             x2, h = ctx.saved_tensors
             dS = None
             do = dy.view(-1, dy.shape[-1])
+        drop, (site_hidden, site_out) = ctx.drop, ctx.sites
+        if drop is not None and site_out is not None:
+            do = dropout_raw(do, drop, site_out)
         wgrad2d(do, h, w2, b2)
         dpre = dgrad2d(do, w2, mask=h)          # relu backward fused: (do W2) * (h > 0)
+        if drop is not None:
+            dropout_raw(dpre, drop, site_hidden, out=dpre)     # the 1 / (1 - p) of the kept (h > 0) elements
         wgrad2d(dpre, x2, w1, b1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -427,12 +509,12 @@ class MLPFn(torch.autograd.Function):
             if dS is not None:
                 dx = dx + dS
             dx = dx.view(*dy.shape[:-1], x2.shape[1])
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None
 
 
-def mlp(x, lin1, lin2, norm=None):
+def mlp(x, lin1, lin2, norm=None, drop=None, site_hidden=0, site_out=None):
     return MLPFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, None if norm is None else norm.weight,
-                       None if norm is None else norm.bias)
+                       None if norm is None else norm.bias, drop, site_hidden, site_out)
 
 
 class LinearFn(torch.autograd.Function):

@@ -104,6 +104,28 @@ int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void
                       void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S,
                       int Sp, int nsplit, void* stream);
 
+/* ---- training-mode dropout (ChainedDiffuser transformer, p = 0.1: layers.py:10,34,58,82-84; diffusion_head.py:46,183,193;
+ *      attention weights multihead_custom_attention.py:413) ---------------------------------------------------------
+ * Counter-based (Philox4x32-10): the keep flag of an element is a pure function of (drop_state = {seed, offset} uint64[2]
+ * on the device, site, element index), so backward passes regenerate the mask and a training step is capturable.
+ * An element is kept iff its 16-bit draw >= round(p * 65536); kept values are scaled by 1 / (1 - p).
+ * y = x o keep / (1 - p) over a flat fp32 array; the same call is its own backward (dx from dy).  y may alias x. */
+int a3d_dropout(const float* x, float* y, size_t n, const unsigned long long* drop_state, unsigned int site, float p,
+                void* stream);
+/* out[i] = keep flag (0 / 1) of element i of a block row: c2 == 0xFFFFFFFF selects the flat elementwise indexing of
+ * a3d_dropout (c1 ignored); otherwise (c2 = b * H + h, c1 = query) the attention-weight indexing, i = key.  Test hook. */
+int a3d_dropout_mask(unsigned char* out, size_t n, const unsigned long long* drop_state, unsigned int c2, unsigned int c1,
+                     unsigned int site, float p, void* stream);
+/* a3d_attn_fwd / a3d_attn_bwd_bf16 with dropout on the attention weights: O = (keep o softmax(..) / (1 - p)) V. */
+int a3d_attn_fwd_dropout(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, float* O, float* LSE,
+                         float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
+                         const unsigned long long* drop_state, unsigned int site, float p, void* stream);
+int a3d_attn_bwd_bf16_dropout(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
+                              const unsigned char* kmask, const float* O, const float* dO, const float* LSE, void* dOs,
+                              void* dOt, float* D, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S,
+                              int Sp, int nsplit, const unsigned long long* drop_state, unsigned int site, float p,
+                              void* stream);
+
 /* ---- scene tokens --------------------------------------------------------------------------------------- */
 /* out[b][(cam*h + y)*w + x][:] = bilinear(pcd[(b,cam)], 1/factor)  (act3d.py:379-383, encoder.py:147-158) */
 int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C, int Hin, int Win, int factor, void* stream);

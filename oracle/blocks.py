@@ -43,7 +43,7 @@ def sinusoidal(x, E):
 
 
 def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, H, q_xyz=None, k_xyz=None, key_padding_mask=None,
-        return_weights=False):
+        return_weights=False, drop=None, site=0):
     """multihead_custom_attention.py:157-462 restricted to the paths the hot path takes.
 
     Batch-first: q_in (B, Lq, E), k_in/v_in (B, S, E).  q is scaled by d^-1/2 BEFORE the rotation (:325), the
@@ -67,6 +67,8 @@ def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, H, q_xyz=None, k_xyz=None, k
     if key_padding_mask is not None:
         w = w.masked_fill(key_padding_mask[:, None, None, :].bool(), float("-inf"))
     w = torch.softmax(w, dim=-1)
+    if drop is not None:                                  # F.dropout on the attention weights (:413), training mode
+        w = w * torch.from_numpy(drop.attn(site, B, H, Lq, S))
     o = (w @ vh).transpose(1, 2).reshape(B, Lq, E)
     o = F.linear(o, out_w, out_b)
     return (o, w) if return_weights else o
@@ -101,10 +103,18 @@ def adaln(x, t, w, b):
     return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
 
 
+def _drop(x, drop, site):
+    """nn.Dropout in training mode with the device's mask (oracle.sampling.DropoutTwin); identity when drop is None"""
+    return x if drop is None else x * torch.from_numpy(drop.flat(site, tuple(x.shape)))
+
+
 def parallel_attention_layer(P, prefix, seq1, seq1_mask, seq2, H, seq1_xyz=None, seq2_xyz=None, seq1_sem=None,
-                             ada=None, self_attn=True, apply_ffn=True, use_adaln=True):
+                             ada=None, self_attn=True, apply_ffn=True, use_adaln=True, drop=None, name_root="prediction_head."):
     """layers.py:115-218 ParallelAttentionLayer as configured on the hot path (pre_norm=False, only the seq1
-    stream is updated, cross_attention1=True, self_attention1=self_attn, dropout inactive / eval).
+    stream is updated, cross_attention1=True, self_attention1=self_attn).  drop: None (eval / p = 0) or a
+    DropoutTwin -- training-mode dropout (layers.py:10,34,58,82-84) on the attention weights (site + 0 / + 2), the
+    residual branches (+ 1 / + 3) and the FFN (+ 4 hidden, + 5 output), sites named after the module path below
+    `name_root`.
 
     (1) cross: q = AdaLN12(seq1 + sem); key = value = seq2;  seq1 = LN12(seq1 + MHA)
     (2) self : q = k = AdaLN1(seq1 + sem), v = AdaLN1(seq1), key_padding_mask = seq1_mask; seq1 = LN1(seq1 + MHA)
@@ -117,24 +127,27 @@ def parallel_attention_layer(P, prefix, seq1, seq1_mask, seq2, H, seq1_xyz=None,
             return adaln(x, ada, P[f"{prefix}.{name}.modulation.1.weight"], P[f"{prefix}.{name}.modulation.1.bias"])
         return x
 
+    sb = 0
+    if drop is not None:
+        sb = drop.site_id(prefix[len(name_root):] if prefix.startswith(name_root) else prefix)
     q1 = seq1 if seq1_sem is None else seq1 + seq1_sem
     o = mha(ada_or_id(q1, "adaln_12"), seq2, seq2, P[prefix + ".cross_12.in_proj_weight"],
             P[prefix + ".cross_12.in_proj_bias"], P[prefix + ".cross_12.out_proj.weight"],
-            P[prefix + ".cross_12.out_proj.bias"], H, seq1_xyz, seq2_xyz)
-    seq1 = layer_norm(seq1 + o, P[prefix + ".norm_12.weight"], P[prefix + ".norm_12.bias"])
+            P[prefix + ".cross_12.out_proj.bias"], H, seq1_xyz, seq2_xyz, drop=drop, site=sb)
+    seq1 = layer_norm(seq1 + _drop(o, drop, sb + 1), P[prefix + ".norm_12.weight"], P[prefix + ".norm_12.bias"])
     if self_attn:
         q1 = seq1 if seq1_sem is None else seq1 + seq1_sem
         qk = ada_or_id(q1, "adaln_1")
         vv = ada_or_id(seq1, "adaln_1")
         o = mha(qk, qk, vv, P[prefix + ".sa1.in_proj_weight"], P[prefix + ".sa1.in_proj_bias"],
                 P[prefix + ".sa1.out_proj.weight"], P[prefix + ".sa1.out_proj.bias"], H, seq1_xyz, seq1_xyz,
-                key_padding_mask=seq1_mask)
-        seq1 = layer_norm(seq1 + o, P[prefix + ".norm_1.weight"], P[prefix + ".norm_1.bias"])
+                key_padding_mask=seq1_mask, drop=drop, site=sb + 2)
+        seq1 = layer_norm(seq1 + _drop(o, drop, sb + 3), P[prefix + ".norm_1.weight"], P[prefix + ".norm_1.bias"])
     if apply_ffn:
         y = ada_or_id(seq1, "adaln_ff1")
-        hdn = F.relu(F.linear(y, P[prefix + ".ffn_12.0.weight"], P[prefix + ".ffn_12.0.bias"]))
-        seq1 = layer_norm(y + F.linear(hdn, P[prefix + ".ffn_12.3.weight"], P[prefix + ".ffn_12.3.bias"]),
-                          P[prefix + ".norm_122.weight"], P[prefix + ".norm_122.bias"])
+        hdn = _drop(F.relu(F.linear(y, P[prefix + ".ffn_12.0.weight"], P[prefix + ".ffn_12.0.bias"])), drop, sb + 4)
+        ffn = _drop(F.linear(hdn, P[prefix + ".ffn_12.3.weight"], P[prefix + ".ffn_12.3.bias"]), drop, sb + 5)
+        seq1 = layer_norm(y + ffn, P[prefix + ".norm_122.weight"], P[prefix + ".norm_122.bias"])
     return seq1
 
 
@@ -145,7 +158,10 @@ def parallel_attention(P, prefix, n_layers, seq1, seq1_mask, seq2, H, **kw):
     return seq1
 
 
-def mlp2(x, P, prefix, i0="0", i1="2"):
-    """Linear-ReLU-Linear heads (act3d.py:162-166; diffusion_head.py:41-46 uses indices 0 and 3)."""
-    return F.linear(F.relu(F.linear(x, P[f"{prefix}.{i0}.weight"], P[f"{prefix}.{i0}.bias"])),
-                    P[f"{prefix}.{i1}.weight"], P[f"{prefix}.{i1}.bias"])
+def mlp2(x, P, prefix, i0="0", i1="2", drop=None, name_root="prediction_head."):
+    """Linear-ReLU-Linear heads (act3d.py:162-166; diffusion_head.py:41-46 uses indices 0 and 3, with an nn.Dropout(0.1)
+    between the ReLU and the second Linear: `drop` applies it, site = (module path, 4))."""
+    hdn = F.relu(F.linear(x, P[f"{prefix}.{i0}.weight"], P[f"{prefix}.{i0}.bias"]))
+    if drop is not None:
+        hdn = _drop(hdn, drop, drop.site_id(prefix[len(name_root):] if prefix.startswith(name_root) else prefix, 4))
+    return F.linear(hdn, P[f"{prefix}.{i1}.weight"], P[f"{prefix}.{i1}.bias"])

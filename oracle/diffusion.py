@@ -161,27 +161,28 @@ def unnormalize_pos(pos, bounds):
 
 
 # ------------------------------------------------------------------------------------------ the prediction head
-def head_context(P, ctx_feats, instruction, H, n_vl_layers=2, pre="prediction_head."):
+def head_context(P, ctx_feats, instruction, H, n_vl_layers=2, pre="prediction_head.", drop=None):
     """Step-invariant part of DiffusionHead.forward (diffusion_head.py:222-232, 290-314): instruction encoding and
     the vision->language attention over the visual tokens.  ctx_feats (B, S_vis, E)."""
     instr = F.linear(instruction, P[pre + "instruction_encoder.weight"], P[pre + "instruction_encoder.bias"])
     ctx = OB.parallel_attention(P, pre + "vl_attention.0", n_vl_layers, ctx_feats, None, instr, H, self_attn=False,
-                                use_adaln=False)
+                                use_adaln=False, drop=drop, name_root=pre)
     return ctx, instr
 
 
 def head_forward(P, trajectory, traj_mask, timestep, ctx_feats, ctx_xyz, curr_gripper, goal_gripper, instruction, H,
-                 n_traj_layers=4, pre="prediction_head."):
+                 n_traj_layers=4, pre="prediction_head.", drop=None):
     """DiffusionHead.forward / _one_attention_round (diffusion_head.py:200-363) for the script configuration
     (use_instruction, use_goal, 1 scale, 1 round, 6D rotations).  Inputs are already normalised / converted;
     ctx_feats (B, C*1024, E) are the FPN res3 tokens, ctx_xyz their down-sampled (normalised) coordinates.
-    Returns the single-element prediction list's tensor (B, L, 9)."""
+    Returns the single-element prediction list's tensor (B, L, 9).  drop: oracle.sampling.DropoutTwin for training mode
+    (p = 0.1 everywhere in the reference), None for eval."""
     E = ctx_feats.shape[-1]
     B, Ln, _ = trajectory.shape
-    tf = OB.mlp2(trajectory, P, pre + "traj_encoder", "0", "3")
+    tf = OB.mlp2(trajectory, P, pre + "traj_encoder", "0", "3", drop=drop, name_root=pre)
     traj_xyz = trajectory[..., :3]
     time_feats = OB.sinusoidal(timestep, E)
-    ctx, instr = head_context(P, ctx_feats, instruction, H, pre=pre)
+    ctx, instr = head_context(P, ctx_feats, instruction, H, pre=pre, drop=drop)
     cg = F.linear(curr_gripper, P[pre + "curr_gripper_encoder.weight"], P[pre + "curr_gripper_encoder.bias"])[:, None] \
         + P[pre + "curr_gripper_embed.weight"][None]
     gg = F.linear(goal_gripper, P[pre + "goal_gripper_encoder.weight"], P[pre + "goal_gripper_encoder.bias"])[:, None] \
@@ -190,18 +191,18 @@ def head_forward(P, trajectory, traj_mask, timestep, ctx_feats, ctx_xyz, curr_gr
     cxyz = torch.cat([ctx_xyz, curr_gripper[:, None, :3], goal_gripper[:, None, :3]], dim=1)
     sem = OB.sinusoidal(torch.arange(Ln, dtype=torch.float32), E)[None].expand(B, -1, -1)
     tf = OB.parallel_attention(P, pre + "traj_lang_attention.0", 1, tf, traj_mask, instr, H, seq1_sem=sem,
-                               self_attn=False, apply_ffn=False, use_adaln=False)
-    kw = dict(seq1_xyz=traj_xyz, seq2_xyz=cxyz, seq1_sem=sem, ada=time_feats)
+                               self_attn=False, apply_ffn=False, use_adaln=False, drop=drop, name_root=pre)
+    kw = dict(seq1_xyz=traj_xyz, seq2_xyz=cxyz, seq1_sem=sem, ada=time_feats, drop=drop, name_root=pre)
     tf = OB.parallel_attention(P, pre + "traj_attention.0", n_traj_layers, tf, traj_mask, ctx, H, **kw)
     pf = OB.parallel_attention(P, pre + "pos_attention.0", 2, tf, traj_mask, ctx, H, **kw)
     rf = OB.parallel_attention(P, pre + "rot_attention.0", 2, tf, traj_mask, ctx, H, **kw)
-    upd = torch.cat([OB.mlp2(pf, P, pre + "pos_regressor.0", "0", "3"),
-                     OB.mlp2(rf, P, pre + "rot_regressor.0", "0", "3")], dim=-1)
+    upd = torch.cat([OB.mlp2(pf, P, pre + "pos_regressor.0", "0", "3", drop=drop, name_root=pre),
+                     OB.mlp2(rf, P, pre + "rot_regressor.0", "0", "3", drop=drop, name_root=pre)], dim=-1)
     return torch.cat([traj_xyz + upd[..., :3], upd[..., 3:]], dim=-1)
 
 
 def planner_loss(P, sched, gt_trajectory, traj_mask, ctx_feats, ctx_xyz_world, instruction, curr_gripper, goal_gripper,
-                 bounds, noise, timesteps, H, ctx_xyz_norm=None):
+                 bounds, noise, timesteps, H, ctx_xyz_norm=None, drop=None):
     """DiffusionPlanner.forward training branch (diffusion_model.py:253-324) with injected noise / timesteps.
     ctx_xyz_world: down-sampled point cloud in world metres (normalised here, which commutes with the bilinear
     down-sampling up to rounding)."""
@@ -213,7 +214,7 @@ def planner_loss(P, sched, gt_trajectory, traj_mask, ctx_feats, ctx_xyz_world, i
     gg[:, :3] = normalize_pos(gg[:, :3], bounds)
     gt, cg, gg = convert_rot(gt), convert_rot(cg), convert_rot(gg)
     noisy = sched.add_noise(gt, noise, timesteps)
-    pred = head_forward(P, noisy, traj_mask, timesteps, ctx_feats, cxyz, cg, gg, instruction, H)
+    pred = head_forward(P, noisy, traj_mask, timesteps, ctx_feats, cxyz, cg, gg, instruction, H, drop=drop)
     loss = 100 * F.l1_loss(pred[..., :3], gt[..., :3]) + 10 * F.l1_loss(pred[..., 3:9], gt[..., 3:9])
     return loss, pred, gt
 

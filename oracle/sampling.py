@@ -115,6 +115,51 @@ def philox_ghost_points(seed, offset, bounds, anchor, radius, B, Ng, level, max_
     return out
 
 
+class DropoutTwin:
+    """CPU twin of the device dropout masks (csrc/a3d_common.h drop_keep8, csrc/dropout.hip, attention kernels):
+    one Philox4x32-10 call per block of 8 elements, counter = (c0, c1, c2, site), key = (seed_lo ^ offset_lo,
+    seed_hi ^ offset_hi); element j of the block is kept iff the j-th 16-bit field of the 128 output bits is
+    >= round(p * 65536); kept elements are scaled by 1 / (1 - p) (fp32).  Restates nn.Dropout / F.dropout in training
+    mode (layers.py:34,58,82-84; multihead_custom_attention.py:413; diffusion_head.py:46,183,193) up to the random
+    stream, which is the device's own."""
+
+    def __init__(self, seed, offset, p):
+        self.k0 = (seed ^ offset) & 0xFFFFFFFF
+        self.k1 = ((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFF
+        self.p = float(p)
+        self.thr = int(np.rint(np.float32(p) * np.float32(65536.0)))
+        self.scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+
+    @staticmethod
+    def site_id(name, sub=0):
+        import zlib
+        return ((zlib.crc32(name.encode()) & 0xFFFFFFF8) | sub) & 0xFFFFFFFF
+
+    def _keep(self, c0, c1, c2, site):
+        n = c0.shape[0]
+        r = philox4x32_10(c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), np.full(n, site, np.uint32),
+                          self.k0, self.k1)
+        f = np.stack([r[0] & np.uint32(0xFFFF), r[0] >> np.uint32(16), r[1] & np.uint32(0xFFFF), r[1] >> np.uint32(16),
+                      r[2] & np.uint32(0xFFFF), r[2] >> np.uint32(16), r[3] & np.uint32(0xFFFF), r[3] >> np.uint32(16)], axis=1)
+        return f >= self.thr                                           # (n, 8) bool
+
+    def flat(self, site, shape):
+        """scaled keep mask (float32) of a contiguous tensor of `shape`, flat element indexing"""
+        n = int(np.prod(shape))
+        nblk = (n + 7) // 8
+        blk = np.arange(nblk, dtype=np.uint64)
+        keep = self._keep(blk & np.uint64(0xFFFFFFFF), blk >> np.uint64(32), np.full(nblk, 0xFFFFFFFF, np.uint64), site)
+        return (keep.reshape(-1)[:n].reshape(shape).astype(np.float32) * self.scale)
+
+    def attn(self, site, B, H, Lq, S):
+        """scaled keep mask (B, H, Lq, S) of the attention weights: block = 8 consecutive keys of one (b, h, query)"""
+        nblk = (S + 7) // 8
+        bh, q, kb = np.meshgrid(np.arange(B * H), np.arange(Lq), np.arange(nblk), indexing="ij")
+        keep = self._keep(kb.reshape(-1), q.reshape(-1), bh.reshape(-1), site)
+        keep = keep.reshape(B, H, Lq, nblk * 8)[..., :S]
+        return keep.astype(np.float32) * self.scale
+
+
 # ----------------------------------------------------------------------------- scene selection
 def pcd_downsample(pcd, factor):
     """act3d.py:379-383 / encoder.py:147-158: F.interpolate(pcd, scale_factor=1/f, mode='bilinear') followed by

@@ -30,7 +30,8 @@ def setup(a3d, dev):
     cfg = r["cfg"]
     m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
                              use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
-                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100,
+                             dropout=0.0)          # the reference goldens were recorded with dropout disabled
     res = m.load_state_dict(_diffusion_params(r), strict=False)
     assert not res.unexpected_keys
     assert all(".backbone." in k or "feature_pyramid" in k for k in res.missing_keys), res.missing_keys

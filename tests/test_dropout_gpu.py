@@ -1,0 +1,209 @@
+"""Training-mode dropout of the ChainedDiffuser path (reference: p = 0.1 in every ParallelAttentionLayer and in the
+traj_encoder / regressor MLPs) on the device Philox stream, against the CPU twin (oracle.sampling.DropoutTwin +
+oracle.blocks / oracle.diffusion with `drop=`) that applies the SAME masks:
+  * mask bits and the elementwise kernel bit-exact, kept fraction statistics;
+  * attention block (weights dropout inside the MFMA kernels + residual-branch dropout), forward and all gradients,
+    for the cross / self / key-split shapes;
+  * the whole DiffusionPlanner training step (loss + gradients) at p = 0.1;  p = 0 is the golden-pinned path
+    (tests/test_diffusion_gpu.py constructs with dropout=0.0)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import common as C  # noqa: E402
+from oracle import blocks as OB  # noqa: E402
+from oracle import diffusion as OD  # noqa: E402
+from oracle import sampling as OS  # noqa: E402
+from test_kernels_gpu import _mha_params, _mk_modules, report  # noqa: E402
+from test_oracle_golden import _diffusion_params, load  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(a3d, dev, seed, offset, p):
+    state = torch.tensor([seed, offset], dtype=torch.int64, device=dev)
+    return a3d.ops.DropCtx(state, p), OS.DropoutTwin(seed, offset, p)
+
+
+def test_masks_and_elementwise_kernel_match_the_cpu_twin(a3d, dev):
+    O = a3d.ops
+    seed, offset, p = (7 << 33) | 12345, (1 << 32) | 17, 0.1
+    drop, twin = _ctx(a3d, dev, seed, offset, p)
+    site = O.site_id("traj_attention.0.layers.1", 4)
+    assert site == twin.site_id("traj_attention.0.layers.1", 4)
+    n = 120 * 1000 + 5                                     # not a multiple of 8: tail path
+    keep = O.dropout_mask(drop, site, n).cpu().numpy().astype(bool)
+    ref = twin.flat(site, (n,)) > 0
+    assert np.array_equal(keep, ref)
+    frac = keep.mean()
+    assert abs(frac - 0.9) < 4 * math.sqrt(0.09 / n), frac
+    # runs of the mask look independent: lag-1 autocorrelation ~ 0
+    k = keep.astype(np.float64) - frac
+    assert abs((k[1:] * k[:-1]).mean() / k.var()) < 0.02
+    x = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    y = O.dropout_raw(x.to(dev), drop, site).cpu()
+    assert torch.equal(y, x * torch.from_numpy(twin.flat(site, (n,))))
+    # attention-weight indexing: (b*H+h, query) rows of 8-key blocks
+    S = 1029
+    a = twin.attn(site, 2, 8, 5, S)
+    for bh, q in ((0, 0), (3, 4), (15, 2)):
+        row = O.dropout_mask(drop, site, S, bh=bh, q=q).cpu().numpy().astype(bool)
+        assert np.array_equal(row, a[bh // 8, bh % 8, q] > 0)
+    # a different forward pass (offset + 1) and a different site give different masks
+    drop2, _ = _ctx(a3d, dev, seed, offset + 1, p)
+    assert not np.array_equal(O.dropout_mask(drop2, site, n).cpu().numpy().astype(bool), keep)
+    assert not np.array_equal(O.dropout_mask(drop, site ^ 1, n).cpu().numpy().astype(bool), keep)
+
+
+@pytest.mark.parametrize("B,Lq,S,E,H,rope,masked,mode", [
+    (2, 16, 70, 120, 8, True, False, "kv"),          # trajectory -> context
+    (2, 16, 16, 120, 8, True, True, "qk"),           # trajectory self-attention with padded steps
+    (2, 600, 53, 120, 8, False, False, "kv"),        # vision -> language
+    (1, 16, 3076, 120, 8, True, False, "kv"),        # key-split forward / dQ (nsplit > 1)
+    (2, 50, 4098, 120, 8, True, False, "kv"),        # script horizon, 4 cameras
+])
+def test_attn_block_with_dropout_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
+    O = a3d.ops
+    g = torch.Generator().manual_seed(B * 1000 + Lq + S)
+    drop, twin = _ctx(a3d, dev, 99, 3, 0.1)
+    site = O.site_id("pos_attention.0.layers.0", 0)
+    in_w, in_b, out_w, out_b = _mha_params(E, g, scale=1.5)
+    ln_g = torch.rand(E, generator=g) + 0.5
+    ln_b = torch.randn(E, generator=g) * 0.1
+    xq = torch.randn(B, Lq, E, generator=g)
+    xk = torch.randn(B, S, E, generator=g) if mode != "qk" else xq
+    xv = xk if mode == "kv" else torch.randn(B, S, E, generator=g)
+    resid = torch.randn(B, Lq, E, generator=g)
+    q_xyz = torch.rand(B, Lq, 3, generator=g) * 2 - 0.5 if rope else None
+    k_xyz = (torch.rand(B, S, 3, generator=g) * 2 - 0.5 if mode != "qk" else q_xyz) if rope else None
+    kmask = None
+    if masked:
+        kmask = torch.zeros(B, S, dtype=torch.bool)
+        kmask[1, -(S // 4):] = True
+    leaves = [t.clone().requires_grad_() for t in (xq, xk, xv, resid, in_w, in_b, out_w, out_b, ln_g, ln_b)]
+    cq, ck, cv, cr, ciw, cib, cow, cob, cg, cb = leaves
+    if mode == "qk":
+        ck = cq
+    if mode == "kv":
+        cv = ck
+    o = OB.mha(cq, ck, cv, ciw, cib, cow, cob, H, q_xyz, k_xyz, kmask, drop=twin, site=site)
+    ref = OB.layer_norm(cr + OB._drop(o, twin, site + 1), cg, cb)
+    dy = torch.randn(B, Lq, E, generator=g)
+    ref.backward(dy)
+    mha, norm = _mk_modules(dev, in_w, in_b, out_w, out_b, ln_g, ln_b)
+    dq = xq.to(dev).requires_grad_()
+    dk = dq if mode == "qk" else xk.to(dev).requires_grad_()
+    dv = dk if mode == "kv" else xv.to(dev).requires_grad_()
+    dr = resid.to(dev).requires_grad_()
+    y = O.attn_block(dq, dk, dv, dr, None if q_xyz is None else q_xyz.to(dev), None if k_xyz is None else k_xyz.to(dev),
+                     None if kmask is None else kmask.to(dev), mha, norm, H, drop=drop, site=site)
+    report(f"dropout attn_block[{mode}] fwd", y, ref, 1e-4)
+    y.backward(dy.to(dev))
+    gtol = 5e-4
+    report("dropout attn_block d q_in", dq.grad, cq.grad, gtol, 1e-3)
+    if mode != "qk":
+        report("dropout attn_block d k_in", dk.grad, ck.grad, gtol, 1e-3)
+    report("dropout attn_block d resid", dr.grad, cr.grad, gtol, 1e-3)
+    sc = max(1.0, math.sqrt(B * max(Lq, S)) / 8)
+    report("dropout attn_block d in_w", mha.in_proj_weight.grad, ciw.grad, gtol * sc, 2e-3)
+    report("dropout attn_block d in_b", mha.in_proj_bias.grad, cib.grad, gtol * sc, 2e-3)
+    report("dropout attn_block d out_w", mha.out_proj.weight.grad, cow.grad, gtol * sc, 2e-3)
+    report("dropout attn_block d ln_g", norm.weight.grad, cg.grad, gtol * sc, 2e-3)
+    # and without a context the block is the p = 0 path, bit for bit what it was
+    y0 = O.attn_block(dq, dk, dv, dr, None if q_xyz is None else q_xyz.to(dev), None if k_xyz is None else k_xyz.to(dev),
+                      None if kmask is None else kmask.to(dev), mha, norm, H)
+    y00 = O.attn_block(dq, dk, dv, dr, None if q_xyz is None else q_xyz.to(dev), None if k_xyz is None else k_xyz.to(dev),
+                       None if kmask is None else kmask.to(dev), mha, norm, H, drop=O.DropCtx(drop.state, 0.0), site=site)
+    assert torch.equal(y0, y00)
+
+
+def test_mlp_with_dropout_vs_twin(a3d, dev):
+    O = a3d.ops
+    drop, twin = _ctx(a3d, dev, 5, 0, 0.1)
+    g = torch.Generator().manual_seed(3)
+    E = 120
+    P = {"f.0.weight": torch.randn(4 * E, E, generator=g) / 11, "f.0.bias": torch.randn(4 * E, generator=g) * 0.1,
+         "f.3.weight": torch.randn(E, 4 * E, generator=g) / 22, "f.3.bias": torch.randn(E, generator=g) * 0.1}
+    lin = {k: torch.nn.Parameter(v.to(dev)) for k, v in P.items()}
+    Pc = {k: v.clone().requires_grad_() for k, v in P.items()}
+    x = torch.randn(2, 16, E, generator=g)
+    ln_g, ln_b = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.1
+    sh, so = O.site_id("x", 4), O.site_id("x", 5)
+    xc = x.clone().requires_grad_()
+    cg, cb = ln_g.clone().requires_grad_(), ln_b.clone().requires_grad_()
+    hdn = OB._drop(torch.relu(torch.nn.functional.linear(xc, Pc["f.0.weight"], Pc["f.0.bias"])), twin, sh)
+    ref = OB.layer_norm(xc + OB._drop(torch.nn.functional.linear(hdn, Pc["f.3.weight"], Pc["f.3.bias"]), twin, so), cg, cb)
+    dy = torch.randn(2, 16, E, generator=g)
+    ref.backward(dy)
+    xd = x.to(dev).requires_grad_()
+    gd, bd = torch.nn.Parameter(ln_g.to(dev)), torch.nn.Parameter(ln_b.to(dev))
+    y = O.MLPFn.apply(xd, lin["f.0.weight"], lin["f.0.bias"], lin["f.3.weight"], lin["f.3.bias"], gd, bd, drop, sh, so)
+    report("dropout ffn fwd", y, ref, 2e-5)
+    y.backward(dy.to(dev))
+    report("dropout ffn dx", xd.grad, xc.grad, 5e-5, 1e-4)
+    for k in P:
+        report("dropout ffn d " + k, lin[k].grad, Pc[k].grad, 1e-4, 1e-4)
+    report("dropout ffn d ln_g", gd.grad, cg.grad, 1e-4, 1e-4)
+
+
+def test_planner_training_step_with_dropout_vs_oracle(a3d, dev):
+    """DiffusionPlanner.forward in train() with the reference's p = 0.1: loss and every gradient against the oracle applying
+    the twin masks; a second forward pass draws different masks (the generator advanced on the device)."""
+    r = load("diffusion.pt")
+    cfg = r["cfg"]
+    seed = 4242
+    m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100,
+                             dropout=0.1, dropout_seed=seed)
+    Pc = _diffusion_params(r)
+    m.load_state_dict(Pc, strict=False)
+    m.to(dev).train()
+    inp = C.trajectory_inputs(r["seed"], cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"])
+    tokens = C.tokens_from_maps(inp["fmap"])
+    d = {k: v.to(dev) for k, v in inp.items()}
+    for p_ in m.parameters():
+        p_.grad = None
+    loss = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
+             noise=d["noise"], timesteps=d["timesteps"], visual_tokens=tokens.to(dev))
+    loss.backward()
+    assert m.prediction_head._drop_state.cpu().tolist() == [seed, 1]
+    # oracle with the masks of forward pass 0
+    P = {n: t.clone().requires_grad_() for n, t in Pc.items()}
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
+    twin = OS.DropoutTwin(seed, 0, 0.1)
+    oloss, _, _ = OD.planner_loss(P, OD.DDPMSchedules(100), inp["trajectory"], inp["mask"], tokens, None, inp["instr"],
+                                  inp["curr_gripper"], inp["goal_gripper"], bounds, inp["noise"], inp["timesteps"], 8,
+                                  ctx_xyz_norm=cxyz_n, drop=twin)
+    oloss.backward()
+    err = abs(loss.item() - oloss.item())
+    print(f"[parity] dropout train loss: {loss.item():.6f} vs oracle {oloss.item():.6f}")
+    assert err <= 1e-3 * max(1.0, abs(oloss.item()))
+    assert abs(oloss.item() - r["train_loss"].item()) > 1e-2, "the dropped loss must differ from the p = 0 golden"
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for n, p_ in P.items():
+        if p_.grad is None or n not in named:
+            continue
+        ref = p_.grad
+        scale = max(1e-3, ref.abs().max().item())
+        e = (named[n].grad.cpu() - ref).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e <= 1.5e-3, f"grad {n}: {e:.3e} of scale"
+    print(f"[parity] dropout train gradients: worst {worst:.3e} of scale")
+    loss2 = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
+              noise=d["noise"], timesteps=d["timesteps"], visual_tokens=tokens.to(dev))
+    assert abs(loss2.item() - loss.item()) > 1e-4, "second pass drew the same masks"
+    m.eval()
+    with torch.no_grad():
+        le = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
+               noise=d["noise"], timesteps=d["timesteps"], visual_tokens=tokens.to(dev))
+    assert abs(le.item() - r["train_loss"].item()) <= 1e-3 * abs(r["train_loss"].item()), "eval mode = no dropout"

@@ -218,3 +218,28 @@ def test_flat_data_parallel_two_ranks_gloo():
         assert ok and ok2, f"rank {rank}: all-reduced gradient wrong"
         assert same, "parameters differ across ranks after broadcast"
         assert scale == 0.5
+
+
+def test_dropout_twin_statistics_and_site_ids():
+    """CPU side of the dropout contract: site ids of the product (ops.site_id) and of the oracle twin agree, the twin's
+    keep rate is 1 - p with the fp32 scale 1 / (1 - p), blocks / sites / passes are decorrelated."""
+    import numpy as np
+    from oracle.sampling import DropoutTwin
+    a3d = load_pkg()
+    for name in ("traj_attention.0.layers.3", "vl_attention.0.layers.0", "traj_encoder"):
+        for sub in (0, 4, 5):
+            assert a3d.ops.site_id(name, sub) == DropoutTwin.site_id(name, sub)
+            assert a3d.ops.site_id(name, sub) & 7 == sub
+    t = DropoutTwin(seed=11, offset=0, p=0.1)
+    assert t.thr == 6554 and abs(float(t.scale) - 1.0 / 0.9) < 1e-6
+    m = t.flat(t.site_id("x", 4), (64, 1000))
+    keep = m > 0
+    assert abs(keep.mean() - 0.9) < 5e-3 and np.allclose(m[keep], t.scale)
+    m2 = DropoutTwin(11, 1, 0.1).flat(t.site_id("x", 4), (64, 1000)) > 0
+    m3 = t.flat(t.site_id("x", 5), (64, 1000)) > 0
+    for other in (m2, m3):
+        agree = (other == keep).mean()
+        assert abs(agree - (0.81 + 0.01)) < 1e-2           # independent masks agree with probability p^2 + (1-p)^2
+    a = t.attn(3, 2, 8, 16, 70) > 0
+    assert a.shape == (2, 8, 16, 70) and abs(a.mean() - 0.9) < 2e-2
+    assert (DropoutTwin(11, 0, 0.0).flat(1, (100,)) == 1.0).all()
