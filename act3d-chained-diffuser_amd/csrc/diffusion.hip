@@ -124,6 +124,122 @@ __global__ void traj_update_kernel(const float* __restrict__ traj, const float* 
   }
 }
 
+// ---------------------------------------------------------------- pose <-> network signal (one launch each way)
+// diffusion_model.py:187-230: workspace normalisation of xyz to [-1, 1] and the quaternion <-> 6D rotation change of
+// variables (model/utils/utils.py:51-52,117-139 and the quaternion <-> matrix maps of utils/pytorch3d_transforms.py),
+// written from the closed forms: R(q) for a unit quaternion (w, x, y, z); 6D = the first two columns of R; back:
+// Gram-Schmidt of the two 3-vectors, then the quaternion from the best-conditioned of the four trace identities.
+// One thread per pose row; rows carry `extra` trailing channels that pass through.
+__global__ void pose_to_signal_kernel(const float* __restrict__ in, const float* __restrict__ bounds,
+                                      float* __restrict__ out, int n, int extra) {
+  const int Din = 7 + extra, Dout = 9 + extra;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* r = in + (size_t)i * Din;
+    float* o = out + (size_t)i * Dout;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (bounds) {
+        const float lo = bounds[a], hi = bounds[3 + a];
+        o[a] = (r[a] - lo) / (hi - lo) * 2.0f - 1.0f;
+      } else {
+        o[a] = r[a];
+      }
+    }
+    float w = r[3], x = r[4], y = r[5], z = r[6];
+    const float nrm = fmaxf(sqrtf(w * w + x * x + y * y + z * z), 1e-10f);
+    w /= nrm; x /= nrm; y /= nrm; z /= nrm;
+    const float t = 2.0f / (w * w + x * x + y * y + z * z);
+    // first column of R, then the second
+    o[3] = 1.0f - t * (y * y + z * z);
+    o[4] = t * (x * y + z * w);
+    o[5] = t * (x * z - y * w);
+    o[6] = t * (x * y - z * w);
+    o[7] = 1.0f - t * (x * x + z * z);
+    o[8] = t * (y * z + x * w);
+    for (int e = 0; e < extra; ++e) o[9 + e] = r[7 + e];
+  }
+}
+
+__global__ void signal_to_pose_kernel(const float* __restrict__ in, const float* __restrict__ bounds,
+                                      float* __restrict__ out, int n, int extra) {
+  const int Din = 9 + extra, Dout = 7 + extra;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* r = in + (size_t)i * Din;
+    float* o = out + (size_t)i * Dout;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (bounds) {
+        const float lo = bounds[a], hi = bounds[3 + a];
+        o[a] = (r[a] + 1.0f) / 2.0f * (hi - lo) + lo;
+      } else {
+        o[a] = r[a];
+      }
+    }
+    // orthonormal frame (c0, c1, c2) from the two raw 3-vectors: c0 = a / |a|, c2 = (c0 x b) / |c0 x b|, c1 = c2 x c0
+    float c0[3] = {r[3], r[4], r[5]};
+    const float n0 = fmaxf(sqrtf(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]), 1e-8f);
+    c0[0] /= n0; c0[1] /= n0; c0[2] /= n0;
+    float c2[3] = {c0[1] * r[8] - c0[2] * r[7], c0[2] * r[6] - c0[0] * r[8], c0[0] * r[7] - c0[1] * r[6]};
+    const float n2 = fmaxf(sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]), 1e-8f);
+    c2[0] /= n2; c2[1] /= n2; c2[2] /= n2;
+    const float c1[3] = {c2[1] * c0[2] - c2[2] * c0[1], c2[2] * c0[0] - c2[0] * c0[2], c2[0] * c0[1] - c2[1] * c0[0]};
+    // R[row][col] = c_col[row]
+    const float r00 = c0[0], r10 = c0[1], r20 = c0[2], r01 = c1[0], r11 = c1[1], r21 = c1[2], r02 = c2[0], r12 = c2[1], r22 = c2[2];
+    // 4 w^2 = 1 + tr, 4 x^2 = 1 + r00 - r11 - r22, ...: take the largest component as the pivot
+    const float d[4] = {1.0f + r00 + r11 + r22, 1.0f + r00 - r11 - r22, 1.0f - r00 + r11 - r22, 1.0f - r00 - r11 + r22};
+    float mag[4];
+    int piv = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mag[c] = d[c] > 0.f ? sqrtf(d[c]) : 0.f;
+      if (mag[c] > mag[piv]) piv = c;
+    }
+    const float den = 2.0f * fmaxf(mag[piv], 0.1f);
+    float q[4];
+    if (piv == 0) { q[0] = mag[0] * mag[0]; q[1] = r21 - r12; q[2] = r02 - r20; q[3] = r10 - r01; }
+    else if (piv == 1) { q[0] = r21 - r12; q[1] = mag[1] * mag[1]; q[2] = r10 + r01; q[3] = r02 + r20; }
+    else if (piv == 2) { q[0] = r02 - r20; q[1] = r10 + r01; q[2] = mag[2] * mag[2]; q[3] = r12 + r21; }
+    else { q[0] = r10 - r01; q[1] = r20 + r02; q[2] = r21 + r12; q[3] = mag[3] * mag[3]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[3 + c] = q[c] / den;
+    for (int e = 0; e < extra; ++e) o[7 + e] = r[9 + e];
+  }
+}
+
+// per-trajectory error columns of TrajectoryCriterion.compute_metrics (main_trajectory.py:303-343); one wave per sample.
+// cols[b] = { mean_l pos_l2, mean_l [pos_l2 < 0.01], mean_l rot_l1, mean_l [rot_l1 < 0.025], mean_{l,c} (pred - gt)^2,
+//             and the same four position / rotation figures at the last step }, rot_l1 = min(|q - g|_1, |q + g|_1)
+__global__ __launch_bounds__(64) void traj_errors_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         float* __restrict__ cols, int L, int D) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s_pos = 0.f, s_pacc = 0.f, s_rot = 0.f, s_racc = 0.f, s_sq = 0.f;
+  float last[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l = lane; l < L; l += 64) {
+    const float* p = pred + ((size_t)b * L + l) * D;
+    const float* g = gt + ((size_t)b * L + l) * D;
+    float d2 = 0.f, a = 0.f, a_neg = 0.f, sq = 0.f;
+    for (int c = 0; c < D; ++c) {
+      const float e = p[c] - g[c];
+      sq += e * e;
+      if (c < 3) d2 += e * e;
+      else if (c < 7) { a += fabsf(e); a_neg += fabsf(p[c] + g[c]); }
+    }
+    const float pos = sqrtf(d2), rot = fminf(a, a_neg);
+    s_pos += pos; s_pacc += pos < 0.01f ? 1.f : 0.f;
+    s_rot += rot; s_racc += rot < 0.025f ? 1.f : 0.f;
+    s_sq += sq;
+    if (l == L - 1) { last[0] = pos; last[1] = pos < 0.01f ? 1.f : 0.f; last[2] = rot; last[3] = rot < 0.025f ? 1.f : 0.f; }
+  }
+  s_pos = wave_sum(s_pos); s_pacc = wave_sum(s_pacc); s_rot = wave_sum(s_rot); s_racc = wave_sum(s_racc); s_sq = wave_sum(s_sq);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) last[c] = wave_sum(last[c]);
+  if (lane == 0) {
+    float* o = cols + (size_t)b * 9;
+    o[0] = s_pos / L; o[1] = s_pacc / L; o[2] = s_rot / L; o[3] = s_racc / L; o[4] = s_sq / ((float)L * D);
+    o[5] = last[0]; o[6] = last[1]; o[7] = last[2]; o[8] = last[3];
+  }
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -179,4 +295,20 @@ extern "C" int a3d_traj_update(const float* traj, const float* upd, float* out, 
   if (!traj || !upd || !out || rows <= 0 || D <= 0) { set_error("a3d_traj_update: bad argument"); return A3D_ERR_ARG; }
   hipLaunchKernelGGL(traj_update_kernel, dim3(gsz((size_t)rows * D)), dim3(256), 0, (hipStream_t)stream, traj, upd, out, rows, D, npos);
   return check_launch("a3d_traj_update");
+}
+
+extern "C" int a3d_pose_to_signal(const float* pose, const float* bounds, float* out, int n, int extra, void* stream) {
+  if (!pose || !out || n <= 0 || extra < 0) { set_error("a3d_pose_to_signal: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(pose_to_signal_kernel, dim3(gsz((size_t)n)), dim3(256), 0, (hipStream_t)stream, pose, bounds, out, n, extra);
+  return check_launch("a3d_pose_to_signal");
+}
+extern "C" int a3d_signal_to_pose(const float* signal, const float* bounds, float* out, int n, int extra, void* stream) {
+  if (!signal || !out || n <= 0 || extra < 0) { set_error("a3d_signal_to_pose: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(signal_to_pose_kernel, dim3(gsz((size_t)n)), dim3(256), 0, (hipStream_t)stream, signal, bounds, out, n, extra);
+  return check_launch("a3d_signal_to_pose");
+}
+extern "C" int a3d_traj_errors(const float* pred, const float* gt, float* cols, int B, int L, int D, void* stream) {
+  if (!pred || !gt || !cols || B <= 0 || L <= 0 || D < 7) { set_error("a3d_traj_errors: bad argument (B=%d L=%d D=%d, D >= 7)", B, L, D); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(traj_errors_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, gt, cols, L, D);
+  return check_launch("a3d_traj_errors");
 }

@@ -287,6 +287,58 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 __global__ void step_inc_kernel(float* step) { step[0] += 1.0f; }
 
+// ---------------------------------------------------------------- keypose evaluation metrics, per-sample columns
+// LossAndMetrics.compute_metrics (main_keypose.py:431-482) as a table: one thread per sample writes
+//   cols[b] = { e_final, [e_final < 0.01], e_level_0 .. e_level_{nlev-1}, rot_l1, [rot_l1 < 0.05], [rot_l1 < 0.025], grip_ok }
+// with e = |position - gt_xyz|_2, rot_l1 = |quat - gt_quat|_1 (symmetric: min over +-gt), grip_ok = (open > 0.5) == gt_open;
+// the per-task / overall means are one small matrix product with the group-indicator matrix on the host side of the API.
+__global__ void keypose_errors_kernel(const float* __restrict__ pos, const float* __restrict__ rot,
+                                      const float* __restrict__ grip, const float* __restrict__ gt, int ldgt,
+                                      float* __restrict__ cols, int B, int nlev, int symmetric) {
+  const int K = 6 + nlev;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const float* g = gt + (size_t)b * ldgt;
+    float* o = cols + (size_t)b * K;
+    for (int s = 0; s <= nlev; ++s) {
+      const float* p = pos + ((size_t)s * B + b) * 3;
+      const float dx = p[0] - g[0], dy = p[1] - g[1], dz = p[2] - g[2];
+      const float e = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (s == 0) { o[0] = e; o[1] = e < 0.01f ? 1.f : 0.f; }
+      else o[1 + s] = e;
+    }
+    float a = 0.f, a_neg = 0.f;
+    for (int c = 0; c < 4; ++c) { a += fabsf(rot[b * 4 + c] - g[3 + c]); a_neg += fabsf(rot[b * 4 + c] + g[3 + c]); }
+    const float l1 = symmetric ? fminf(a, a_neg) : a;
+    o[2 + nlev] = l1;
+    o[3 + nlev] = l1 < 0.05f ? 1.f : 0.f;
+    o[4 + nlev] = l1 < 0.025f ? 1.f : 0.f;
+    o[5 + nlev] = ((grip[b] > 0.5f) == (g[7] != 0.f)) ? 1.f : 0.f;
+  }
+}
+
+// symmetric quaternion regression loss (main_keypose.py:370-376): coeff * mean_b min(mse(q, g), mse(q, -g)); grad optional
+__global__ __launch_bounds__(256) void sym_quat_loss_kernel(const float* __restrict__ q, const float* __restrict__ gt, int ldgt,
+                                                            float coeff, float* __restrict__ loss, float* __restrict__ grad, int B) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float a = 0.f, an = 0.f;
+    for (int c = 0; c < 4; ++c) {
+      const float d = q[b * 4 + c] - gt[(size_t)b * ldgt + c], dn = q[b * 4 + c] + gt[(size_t)b * ldgt + c];
+      a += d * d; an += dn * dn;
+    }
+    const bool pos = a < an;                                    // select_mask = (quat_loss < quat_loss_)
+    acc += (pos ? a : an) * 0.25f;
+    if (grad)
+      for (int c = 0; c < 4; ++c)
+        grad[b * 4 + c] = coeff * 0.5f / (float)B * (q[b * 4 + c] + (pos ? -1.f : 1.f) * gt[(size_t)b * ldgt + c]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = coeff * (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -373,4 +425,21 @@ extern "C" int a3d_adamw_step(float* p, const float* g, float* m, float* v, floa
   if (rc) return rc;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
   return check_launch("a3d_adamw_step(inc)");
+}
+
+extern "C" int a3d_keypose_errors(const float* pos, const float* rot, const float* grip, const float* gt, int ldgt, float* cols,
+                                  int B, int nlev, int symmetric, void* stream) {
+  if (!pos || !rot || !grip || !gt || !cols || B <= 0 || nlev < 0 || nlev > 8 || ldgt < 8) {
+    set_error("a3d_keypose_errors: bad argument (B=%d nlev=%d ldgt=%d)", B, nlev, ldgt);
+    return A3D_ERR_ARG;
+  }
+  hipLaunchKernelGGL(keypose_errors_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, pos, rot, grip, gt, ldgt, cols, B,
+                     nlev, symmetric);
+  return check_launch("a3d_keypose_errors");
+}
+extern "C" int a3d_sym_quat_loss(const float* q, const float* gt, int ldgt, float coeff, float* loss, float* grad, int B,
+                                 void* stream) {
+  if (!q || !gt || !loss || B <= 0 || ldgt < 4) { set_error("a3d_sym_quat_loss: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(sym_quat_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, gt, ldgt, coeff, loss, grad, B);
+  return check_launch("a3d_sym_quat_loss");
 }

@@ -64,46 +64,26 @@ class DDPMTables:
         return torch.stack(rows).float().contiguous()
 
 
-# ------------------------------------------------------------------------------------------------ rotations (tiny, no grad)
-def normalise_quat(x):
-    return x / torch.clamp(x.square().sum(dim=-1).sqrt().unsqueeze(-1), min=1e-10)
+# ------------------------------------------------------------------------------------------------ pose <-> signal
+def pose_to_signal(pose, bounds=None):
+    """[xyz | quaternion (w, x, y, z) | extra] -> [normalised xyz | 6D rotation | extra] in one launch
+    (diffusion_model.py:187-212; csrc/diffusion.hip).  bounds: (2, 3) device tensor or None (xyz untouched).  No grad."""
+    x = O._c(pose.detach().float())
+    n, D = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (D + 2,), device=x.device, dtype=torch.float32)
+    O.L.call("a3d_pose_to_signal", x.data_ptr(), None if bounds is None else bounds.data_ptr(), out.data_ptr(), n, D - 7,
+             O.L.stream())
+    return out
 
 
-def quaternion_to_matrix(q):
-    r, i, j, k = torch.unbind(q, -1)
-    two_s = 2.0 / (q * q).sum(-1)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
-    return o.reshape(q.shape[:-1] + (3, 3))
-
-
-def matrix_to_quaternion(matrix):
-    bd = matrix.shape[:-2]
-    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(bd + (9,)), dim=-1)
-    x = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
-    q_abs = torch.sqrt(torch.clamp(x, min=0.0))
-    cand = torch.stack([
-        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
-        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
-        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
-        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
-    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
-    best = q_abs.argmax(dim=-1)                                      # gather instead of boolean indexing: no host sync
-    return torch.gather(cand, -2, best[..., None, None].expand(bd + (1, 4))).squeeze(-2)
-
-
-def ortho6d_from_matrix(m):
-    return m[..., :, :2].transpose(-1, -2).flatten(-2)
-
-
-def matrix_from_ortho6d(o):
-    def nrm(v):
-        return v / torch.clamp(v.pow(2).sum(-1, keepdim=True).sqrt(), min=1e-8)
-    x = nrm(o[..., 0:3])
-    z = nrm(torch.cross(x, o[..., 3:6], dim=-1))
-    y = torch.cross(z, x, dim=-1)
-    return torch.stack((x, y, z), dim=-1)
+def signal_to_pose(signal, bounds=None):
+    """inverse map (diffusion_model.py:192-195,214-230)"""
+    x = O._c(signal.detach().float())
+    n, D = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (D - 2,), device=x.device, dtype=torch.float32)
+    O.L.call("a3d_signal_to_pose", x.data_ptr(), None if bounds is None else bounds.data_ptr(), out.data_ptr(), n, D - 9,
+             O.L.stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ prediction head
@@ -324,11 +304,10 @@ class DiffusionPlanner(nn.Module):
         return (pos + 1.0) / 2.0 * (hi - lo) + lo
 
     def convert_rot(self, signal):
-        q = normalise_quat(signal[..., 3:7])
-        return torch.cat([signal[..., :3], ortho6d_from_matrix(quaternion_to_matrix(q)), signal[..., 7:]], dim=-1)
+        return pose_to_signal(signal)
 
     def unconvert_rot(self, signal):
-        return torch.cat([signal[..., :3], matrix_to_quaternion(matrix_from_ortho6d(signal[..., 3:9])), signal[..., 9:]], dim=-1)
+        return signal_to_pose(signal)
 
     def _prepare(self, rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens):
         """Normalised, converted conditioning + visual tokens and their (normalised, down-sampled) coordinates."""
@@ -336,10 +315,8 @@ class DiffusionPlanner(nn.Module):
         with torch.no_grad():
             pcd_n = self.normalize_pos(pcd_obs.float().permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3).contiguous()
             ctx_xyz = O.pcd_downsample(pcd_n, head.downscaling_factor_pyramid[0])
-            cg = curr_gripper.float().clone()
-            cg = self.convert_rot(torch.cat([self.normalize_pos(cg[:, :3]), cg[:, 3:]], dim=-1)).contiguous()
-            gg = goal_gripper.float().clone()
-            gg = self.convert_rot(torch.cat([self.normalize_pos(gg[:, :3]), gg[:, 3:]], dim=-1)).contiguous()
+            cg = pose_to_signal(curr_gripper, self.gripper_loc_bounds)
+            gg = pose_to_signal(goal_gripper, self.gripper_loc_bounds)
         tokens = visual_tokens if visual_tokens is not None else head.encode_images(rgb_obs, pcd_n)
         return tokens, ctx_xyz, cg, gg
 
@@ -354,8 +331,7 @@ class DiffusionPlanner(nn.Module):
         tb = self.tables(dev)
         tokens, ctx_xyz, cg, gg = self._prepare(rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens)
         with torch.no_grad():
-            gt = gt_trajectory.float()
-            gt = self.convert_rot(torch.cat([self.normalize_pos(gt[..., :3]), gt[..., 3:]], dim=-1)).contiguous()
+            gt = pose_to_signal(gt_trajectory, self.gripper_loc_bounds)
             if noise is None:
                 noise = torch.randn(gt.shape, device=dev)
             if timesteps is None:
@@ -445,6 +421,5 @@ class DiffusionPlanner(nn.Module):
             traj = gr["out"]
         else:
             traj = run_loop(traj)
-        final = self.unconvert_rot(traj)
-        final = torch.cat([self.unnormalize_pos(final[..., :3]), final[..., 3:]], dim=-1)
+        final = signal_to_pose(traj, self.gripper_loc_bounds)
         return (final, trace) if return_trace else final

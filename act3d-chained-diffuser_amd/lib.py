@@ -35,6 +35,11 @@ SIGNATURES = {
     "a3d_attn_fwd_ws_floats": (_z, [_i, _i, _i, _i]),
     "a3d_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_bwd_bf16": (_i, [_p] * 15 + [_i] * 7 + [_p]),
+    "a3d_pose_to_signal": (_i, [_p, _p, _p, _i, _i, _p]),
+    "a3d_signal_to_pose": (_i, [_p, _p, _p, _i, _i, _p]),
+    "a3d_traj_errors": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_keypose_errors": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
+    "a3d_sym_quat_loss": (_i, [_p, _p, _i, _f, _p, _p, _i, _p]),
     "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
     "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),
     "a3d_attn_fwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_uint, _f, _p]),

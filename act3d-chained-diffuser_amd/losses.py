@@ -1,9 +1,27 @@
-"""Loss / metric objects with the reference's interface (main_keypose.py:295-482, main_trajectory.py:295-343); the
-losses are fused HIP kernels (soft cross-entropy over ghost points, MSE), the metrics are tiny no-grad reductions."""
+"""Loss / metric objects with the reference's interface (main_keypose.py:295-482, main_trajectory.py:295-343).
+
+Losses are fused HIP kernels (soft cross-entropy over ghost points, MSE / L1, symmetric quaternion regression).
+Metrics are table-driven: one kernel writes a per-sample column table of errors and threshold indicators
+(a3d_keypose_errors / a3d_traj_errors), and the per-task and overall means are ONE small matrix product of that table
+with a row-normalised group-indicator matrix -- the metric names (the reference's dictionary keys) only label entries
+of the result.
+"""
 import numpy as np
 import torch
 
 from . import ops as O
+
+F32 = torch.float32
+
+
+def _group_means(groups, cols):
+    """groups (G, B) row-normalised indicators, cols (B, K) -> (G, K) group means on the device (a3d_linear_fwd)."""
+    G, B = groups.shape
+    K = cols.shape[1]
+    out = torch.empty((G, K), device=cols.device, dtype=F32)
+    O.L.call("a3d_linear_fwd", groups.data_ptr(), B, cols.data_ptr(), K, None, out.data_ptr(), K, None, 0, G, K, B, 0, 1,
+             O.L.stream())
+    return out
 
 
 class LossAndMetrics:
@@ -12,9 +30,10 @@ class LossAndMetrics:
                  position_loss_coeff=1.0, position_offset_loss_coeff=10000.0, rotation_loss_coeff=10.0,
                  gripper_loss_coeff=1.0, symmetric_rotation_loss=False):
         assert position_loss in ["mse", "ce", "ce+mse"]
-        if position_loss != "ce" or symmetric_rotation_loss or "quat" not in rotation_parametrization:
-            raise NotImplementedError("only position_loss='ce', quaternion rotation and symmetric_rotation_loss=False "
-                                      "(the shipped training configuration) are implemented")
+        if "quat" not in rotation_parametrization:
+            # the reference's own _compute_rotation_loss only has a quaternion branch (main_keypose.py:368-380): with a 6D
+            # head it fails on the missing "rotation" key, so there is no behaviour to reproduce
+            raise NotImplementedError("the reference defines the rotation loss for quaternion heads only")
         self.position_loss = position_loss
         self.rotation_parametrization = rotation_parametrization
         self.position_prediction_only = position_prediction_only
@@ -29,80 +48,97 @@ class LossAndMetrics:
 
     def compute_loss(self, pred, sample):
         device = pred["position"].device
-        gt_action = sample["action"].to(device).float()
-        losses = {}
-        levels = len(pred["ghost_pcd_masks_pyramid"])
+        gt_action = sample["action"].to(device).float().contiguous()
         gt_pos = gt_action[:, :3].contiguous()
-        # soft cross-entropy with a Gaussian label around the ground truth (main_keypose.py:382-405); the reference
-        # re-assigns the same dictionary key for every layer, so only the last decoder layer is supervised
-        for i, (ghost, masks) in enumerate(zip(pred["ghost_pcd_pyramid"], pred["ghost_pcd_masks_pyramid"])):
-            losses[f"position_ce_level{i}"] = O.SoftCEFn.apply(
-                masks[-1], ghost.transpose(1, 2), gt_pos, float(self.ground_truth_gaussian_spread),
-                float(self.label_smoothing), float(self.position_loss_coeff) / levels)
-        pred["position"] = pred["position"].detach()
-        losses["rotation"] = O.ElemLossFn.apply(pred["rotation"], gt_action[:, 3:7], 0, float(self.rotation_loss_coeff))
+        losses = {}
+        if self.position_loss == "mse":
+            # HiveFormer-style regression on the selected point (main_keypose.py:383-385)
+            losses["position_mse"] = O.ElemLossFn.apply(pred["position"], gt_pos, 0, float(self.position_loss_coeff))
+        else:
+            levels = len(pred["ghost_pcd_masks_pyramid"])
+            # soft cross-entropy against a Gaussian label around the ground truth (:387-405).  The reference writes every
+            # decoder layer's loss under the same key, so with compute_loss_at_all_layers only the last one survives
+            for i, (ghost, masks) in enumerate(zip(pred["ghost_pcd_pyramid"], pred["ghost_pcd_masks_pyramid"])):
+                losses[f"position_ce_level{i}"] = O.SoftCEFn.apply(
+                    masks[-1], ghost.transpose(1, 2), gt_pos, float(self.ground_truth_gaussian_spread),
+                    float(self.label_smoothing), float(self.position_loss_coeff) / levels)
+            off = pred.get("fine_ghost_pcd_offsets")
+            if off is not None:                                # supervised offsets of the last level's points (:407-419)
+                pts = pred["ghost_pcd_pyramid"][-1] + off
+                target = gt_pos.unsqueeze(-1).expand_as(pts)
+                losses["position_offset"] = O.ElemLossFn.apply(
+                    pts, target, 0, float(self.position_offset_loss_coeff * self.position_loss_coeff))
+            if self.position_loss == "ce":
+                pred["position"] = pred["position"].detach()
+            else:
+                losses["position_mse"] = O.ElemLossFn.apply(pred["position"], gt_pos, 0, float(self.position_loss_coeff))
+        if self.symmetric_rotation_loss:
+            losses["rotation"] = O.SymQuatLossFn.apply(pred["rotation"], gt_action[:, 3:7], float(self.rotation_loss_coeff))
+        else:
+            losses["rotation"] = O.ElemLossFn.apply(pred["rotation"], gt_action[:, 3:7], 0, float(self.rotation_loss_coeff))
         losses["gripper"] = O.ElemLossFn.apply(pred["gripper"], gt_action[:, 7:8], 0, float(self.gripper_loss_coeff))
         return losses
 
     @torch.no_grad()
     def compute_metrics(self, pred, sample):
         device = pred["position"].device
-        dtype = pred["position"].dtype
-        outputs = sample["action"].to(device).float()
+        gt = sample["action"].to(device).float().contiguous()
+        B = gt.shape[0]
+        levels = [p.reshape(B, 3) for p in pred["position_pyramid"]]
+        pos = torch.stack([pred["position"].reshape(B, 3)] + levels).float().contiguous()        # slot 0: final
+        nlev = len(levels)
+        cols = torch.empty((B, 6 + nlev), device=device, dtype=F32)
+        O.L.call("a3d_keypose_errors", pos.data_ptr(), O._c(pred["rotation"].float()).data_ptr(),
+                 O._c(pred["gripper"].float().reshape(B)).data_ptr(), gt.data_ptr(), gt.shape[1], cols.data_ptr(), B, nlev,
+                 1 if self.symmetric_rotation_loss else 0, O.L.stream())
+        # group 0 = all samples ("mean"), then one group per task name
+        names, member = np.unique(np.asarray(sample["task"]), return_inverse=True)
+        ind = np.zeros((1 + len(names), B), dtype=np.float32)
+        ind[0] = 1.0 / B
+        for t in range(len(names)):
+            sel = member == t
+            ind[1 + t, sel] = 1.0 / sel.sum()
+        table = _group_means(torch.from_numpy(ind).to(device), cols).to(pred["position"].dtype)
+        c_rot = 2 + nlev
         metrics = {}
-        tasks = np.array(sample["task"])
-        final_pos_l2 = ((pred["position"] - outputs[:, :3]) ** 2).sum(1).sqrt()
-        metrics["mean/pos_l2_final"] = final_pos_l2.to(dtype).mean()
-        metrics["mean/pos_l2_final<0.01"] = (final_pos_l2 < 0.01).to(dtype).mean()
-        for i in range(len(pred["position_pyramid"])):
-            pos_l2_i = ((pred["position_pyramid"][i].squeeze(1) - outputs[:, :3]) ** 2).sum(1).sqrt()
-            metrics[f"mean/pos_l2_level{i}"] = pos_l2_i.to(dtype).mean()
-        for task in np.unique(tasks):
-            sel = torch.from_numpy(tasks == task).to(device)
-            metrics[f"{task}/pos_l2_final"] = final_pos_l2[sel].to(dtype).mean()
-            metrics[f"{task}/pos_l2_final<0.01"] = (final_pos_l2[sel] < 0.01).to(dtype).mean()
-        acc = (pred["gripper"] > 0.5).squeeze(-1) == outputs[:, 7].bool()
-        metrics["gripper"] = acc.to(dtype).mean()
-        l1 = (pred["rotation"] - outputs[:, 3:7]).abs().sum(1)
-        metrics["mean/rot_l1"] = l1.to(dtype).mean()
-        metrics["mean/rot_l1<0.05"] = (l1 < 0.05).to(dtype).mean()
-        metrics["mean/rot_l1<0.025"] = (l1 < 0.025).to(dtype).mean()
-        for task in np.unique(tasks):
-            sel = torch.from_numpy(tasks == task).to(device)
-            metrics[f"{task}/rot_l1"] = l1[sel].to(dtype).mean()
-            metrics[f"{task}/rot_l1<0.05"] = (l1[sel] < 0.05).to(dtype).mean()
-            metrics[f"{task}/rot_l1<0.025"] = (l1[sel] < 0.025).to(dtype).mean()
+        for row, tag in enumerate(["mean"] + [str(n) for n in names]):
+            metrics[f"{tag}/pos_l2_final"] = table[row, 0]
+            metrics[f"{tag}/pos_l2_final<0.01"] = table[row, 1]
+            metrics[f"{tag}/rot_l1"] = table[row, c_rot]
+            metrics[f"{tag}/rot_l1<0.05"] = table[row, c_rot + 1]
+            metrics[f"{tag}/rot_l1<0.025"] = table[row, c_rot + 2]
+        for i in range(nlev):
+            metrics[f"mean/pos_l2_level{i}"] = table[0, 2 + i]
+        metrics["gripper"] = table[0, c_rot + 3]
         return metrics
 
 
 class TrajectoryCriterion:
     """main_trajectory.py:295-343: the training loss is computed inside DiffusionPlanner.forward."""
 
+    _COLS = ("pos_l2", "pos_acc_001", "rot_l1", "rot_acc_0025")
+
     def compute_loss(self, pred, gt=None, mask=None, is_loss=True):
         if not is_loss:
             assert gt is not None and mask is not None
-            return self.compute_metrics(pred, gt, mask)[0]['action_mse']
+            # the reference indexes ['action_mse'], a key its own compute_metrics never produces (it is 'traj_action_mse',
+            # main_trajectory.py:303,318): the evident intent is returned instead of the KeyError
+            return self.compute_metrics(pred, gt, mask)[0]["traj_action_mse"]
         return pred
 
     @staticmethod
     @torch.no_grad()
     def compute_metrics(pred, gt, mask):
-        pos_l2 = ((pred[..., :3] - gt[..., :3]) ** 2).sum(-1).sqrt()
-        quat_l1 = (pred[..., 3:7] - gt[..., 3:7]).abs().sum(-1)
-        quat_l1_ = (pred[..., 3:7] + gt[..., 3:7]).abs().sum(-1)
-        sel = (quat_l1 < quat_l1_).float()
-        quat_l1 = sel * quat_l1 + (1 - sel) * quat_l1_
-        tr = 'traj_'
-        ret_1 = {tr + 'action_mse': ((pred - gt) ** 2).mean(), tr + 'pos_l2': pos_l2.mean(),
-                 tr + 'pos_acc_001': (pos_l2 < 0.01).float().mean(), tr + 'rot_l1': quat_l1.mean(),
-                 tr + 'rot_acc_0025': (quat_l1 < 0.025).float().mean()}
-        ret_2 = {tr + 'pos_l2': pos_l2.mean(-1), tr + 'pos_acc_001': (pos_l2 < 0.01).float().mean(-1),
-                 tr + 'rot_l1': quat_l1.mean(-1), tr + 'rot_acc_0025': (quat_l1 < 0.025).float().mean(-1)}
-        pos_l2 = ((pred[:, -1, :3] - gt[:, -1, :3]) ** 2).sum(-1).sqrt()
-        quat_l1 = (pred[:, -1, 3:7] - gt[:, -1, 3:7]).abs().sum(-1)
-        quat_l1_ = (pred[:, -1, 3:7] + gt[:, -1, 3:7]).abs().sum(-1)
-        sel = (quat_l1 < quat_l1_).float()
-        quat_l1 = sel * quat_l1 + (1 - sel) * quat_l1_
-        ret_1.update({'pos_l2': pos_l2.mean(), 'pos_acc_001': (pos_l2 < 0.01).float().mean(), 'rot_l1': quat_l1.mean(),
-                      'rot_acc_0025': (quat_l1 < 0.025).float().mean()})
-        return ret_1, ret_2
+        """(summary scalars, per-trajectory vectors); `mask` is accepted and ignored, as in the reference."""
+        pred, gt = O._c(pred.float()), O._c(gt.to(pred.device).float())
+        B, Ln, D = pred.shape
+        cols = torch.empty((B, 9), device=pred.device, dtype=F32)
+        O.L.call("a3d_traj_errors", pred.data_ptr(), gt.data_ptr(), cols.data_ptr(), B, Ln, D, O.L.stream())
+        mean = _group_means(torch.full((1, B), 1.0 / B, device=pred.device, dtype=F32), cols)[0]
+        summary = {"traj_action_mse": mean[4]}
+        per_traj = {}
+        for j, name in enumerate(TrajectoryCriterion._COLS):
+            summary["traj_" + name] = mean[j]                # averaged over all steps of all trajectories
+            summary[name] = mean[5 + j]                      # the last step only
+            per_traj["traj_" + name] = cols[:, j]
+        return summary, per_traj

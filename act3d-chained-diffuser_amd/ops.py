@@ -710,6 +710,27 @@ class ElemLossFn(torch.autograd.Function):
         return out, None, None, None
 
 
+class SymQuatLossFn(torch.autograd.Function):
+    """coeff * mean_b min(mse(q_b, g_b), mse(q_b, -g_b)): symmetric_rotation_loss of main_keypose.py:370-376"""
+
+    @staticmethod
+    def forward(ctx, pred, target, coeff):
+        pred, target = _c(pred), _c(target.to(F32))
+        loss = torch.empty((), device=pred.device, dtype=F32)
+        grad = torch.empty_like(pred)
+        L.call("a3d_sym_quat_loss", pred.data_ptr(), target.data_ptr(), 4, coeff, loss.data_ptr(), grad.data_ptr(),
+               pred.shape[0], L.stream())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        L.call("a3d_scale_by_scalar", grad.data_ptr(), _c(g).data_ptr(), out.data_ptr(), grad.numel(), L.stream())
+        return out, None, None
+
+
 class QuatSigmoidFn(torch.autograd.Function):
     """pred (B,5) -> normalise_quat(pred[:, :4]), sigmoid(pred[:, 4:])   (act3d.py:526-533)"""
 

@@ -191,6 +191,21 @@ int a3d_add_rows(const float* x, const float* r, float* y, int B, int L, int E, 
 /* out = cat(traj[..., :npos] + upd[..., :npos], upd[..., npos:])  (diffusion_head.py:268-272) */
 int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, int D, int npos, void* stream);
 
+/* out[i] = [ (xyz - lo) / (hi - lo) * 2 - 1 | first two columns of R(normalise(quat)) | extra.. ] for pose rows
+ * [xyz | quat (w, x, y, z) | extra..] (diffusion_model.py:187-212: normalize_pos + convert_rot, rotation_parametrization "6D");
+ * bounds: device [2][3], NULL = leave xyz as is.  a3d_signal_to_pose is the inverse map (unconvert_rot + unnormalize_pos, :192-195,214-230):
+ * Gram-Schmidt of the 6D part, quaternion from the best-conditioned trace identity. */
+int a3d_pose_to_signal(const float* pose, const float* bounds, float* out, int n, int extra, void* stream);
+int a3d_signal_to_pose(const float* signal, const float* bounds, float* out, int n, int extra, void* stream);
+/* cols[b][9] of TrajectoryCriterion.compute_metrics (main_trajectory.py:303-343), see diffusion.hip; pred, gt: [B][L][D], D >= 7. */
+int a3d_traj_errors(const float* pred, const float* gt, float* cols, int B, int L, int D, void* stream);
+/* cols[b][6 + nlev] of LossAndMetrics.compute_metrics (main_keypose.py:431-482), see heads.hip; pos: [nlev + 1][B][3] with
+ * slot 0 = the final position, gt rows of ldgt >= 8 floats [xyz | quat | open]. */
+int a3d_keypose_errors(const float* pos, const float* rot, const float* grip, const float* gt, int ldgt, float* cols, int B,
+                       int nlev, int symmetric, void* stream);
+/* coeff * mean_b min(mse(q_b, g_b), mse(q_b, -g_b))  (symmetric_rotation_loss, main_keypose.py:370-376); grad optional [B][4]. */
+int a3d_sym_quat_loss(const float* q, const float* gt, int ldgt, float coeff, float* loss, float* grad, int B, void* stream);
+
 /* ---- frozen-backbone BatchNorm (train-mode statistics) + ReLU + residual, bf16 NHWC -------------- */
 /* x, residual, y: bf16, `rows` = N*H*W rows of C channels (torch channels_last storage).  C = 8 * divisor of 256. */
 int a3d_bn_nslab(size_t rows, int C);

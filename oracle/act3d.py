@@ -123,8 +123,9 @@ def keypose_loss(out, gt_action, spread=0.01, position_loss_coeff=1.0, rotation_
     return losses
 
 
-def keypose_metrics(out, gt_action):
-    """LossAndMetrics.compute_metrics, task-independent part (main_keypose.py:431-482)."""
+def keypose_metrics(out, gt_action, tasks=None, symmetric=False):
+    """LossAndMetrics.compute_metrics (main_keypose.py:431-482); per-task entries when `tasks` (list of names) is given;
+    symmetric: rotation error against the closer of +-gt (symmetric_rotation_loss, :463-470)."""
     m = {}
     l2 = ((out["position"] - gt_action[:, :3]) ** 2).sum(1).sqrt()
     m["mean/pos_l2_final"] = l2.mean()
@@ -133,10 +134,35 @@ def keypose_metrics(out, gt_action):
         m[f"mean/pos_l2_level{i}"] = ((p.squeeze(1) - gt_action[:, :3]) ** 2).sum(1).sqrt().mean()
     m["gripper"] = ((out["gripper"] > 0.5).squeeze(-1) == gt_action[:, 7].bool()).float().mean()
     l1 = (out["rotation"] - gt_action[:, 3:7]).abs().sum(1)
+    if symmetric:
+        l1 = torch.minimum(l1, (out["rotation"] + gt_action[:, 3:7]).abs().sum(1))
     m["mean/rot_l1"] = l1.mean()
     m["mean/rot_l1<0.05"] = (l1 < 0.05).float().mean()
     m["mean/rot_l1<0.025"] = (l1 < 0.025).float().mean()
+    if tasks is not None:
+        names = np.asarray(tasks)
+        for t in np.unique(names):
+            sel = torch.from_numpy(names == t)
+            m[f"{t}/pos_l2_final"] = l2[sel].mean()
+            m[f"{t}/pos_l2_final<0.01"] = (l2[sel] < 0.01).float().mean()
+            m[f"{t}/rot_l1"] = l1[sel].mean()
+            m[f"{t}/rot_l1<0.05"] = (l1[sel] < 0.05).float().mean()
+            m[f"{t}/rot_l1<0.025"] = (l1[sel] < 0.025).float().mean()
     return m
+
+
+def keypose_optional_losses(out, gt_action, symmetric, position_loss_coeff=1.0, rotation_loss_coeff=10.0):
+    """The non-default branches of LossAndMetrics.compute_loss: position_loss="mse" (main_keypose.py:383-385) and
+    symmetric_rotation_loss (:370-376: per-sample minimum of the MSE against gt and against -gt)."""
+    losses = {"position_mse": F.mse_loss(out["position"], gt_action[:, :3]) * position_loss_coeff}
+    gq = gt_action[:, 3:7]
+    if symmetric:
+        a = (out["rotation"] - gq).pow(2).mean(1)
+        an = (out["rotation"] + gq).pow(2).mean(1)
+        losses["rotation"] = torch.where(a < an, a, an).mean() * rotation_loss_coeff
+    else:
+        losses["rotation"] = F.mse_loss(out["rotation"], gq) * rotation_loss_coeff
+    return losses
 
 
 def optimizer_groups(named_params):

@@ -258,3 +258,21 @@ def compute_trajectory(P, sched, traj_mask, ctx_feats, ctx_xyz_world, instructio
     final = unconvert_rot(traj)
     final = torch.cat([unnormalize_pos(final[..., :3], bounds), final[..., 3:]], dim=-1)
     return final, trace
+
+
+def traj_metrics(pred, gt):
+    """TrajectoryCriterion.compute_metrics (main_trajectory.py:306-343): position error, symmetric quaternion L1 and
+    their threshold rates over all steps ("traj_" keys), at the last step (plain keys), and per trajectory."""
+    def errs(p, g):
+        pos = (p[..., :3] - g[..., :3]).pow(2).sum(-1).sqrt()
+        a, an = (p[..., 3:7] - g[..., 3:7]).abs().sum(-1), (p[..., 3:7] + g[..., 3:7]).abs().sum(-1)
+        return pos, torch.where(a < an, a, an)
+    pos, rot = errs(pred, gt)
+    summary = {"traj_action_mse": F.mse_loss(pred, gt), "traj_pos_l2": pos.mean(), "traj_pos_acc_001": (pos < 0.01).float().mean(),
+               "traj_rot_l1": rot.mean(), "traj_rot_acc_0025": (rot < 0.025).float().mean()}
+    per = {"traj_pos_l2": pos.mean(-1), "traj_pos_acc_001": (pos < 0.01).float().mean(-1), "traj_rot_l1": rot.mean(-1),
+           "traj_rot_acc_0025": (rot < 0.025).float().mean(-1)}
+    pl, rl = errs(pred[:, -1], gt[:, -1])
+    summary.update({"pos_l2": pl.mean(), "pos_acc_001": (pl < 0.01).float().mean(), "rot_l1": rl.mean(),
+                    "rot_acc_0025": (rl < 0.025).float().mean()})
+    return summary, per

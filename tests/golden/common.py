@@ -126,3 +126,23 @@ def trajectory_inputs(seed, B, L, ncam, E, image=256, bounds=DIFFUSION_BOUNDS, p
                 mask=torch.from_numpy(mask), instr=instr,
                 noise=rs_tensor(rs, (B, L, 9)), timesteps=torch.from_numpy(rs.randint(0, 100, size=(B,))).long(),
                 init_noise=rs_tensor(rs, (B, L, 9)), step_noise=rs_tensor(rs, (100, B, L, 9)))
+
+
+def metrics_inputs():
+    """Seeded predictions / targets for the metric and optional-loss fixtures (shared with the tests)."""
+    rs = np.random.RandomState(17)
+    B, Ln = 6, 7
+    gt = rs_tensor(rs, (B, Ln, 7))
+    gt[..., 3:] = gt[..., 3:] / gt[..., 3:].norm(dim=-1, keepdim=True)
+    pred = gt + 0.02 * rs_tensor(rs, (B, Ln, 7))
+    pred[0] = gt[0] + 0.002 * rs_tensor(rs, (Ln, 7))            # inside the 0.01 / 0.025 thresholds
+    pred[1, :, 3:] = -gt[1, :, 3:] + 0.003 * rs_tensor(rs, (Ln, 4))   # the antipodal quaternion: symmetric branch
+    action = torch.cat([rs_tensor(rs, (B, 3)), torch.nn.functional.normalize(rs_tensor(rs, (B, 4)), dim=-1),
+                        torch.tensor([[1.0], [0.0], [1.0], [1.0], [0.0], [0.0]])], dim=-1)
+    kp = {"position_pyramid": [action[:, None, :3] + s * rs_tensor(rs, (B, 1, 3)) for s in (0.05, 0.01, 0.004)],
+          "rotation": torch.nn.functional.normalize(action[:, 3:7] + 0.01 * rs_tensor(rs, (B, 4)), dim=-1),
+          "gripper": torch.tensor([[0.9], [0.2], [0.4], [0.7], [0.6], [0.1]])}
+    kp["rotation"][2] = -kp["rotation"][2]
+    kp["position"] = kp["position_pyramid"][-1][:, 0].clone()
+    tasks = ["close_jar", "open_drawer", "close_jar", "stack_cups", "open_drawer", "close_jar"]
+    return pred, gt, action, kp, tasks

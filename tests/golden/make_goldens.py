@@ -386,7 +386,30 @@ def golden_optimizer():
     save("optimizer.pt", dict(groups=names, before=before, grads=gr, after={n: p.detach().clone() for n, p in mod.named_parameters()}))
 
 
+def golden_metrics():
+    """G13: evaluation metrics (main_trajectory.py:306-343, main_keypose.py:431-482) and the non-default loss options
+    (symmetric_rotation_loss, position_loss="mse") of main_keypose.py:368-386."""
+    pred, gt, action, kp, tasks = C.metrics_inputs()
+    out = {}
+    r1, r2 = R.main_trajectory.TrajectoryCriterion.compute_metrics(pred, gt, torch.zeros(pred.shape[:2], dtype=torch.bool))
+    out["traj"] = dict(summary={k: v.clone() for k, v in r1.items()}, per_traj={k: v.clone() for k, v in r2.items()})
+    for sym in (False, True):
+        crit = R.main_keypose.LossAndMetrics(position_loss="mse", rotation_parametrization="quat_from_query",
+                                             ground_truth_gaussian_spread=0.01, symmetric_rotation_loss=sym)
+        sample = {"action": action, "task": tasks}
+        p = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in kp.items()}
+        p["rotation"].requires_grad_()
+        p["position"].requires_grad_()
+        losses = crit.compute_loss(p, sample)
+        sum(losses.values()).backward()
+        met = crit.compute_metrics({k: (v.detach() if torch.is_tensor(v) else v) for k, v in p.items()}, sample)
+        out[f"keypose_sym{int(sym)}"] = dict(losses={k: v.detach().clone() for k, v in losses.items()},
+                                             d_rotation=p["rotation"].grad.clone(), d_position=p["position"].grad.clone(),
+                                             metrics={k: v.clone() for k, v in met.items()})
+    save("metrics.pt", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "diffusion", "optimizer"]
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "diffusion", "optimizer", "metrics"]
     for w in which:
         globals()["golden_" + w]()

@@ -5,6 +5,8 @@ Tolerances: indices bit-exact; fp32 kernels 1e-5 class; attention 1e-3 absolute 
 (measured errors are ~1e-5, printed by `report`).
 """
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -627,3 +629,65 @@ def test_attention_edge_shapes(a3d, dev):
         kd = xk.to(dev)
         y = O.attn_block(xq.to(dev), kd, kd, xq.to(dev), None, None, None if kmask is None else kmask.to(dev), mha, norm, H)
         report(f"attn edge B={B} Lq={Lq} S={S} keep={keep}", y, ref, 1e-4)
+
+
+def test_metric_tables_and_optional_losses_vs_reference_golden(a3d, dev):
+    """LossAndMetrics.compute_metrics (per-task table), TrajectoryCriterion.compute_metrics, symmetric_rotation_loss and
+    position_loss="mse" against values recorded from the reference (tests/golden/metrics.pt)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import common as C
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics.pt"), weights_only=False)
+    pred, gt, action, kp, tasks = C.metrics_inputs()
+    summ, per = a3d.TrajectoryCriterion.compute_metrics(pred.to(dev), gt.to(dev), None)
+    assert set(summ) == set(g["traj"]["summary"]) and set(per) == set(g["traj"]["per_traj"])
+    for k, v in g["traj"]["summary"].items():
+        report("traj metric " + k, summ[k], v, 1e-6)
+    for k, v in g["traj"]["per_traj"].items():
+        report("traj per-trajectory " + k, per[k], v, 1e-6)
+    for sym in (False, True):
+        r = g[f"keypose_sym{int(sym)}"]
+        crit = a3d.LossAndMetrics(position_loss="mse", rotation_parametrization="quat_from_query",
+                                  ground_truth_gaussian_spread=0.01, symmetric_rotation_loss=sym)
+        p = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in kp.items()}
+        p["rotation"] = p["rotation"].clone().requires_grad_()
+        sample = {"action": action.to(dev), "task": tasks}
+        losses = crit.compute_loss(p, sample)
+        assert set(losses) == set(r["losses"])
+        for k, v in r["losses"].items():
+            report(f"sym={sym} loss {k}", losses[k], v, 1e-5)
+        sum(losses.values()).backward()
+        report(f"sym={sym} d rotation", p["rotation"].grad, r["d_rotation"], 1e-6)
+        m = crit.compute_metrics({k: (v.detach() if torch.is_tensor(v) else v) for k, v in p.items()}, sample)
+        assert set(m) == set(r["metrics"]), sorted(set(m) ^ set(r["metrics"]))
+        for k, v in r["metrics"].items():
+            report(f"sym={sym} metric {k}", m[k], v, 1e-6)
+
+
+def test_pose_signal_kernels_vs_oracle_and_golden(a3d, dev):
+    """a3d_pose_to_signal / a3d_signal_to_pose (normalisation + quaternion <-> 6D) vs the oracle's restatement of
+    diffusion_model.py:187-230 and the reference's recorded conversions (tests/golden/diffusion.pt "rot")."""
+    from oracle import diffusion as OD
+    D = a3d.diffusion
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import common as C
+    g = torch.Generator().manual_seed(4)
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS).float()
+    for extra in (0, 1):
+        pose = torch.cat([torch.rand(3, 37, 3, generator=g) * 2 - 1, torch.randn(3, 37, 4, generator=g),
+                          torch.rand(3, 37, extra, generator=g)], dim=-1)
+        ref = pose.clone()
+        ref[..., :3] = OD.normalize_pos(ref[..., :3], bounds)
+        ref = OD.convert_rot(ref)
+        got = D.pose_to_signal(pose.to(dev), bounds.to(dev))
+        report("pose -> signal", got, ref, 2e-6)
+        report("pose -> signal (no bounds)", D.pose_to_signal(pose.to(dev)), OD.convert_rot(pose), 2e-6)
+        sig = torch.cat([torch.rand(3, 37, 3, generator=g) * 2 - 1, torch.randn(3, 37, 6, generator=g),
+                         torch.rand(3, 37, extra, generator=g)], dim=-1)
+        back = OD.unconvert_rot(sig)
+        back = torch.cat([OD.unnormalize_pos(back[..., :3], bounds), back[..., 3:]], dim=-1)
+        report("signal -> pose", D.signal_to_pose(sig.to(dev), bounds.to(dev)), back, 5e-6)
+    r = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "diffusion.pt"), weights_only=False)["rot"]
+    pose = torch.cat([torch.zeros(6, 3), r["q"]], dim=-1)
+    report("reference 6D", D.pose_to_signal(pose.to(dev))[:, 3:], r["o6"], 2e-6)
+    sig = torch.cat([torch.zeros(6, 3), r["o6"]], dim=-1)
+    report("reference quaternion", D.signal_to_pose(sig.to(dev))[:, 3:], r["q_back"], 2e-6)

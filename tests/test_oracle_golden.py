@@ -300,3 +300,28 @@ def test_optimizer_grouping_and_step():
         opt.step()
     for n in names:
         assert torch.equal(ps[n].detach(), r["after"][n])
+
+
+def test_metrics_and_optional_losses():
+    """oracle metrics / optional losses == the reference's (tests/golden/metrics.pt)."""
+    g = load("metrics.pt")
+    pred, gt, action, kp, tasks = C.metrics_inputs()
+    summ, per = OD.traj_metrics(pred, gt)
+    assert set(summ) == set(g["traj"]["summary"]) and set(per) == set(g["traj"]["per_traj"])
+    for k, v in g["traj"]["summary"].items():
+        close("traj " + k, summ[k], v, 1e-6)
+    for k, v in g["traj"]["per_traj"].items():
+        close("traj per " + k, per[k], v, 1e-6)
+    for sym in (False, True):
+        r = g[f"keypose_sym{int(sym)}"]
+        m = OA.keypose_metrics(kp, action, tasks=tasks, symmetric=sym)
+        assert set(m) == set(r["metrics"])
+        for k, v in r["metrics"].items():
+            close(f"keypose metric {k}", m[k], v, 1e-6)
+        p = dict(kp)
+        p["rotation"] = kp["rotation"].clone().requires_grad_()
+        lo = OA.keypose_optional_losses(p, action, sym)
+        close("rotation loss", lo["rotation"], r["losses"]["rotation"], 1e-5)
+        close("position mse", lo["position_mse"], r["losses"]["position_mse"], 1e-6)
+        lo["rotation"].backward()
+        close("d rotation", p["rotation"].grad, r["d_rotation"], 1e-6)
