@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float bc2s = sqrtf(bc2);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
+    // an element that has never seen a gradient is left alone, as torch.optim.AdamW skips parameters whose .grad is None
+    // (engine.py:121-124 find_unused_parameters): no weight decay on the FPN blocks / embeddings a configuration never uses
+    if (gi == 0.0f && m[i] == 0.0f && v[i] == 0.0f) continue;
     const float wd = (i < n_nodecay) ? wd0 : wd1;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;

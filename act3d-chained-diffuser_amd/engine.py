@@ -51,6 +51,11 @@ class FlatParams:
             nd, late = _is_no_decay(n), is_late(n)
             segs[0 if (nd and not late) else 1 if (nd and late) else 2 if late else 3].append((n, p))
         self.order = [x for s in segs for x in s]
+        # torch.optim.AdamW indices of the reference's optimizer (engine.py:89-102): every named parameter, the "bias"
+        # group first, each group in named_parameters() order -- used to exchange optimizer state with reference checkpoints
+        every = [n for n, _ in model.named_parameters()]
+        self.torch_groups = [[n for n in every if _is_no_decay(n)], [n for n in every if not _is_no_decay(n)]]
+        self.torch_index = {n: i for i, n in enumerate(self.torch_groups[0] + self.torch_groups[1])}
         sizes = [sum(p.numel() for _, p in s) for s in segs]
         self.n = sum(sizes)
         self.n_nodecay = sizes[0] + sizes[1]
@@ -103,25 +108,70 @@ class FlatAdamW:
                self.betas[0], self.betas[1], self.eps, 0.0, float(self.weight_decay), float(grad_scale), L.stream())
 
     def state_dict(self):
-        """Per-parameter state keyed by name (exp_avg / exp_avg_sq views) + the scalar step."""
-        st = {}
-        for n, _ in self.flat.order:
-            a, b = self.flat.slices[n]
-            st[n] = {"exp_avg": self.exp_avg[a:b].clone(), "exp_avg_sq": self.exp_avg_sq[a:b].clone()}
-        return {"state": st, "step": self.step_count.clone(), "lr": self.lr, "betas": self.betas, "eps": self.eps,
-                "weight_decay": self.weight_decay}
+        """torch.optim.AdamW's state_dict layout for the reference's optimizer (engine.py:89-102: two groups over ALL named
+        parameters, int-indexed state with per-parameter `step`), so that the reference's `optimizer.load_state_dict`
+        (engine.py:199) accepts a checkpoint written here and vice versa.  Parameters outside the flat buffer (frozen
+        backbone, never-used FPN blocks) have no state, exactly like parameters whose .grad stayed None in torch."""
+        f = self.flat
+        state = {}
+        step = self.step_count.detach().cpu().reshape(()).clone()
+        if float(step) > 0:
+            for n, p in f.order:
+                a, b = f.slices[n]
+                state[f.torch_index[n]] = {"step": step.clone(), "exp_avg": self.exp_avg[a:b].detach().clone().view(p.shape),
+                                           "exp_avg_sq": self.exp_avg_sq[a:b].detach().clone().view(p.shape)}
+        groups, off = [], 0
+        for names, wd in zip(f.torch_groups, (0.0, self.weight_decay)):
+            groups.append({"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd,
+                           "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                           "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+                           "params": list(range(off, off + len(names)))})
+            off += len(names)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        for n, _ in self.flat.order:
-            if n in sd["state"]:
-                a, b = self.flat.slices[n]
-                self.exp_avg[a:b].copy_(sd["state"][n]["exp_avg"].reshape(-1))
-                self.exp_avg_sq[a:b].copy_(sd["state"][n]["exp_avg_sq"].reshape(-1))
-        self.step_count.copy_(sd["step"])
+        """Accepts the torch.optim.AdamW layout (a reference checkpoint's "optimizer" entry).  Raises on a layout that does
+        not describe this model's parameters instead of silently resuming with zeroed moments."""
+        f = self.flat
+        if not isinstance(sd, dict) or "state" not in sd or "param_groups" not in sd:
+            raise ValueError("optimizer state: expected torch.optim.AdamW's {'state', 'param_groups'} layout")
+        sizes = [len(g["params"]) for g in sd["param_groups"]]
+        if sizes != [len(g) for g in f.torch_groups]:
+            raise ValueError("optimizer state: parameter groups of sizes %s do not match this model's %s "
+                             "(reference grouping, engine.py:89-102)" % (sizes, [len(g) for g in f.torch_groups]))
+        by_index = {i: n for n, i in f.torch_index.items()}
+        steps = []
+        seen = set()
+        for idx, st in sd["state"].items():
+            n = by_index.get(int(idx))
+            if n is None:
+                raise ValueError("optimizer state: index %r is not a parameter of this model" % (idx,))
+            if n not in f.slices:
+                continue                       # state of a parameter that is not trained here (no gradient path)
+            a, b = f.slices[n]
+            if st["exp_avg"].numel() != b - a:
+                raise ValueError("optimizer state of %s has %d elements, the parameter %d" % (n, st["exp_avg"].numel(), b - a))
+            self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.append(float(st["step"]))
+            seen.add(n)
+        if steps:
+            missing = [n for n, _ in f.order if n not in seen]
+            if missing:
+                raise ValueError("optimizer state lacks %d trained parameters (e.g. %s)" % (len(missing), missing[:3]))
+            if max(steps) != min(steps):
+                raise ValueError("optimizer state: per-parameter steps differ (%g .. %g); the flat optimizer keeps one"
+                                 % (min(steps), max(steps)))
+            self.step_count.fill_(steps[0])
+        else:
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
+        self.param_groups[0]["lr"] = self.param_groups[1]["lr"] = sd["param_groups"][0].get("lr", self.lr)
 
 
 def get_optimizer(model, lr=1e-4, active_names=None):
-    """engine.py:89-102 on the flat buffers.  Returns (FlatParams, FlatAdamW)."""
+    """engine.py:89-102 on the flat buffers.  Returns (FlatParams, FlatAdamW).  With active_names=None every trainable
+    parameter is placed in the buffer; elements that never receive a gradient are left untouched by the fused AdamW kernel
+    (as torch.optim.AdamW skips parameters whose .grad is None -- no weight decay on unused FPN blocks)."""
     flat = FlatParams(model, active_names)
     return flat, FlatAdamW(flat, lr=lr)
 
@@ -216,21 +266,25 @@ def train_one_step_trajectory(model, criterion, optimizer, step_id, sample, ddp=
 
 
 def save_checkpoint(path, model, optimizer, step_id, best_loss=None):
-    """engine.py:214-230 format; weights carry DDP's "module." prefix so that reference tooling can load them."""
+    """engine.py:214-230 format: {"weight" (DDP's "module." prefix), "optimizer" (torch.optim.AdamW layout), "iter",
+    "best_loss"} -- loadable by the reference's load_checkpoint (engine.py:195-212)."""
     weight = {"module." + k: v.detach().clone() for k, v in model.state_dict().items()}
     torch.save({"weight": weight, "optimizer": optimizer.state_dict(), "iter": step_id + 1, "best_loss": best_loss}, path)
 
 
-def load_checkpoint(path, model, optimizer=None):
-    """engine.py:195-212 (+ online_evaluation/eval1.py:138-152 prefix stripping).  Returns (start_iter, best_loss)."""
+def load_checkpoint(path, model, optimizer=None, strict=True):
+    """engine.py:195-212 (+ online_evaluation/eval1.py:138-152 prefix stripping).  Returns (start_iter, best_loss).
+    strict (the reference's load_state_dict default): missing / unexpected weight keys raise.  Parameters keep their
+    storage (the flat buffer views): values are copied in place."""
     d = torch.load(path, map_location="cpu", weights_only=False)
     weight = {(k[7:] if k.startswith("module.") else k): v for k, v in d["weight"].items()}
-    with torch.no_grad():
-        own = model.state_dict()
-        for k, v in weight.items():
-            if k in own:
-                own[k].copy_(v)
-    if optimizer is not None and isinstance(d.get("optimizer"), dict) and "state" in d["optimizer"] and "step" in d["optimizer"]:
+    res = model.load_state_dict(weight, strict=False)
+    if strict and (res.missing_keys or res.unexpected_keys):
+        raise RuntimeError("checkpoint %s does not match the model: missing %s, unexpected %s" %
+                           (path, res.missing_keys[:5], res.unexpected_keys[:5]))
+    if optimizer is not None:
+        if "optimizer" not in d:
+            raise RuntimeError("checkpoint %s holds no optimizer state" % path)
         optimizer.load_state_dict(d["optimizer"])
     return d.get("iter", 0), d.get("best_loss", None)
 

@@ -189,18 +189,21 @@ def test_planner_training_step_with_dropout_vs_oracle(a3d, dev):
     assert err <= 1e-3 * max(1.0, abs(oloss.item()))
     assert abs(oloss.item() - r["train_loss"].item()) > 1e-2, "the dropped loss must differ from the p = 0 golden"
     named = dict(m.named_parameters())
-    worst = 0.0
+    # EVERY parameter is compared (the p = 0 golden test stores six gradient tensors and the norms of the rest).  This
+    # fixture's gradients are ill-conditioned at the 1e-3 level -- two fp32 CPU evaluations (the reference and the oracle)
+    # already differ by 2e-3 in places (tests/test_oracle_golden.py) -- so: relative L2 error 1.5e-3, max-abs 6e-3 of scale.
+    worst, worst_l2 = 0.0, 0.0
     for n, p_ in P.items():
         if p_.grad is None or n not in named:
             continue
         ref = p_.grad
+        got = named[n].grad.cpu()
         scale = max(1e-3, ref.abs().max().item())
-        e = (named[n].grad.cpu() - ref).abs().max().item() / scale
-        worst = max(worst, e)
-        # the p = 0 golden test asserts 1.5e-3; with 1 / (1 - p)-scaled, sparser signals through 10 layers and an L1 loss
-        # the deepest layers (vl_attention) were observed at 1.9e-3
-        assert e <= 3e-3, f"grad {n}: {e:.3e} of scale"
-    print(f"[parity] dropout train gradients: worst {worst:.3e} of scale")
+        e = (got - ref).abs().max().item() / scale
+        l2 = (got - ref).norm().item() / max(1e-6, ref.norm().item())
+        worst, worst_l2 = max(worst, e), max(worst_l2, l2)
+        assert e <= 6e-3 and l2 <= 1.5e-3, f"grad {n}: max-abs {e:.3e} of scale, relative L2 {l2:.3e}"
+    print(f"[parity] dropout train gradients: worst max-abs {worst:.3e} of scale, worst relative L2 {worst_l2:.3e}")
     loss2 = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
               noise=d["noise"], timesteps=d["timesteps"], visual_tokens=tokens.to(dev))
     assert abs(loss2.item() - loss.item()) > 1e-4, "second pass drew the same masks"

@@ -109,7 +109,8 @@ def test_graphed_step_equals_eager_train_one_step(a3d, dev):
     flatB, optB = E.get_optimizer(mB, lr=1e-4)
     assert torch.equal(flatA.flat, flatB.flat)
     warm, replays = 2, 3
-    lossesA = [E.train_one_step(mA, crit, optA, i, s) for i in range(warm + replays)]
+    for i in range(warm):
+        E.train_one_step(mA, crit, optA, i, s)
 
     def fwd_bwd(sample):
         out = mB(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"], gt_action=sample["action"])
@@ -118,27 +119,39 @@ def test_graphed_step_equals_eager_train_one_step(a3d, dev):
         return loss.detach()
 
     graphed = E.GraphedStep(fwd_bwd, optB, s, warmup=warm)          # `warm` eager steps, then the capture
-    for i in range(replays):
-        lossB = graphed(s).clone()
-        ref = lossesA[warm + i]
-        assert abs(lossB.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item())), (i, lossB.item(), ref.item())
+    assert torch.equal(optA.step_count, optB.step_count) and torch.equal(mA._rng_state, mB._rng_state)
+    # Two runs of the same step differ by accumulation-order noise (float atomics in the small-M weight gradients), and
+    # AdamW turns that noise into +-lr steps on elements whose gradient is mathematically zero (e.g. the last ghost
+    # LayerNorm's bias: q * sum_n (softmax - label)_n = 0), after which the two models drift apart like any two runs.
+    # So: put B in exactly A's state (in place -- the graph keeps its buffers), then compare ONE step tightly.
+    with torch.no_grad():
+        flatB.flat.copy_(flatA.flat)
+        optB.exp_avg.copy_(optA.exp_avg)
+        optB.exp_avg_sq.copy_(optA.exp_avg_sq)
+        for (n, a), (_, b) in zip(mA.backbone.named_buffers(), mB.backbone.named_buffers()):
+            b.copy_(a)
+    lossA = E.train_one_step(mA, crit, optA, warm, s)
+    lossB = graphed(s).clone()
     torch.cuda.synchronize()
-    # last step's gradients agree to accumulation-order noise ...
+    assert abs(lossB.item() - lossA.item()) <= 1e-6 * max(1.0, abs(lossA.item())), (lossB.item(), lossA.item())
     gA, gB = flatA.grad, flatB.grad
     gscale = gA.abs().max().item()
     gdiff = (gA - gB).abs().max().item()
-    print(f"[parity] graphed vs eager gradients at step {warm + replays}: max abs diff {gdiff:.3e} (scale {gscale:.3e})")
+    print(f"[parity] graphed vs eager gradients, one step from the same state: max abs diff {gdiff:.3e} (scale {gscale:.3e})")
     assert gdiff <= 2e-5 * gscale, (gdiff, gscale)
-    # ... and so do the parameters wherever the gradient is above that noise.  (AdamW normalises every element by its own
-    # magnitude, so an element whose gradient is mathematically zero -- e.g. the last ghost LayerNorm's bias, whose
-    # gradient is q * sum_n (softmax - label)_n = 0 -- takes +-lr steps of accumulation-order noise in ANY two runs.)
     solid = gA.abs() > 1e-3 * gscale
     diff = (flatA.flat - flatB.flat).abs()
-    print(f"[parity] graphed vs eager parameters after {warm + replays} steps: max abs diff {diff[solid].max().item():.3e} "
-          f"on {int(solid.sum())} of {solid.numel()} elements; {diff.max().item():.3e} overall")
-    assert diff[solid].max().item() <= 1e-6
-    assert diff.max().item() <= 2.5e-4 * (warm + replays)      # never more than opposite +-lr steps
-    assert torch.equal(optA.step_count, optB.step_count)
-    assert torch.equal(mA._rng_state, mB._rng_state)
+    print(f"[parity] graphed vs eager parameters after that step: max abs diff {diff[solid].max().item():.3e} on "
+          f"{int(solid.sum())} of {solid.numel()} elements with a solid gradient; {diff.max().item():.3e} overall")
+    assert diff[solid].max().item() <= 1e-7
+    assert diff.max().item() <= 2.01e-4                              # at most opposite +-lr steps on the noise elements
     for (n, a), (_, b) in zip(mA.backbone.named_buffers(), mB.backbone.named_buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), n
+    # further replays keep tracking the eager run (loosely: the models are now two independent runs)
+    for i in range(1, replays):
+        lossA = E.train_one_step(mA, crit, optA, warm + i, s)
+        lossB = graphed(s).clone()
+        assert abs(lossB.item() - lossA.item()) <= 2e-3 * max(1.0, abs(lossA.item())), (i, lossB.item(), lossA.item())
+    torch.cuda.synchronize()
+    assert torch.equal(optA.step_count, optB.step_count)
+    assert torch.equal(mA._rng_state, mB._rng_state)

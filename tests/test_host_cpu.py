@@ -170,6 +170,75 @@ def test_flat_params_layout_and_checkpoint_roundtrip(tmp_path):
     assert it == 42 and best == 0.5
     for k, v in m2.state_dict().items():
         assert torch.equal(v, m.state_dict()[k]), k
+    # strict, like the reference's model.load_state_dict(model_dict["weight"]) (engine.py:198): a mis-named checkpoint raises
+    d["weight"]["module.query_embed.weightX"] = d["weight"].pop("module.query_embed.weight")
+    torch.save(d, path)
+    with pytest.raises(RuntimeError, match="does not match the model"):
+        a3d.engine.load_checkpoint(path, m2)
+    a3d.engine.load_checkpoint(path, m2, strict=False)
+    with pytest.raises(ValueError, match="torch.optim.AdamW"):
+        a3d.engine.load_checkpoint(path, m2, optimizer=a3d.engine.FlatAdamW(a3d.engine.FlatParams(m2, names)), strict=False)
+
+
+def _reference_adamw(model):
+    """the reference's optimizer (engine.py:89-102) on a torch model"""
+    groups = [{"params": [], "weight_decay": 0.0, "lr": 1e-4}, {"params": [], "weight_decay": 5e-4, "lr": 1e-4}]
+    for name, p in model.named_parameters():
+        groups[0 if any(nd in name for nd in ["bias", "LayerNorm.weight", "LayerNorm.bias"]) else 1]["params"].append(p)
+    return torch.optim.AdamW(groups)
+
+
+def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
+    """A checkpoint written here loads into the reference's torch.optim.AdamW (same param_groups / int-indexed state with
+    per-parameter step) and a reference-format optimizer state loads here (it used to be silently dropped)."""
+    a3d = load_pkg()
+    bounds = np.array([[-1, -1, -1], [1, 1, 1.0]])
+    torch.manual_seed(0)
+    m = a3d.Act3D(gripper_loc_bounds=bounds, num_sampling_level=2)
+    hot = [n for n, p in m.named_parameters() if p.requires_grad and "feature_pyramid" not in n]
+    flat = a3d.engine.FlatParams(m, hot)
+    opt = a3d.engine.FlatAdamW(flat)
+    g = torch.Generator().manual_seed(1)
+    opt.exp_avg.copy_(torch.randn(flat.n, generator=g))
+    opt.exp_avg_sq.copy_(torch.rand(flat.n, generator=g))
+    opt.step_count.fill_(7)
+    path = str(tmp_path / "last.pth")
+    a3d.engine.save_checkpoint(path, m, opt, 6, best_loss=1.25)
+    d = torch.load(path, weights_only=False)
+    # --- into the reference's optimizer, on an identically structured torch model
+    torch.manual_seed(0)
+    m2 = a3d.Act3D(gripper_loc_bounds=bounds, num_sampling_level=2)
+    m2.load_state_dict({k[7:]: v for k, v in d["weight"].items()})
+    ref_opt = _reference_adamw(m2)
+    ref_opt.load_state_dict(d["optimizer"])                       # raises on any layout mismatch
+    named2 = dict(m2.named_parameters())
+    n0 = "query_cross_attn_pyramid.0.attn_layers.1.multihead_attn.in_proj_weight"
+    st = ref_opt.state[named2[n0]]
+    a, b = flat.slices[n0]
+    assert float(st["step"]) == 7 and torch.equal(st["exp_avg"].reshape(-1), opt.exp_avg[a:b])
+    assert named2["backbone.conv1.weight"] not in ref_opt.state   # never-trained parameters carry no state, as in torch
+    assert [g_["weight_decay"] for g_ in ref_opt.param_groups] == [0.0, 5e-4]
+    # --- and back: two reference steps on the hot parameters, then the reference-format state into a fresh flat optimizer
+    for it in range(2):
+        for n in hot:
+            named2[n].grad = torch.randn(named2[n].shape, generator=g)
+        ref_opt.step()
+    torch.save({"weight": m2.state_dict(), "optimizer": ref_opt.state_dict(), "iter": 9, "best_loss": None}, path)
+    torch.manual_seed(5)
+    m3 = a3d.Act3D(gripper_loc_bounds=bounds, num_sampling_level=2)
+    flat3 = a3d.engine.FlatParams(m3, hot)
+    opt3 = a3d.engine.FlatAdamW(flat3)
+    it, _ = a3d.engine.load_checkpoint(path, m3, opt3)
+    assert it == 9 and float(opt3.step_count) == 9
+    a3, b3 = flat3.slices[n0]
+    assert torch.equal(opt3.exp_avg[a3:b3], ref_opt.state[named2[n0]]["exp_avg"].reshape(-1))
+    assert torch.equal(dict(m3.named_parameters())[n0].detach(), named2[n0].detach())
+    assert dict(m3.named_parameters())[n0].data_ptr() == flat3.flat.data_ptr() + a3 * 4     # still a view of the flat buffer
+    # a state that does not describe this model is an error, not a silent reset
+    bad = ref_opt.state_dict()
+    bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+    with pytest.raises(ValueError, match="parameter groups"):
+        opt3.load_state_dict(bad)
 
 
 # ------------------------------------------------------------------------------------------------ 2-process gloo

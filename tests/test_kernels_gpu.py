@@ -414,6 +414,21 @@ def test_adamw_matches_torch(a3d, dev):
                n0, 1e-4, 0.9, 0.999, 1e-8, 0.0, 5e-4, 1.0, L.stream())
     report("adamw", pd, torch.cat([ref_a.detach(), ref_b.detach()]), 1e-6, 1e-6)
     assert step.item() == 3.0
+    # a third tensor that never receives a gradient: torch skips it (grad is None) -- no weight decay, no state; in the flat
+    # buffer it is a stretch of elements whose gradient and moments are all still zero
+    ref_c = torch.nn.Parameter(torch.randn(64, generator=g))
+    opt.add_param_group({"params": [ref_c], "weight_decay": 5e-4})
+    pd2 = torch.cat([pd, ref_c.detach().to(dev)])
+    m2, v2 = torch.cat([m, torch.zeros(64, device=dev)]), torch.cat([v, torch.zeros(64, device=dev)])
+    for it in range(2):
+        gr = torch.randn(n0 + n1, generator=g)
+        ref_a.grad, ref_b.grad = gr[:n0].clone(), gr[n0:].clone()
+        opt.step()
+        gd = torch.cat([gr, torch.zeros(64)]).to(dev)
+        L.call("a3d_adamw_step", pd2.data_ptr(), gd.data_ptr(), m2.data_ptr(), v2.data_ptr(), step.data_ptr(), n0 + n1 + 64,
+               n0, 1e-4, 0.9, 0.999, 1e-8, 0.0, 5e-4, 1.0, L.stream())
+    assert torch.equal(pd2[n0 + n1:].cpu(), ref_c.detach()), "unused parameters must not decay"
+    report("adamw (with an unused tensor)", pd2[:n0 + n1], torch.cat([ref_a.detach(), ref_b.detach()]), 1e-6, 1e-6)
 
 
 def test_sampler_matches_cpu_twin(a3d, dev):
