@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true",
                     help="only the dominant-kernel micro-benchmarks (used for the rocprofv3 --pmc passes)")
+    ap.add_argument("--skip-secondary", action="store_true",
+                    help="skip the ChainedDiffuser entries (diffusion training step, 100-step sampling) of `secondary`")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -331,6 +333,23 @@ def main():
                               for k, v in ks.items()}
         except Exception as e:
             res["roofline"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.skip_secondary:
+            # the diffusion half of the metric and BASELINE configs[2], timed by this same driver-run process (N = 1 only:
+            # the scaling runs stay short).  Each entry carries its own roofline.
+            del graphed, model, flat, opt
+            torch.cuda.empty_cache()
+            import bench_denoise as BD
+            res["secondary"] = []
+            for name, fn in (("diffusion_train_script_shape", lambda: BD.training_bench(a3d, device, 22, 50, 3, steps=10, warmup=3)),
+                             ("diffusion_train_cfg3_shape", lambda: BD.training_bench(a3d, device, 64, 16, 3, steps=10, warmup=3)),
+                             ("diffusion_sampling_cfg3", lambda: BD.sampling_bench(a3d, device, 64, 16, 3, reps=3))):
+                try:
+                    r = fn()
+                except Exception as e:
+                    r = {"error": repr(e)[:300]}
+                r["name"] = name
+                res["secondary"].append(r)
+                torch.cuda.empty_cache()
         if world == 1 and not args.skip_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a3d, args.cpu_batch, args.cpu_steps)

@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
-"""Secondary benchmark (BASELINE.json configs[2]): ChainedDiffuser DDPM sampling, 100 denoise steps, horizon 16,
-batch 64, hipGraph-captured, on ONE MI355X.  Not the driver's bench.py contract; prints one JSON line with
-trajectories/s and the K/V-cache streaming roofline of the cross-attention layers (HBM-bound).
+"""ChainedDiffuser workloads of the benchmark (BASELINE.json configs[2] and the diffusion half of the metric): used by
+bench.py for the `secondary` entries of its JSON line, and runnable on its own:
 
-  python bench_denoise.py [--batch 64] [--horizon 16] [--cams 3] [--reps 5] [--no-graph]
+  python bench_denoise.py [--mode sample|train] [--batch 64] [--horizon 16] [--cams 3] [--reps 5] [--no-graph]
+
+  sample: DiffusionPlanner.compute_trajectory, 100 denoise steps, context + K/V cache built once, loop hipGraph-captured
+          -> trajectories/s; roofline = the cross-attention against the K/V cache (HBM-bound) on
+          ALGORITHMIC bytes (64 B per key and head: a 16-channel bf16 K row + V row).
+  train : one training step of main_trajectory.py:177-204 -- zero_grad + frozen backbone (bf16) + FPN + denoiser forward
+          with the reference's dropout 0.1 + L1 loss + backward + fused AdamW, hipGraph-captured (noise, timesteps and
+          dropout masks drawn on the device inside the graph) -> trajectories/s; roofline = the trajectory->context
+          cross-attention forward + backward (MFMA-bound) on algorithmic FLOPs.
 """
 import argparse
 import importlib
@@ -18,94 +25,206 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 DIFFUSION_BOUNDS = np.array([[-0.7342, -0.7915, 0.7098], [0.6944, 0.8437, 1.8645]])
+E, H = 120, 8
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--horizon", type=int, default=16)
-    ap.add_argument("--cams", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--no-graph", action="store_true")
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
-    a3d = importlib.import_module("act3d-chained-diffuser_amd")
-    a3d.lib.load()
+def build_planner(a3d, dev, train):
     torch.manual_seed(0)
-    B, Ln, C, E, H = args.batch, args.horizon, args.cams, 120, 8
     m = a3d.DiffusionPlanner(embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
                              use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
-                             gripper_loc_bounds=DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100).to(dev)
+                             gripper_loc_bounds=DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100,
+                             dropout=0.1).to(dev)        # scripts/train_trajectory.sh:21-31; dropout as the reference (layers.py:10)
     for mod in m.modules():                      # AdaLN is zero-initialised in the reference; give it non-trivial weights
         if isinstance(mod, a3d.nn.AdaLN):
             torch.nn.init.normal_(mod.modulation[1].weight, std=0.02)
-    m.eval()
+    m.train(train)
     m.prediction_head.backbone_dtype = torch.bfloat16
-    g = torch.Generator().manual_seed(1)
+    return m
+
+
+def synthetic_inputs(B, Ln, C, dev, seed=1):
+    g = torch.Generator().manual_seed(seed)
     lo, hi = torch.tensor(DIFFUSION_BOUNDS[0], dtype=torch.float32), torch.tensor(DIFFUSION_BOUNDS[1], dtype=torch.float32)
     rgb = torch.rand(B, C, 3, 256, 256, generator=g).to(dev)
     pcd = (lo.view(1, 1, 3, 1, 1) + torch.rand(B, C, 3, 256, 256, generator=g) * (hi - lo).view(1, 1, 3, 1, 1)).to(dev)
 
-    def pose():
-        q = torch.randn(B, 4, generator=g)
-        return torch.cat([lo + 0.15 * (hi - lo) + torch.rand(B, 3, generator=g) * 0.7 * (hi - lo), q / q.norm(dim=-1, keepdim=True)], -1).to(dev)
+    def pose(n):
+        q = torch.randn(*n, 4, generator=g)
+        return torch.cat([lo + 0.15 * (hi - lo) + torch.rand(*n, 3, generator=g) * 0.7 * (hi - lo), q / q.norm(dim=-1, keepdim=True)], -1)
 
-    cg, gg = pose(), pose()
-    instr = torch.randn(B, 53, 512, generator=g).to(dev)
-    mask = torch.zeros(B, Ln, dtype=torch.bool, device=dev)
+    cg, gg = pose((B,)), pose((B,))
+    w = torch.linspace(0, 1, Ln).view(1, Ln, 1)
+    traj = cg[:, None] * (1 - w) + gg[:, None] * w + 0.01 * torch.randn(B, Ln, 7, generator=g)
+    traj[..., 3:] = traj[..., 3:] / traj[..., 3:].norm(dim=-1, keepdim=True)
+    return {"rgbs": rgb, "pcds": pcd, "curr_gripper": cg.to(dev), "action": gg.to(dev), "trajectory": traj.to(dev),
+            "instr": torch.randn(B, 53, 512, generator=g).to(dev), "trajectory_mask": torch.zeros(B, Ln, dtype=torch.bool, device=dev)}
+
+
+def _time(fn, iters):
+    for _ in range(3):
+        fn()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters * 1e-3
+
+
+def cached_attention_roofline(a3d, B, Ln, S, dev):
+    """One cross-attention launch against the K/V cache at the sampling shapes, timed with events on the launch stream.
+    ALGORITHMIC bytes: a 16-channel bf16 K row and V row per key and head (64 B) + the query rows and the
+    fp32 output; `stored_bytes` is what the split-operand cache actually holds."""
+    O = a3d.ops
+    Lqp, Sp = (Ln + 63) // 64 * 64, (S + 63) // 64 * 64
+    Qs = torch.randn(B, H, Lqp, O.QKW, device=dev).to(torch.bfloat16)
+    Ks = torch.randn(B, H, Sp, O.QKW, device=dev).to(torch.bfloat16)
+    Vt = torch.randn(B, H, 2, 16, Sp, device=dev).to(torch.bfloat16)
+    ns = O.pick_nsplit(B, H, Lqp, Sp)
+    t = _time(lambda: O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns), 20)
+    alg = B * H * S * 64.0 + B * H * Ln * 32.0 + B * Ln * E * 4.0
+    stored = B * H * Sp * (2.0 * O.QKW + 64.0)
+    return {"bound": "hbm", "kernel": "attn_fwd (trajectory -> context cross-attention against the K/V cache)",
+            "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0, "ms": t * 1e3,
+            "traffic": None, "algorithmic_bytes_per_launch": alg, "stored_bytes_per_launch": stored,
+            "launches_per_denoise_step": 8, "nsplit": ns}
+
+
+def training_attention_roofline(a3d, B, Ln, S, dev):
+    """Forward + backward of the trajectory -> context cross-attention core at the training shapes (MFMA-bound):
+    algorithmic FLOPs 4 Lq S E B forward (QK^T + PV) + 10 Lq S E B backward (five contractions)."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(1)
+    q_pre = torch.randn(B * Ln, E, generator=g).to(dev)
+    kv_pre = torch.randn(B * S, 2 * E, generator=g).to(dev)
+    q_xyz, k_xyz = torch.rand(B, Ln, 3, generator=g).to(dev), torch.rand(B, S, 3, generator=g).to(dev)
+    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O.attn_operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E,
+                                                               kv_pre.data_ptr() + E * 4, 2 * E, q_xyz, k_xyz, B, Ln, S, E, H,
+                                                               dev, need_bwd=True)
+    ns = O.pick_nsplit(B, H, Lqp, Sp)
+    Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns)
+    dO = torch.randn_like(Oo)
+    tf = _time(lambda: O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns), 20)
+    tb = _time(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Ln, Lqp, S, Sp, ns, extra=extra), 20)
+    fl = 14.0 * Ln * S * E * B
+    return {"bound": "mfma", "kernel": "attn_fwd + attn_bwd (trajectory -> context cross-attention)",
+            "achieved": fl / (tf + tb) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / (tf + tb) / 1e12 / 2500.0,
+            "ms": (tf + tb) * 1e3, "ms_fwd": tf * 1e3, "ms_bwd": tb * 1e3, "traffic": None, "launches_per_step": 8,
+            "dtype": "bf16 (split operands)"}
+
+
+def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
+    m = build_planner(a3d, dev, train=False)
+    s = synthetic_inputs(B, Ln, C, dev)
     with torch.no_grad():
-        tokens = m.prediction_head.encode_images(rgb, None).contiguous()      # one-off per trajectory batch (adjacent)
-    kw = dict(visual_tokens=tokens, use_graph=not args.no_graph)
+        tokens = m.prediction_head.encode_images(s["rgbs"], None).contiguous()      # one-off per trajectory batch (adjacent)
+    kw = dict(visual_tokens=tokens, use_graph=graph)
 
     def run():
-        return m.compute_trajectory(mask, None, pcd, instr, cg, gg, init_noise=torch.randn(B, Ln, 9, device=dev),
+        return m.compute_trajectory(s["trajectory_mask"], None, s["pcds"], s["instr"], s["curr_gripper"], s["action"],
+                                    init_noise=torch.randn(B, Ln, 9, device=dev),
                                     step_noise=torch.randn(100, B, Ln, 9, device=dev), **kw)
 
     out = run()
     out = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.reps):
+    for _ in range(reps):
         out = run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.reps
+    dt = (time.perf_counter() - t0) / reps
     assert torch.isfinite(out).all()
     S = C * 1024 + 2
-    Sp = (S + 63) // 64 * 64
-    # K/V cache actually streamed per denoise step: 8 cross-attention layers x (K: 96 B (hi|lo|lo2) + V: 64 B per key and head)
-    KV_BYTES = 2 * a3d.ops.QKW + 64
-    bytes_step = 8 * B * H * Sp * KV_BYTES
-    flops_step = 8 * 4.0 * Ln * S * E * B                  # QK^T + PV of the 8 cross-attention layers
-    # live timing of one cross-attention core launch at these shapes
-    O = a3d.ops
-    Lqp = 64
-    Qs = torch.randn(B, H, Lqp, O.QKW, device=dev).to(torch.bfloat16)
-    Ks = torch.randn(B, H, Sp, O.QKW, device=dev).to(torch.bfloat16)
-    Vt = torch.randn(B, H, 2, 16, Sp, device=dev).to(torch.bfloat16)
-    ns = O.pick_nsplit(B, H, Lqp, Sp)
-    for _ in range(3):
-        O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns)
-    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    st.record()
-    for _ in range(20):
-        O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns)
-    en.record()
-    torch.cuda.synchronize()
-    t_attn = st.elapsed_time(en) / 20 * 1e-3
-    kv_bytes_launch = B * H * Sp * KV_BYTES
-    res = {
+    rl = cached_attention_roofline(a3d, B, Ln, S, dev)
+    return {
         "metric": "DDPM trajectory sampling, 100 denoise steps (trajectories/s)", "value": B / dt, "unit": "trajectories/s",
-        "n_gpus": 1, "ms_per_100_step_batch": dt * 1e3, "ms_per_denoise_step": dt * 10, "higher_is_better": True,
-        "dtype": "bf16 MFMA on split operands (q,k hi+lo+lo2; p,v hi+lo) attention, fp32 elsewhere", "data": "synthetic",
-        "config": {"workload": f"ChainedDiffuser compute_trajectory: B={B}, horizon={Ln}, {C} cameras (S={S} context tokens), "
-                               "E=120, H=8, 100 steps, context + K/V cache built once, loop hipGraph-captured"
-                               if not args.no_graph else "eager loop", "hipgraph": not args.no_graph},
-        "roofline": {"bound": "hbm", "kernel": "attn_fwd (cross-attention against the K/V cache)",
-                     "achieved": kv_bytes_launch / t_attn / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": kv_bytes_launch / t_attn / 1e9 / 8000.0, "ms": t_attn * 1e3, "traffic": None,
-                     "kv_cache_bytes_per_step": bytes_step, "attn_flops_per_step": flops_step},
+        "ms_per_100_step_batch": dt * 1e3, "ms_per_denoise_step": dt * 10, "higher_is_better": True,
+        "dtype": "bf16 MFMA on split operands in attention, fp32 elsewhere", "data": "synthetic",
+        "config": {"workload": f"ChainedDiffuser compute_trajectory (BASELINE configs[2]): B={B}, horizon={Ln}, {C} cameras "
+                               f"(S={S} context tokens), E=120, H=8, 100 steps, context + K/V cache built once",
+                   "hipgraph": graph},
+        "roofline": rl,
     }
+
+
+def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
+    Eg = a3d.engine
+    m = build_planner(a3d, dev, train=True)
+    s = synthetic_inputs(B, Ln, C, dev)
+    crit = a3d.TrajectoryCriterion()
+
+    def fwd_bwd(sample):
+        loss = crit.compute_loss(m(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
+                                   sample["instr"], sample["curr_gripper"], sample["action"]))
+        loss.backward()
+        return loss.detach()
+
+    active = Eg.discover_active_parameters(m, lambda: fwd_bwd(s))
+    flat, opt = Eg.get_optimizer(m, lr=1e-4, active_names=active)
+    graphed, err = None, None
+    if graph:
+        try:
+            graphed = Eg.GraphedStep(fwd_bwd, opt, s, warmup=2)
+        except Exception as e:                               # recorded in the output: never a silent fallback
+            err = repr(e)[:200]
+            torch.cuda.synchronize()
+            flat.rebind_grads()
+
+    def step():
+        if graphed is not None:
+            return graphed()
+        opt.zero_grad()
+        loss = fwd_bwd(s)
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss).all()
+    S = C * 1024 + 2
+    rl = training_attention_roofline(a3d, B, Ln, S, dev)
+    res = {
+        "metric": "train samples/sec (ChainedDiffuser trajectory-diffusion fwd+bwd+AdamW step)", "value": B / dt,
+        "unit": "samples/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "higher_is_better": True,
+        "dtype": "bf16 MFMA on split operands in attention; fp32 MFMA linears; bf16 frozen backbone; fp32 FPN",
+        "data": "synthetic",
+        "config": {"workload": f"DiffusionPlanner training step (main_trajectory.py:177-204): B={B} trajectories, horizon "
+                               f"{Ln}, {C} cameras 256x256 (S={S}), E=120, H=8, dropout 0.1, frozen synthetic CLIP-RN50-shaped "
+                               "backbone + trainable FPN included", "hipgraph": graphed is not None,
+                   "final_loss": float(loss.item())},
+        "roofline": rl,
+    }
+    if err:
+        res["config"]["graph_capture_error"] = err
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--cams", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = True
+    a3d = importlib.import_module("act3d-chained-diffuser_amd")
+    a3d.lib.load()
+    if args.mode == "sample":
+        res = sampling_bench(a3d, dev, args.batch or 64, args.horizon or 16, args.cams, args.reps, not args.no_graph)
+    else:
+        res = training_bench(a3d, dev, args.batch or 22, args.horizon or 50, args.cams, args.reps, 3, not args.no_graph)
+    res["n_gpus"] = 1
     print(json.dumps(res))
 
 
