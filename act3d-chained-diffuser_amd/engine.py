@@ -181,9 +181,12 @@ class FlatDataParallel:
 
     broadcast_parameters(): rank 0 -> all (DDP's initial broadcast).
     sync_gradients(): all-reduce(SUM); the 1/world_size averaging is returned as the grad_scale for FlatAdamW.step.
-    With `overlap=True` the hot-path segments are reduced on a side stream as soon as `hot_path_done()` is called
-    (from an autograd hook on the FPN output), while the FPN backward still runs; the FPN segment follows at the end.
-    Works with backend "nccl" (= RCCL on ROCm) on device buffers and with "gloo" on CPU buffers (tests)."""
+    With `overlap=True` the hot-path segments [hot no-decay] and [hot decay] of the buffer are reduced on a side stream as
+    soon as `hot_path_done()` is called -- by the split backward of `fwd_bwd_keypose` / `fwd_bwd_trajectory`, the moment
+    the gradients of the FPN's output tokens exist and before the FPN / convolution backward is enqueued -- while that
+    backward runs on the main stream; the FPN segment follows in sync_gradients().  `arm(False)` disables the early
+    reduction for the non-final micro-batches of a gradient-accumulation window.
+    Works with backend "nccl" (= RCCL on ROCm) and with "gloo" (device or CPU buffers; tests)."""
 
     def __init__(self, flat, process_group=None, overlap=True):
         self.flat = flat
@@ -193,6 +196,7 @@ class FlatDataParallel:
         self._pending = []
         self._side = torch.cuda.Stream() if self.overlap else None
         self._early_done = False
+        self._armed = True
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
@@ -202,9 +206,12 @@ class FlatDataParallel:
         a, b = self.flat.late_range
         return [(0, a), (b, self.flat.n)], (a, b)
 
+    def arm(self, on=True):
+        self._armed = bool(on)
+
     def hot_path_done(self):
-        """Call when every hot-path gradient has been produced (FPN backward not yet run)."""
-        if self.world == 1 or not self.overlap or self._early_done:
+        """Call when every hot-path gradient has been produced (FPN backward not yet enqueued)."""
+        if self.world == 1 or not self.overlap or not self._armed or self._early_done:
             return
         hot, _ = self._segments()
         ev = torch.cuda.Event()
@@ -234,35 +241,80 @@ class FlatDataParallel:
         return 1.0 / self.world
 
 
-def train_one_step(model, criterion, optimizer, step_id, sample, ddp=None, accumulate_grad_batches=1,
-                   use_ground_truth_position_for_sampling_train=True):
-    """TrainTester.train_one_step for the keypose model (main_keypose.py:207-234): zero_grad, forward, loss, backward,
-    (all-reduce), optimizer step.  Returns the detached total loss."""
-    if step_id % accumulate_grad_batches == 0:
-        optimizer.zero_grad()
-    out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"],
-                gt_action=sample["action"] if use_ground_truth_position_for_sampling_train else None)
-    loss = criterion.compute_loss(out, sample)
-    loss = sum(list(loss.values()))
+# ------------------------------------------------------------------------------------------------ the step, split at the tokens
+def _split_backward(tokens, run_hot, on_hot_done):
+    """Backward in two stages around the FPN's output tokens: the hot path runs on detached leaves, its backward fills
+    every hot-path parameter gradient and the token gradients; `on_hot_done()` (the early all-reduce) is called; then the
+    token gradients are pushed through the FPN (MIOpen convolution backward).  Same gradients as one backward() call."""
+    uniq, leaves = {}, []
+    for t in tokens:
+        if id(t) not in uniq:
+            uniq[id(t)] = (t, t.detach().requires_grad_(t.requires_grad))
+        leaves.append(uniq[id(t)][1])
+    loss = run_hot(leaves)
     loss.backward()
+    if on_hot_done is not None:
+        on_hot_done()
+    pairs = [(t, l.grad) for t, l in uniq.values() if t.requires_grad and l.grad is not None]
+    if pairs:
+        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+    return loss.detach()
+
+
+def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=None):
+    """forward + loss + backward of main_keypose.py:207-224 with the backward split at the FPN tokens"""
+    tokens = model.compute_visual_tokens(sample["rgbs"])
+
+    def hot(leaves):
+        out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"],
+                    gt_action=sample["action"] if use_gt_sampling else None, visual_features=leaves)
+        return sum(criterion.compute_loss(out, sample).values())
+
+    return _split_backward(tokens, hot, on_hot_done)
+
+
+def fwd_bwd_trajectory(model, criterion, sample, on_hot_done=None):
+    """forward + loss + backward of main_trajectory.py:177-195 with the backward split at the FPN tokens"""
+    tokens = model.prediction_head.encode_images(sample["rgbs"], None)
+
+    def hot(leaves):
+        return criterion.compute_loss(model(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
+                                            sample["instr"], sample["curr_gripper"], sample["action"], visual_tokens=leaves[0]))
+
+    return _split_backward([tokens], hot, on_hot_done)
+
+
+def _finish_step(optimizer, ddp, step_id, accumulate_grad_batches):
     if step_id % accumulate_grad_batches == accumulate_grad_batches - 1:
         scale = ddp.sync_gradients() if ddp is not None else 1.0
         optimizer.step(grad_scale=scale) if isinstance(optimizer, FlatAdamW) else optimizer.step()
-    return loss.detach()
+
+
+def train_one_step(model, criterion, optimizer, step_id, sample, ddp=None, accumulate_grad_batches=1,
+                   use_ground_truth_position_for_sampling_train=True):
+    """TrainTester.train_one_step for the keypose model (main_keypose.py:207-234): zero_grad, forward, loss, backward,
+    (all-reduce, overlapped with the FPN backward), optimizer step.  Returns the detached total loss."""
+    if step_id % accumulate_grad_batches == 0:
+        optimizer.zero_grad()
+    last = step_id % accumulate_grad_batches == accumulate_grad_batches - 1
+    if ddp is not None:
+        ddp.arm(last)                       # only the window's final micro-batch may start reducing its gradients early
+    loss = fwd_bwd_keypose(model, criterion, sample, use_ground_truth_position_for_sampling_train,
+                           None if ddp is None else ddp.hot_path_done)
+    _finish_step(optimizer, ddp, step_id, accumulate_grad_batches)
+    return loss
 
 
 def train_one_step_trajectory(model, criterion, optimizer, step_id, sample, ddp=None, accumulate_grad_batches=1):
     """TrainTester.train_one_step for the trajectory model (main_trajectory.py:177-204)."""
     if step_id % accumulate_grad_batches == 0:
         optimizer.zero_grad()
-    out = model(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"], sample["instr"],
-                sample["curr_gripper"], sample["action"])
-    loss = criterion.compute_loss(out)
-    loss.backward()
-    if step_id % accumulate_grad_batches == accumulate_grad_batches - 1:
-        scale = ddp.sync_gradients() if ddp is not None else 1.0
-        optimizer.step(grad_scale=scale) if isinstance(optimizer, FlatAdamW) else optimizer.step()
-    return loss.detach()
+    last = step_id % accumulate_grad_batches == accumulate_grad_batches - 1
+    if ddp is not None:
+        ddp.arm(last)
+    loss = fwd_bwd_trajectory(model, criterion, sample, None if ddp is None else ddp.hot_path_done)
+    _finish_step(optimizer, ddp, step_id, accumulate_grad_batches)
+    return loss
 
 
 def save_checkpoint(path, model, optimizer, step_id, best_loss=None):
@@ -290,39 +342,62 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
 
 
 class GraphedStep:
-    """Captures one full training step (zero_grad + forward + loss + backward + AdamW) into a hipGraph and replays it.
+    """Captures one full training step into hipGraphs and replays it.
 
     Every kernel of the hot path is enqueued on the caller's stream with static shapes and no host sync, the ghost
-    sampler and the AdamW step counter live on the device, so the step is capturable as is.  Inputs are copied into
-    static buffers before each replay.  For world_size > 1 the gradient all-reduce runs between the captured
-    forward/backward graph and the captured optimizer graph."""
+    sampler, the dropout generator and the AdamW step counter live on the device, so the step is capturable as is.
+    Inputs are copied into static buffers before each replay.
+      world == 1 : ONE graph  [zero_grad + forward + loss + backward + AdamW].
+      world  > 1 : `step_fwd_bwd(inputs, on_hot_done)` must split its backward at the FPN tokens (fwd_bwd_keypose /
+                   fwd_bwd_trajectory).  Three graphs around the two collectives:
+                   [zero_grad + forward + hot-path backward] -> all-reduce(hot segments) on a side stream, concurrent with
+                   [FPN backward] -> all-reduce(FPN segment) -> [AdamW with 1/world].
+    The collectives themselves are issued eagerly between the replays (RCCL calls are not captured)."""
 
     def __init__(self, step_fwd_bwd, optimizer, static_inputs, ddp=None, warmup=3):
         self.static_inputs = static_inputs
         self.optimizer = optimizer
         self.ddp = ddp
         self.world = ddp.world if ddp is not None else 1
+        split = self.world > 1
+        call = (lambda cb: step_fwd_bwd(static_inputs, cb)) if split else (lambda cb: step_fwd_bwd(static_inputs))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 optimizer.zero_grad()
-                step_fwd_bwd(static_inputs)
+                call(ddp.hot_path_done if split else None)
                 scale = ddp.sync_gradients() if ddp is not None else 1.0
                 optimizer.step(grad_scale=scale)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            optimizer.zero_grad()
-            self.loss = step_fwd_bwd(static_inputs)
-            if self.world == 1:
+        self.g_late = self.g_opt = None
+        if not split:
+            with torch.cuda.graph(self.g_fb):
+                optimizer.zero_grad()
+                self.loss = call(None)
                 optimizer.step(grad_scale=1.0)
-        self.g_opt = None
-        if self.world > 1:
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                optimizer.step(grad_scale=1.0 / self.world)
+            return
+        # world > 1: the capture of the first graph ends inside the callback (hot path done), the second one starts there
+        self.g_late = torch.cuda.CUDAGraph()
+        ctx = {}
+
+        def switch_graphs():
+            ctx["first"].__exit__(None, None, None)
+            ctx["second"] = torch.cuda.graph(self.g_late, pool=self.g_fb.pool())
+            ctx["second"].__enter__()
+
+        ctx["first"] = torch.cuda.graph(self.g_fb)
+        ctx["first"].__enter__()
+        try:
+            optimizer.zero_grad()
+            self.loss = call(switch_graphs)
+        finally:
+            (ctx.get("second") or ctx["first"]).__exit__(None, None, None)
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+            optimizer.step(grad_scale=1.0 / self.world)
 
     def __call__(self, inputs=None):
         if inputs is not None:
@@ -331,6 +406,9 @@ class GraphedStep:
                     self.static_inputs[k].copy_(v, non_blocking=True)
         self.g_fb.replay()
         if self.world > 1:
-            dist.all_reduce(self.optimizer.flat.grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
+            self.ddp.arm(True)
+            self.ddp.hot_path_done()           # hot segments on the side stream (whole buffer later if overlap is off) ...
+            self.g_late.replay()               # ... while the FPN backward runs
+            self.ddp.sync_gradients()
             self.g_opt.replay()
         return self.loss

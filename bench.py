@@ -226,17 +226,16 @@ def main():
     crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
     batch = synthetic_batch(B, 4, device, seed=1000 + rank)
 
-    def fwd_bwd(sample):
-        out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"], gt_action=sample["action"])
-        loss = sum(crit.compute_loss(out, sample).values())
-        loss.backward()
-        return loss.detach()
+    def fwd_bwd(sample, on_hot_done=None):
+        # backward split at the FPN tokens: the hot-path gradient segments start their all-reduce (on_hot_done) while the
+        # FPN / convolution backward is still to run (engine.fwd_bwd_keypose)
+        return E.fwd_bwd_keypose(model, crit, sample, True, on_hot_done)
 
     active = E.discover_active_parameters(model, lambda: fwd_bwd(batch))
     flat, opt = E.get_optimizer(model, lr=1e-4, active_names=active)
     ddp = None
     if world > 1:
-        ddp = E.FlatDataParallel(flat, overlap=False)
+        ddp = E.FlatDataParallel(flat, overlap=os.environ.get("A3D_DP_OVERLAP", "1") == "1")
         ddp.broadcast_parameters()
 
     graphed = None
@@ -254,7 +253,7 @@ def main():
         if graphed is not None:
             return graphed()
         opt.zero_grad()
-        loss = fwd_bwd(batch)
+        loss = fwd_bwd(batch, None if ddp is None else ddp.hot_path_done)
         scale = ddp.sync_gradients() if ddp is not None else 1.0
         opt.step(grad_scale=scale)
         return loss
@@ -291,7 +290,9 @@ def main():
                                    "+ trainable FPN included in the step",
                        "per_gpu_batch_keyframes": B, "global_batch": world * B, "parallelism": f"dp{world}",
                        "batch_note": "keyframe rows; reference default = 16 episodes x <=5 keyframes per step",
-                       "hipgraph": graphed is not None, "final_loss": loss_val},
+                       "hipgraph": graphed is not None, "final_loss": loss_val,
+                       "allreduce": None if ddp is None else ("hot-path segments overlapped with the FPN backward" if ddp.overlap
+                                                              else "one all-reduce after backward")},
         }
         if graph_err:
             res["config"]["graph_capture_error"] = graph_err

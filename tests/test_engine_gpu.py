@@ -158,3 +158,105 @@ def test_graphed_step_equals_eager_train_one_step(a3d, dev):
     torch.cuda.synchronize()
     assert torch.equal(optA.step_count, optB.step_count)
     assert torch.equal(mA._rng_state, mB._rng_state)
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, 2 ranks
+def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
+    """Two ranks share the one device (gloo moves the device buffers; RCCL refuses two ranks per GPU).  Each rank runs the
+    keypose step on ITS batch through FlatDataParallel; rank 0 additionally computes, without any collective, the gradients
+    of both batches from the same initial state and their mean -- the gradient of the mean-of-means loss DDP defines."""
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        a3d = importlib.import_module("act3d-chained-diffuser_amd")
+        E = a3d.engine
+        dev = torch.device("cuda:0")
+        crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+
+        def make(seed):
+            torch.manual_seed(seed)
+            m = a3d.Act3D(image_size=(128, 128), embedding_dim=60, num_attn_heads=4, gripper_loc_bounds=C.PERACT_BOUNDS,
+                          num_ghost_points=128, num_ghost_points_val=128, num_sampling_level=2, sampler_seed=5).to(dev)
+            return m.train()
+
+        batches = [_sample(2, 1, 128, dev, 50 + r) for r in range(world)]
+        m = make(100 + rank)                                   # different weights per rank: the broadcast must fix that
+        flat, opt = E.get_optimizer(m, lr=1e-4)
+        ddp = E.FlatDataParallel(flat, overlap=overlap)
+        ddp.broadcast_parameters()
+        assert ddp.overlap == overlap
+        p0 = flat.flat.clone()
+        res = {"rank": rank}
+        if rank == 0:
+            # reference: rank 0's post-broadcast weights are make(100); both batches, same sampler state, no collective
+            ref = make(100)
+            rflat, _ = E.get_optimizer(ref, lr=1e-4)
+            assert torch.equal(rflat.flat, p0)
+            grads = []
+            for b in batches:
+                ref._rng_state.copy_(m._rng_state)
+                rflat.zero_grad()
+                E.fwd_bwd_keypose(ref, crit, b)
+                grads.append(rflat.grad.clone())
+            g_ref = sum(grads) / world
+        if graphed:
+            def fwd_bwd(sample, cb=None):
+                return E.fwd_bwd_keypose(m, crit, sample, True, cb)
+            state = m._rng_state.clone()
+            step = E.GraphedStep(fwd_bwd, opt, batches[rank], ddp=ddp, warmup=1)
+            # the warm-up step moved the weights: restore the broadcast state (in place) and replay ONE step
+            flat.flat.copy_(p0)
+            opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count.zero_()
+            m._rng_state.copy_(state)
+            for (_, a), (_, b) in zip(make(100).backbone.named_buffers(), m.backbone.named_buffers()):
+                b.copy_(a)
+            step(batches[rank])
+            torch.cuda.synchronize()
+            g = flat.grad / world
+        else:
+            opt.zero_grad()
+            ddp.arm(True)
+            E.fwd_bwd_keypose(m, crit, batches[rank], True, ddp.hot_path_done)
+            scale = ddp.sync_gradients()
+            torch.cuda.synchronize()
+            g = flat.grad * scale
+        if rank == 0:
+            sc = g_ref.abs().max().item()
+            res.update(err=(g - g_ref).abs().max().item(), scale=sc, late=flat.late_range, n=flat.n,
+                       err_late=(g - g_ref)[flat.late_range[0]:flat.late_range[1]].abs().max().item())
+        gathered = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gathered, g)
+        res["same_on_all_ranks"] = all(torch.equal(gathered[0], t) for t in gathered)
+        q.put(res)
+        dist.destroy_process_group()
+    except Exception as e:                                      # surface the failure instead of a queue timeout
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()[-1500:]})
+
+
+@pytest.mark.parametrize("overlap,graphed", [(False, False), (True, False), (True, True)])
+def test_data_parallel_two_ranks_equals_mean_of_rank_gradients(dev, overlap, graphed):
+    """FlatDataParallel on the device: averaged 2-rank gradients == the mean of the two per-batch gradients (DDP's
+    mean-of-means), with the hot-path segments reduced early on the side stream (overlap) or in one piece, eagerly and
+    through the three-graph GraphedStep.  Reference semantics: DistributedDataParallel at engine.py:121-124."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000) + (2 if overlap else 0) + (1 if graphed else 0)
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, overlap, graphed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+        assert r["same_on_all_ranks"]
+    r0 = [r for r in res if r["rank"] == 0][0]
+    print(f"[parity] DP overlap={overlap} graphed={graphed}: max grad err {r0['err']:.3e} (scale {r0['scale']:.3e}), "
+          f"FPN segment {r0['late']} of {r0['n']}: {r0['err_late']:.3e}")
+    assert r0["late"][1] > r0["late"][0], "the test must exercise the late (FPN) segment"
+    assert r0["err"] <= 2e-4 * r0["scale"]
