@@ -19,6 +19,7 @@
 //   (S^T for dQ, S for dK/dV) puts P / dS directly in B-operand layout, so again no LDS transposes of scores.
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
+#include <stdlib.h>
 
 namespace a3d {
 
@@ -31,11 +32,17 @@ struct FwdStage {
 };
 
 // __launch_bounds__(256, 2): <= 256 VGPRs, which lets the compiler keep MFMA results in VGPRs (no v_accvgpr_read copies)
+// QT: 16-query tiles per wave.  A workgroup covers 64 * QT queries of one (sample, head); every K / V fragment a wave
+// reads from LDS (16 ds_read_b128 per 64-key chunk) and every chunk the workgroup stages (14.5 KB of ds_write) feeds QT
+// times as many MFMAs.  With QT = 1 the kernel is LDS-bound: per 64-key chunk and CU (8 waves) ~510 LDS-array cycles of
+// fragment reads + ~400 of staging stores against 18 MFMAs x 17 cycles x 2 waves = 610 per SIMD; QT = 2 halves the LDS
+// side and doubles the independent MFMA chains per wave.  QT = 1 stays for short query sets (Lq <= 64: the query stream
+// of Act3D, the 16-step trajectories of the denoiser), where a second tile would be padding.
 // DROP: training-mode dropout of the attention weights (multihead_custom_attention.py:413): A = softmax(..) is
 // normalised by the UN-dropped row sum, then every weight is kept with probability 1 - p and scaled by 1 / (1 - p).  The
 // keep flags of a lane's 8 consecutive keys come from one Philox call (a3d_common.h); the denominator is a per-lane f32
 // sum (the ones-channel of V would see the dropped weights).
-template <bool DROP>
+template <bool DROP, int QT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
     const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
@@ -49,24 +56,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int tiles_x = (Lqp + 63) >> 6;
+  constexpr int QW = 64 * QT;                       // queries per workgroup
+  const int tiles_x = (Lqp + QW - 1) / QW;
   int group, within;
   if (!xcd_decode(tiles_x * nsplit, B * H, group, within)) return;
   const int b = group / H, h = group - b * H;
   const int sp = within / tiles_x;
   const int E = H * HD;
-  const int q0 = (within - sp * tiles_x) * 64 + wave * 16;
-  const bool active = q0 < Lqp;
+  const int qbase = (within - sp * tiles_x) * QW + wave * (16 * QT);
   const size_t bh = (size_t)b * H + h;
 
   // B operands of the three score MFMAs: [q_hi | q_hi], [q_lo | q_lo], [q_lo2 | q_hi]  (against A = [k_hi | k_lo],
   // [k_hi | k_lo], [k_hi | k_lo2]): every product of (k_hi + k_lo + k_lo2)(q_hi + q_lo + q_lo2) above 2^-24
-  s16x8 qhi = {0, 0, 0, 0, 0, 0, 0, 0}, qlo = {0, 0, 0, 0, 0, 0, 0, 0}, q3 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (active) {
-    const unsigned short* qp = Qs + (bh * Lqp + q0 + li) * QKW;
-    qhi = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
-    qlo = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
-    q3 = *reinterpret_cast<const s16x8*>(qp + ((g < 2) ? 32 + g * 8 : (g & 1) * 8));   // g < 2: q_lo2, else q_hi
+  s16x8 qhi[QT], qlo[QT], q3[QT];
+  bool active[QT];
+  bool any_active = false;
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    const int q0 = qbase + u * 16;
+    active[u] = q0 < Lqp;
+    any_active = any_active || active[u];
+    qhi[u] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    qlo[u] = qhi[u];
+    q3[u] = qhi[u];
+    if (active[u]) {
+      const unsigned short* qp = Qs + (bh * Lqp + q0 + li) * QKW;
+      qhi[u] = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
+      qlo[u] = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
+      q3[u] = *reinterpret_cast<const s16x8*>(qp + ((g < 2) ? 32 + g * 8 : (g & 1) * 8));   // g < 2: q_lo2, else q_hi
+    }
   }
 
   const int nch = Sp / KC;
@@ -110,11 +128,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   for (int j = 0; j < 4; ++j) koff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
   const int voff = plane_off(li, g);
 
-  float m_run = -INFINITY;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // one accumulator per 32-key half: two PV chains
-  float l_run = 0.f;                                                  // DROP: this lane's share of sum_k p (un-dropped)
+  float m_run[QT], l_run[QT];                       // l_run (DROP): this lane's share of sum_k p (un-dropped)
+  f32x4 acc0[QT], acc1[QT];                         // one accumulator per 32-key half: two PV chains per query tile
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    m_run[u] = -INFINITY;
+    l_run[u] = 0.f;
+    acc0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[u] = acc0[u];
+  }
   DropKey dkey = {0u, 0u};
   if (DROP) dkey = drop_key(drop_state);
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
   if (c_beg < c_end) {
     stage_store(stage_load(c_beg), 0);
@@ -126,114 +153,125 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const bool has_next = (c + 1 < c_end);
     if (has_next) nxt = stage_load(c + 1);
 
-    if (active) {
-      // ---- all LDS fragment reads of the chunk up front, then the MFMAs as four independent chains
+    if (any_active) {
+      // ---- all LDS fragment reads of the chunk up front (shared by the wave's QT query tiles)
       s16x8 kf[4], k3[4], vh[2], vl[2];
-      f32x4 s[4];
+      f32x4 bias4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         kf[j] = *reinterpret_cast<const s16x8*>(&Ksm[buf][koff[j]]);
         k3[j] = *reinterpret_cast<const s16x8*>(&K3sm[buf][koff[j]]);
-        s[j] = *reinterpret_cast<const f32x4*>(&biasS[buf][(j >> 1) * 32 + g * 8 + (j & 1) * 4]);
+        bias4[j] = *reinterpret_cast<const f32x4*>(&biasS[buf][(j >> 1) * 32 + g * 8 + (j & 1) * 4]);
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         vh[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((0 * 2 + hf) * 16) * 32 + voff]);
         vl[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((1 * 2 + hf) * 16) * 32 + voff]);
       }
+      // ---- scores of every tile: 4 * QT independent MFMA chains
+      f32x4 s[QT][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(kf[j], qhi, s[j]);
+      for (int u = 0; u < QT; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(kf[j], qlo, s[j]);
+        for (int j = 0; j < 4; ++j) s[u][j] = mfma_bf16_16x16x32(kf[j], qhi[u], bias4[j]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] = mfma_bf16_16x16x32(k3[j], q3, s[j]);
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[u][j] = mfma_bf16_16x16x32(kf[j], qlo[u], s[u][j]);
+#pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[u][j] = mfma_bf16_16x16x32(k3[j], q3[u], s[u][j]);
 
-      // running max: a depth-3 tree over the lane's 16 scores, then across the column's four lanes
-      float mt[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mt[j] = fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3]));
-      const float mx = colmax4(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      // p = exp(s - m) as exp2(fma(s, log2 e, -m log2 e)): one packed FMA per two scores + v_exp_f32
-      typedef __attribute__((ext_vector_type(2))) float f32x2;
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-      const float nm = -m_use * LOG2E_F;
-      const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));   // m_run = -inf -> 0
-      const f32x2 c2 = {LOG2E_F, LOG2E_F}, nm2 = {nm, nm};
-      s16x8 phi[2], plo[2];
-      float l_tile = 0.f;
+      for (int u = 0; u < QT; ++u) {
+        // running max: a depth-3 tree over the lane's 16 scores, then across the column's four lanes
+        float mt[4];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        unsigned int hw[4], lw[4];
-        unsigned int keep = 0xFFu;
-        if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (KC / 8) + hf * 4 + g), (uint32_t)(q0 + li), (uint32_t)bh, drop_site, drop_thr);
+        for (int j = 0; j < 4; ++j) mt[j] = fmaxf(fmaxf(s[u][j][0], s[u][j][1]), fmaxf(s[u][j][2], s[u][j][3]));
+        const float mx = colmax4(fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3])));
+        const float m_new = fmaxf(m_run[u], mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        // p = exp(s - m) as exp2(fma(s, log2 e, -m log2 e)): one packed FMA per two scores + v_exp_f32
+        const float nm = -m_use * LOG2E_F;
+        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run[u], LOG2E_F, nm));   // m_run = -inf -> 0
+        const f32x2 c2 = {LOG2E_F, LOG2E_F}, nm2 = {nm, nm};
+        s16x8 phi[2], plo[2];
+        float l_tile = 0.f;
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
+        for (int hf = 0; hf < 2; ++hf) {
+          unsigned int hw[4], lw[4];
+          unsigned int keep = 0xFFu;
+          if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (KC / 8) + hf * 4 + g), (uint32_t)(qbase + u * 16 + li), (uint32_t)bh, drop_site, drop_thr);
 #pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const f32x4& sj = s[hf * 2 + T];
-            const f32x2 arg = __builtin_elementwise_fma((f32x2){sj[2 * pr], sj[2 * pr + 1]}, c2, nm2);
-            f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-            if (DROP) {
-              l_tile += p2.x + p2.y;
-              const int j = T * 4 + 2 * pr;          // this lane's keys of the half: g * 8 + j, g * 8 + j + 1
-              p2.x = ((keep >> j) & 1u) ? p2.x * drop_scale : 0.f;
-              p2.y = ((keep >> (j + 1)) & 1u) ? p2.y * drop_scale : 0.f;
+          for (int T = 0; T < 2; ++T) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const f32x4& sj = s[u][hf * 2 + T];
+              const f32x2 arg = __builtin_elementwise_fma((f32x2){sj[2 * pr], sj[2 * pr + 1]}, c2, nm2);
+              f32x2 p2 = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+              if (DROP) {
+                l_tile += p2.x + p2.y;
+                const int j = T * 4 + 2 * pr;          // this lane's keys of the half: g * 8 + j, g * 8 + j + 1
+                p2.x = ((keep >> j) & 1u) ? p2.x * drop_scale : 0.f;
+                p2.y = ((keep >> (j + 1)) & 1u) ? p2.y * drop_scale : 0.f;
+              }
+              // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
+              // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
+              const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
+              const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
+              hw[T * 2 + pr] = h2;
+              lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
             }
-            // x = hi + lo, both halves rounded to nearest-even; the compiler lowers the conversion to
-            // v_cvt_pk_bf16_f32 and tracks its hazards (a hand-written asm statement is opaque to it)
-            const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
-            const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
-            hw[T * 2 + pr] = h2;
-            lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
           }
+          phi[hf] = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+          plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
         }
-        phi[hf] = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-        plo[hf] = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-      }
-      m_run = m_new;
-      if (DROP) l_run = l_run * alpha + l_tile;
+        m_run[u] = m_new;
+        if (DROP) l_run[u] = l_run[u] * alpha + l_tile;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
-      acc0 = mfma_bf16_16x16x32(vh[0], phi[0], acc0);
-      acc1 = mfma_bf16_16x16x32(vh[1], phi[1], acc1);
-      acc0 = mfma_bf16_16x16x32(vh[0], plo[0], acc0);
-      acc1 = mfma_bf16_16x16x32(vh[1], plo[1], acc1);
-      acc0 = mfma_bf16_16x16x32(vl[0], phi[0], acc0);
-      acc1 = mfma_bf16_16x16x32(vl[1], phi[1], acc1);
+        for (int r = 0; r < 4; ++r) { acc0[u][r] *= alpha; acc1[u][r] *= alpha; }
+        acc0[u] = mfma_bf16_16x16x32(vh[0], phi[0], acc0[u]);
+        acc1[u] = mfma_bf16_16x16x32(vh[1], phi[1], acc1[u]);
+        acc0[u] = mfma_bf16_16x16x32(vh[0], plo[0], acc0[u]);
+        acc1[u] = mfma_bf16_16x16x32(vh[1], plo[1], acc1[u]);
+        acc0[u] = mfma_bf16_16x16x32(vl[0], phi[0], acc0[u]);
+        acc1[u] = mfma_bf16_16x16x32(vl[1], phi[1], acc1[u]);
+      }
     }
     if (has_next) stage_store(nxt, buf ^ 1);
     __syncthreads();
   }
 
-  if (!active) return;
-  f32x4 acc;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
-  float l_tot;
-  if (DROP) {
-    l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);              // the four lane groups hold disjoint key subsets of column li
-  } else {
-    l_tot = __shfl(acc[3], 48 + li, 64);             // channel 15 (lane group g = 3, register 3) holds sum_k p
-  }
-  const int q = q0 + li;
-  if (nsplit == 1) {
-    const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-    if (q < Lq) {
+  for (int u = 0; u < QT; ++u) {
+    if (!active[u]) continue;
+    f32x4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int d = g * 4 + r;
-        if (d < HD) O[((size_t)b * Lq + q) * E + h * HD + d] = acc[r] * inv;
-      }
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[u][r] + acc1[u][r];
+    float l_tot;
+    if (DROP) {
+      l_tot = l_run[u] + __shfl_xor(l_run[u], 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);              // the four lane groups hold disjoint key subsets of column li
+    } else {
+      l_tot = __shfl(acc[3], 48 + li, 64);             // channel 15 (lane group g = 3, register 3) holds sum_k p
     }
-    if (g == 0) LSE[bh * Lqp + q] = (l_tot > 0.f) ? (m_run + logf(l_tot)) : -INFINITY;
-  } else {
-    const size_t row = (((size_t)sp * B + b) * H + h) * Lqp + q;
-    *reinterpret_cast<f32x4*>(&Op[row * HDP + g * 4]) = acc;
-    if (g == 0) { Mp[row] = m_run; Lp[row] = l_tot; }
+    const int q = qbase + u * 16 + li;
+    if (nsplit == 1) {
+      const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+      if (q < Lq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = g * 4 + r;
+          if (d < HD) O[((size_t)b * Lq + q) * E + h * HD + d] = acc[r] * inv;
+        }
+      }
+      if (g == 0) LSE[bh * Lqp + q] = (l_tot > 0.f) ? (m_run[u] + logf(l_tot)) : -INFINITY;
+    } else {
+      const size_t row = (((size_t)sp * B + b) * H + h) * Lqp + q;
+      *reinterpret_cast<f32x4*>(&Op[row * HDP + g * 4]) = acc;
+      if (g == 0) { Mp[row] = m_run[u]; Lp[row] = l_tot; }
+    }
   }
 }
 
@@ -522,15 +560,23 @@ static int attn_fwd_launch(const void* Qs, const void* Ks, const void* Vt, const
   float* Op = ws;
   float* Mp = ws ? ws + (size_t)nsplit * rows * HDP : nullptr;
   float* Lp = ws ? Mp + (size_t)nsplit * rows : nullptr;
-  dim3 grid(xcd_grid(B * H, cdiv(Lqp, 64) * nsplit));
-  if (drop)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, s, (const unsigned short*)Qs,
-                       (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
-                       Lqp, S, Sp, nsplit, drop_state, drop_site, thr, dscale);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, s, (const unsigned short*)Qs,
-                       (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq,
-                       Lqp, S, Sp, nsplit, (const unsigned long long*)nullptr, 0u, 0u, 1.0f);
+  // two query tiles per wave (128 queries per workgroup) once the query set fills them; A3D_ATTN_QT=1 forces the narrow form
+  static const int qt_env = getenv("A3D_ATTN_QT") ? atoi(getenv("A3D_ATTN_QT")) : 0;
+  const int QT = qt_env ? qt_env : (Lq > 64 ? 2 : 1);
+  dim3 grid(xcd_grid(B * H, cdiv(Lqp, 64 * QT) * nsplit));
+  const unsigned long long* nostate = nullptr;
+#define A3D_LAUNCH_FWD(DROPV, QTV, ST, SITE, THR, SC)                                                                    \
+  hipLaunchKernelGGL((attn_fwd_kernel<DROPV, QTV>), grid, dim3(256), 0, s, (const unsigned short*)Qs,                   \
+                     (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, O, LSE, Op, Mp, Lp, B, H, Lq, Lqp, S, \
+                     Sp, nsplit, ST, SITE, THR, SC)
+  if (drop) {
+    if (QT == 2) A3D_LAUNCH_FWD(true, 2, drop_state, drop_site, thr, dscale);
+    else A3D_LAUNCH_FWD(true, 1, drop_state, drop_site, thr, dscale);
+  } else {
+    if (QT == 2) A3D_LAUNCH_FWD(false, 2, nostate, 0u, 0u, 1.0f);
+    else A3D_LAUNCH_FWD(false, 1, nostate, 0u, 0u, 1.0f);
+  }
+#undef A3D_LAUNCH_FWD
   rc = check_launch("a3d_attn_fwd");
   if (rc) return rc;
   if (nsplit > 1) {

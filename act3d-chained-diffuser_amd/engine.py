@@ -188,8 +188,9 @@ class FlatDataParallel:
     reduction for the non-final micro-batches of a gradient-accumulation window.
     Works with backend "nccl" (= RCCL on ROCm) and with "gloo" (device or CPU buffers; tests)."""
 
-    def __init__(self, flat, process_group=None, overlap=True):
+    def __init__(self, flat, process_group=None, overlap=True, model=None):
         self.flat = flat
+        self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap and flat.flat.is_cuda
@@ -199,8 +200,23 @@ class FlatDataParallel:
         self._armed = True
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
-            dist.broadcast(self.flat.flat, src=src, group=self.pg)
+        """rank `src`'s state to every rank, as DistributedDataParallel does at construction: the flat (trainable) buffer
+        and, when the model was given, every other state_dict entry -- the frozen backbone's weights and its BatchNorm
+        statistics.  (Per-rank generator states -- ghost sampler, dropout -- are non-persistent buffers and stay per rank.)"""
+        if self.world == 1:
+            return
+        dist.broadcast(self.flat.flat, src=src, group=self.pg)
+        if self.model is not None:
+            flat_ptrs = {p.data_ptr() for _, p in self.flat.order}
+            for name, t in self.model.state_dict().items():
+                if t.data_ptr() in flat_ptrs:
+                    continue
+                if t.is_contiguous():
+                    dist.broadcast(t, src=src, group=self.pg)
+                else:                                   # channels-last convolution weights of the bf16 backbone
+                    c = t.contiguous()
+                    dist.broadcast(c, src=src, group=self.pg)
+                    t.copy_(c)
 
     def _segments(self):
         a, b = self.flat.late_range

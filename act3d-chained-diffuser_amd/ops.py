@@ -115,7 +115,8 @@ ATTN_TARGET_WGS = int(os.environ.get("A3D_ATTN_WGS", "768"))
 
 def pick_nsplit(B, H, Lqp, Sp):
     """Key-range splits of the forward / dQ kernels: enough workgroups for several waves per SIMD on 256 CUs."""
-    wgs = B * H * ((Lqp + 63) // 64)
+    qw = 128 if Lqp > 64 else 64           # queries per workgroup: two 16-query tiles per wave once Lq > 64 (attention.hip)
+    wgs = B * H * ((Lqp + qw - 1) // qw)
     ns = max(1, min(16, Sp // 64, -(-ATTN_TARGET_WGS // wgs)))
     return ns
 

@@ -235,7 +235,7 @@ def main():
     flat, opt = E.get_optimizer(model, lr=1e-4, active_names=active)
     ddp = None
     if world > 1:
-        ddp = E.FlatDataParallel(flat, overlap=os.environ.get("A3D_DP_OVERLAP", "1") == "1")
+        ddp = E.FlatDataParallel(flat, overlap=os.environ.get("A3D_DP_OVERLAP", "1") == "1", model=model)
         ddp.broadcast_parameters()
 
     graphed = None

@@ -185,8 +185,8 @@ def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
         batches = [_sample(2, 1, 128, dev, 50 + r) for r in range(world)]
         m = make(100 + rank)                                   # different weights per rank: the broadcast must fix that
         flat, opt = E.get_optimizer(m, lr=1e-4)
-        ddp = E.FlatDataParallel(flat, overlap=overlap)
-        ddp.broadcast_parameters()
+        ddp = E.FlatDataParallel(flat, overlap=overlap, model=m)
+        ddp.broadcast_parameters()                             # trainable buffer + the (frozen, seed-dependent) backbone
         assert ddp.overlap == overlap
         p0 = flat.flat.clone()
         res = {"rank": rank}

@@ -252,9 +252,9 @@ def _dp_worker(rank, world, port, q):
     m = a3d.Act3D(gripper_loc_bounds=np.array([[-1, -1, -1], [1, 1, 1.0]]), num_sampling_level=2)
     names = [n for n, p in m.named_parameters() if p.requires_grad]
     flat = a3d.engine.FlatParams(m, names)
-    ddp = a3d.engine.FlatDataParallel(flat, overlap=False)
+    ddp = a3d.engine.FlatDataParallel(flat, overlap=False, model=m)
     ddp.broadcast_parameters()
-    ref = flat.flat.clone()
+    ref = torch.cat([flat.flat, m.backbone.conv1.weight.detach().reshape(-1), m.backbone.bn1.running_var])
     # every rank fills its gradient with (rank + 1) * g: the all-reduced sum is 3 g, the returned scale 1/2
     g = torch.linspace(-1, 1, flat.n)
     flat.grad.copy_(g * (rank + 1))
