@@ -168,7 +168,9 @@ class Act3D(nn.Module):
         tokens = {}
         for name, fm in pyr.items():
             n, E, h, w = fm.shape
-            tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E).float()
+            # (cam, h, w, E) rows of the channels-last map: a view, in the FPN's own dtype -- a bf16 map is gathered in place
+            # by a3d_build_context_bf16 (no fp32 copy of the 128 x 128 map, of which a level reads 6 % of the rows)
+            tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
         return [tokens[self.feature_map_pyramid[i]] for i in range(self.num_sampling_level)]
 
     # ------------------------------------------------------------------------------------------------ ghost points
@@ -235,6 +237,9 @@ class Act3D(nn.Module):
             instr_xyz = torch.zeros((B, instr.shape[1], 3), device=device, dtype=torch.float32)
 
         grip_tok = broadcast_row(self.curr_gripper_embed.weight, B, 1)
+        accum = {}                                       # one gradient buffer per distinct token map (levels >= 1 share one)
+        for f_ in feats:
+            accum.setdefault(id(f_), O.GradAccum())
         position_pyramid, ghost_pcd_pyramid, ghost_pcd_masks_pyramid, topk_pyramid = [], [], [], []
         ghost_features_pyramid = []
         query, prev_pos = None, None
@@ -249,7 +254,7 @@ class Act3D(nn.Module):
                 idx = None
             else:
                 idx = O.knn_topk(prev_pos, pcd_pyramid[i], 32 * 32 * ncam)
-            ctx = O.BuildContextFn.apply(feats[i], idx, grip_tok)
+            ctx = O.BuildContextFn.apply(feats[i], idx, grip_tok, accum[id(feats[i])])
             ctx_xyz = O.gather_rows(pcd_pyramid[i], idx, grip_xyz[:, None])
             topk_pyramid.append(idx)
             if self.use_instruction:

@@ -12,6 +12,10 @@ LIB_PATH = os.path.join(PKG_DIR, "libact3d_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 SOURCES = ["api.hip", "linear.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# The attention kernels never produce NaNs on their own (masked rows are handled explicitly, -inf only enters exp2):
+# without IEEE-mode sNaN quieting hipcc drops the canonicalising v_max_f32 x, x it otherwise puts in front of every fmaxf
+# on an MFMA result (12 of 108 VALU instructions per 64-key chunk of the VALU-bound forward loop).
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"], "attention_bwd.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def _hipcc():
@@ -29,7 +33,7 @@ def build(force=False, verbose=False):
     """Compile every csrc/*.hip for gfx950 and link libact3d_hip.so.  Returns the library path."""
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, "a3d_common.h"), os.path.join(INCLUDE, "act3d_hip.h")]
+    deps = [os.path.join(CSRC, "a3d_common.h"), os.path.join(INCLUDE, "act3d_hip.h"), os.path.abspath(__file__)]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     for s in srcs:
@@ -40,7 +44,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

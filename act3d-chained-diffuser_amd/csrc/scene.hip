@@ -328,6 +328,58 @@ __global__ __launch_bounds__(256) void build_context_kernel(
   }
 }
 
+// bf16 token rows (the FPN's channels-last bf16 output read in place: [B][Npts][4 * E4] bf16) -> fp32 context rows
+__global__ __launch_bounds__(256) void build_context_bf16_kernel(
+    const unsigned short* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
+    float* __restrict__ ctx, int B, int Npts, int k, int X, int E4) {
+  const int S = k + X;
+  const size_t total = (size_t)B * S * E4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E4);
+    const size_t row = i / E4;
+    const int s = (int)(row % S), b = (int)(row / S);
+    float4 v;
+    if (s < k) {
+      const long long src = idx ? idx[(size_t)b * k + s] : (long long)s;
+      const s16x4 h = reinterpret_cast<const s16x4*>(feat)[((size_t)b * Npts + src) * E4 + e];
+      v = make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
+    } else {
+      v = reinterpret_cast<const float4*>(extra)[((size_t)b * X + (s - k)) * E4 + e];
+    }
+    reinterpret_cast<float4*>(ctx)[i] = v;
+  }
+}
+
+// d(ctx) rows -> the bf16 gradient map of the token tensor (zero-initialised by the caller, shared by every level that
+// gathered from the map: accumulate = read-add-store, indices unique within one call); extra rows -> dextra (fp32)
+__global__ __launch_bounds__(256) void build_context_bwd_bf16_kernel(
+    const float* __restrict__ dctx, const long long* __restrict__ idx, unsigned short* __restrict__ dfeat,
+    float* __restrict__ dextra, int B, int Npts, int k, int X, int E4, int accumulate) {
+  const int S = k + X;
+  const size_t total = (size_t)B * S * E4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E4);
+    const size_t row = i / E4;
+    const int s = (int)(row % S), b = (int)(row / S);
+    float4 v = reinterpret_cast<const float4*>(dctx)[i];
+    if (s < k) {
+      if (!dfeat) continue;
+      const long long dst = idx ? idx[(size_t)b * k + s] : (long long)s;
+      s16x4* p = reinterpret_cast<s16x4*>(dfeat) + ((size_t)b * Npts + dst) * E4 + e;
+      if (accumulate) {
+        const s16x4 o = *p;
+        v.x += bf2f((unsigned short)o[0]); v.y += bf2f((unsigned short)o[1]);
+        v.z += bf2f((unsigned short)o[2]); v.w += bf2f((unsigned short)o[3]);
+      }
+      s16x4 r;
+      r[0] = (short)f2bf(v.x); r[1] = (short)f2bf(v.y); r[2] = (short)f2bf(v.z); r[3] = (short)f2bf(v.w);
+      *p = r;
+    } else if (dextra) {
+      reinterpret_cast<float4*>(dextra)[((size_t)b * X + (s - k)) * E4 + e] = v;
+    }
+  }
+}
+
 // scalar-width variant for xyz rows (W floats per row)
 __global__ __launch_bounds__(256) void build_context_rows_kernel(
     const float* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
@@ -460,4 +512,31 @@ extern "C" int a3d_build_context_bwd(const float* dctx, const long long* idx, fl
   hipLaunchKernelGGL(build_context_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dctx, idx, dfeat,
                      dextra, B, Npts, k, X, W / 4, accumulate);
   return check_launch("a3d_build_context_bwd");
+}
+
+extern "C" int a3d_build_context_bf16(const void* feat, const long long* idx, const float* extra, float* ctx, int B,
+                                      int Npts, int k, int X, int W, void* stream) {
+  if (!feat || !ctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || (X > 0 && !extra) || (!idx && k != Npts) ||
+      ((((uintptr_t)feat) & 7) != 0) || ((((uintptr_t)ctx | (uintptr_t)extra) & 15) != 0)) {
+    set_error("a3d_build_context_bf16: bad argument (B=%d Npts=%d k=%d X=%d W=%d; W %% 4 == 0, 8 / 16-byte aligned)", B, Npts, k, X, W);
+    return A3D_ERR_ARG;
+  }
+  const size_t total = (size_t)B * (k + X) * (W / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(build_context_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)feat, idx,
+                     extra, ctx, B, Npts, k, X, W / 4);
+  return check_launch("a3d_build_context_bf16");
+}
+
+extern "C" int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, float* dextra, int B,
+                                          int Npts, int k, int X, int W, int accumulate, void* stream) {
+  if (!dctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || (!idx && k != Npts) || ((((uintptr_t)dfeat) & 7) != 0)) {
+    set_error("a3d_build_context_bwd_bf16: bad argument (B=%d Npts=%d k=%d X=%d W=%d)", B, Npts, k, X, W);
+    return A3D_ERR_ARG;
+  }
+  const size_t total = (size_t)B * (k + X) * (W / 4);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(build_context_bwd_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dctx, idx,
+                     (unsigned short*)dfeat, dextra, B, Npts, k, X, W / 4, accumulate);
+  return check_launch("a3d_build_context_bwd_bf16");
 }

@@ -600,37 +600,66 @@ def gather_rows(src, idx, extra=None):
     return out
 
 
+class GradAccum:
+    """One gradient buffer for a token map that several pyramid levels gather from (levels >= 1 share the res1 map,
+    act3d.py:86): every level's backward scatters into it and only the last one hands it to autograd, instead of one
+    dense map per level plus the adds that sum them."""
+
+    def __init__(self):
+        self.buf, self.pending = None, 0
+
+
 class BuildContextFn(torch.autograd.Function):
-    """ctx tokens = [feat[b][idx[b]] | extra[b]]  (act3d.py:247-260).  feat (B, Npts, E), extra (B, X, E)."""
+    """ctx tokens = [feat[b][idx[b]] | extra[b]]  (act3d.py:247-260).  feat (B, Npts, E) fp32, or bf16 (the FPN's
+    channels-last output read in place: no fp32 copy of the map, the gradient goes back as one bf16 map); extra (B, X, E)."""
 
     @staticmethod
-    def forward(ctx, feat, idx, extra):
+    def forward(ctx, feat, idx, extra, accum=None):
         L.require_gpu(feat)
         feat, extra = _c(feat), _c(extra)
         B, Npts, E = feat.shape
         k = idx.shape[1] if idx is not None else Npts
         X = extra.shape[1]
         out = torch.empty((B, k + X, E), device=feat.device, dtype=F32)
-        L.call("a3d_build_context", feat.data_ptr(), None if idx is None else idx.data_ptr(), extra.data_ptr(),
-               out.data_ptr(), B, Npts, k, X, E, L.stream())
+        bf = feat.dtype == torch.bfloat16
+        L.call("a3d_build_context_bf16" if bf else "a3d_build_context", feat.data_ptr(), None if idx is None else idx.data_ptr(),
+               extra.data_ptr(), out.data_ptr(), B, Npts, k, X, E, L.stream())
         ctx.idx = idx
-        ctx.meta = (B, Npts, k, X, E)
+        ctx.accum = accum
+        if accum is not None:
+            accum.pending += 1
+        ctx.meta = (B, Npts, k, X, E, bf)
         return out
 
     @staticmethod
     def backward(ctx, dctx):
-        B, Npts, k, X, E = ctx.meta
+        B, Npts, k, X, E, bf = ctx.meta
         dctx = _c(dctx)
-        idx = ctx.idx
+        idx, accum = ctx.idx, ctx.accum
         dfeat = dextra = None
+        accumulate = 0
         if ctx.needs_input_grad[0]:
-            dfeat = (torch.zeros if idx is not None else torch.empty)((B, Npts, E), device=dctx.device, dtype=F32)
+            dt = torch.bfloat16 if bf else F32
+            if accum is not None and accum.buf is None and accum.pending == 1:
+                accum.pending, accum = 0, None         # the map's only consumer: no shared buffer needed
+            if accum is not None:
+                if accum.buf is None:
+                    accum.buf = torch.zeros((B, Npts, E), device=dctx.device, dtype=dt)
+                dfeat, accumulate = accum.buf, 1
+            else:
+                dfeat = (torch.zeros if idx is not None else torch.empty)((B, Npts, E), device=dctx.device, dtype=dt)
         if ctx.needs_input_grad[2]:
             dextra = torch.empty((B, X, E), device=dctx.device, dtype=F32)
-        L.call("a3d_build_context_bwd", dctx.data_ptr(), None if idx is None else idx.data_ptr(),
-               None if dfeat is None else dfeat.data_ptr(), None if dextra is None else dextra.data_ptr(), B, Npts, k,
-               X, E, 0, L.stream())
-        return dfeat, None, dextra
+        L.call("a3d_build_context_bwd_bf16" if bf else "a3d_build_context_bwd", dctx.data_ptr(),
+               None if idx is None else idx.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
+               None if dextra is None else dextra.data_ptr(), B, Npts, k, X, E, accumulate, L.stream())
+        if accum is not None:
+            accum.pending -= 1
+            if accum.pending > 0:
+                dfeat = None                    # a later backward of the same map returns the shared buffer
+            else:
+                accum.buf = None
+        return dfeat, None, dextra, None
 
 
 # ------------------------------------------------------------------------------------------------ heads / losses

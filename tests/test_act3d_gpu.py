@@ -243,3 +243,39 @@ def test_act3d_full_shapes_vs_oracle_teacher_forced(a3d, dev, name, B, ncam, lev
             assert err <= GRAD_TOL * denom + 1e-4, f"grad {n}: err {err:.3e} vs absmax {denom:.3e}"
     scale_close(f"{name} d feat level0", d0.grad, f0.grad, GRAD_TOL, floor=0.0)
     scale_close(f"{name} d feat fine", d1.grad, f1.grad, GRAD_TOL, floor=0.0)
+
+
+def test_bf16_token_maps_gathered_in_place_equal_the_fp32_copy(a3d, dev):
+    """The bf16 training path (bench.py: fpn_dtype = bf16) hands the FPN's channels-last bf16 map to the hot path as is.
+    Feeding the same bf16 values as an fp32 copy must give the identical forward, and the bf16 gradient map (shared by
+    the two fine levels, accumulated in place) must equal the rounded fp32 one."""
+    r, cfg, names = _act3d_case("train_L3_C1_N64")
+    P = act3d_params(cfg, r["seed"], r["gain"], names)
+    inp, _, _ = _golden_inputs(r, cfg, dev)
+    crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    sample = {"action": inp["action"].to(dev), "task": ["t"] * cfg["B"]}
+    res = {}
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        m = build_model(a3d, dev, cfg, P, cfg["Ng"], True)
+        maps = [f.to(dev).to(torch.bfloat16).to(dt).requires_grad_() for f in inp["feats"][:2]]
+        toks = [C.tokens_from_maps(f) for f in maps]
+        feats = [toks[0]] + [toks[1]] * (cfg["levels"] - 1)
+        out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
+                ghost_points=[g.to(dev) for g in r["ghost"]], visual_features=feats)
+        loss = sum(crit.compute_loss(out, sample).values())
+        loss.backward()
+        res[tag] = (out, loss, maps, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    ob, lb, mb, gb = res["bf16"]
+    of, lf, mf, gf = res["fp32"]
+    assert torch.equal(lb, lf)
+    for i in range(cfg["levels"]):
+        assert torch.equal(ob["ghost_pcd_masks_pyramid"][i][-1], of["ghost_pcd_masks_pyramid"][i][-1])
+    for n in gf:
+        assert torch.equal(gb[n], gf[n]), n
+    for a, b in zip(mb, mf):
+        assert a.grad.dtype == torch.bfloat16
+        ref = b.grad
+        err = (a.grad.float() - ref).abs().max().item()
+        print(f"[parity] bf16 token-map gradient vs fp32: max abs err {err:.3e} (scale {ref.abs().max().item():.3e})")
+        assert err <= 2 ** -7 * ref.abs().max().item()            # two bf16 roundings (one per fine level) at most
+        assert torch.equal(a.grad == 0, ref == 0)                  # same sparsity: only gathered rows receive a gradient
