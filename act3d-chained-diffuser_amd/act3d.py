@@ -162,12 +162,14 @@ class Act3D(nn.Module):
             feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32)
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):
-                pyr = self.feature_pyramid(feats, needed=self._needed_maps())
+                # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row
+                E_ = self.curr_gripper_embed.weight.shape[1]
+                pyr = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64)
         else:
             pyr = self.feature_pyramid(feats, needed=self._needed_maps())
         tokens = {}
         for name, fm in pyr.items():
-            n, E, h, w = fm.shape
+            n, E, h, w = fm.shape                    # E: the map's channel count incl. padding (bf16 path)
             # (cam, h, w, E) rows of the channels-last map: a view, in the FPN's own dtype -- a bf16 map is gathered in place
             # by a3d_build_context_bf16 (no fp32 copy of the 128 x 128 map, of which a level reads 6 % of the rows)
             tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)

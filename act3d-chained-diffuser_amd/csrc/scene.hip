@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void build_context_kernel(
 // bf16 token rows (the FPN's channels-last bf16 output read in place: [B][Npts][4 * E4] bf16) -> fp32 context rows
 __global__ __launch_bounds__(256) void build_context_bf16_kernel(
     const unsigned short* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
-    float* __restrict__ ctx, int B, int Npts, int k, int X, int E4) {
+    float* __restrict__ ctx, int B, int Npts, int k, int X, int E4, int F4) {
   const int S = k + X;
   const size_t total = (size_t)B * S * E4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void build_context_bf16_kernel(
     float4 v;
     if (s < k) {
       const long long src = idx ? idx[(size_t)b * k + s] : (long long)s;
-      const s16x4 h = reinterpret_cast<const s16x4*>(feat)[((size_t)b * Npts + src) * E4 + e];
+      const s16x4 h = reinterpret_cast<const s16x4*>(feat)[((size_t)b * Npts + src) * F4 + e];
       v = make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
     } else {
       v = reinterpret_cast<const float4*>(extra)[((size_t)b * X + (s - k)) * E4 + e];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void build_context_bf16_kernel(
 // gathered from the map: accumulate = read-add-store, indices unique within one call); extra rows -> dextra (fp32)
 __global__ __launch_bounds__(256) void build_context_bwd_bf16_kernel(
     const float* __restrict__ dctx, const long long* __restrict__ idx, unsigned short* __restrict__ dfeat,
-    float* __restrict__ dextra, int B, int Npts, int k, int X, int E4, int accumulate) {
+    float* __restrict__ dextra, int B, int Npts, int k, int X, int E4, int F4, int accumulate) {
   const int S = k + X;
   const size_t total = (size_t)B * S * E4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void build_context_bwd_bf16_kernel(
     if (s < k) {
       if (!dfeat) continue;
       const long long dst = idx ? idx[(size_t)b * k + s] : (long long)s;
-      s16x4* p = reinterpret_cast<s16x4*>(dfeat) + ((size_t)b * Npts + dst) * E4 + e;
+      s16x4* p = reinterpret_cast<s16x4*>(dfeat) + ((size_t)b * Npts + dst) * F4 + e;
       if (accumulate) {
         const s16x4 o = *p;
         v.x += bf2f((unsigned short)o[0]); v.y += bf2f((unsigned short)o[1]);
@@ -514,9 +514,9 @@ extern "C" int a3d_build_context_bwd(const float* dctx, const long long* idx, fl
   return check_launch("a3d_build_context_bwd");
 }
 
-extern "C" int a3d_build_context_bf16(const void* feat, const long long* idx, const float* extra, float* ctx, int B,
+extern "C" int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, float* ctx, int B,
                                       int Npts, int k, int X, int W, void* stream) {
-  if (!feat || !ctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || (X > 0 && !extra) || (!idx && k != Npts) ||
+  if (!feat || !ctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || ldf < W || (ldf % 4) != 0 || (X > 0 && !extra) || (!idx && k != Npts) ||
       ((((uintptr_t)feat) & 7) != 0) || ((((uintptr_t)ctx | (uintptr_t)extra) & 15) != 0)) {
     set_error("a3d_build_context_bf16: bad argument (B=%d Npts=%d k=%d X=%d W=%d; W %% 4 == 0, 8 / 16-byte aligned)", B, Npts, k, X, W);
     return A3D_ERR_ARG;
@@ -524,19 +524,19 @@ extern "C" int a3d_build_context_bf16(const void* feat, const long long* idx, co
   const size_t total = (size_t)B * (k + X) * (W / 4);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(build_context_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)feat, idx,
-                     extra, ctx, B, Npts, k, X, W / 4);
+                     extra, ctx, B, Npts, k, X, W / 4, ldf / 4);
   return check_launch("a3d_build_context_bf16");
 }
 
-extern "C" int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, float* dextra, int B,
+extern "C" int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, int ldf, float* dextra, int B,
                                           int Npts, int k, int X, int W, int accumulate, void* stream) {
-  if (!dctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || (!idx && k != Npts) || ((((uintptr_t)dfeat) & 7) != 0)) {
+  if (!dctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || ldf < W || (ldf % 4) != 0 || (!idx && k != Npts) || ((((uintptr_t)dfeat) & 7) != 0)) {
     set_error("a3d_build_context_bwd_bf16: bad argument (B=%d Npts=%d k=%d X=%d W=%d)", B, Npts, k, X, W);
     return A3D_ERR_ARG;
   }
   const size_t total = (size_t)B * (k + X) * (W / 4);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(build_context_bwd_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dctx, idx,
-                     (unsigned short*)dfeat, dextra, B, Npts, k, X, W / 4, accumulate);
+                     (unsigned short*)dfeat, dextra, B, Npts, k, X, W / 4, ldf / 4, accumulate);
   return check_launch("a3d_build_context_bwd_bf16");
 }

@@ -49,8 +49,8 @@ SIGNATURES = {
     "a3d_knn_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_build_context": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_build_context_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "a3d_build_context_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "a3d_build_context_bwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_build_context_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_build_context_bwd_bf16": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_mask_logits_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_mask_logits_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "a3d_argmax_gather": (_i, [_p, _p, _p, _p, _i, _i, _p]),

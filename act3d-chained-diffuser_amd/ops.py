@@ -617,23 +617,30 @@ class BuildContextFn(torch.autograd.Function):
     def forward(ctx, feat, idx, extra, accum=None):
         L.require_gpu(feat)
         feat, extra = _c(feat), _c(extra)
-        B, Npts, E = feat.shape
+        B, Npts, ldf = feat.shape
+        E = extra.shape[2]                                # bf16 maps may carry pad channels (ldf = 64 for E = 60)
         k = idx.shape[1] if idx is not None else Npts
         X = extra.shape[1]
         out = torch.empty((B, k + X, E), device=feat.device, dtype=F32)
         bf = feat.dtype == torch.bfloat16
-        L.call("a3d_build_context_bf16" if bf else "a3d_build_context", feat.data_ptr(), None if idx is None else idx.data_ptr(),
-               extra.data_ptr(), out.data_ptr(), B, Npts, k, X, E, L.stream())
+        if bf:
+            L.call("a3d_build_context_bf16", feat.data_ptr(), ldf, None if idx is None else idx.data_ptr(), extra.data_ptr(),
+                   out.data_ptr(), B, Npts, k, X, E, L.stream())
+        else:
+            if ldf != E:
+                raise ValueError("fp32 token rows must have exactly the context width (%d vs %d)" % (ldf, E))
+            L.call("a3d_build_context", feat.data_ptr(), None if idx is None else idx.data_ptr(), extra.data_ptr(),
+                   out.data_ptr(), B, Npts, k, X, E, L.stream())
         ctx.idx = idx
         ctx.accum = accum
         if accum is not None:
             accum.pending += 1
-        ctx.meta = (B, Npts, k, X, E, bf)
+        ctx.meta = (B, Npts, k, X, E, bf, ldf)
         return out
 
     @staticmethod
     def backward(ctx, dctx):
-        B, Npts, k, X, E, bf = ctx.meta
+        B, Npts, k, X, E, bf, ldf = ctx.meta
         dctx = _c(dctx)
         idx, accum = ctx.idx, ctx.accum
         dfeat = dextra = None
@@ -644,15 +651,20 @@ class BuildContextFn(torch.autograd.Function):
                 accum.pending, accum = 0, None         # the map's only consumer: no shared buffer needed
             if accum is not None:
                 if accum.buf is None:
-                    accum.buf = torch.zeros((B, Npts, E), device=dctx.device, dtype=dt)
+                    accum.buf = torch.zeros((B, Npts, ldf), device=dctx.device, dtype=dt)
                 dfeat, accumulate = accum.buf, 1
             else:
-                dfeat = (torch.zeros if idx is not None else torch.empty)((B, Npts, E), device=dctx.device, dtype=dt)
+                dense = idx is None and ldf == E
+                dfeat = (torch.empty if dense else torch.zeros)((B, Npts, ldf), device=dctx.device, dtype=dt)
         if ctx.needs_input_grad[2]:
             dextra = torch.empty((B, X, E), device=dctx.device, dtype=F32)
-        L.call("a3d_build_context_bwd_bf16" if bf else "a3d_build_context_bwd", dctx.data_ptr(),
-               None if idx is None else idx.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
-               None if dextra is None else dextra.data_ptr(), B, Npts, k, X, E, accumulate, L.stream())
+        iptr = None if idx is None else idx.data_ptr()
+        fptr = None if dfeat is None else dfeat.data_ptr()
+        eptr = None if dextra is None else dextra.data_ptr()
+        if bf:
+            L.call("a3d_build_context_bwd_bf16", dctx.data_ptr(), iptr, fptr, ldf, eptr, B, Npts, k, X, E, accumulate, L.stream())
+        else:
+            L.call("a3d_build_context_bwd", dctx.data_ptr(), iptr, fptr, eptr, B, Npts, k, X, E, accumulate, L.stream())
         if accum is not None:
             accum.pending -= 1
             if accum.pending > 0:

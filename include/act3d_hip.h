@@ -141,13 +141,14 @@ int a3d_build_context(const float* feat, const long long* idx, const float* extr
 int a3d_build_context_bwd(const float* dctx, const long long* idx, float* dfeat, float* dextra, int B, int Npts,
                           int k, int X, int W, int accumulate, void* stream);
 
-/* Same with bf16 token rows: `feat` is the FPN's bf16 channels-last output read in place ([B][Npts][W] bf16, 8-byte
- * aligned, W % 4 == 0), ctx / extra stay fp32; the backward accumulates into a bf16 gradient map of the same layout
- * (zero-initialised by the caller and shared by every level that gathers from the map). */
-int a3d_build_context_bf16(const void* feat, const long long* idx, const float* extra, float* ctx, int B, int Npts, int k,
-                           int X, int W, void* stream);
-int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, float* dextra, int B, int Npts,
-                               int k, int X, int W, int accumulate, void* stream);
+/* Same with bf16 token rows: `feat` is the FPN's bf16 channels-last output read in place ([B][Npts][ldf] bf16 with the
+ * W token channels first -- ldf = 64 when the FPN runs channel-padded for MIOpen -- 8-byte aligned, W, ldf % 4 == 0);
+ * ctx / extra stay fp32; the backward accumulates into a bf16 gradient map of the same layout (zero-initialised by the
+ * caller and shared by every level that gathers from the map; pad channels are never written). */
+int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, float* ctx, int B, int Npts,
+                           int k, int X, int W, void* stream);
+int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, int ldf, float* dextra, int B,
+                               int Npts, int k, int X, int W, int accumulate, void* stream);
 
 /* ---- decoding heads, losses, sampler, optimizer ----------------------------------------------------------- */
 int a3d_mask_logits_fwd(const float* q, const float* F, float* out, int B, int Ng, int E, void* stream);
