@@ -276,8 +276,10 @@ def test_bf16_token_maps_gathered_in_place_equal_the_fp32_copy(a3d, dev):
         assert torch.equal(a.grad[..., :60], C.tokens_from_maps(b.grad)) and (a.grad[..., 60:] == 0).all()
     for i in range(cfg["levels"]):
         assert torch.equal(ob["ghost_pcd_masks_pyramid"][i][-1], of["ghost_pcd_masks_pyramid"][i][-1])
-    for n in gf:      # same arithmetic; the small-M weight gradients accumulate with float atomics (order noise only)
-        assert (gb[n] - gf[n]).abs().max().item() <= 1e-5 * max(1e-3, gf[n].abs().max().item()), n
+    gmax = max(g_.abs().max().item() for g_ in gf.values())
+    for n in gf:      # same arithmetic; the small-M weight gradients accumulate with float atomics (order noise only, also
+        #               on tensors whose gradient is mathematically zero -- hence the scale of ALL gradients in the bound)
+        assert (gb[n] - gf[n]).abs().max().item() <= 1e-5 * max(1e-3 * gmax, gf[n].abs().max().item()), n
     for a, b in zip(mb, mf):
         assert a.grad.dtype == torch.bfloat16
         ref = b.grad
