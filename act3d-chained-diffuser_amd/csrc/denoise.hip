@@ -1,0 +1,586 @@
+// One evaluation of the ChainedDiffuser denoising network, fused for the 100-step sampling loop (inference only).
+//
+// Reference: DiffusionHead.forward / _one_attention_round (model/trajectory_optimization/diffusion_head.py:200-363) called
+// once per step by DiffusionPlanner.conditional_sample (diffusion_model.py:86-119), on top of ParallelAttentionLayer
+// (model/utils/layers.py:115-218) and MultiheadCustomAttention (multihead_custom_attention.py:157-462).
+//
+// The unfused path issues ~200 launches per step for B * L = 1024 trajectory rows (25 per layer: AdaLN, projection,
+// RoPE + operand split, attention, combine, out-projection, LayerNorm, ...), each a few microseconds of latency.  Here a
+// step is 18 launches:
+//   a3d_dn_head   per sample:  traj_encoder MLP -> [+ index embedding -> q-proj -> attention over the 53 instruction
+//                 tokens -> out-proj -> LayerNorm]                                     (diffusion_head.py:214-219,330-335)
+//   per layer (8): a3d_dn_cross  per (sample, head, key split): AdaLN(x + index embedding) -> this head's q-projection
+//                 -> RoPE -> flash attention of the L <= 16 queries against the cached context K / V, streamed from
+//                 HBM straight into MFMA operands (no LDS staging: a 16-query tile has no reuse to stage for)
+//                 a3d_dn_rest   per sample: combine the key splits -> out-proj -> LayerNorm -> self-attention block
+//                 (AdaLN, q/k/v projection, RoPE, 16 x 16 softmax, out-proj, LayerNorm) -> AdaLN -> FFN -> LayerNorm
+//   a3d_dn_tail   per sample: position / rotation regressors -> trajectory update -> DDPM step (inpainting, clipping,
+//                 posterior mean + noise)                      (diffusion_head.py:268-272, diffusion_model.py:106-117)
+// Context K is cached as fp32 rows [B][H][Sp][16] (64 B per key and head) and multiplied with the exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32): fp32 logits at 2/3 of the bytes of the three-part bf16 rows; V stays two-part bf16 planes
+// (64 B): 128 B per key and head.  The kernel is HBM-bound (Lq = 16), so the slower f32 MFMA costs nothing.
+// All dense layers use the same exact-f32 MFMA as linear.hip (an fmaf chain in k order).
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int DR = 16;            // trajectory rows (steps) per sample: one MFMA tile
+constexpr int LDX = 132;          // LDS row stride (floats) of the [16][<=128] tiles
+constexpr int LDQK = 260;         // [16][<=256]
+constexpr int LDH = 516;          // [16][<=512]
+
+// Y[16][N] = act(X[16][K] W[N][K]^T + bias), X / Y in LDS (X zero-padded to a multiple of 16 columns), W / bias in
+// global memory.  The four waves take the 16-column output tiles round-robin.  Contraction index permutation: MFMA j of a
+// 16-channel block contracts lane group g with channel 4 g + j, so that A and B are one float4 each per block.
+template <int ACT>
+__device__ __forceinline__ void wg_linear(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
+                                          const float* __restrict__ bias, int N, float* Ys, int ldy) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const bool vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  const int ntile = (N + 15) >> 4;
+  for (int ct = wave; ct < ntile; ct += 4) {
+    const int n = ct * 16 + li;
+    const float* wrow = W + (size_t)min(n, N - 1) * ldw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < K; kk += 16) {
+      const int k0 = kk + 4 * g;
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + k0]);
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        if (vec && k0 + 3 < K) {
+          wv = *reinterpret_cast<const float4*>(wrow + k0);
+        } else {
+          if (k0 + 0 < K) wv.x = wrow[k0 + 0];
+          if (k0 + 1 < K) wv.y = wrow[k0 + 1];
+          if (k0 + 2 < K) wv.z = wrow[k0 + 2];
+          if (k0 + 3 < K) wv.w = wrow[k0 + 3];
+        }
+      }
+      acc = mfma_f32_16x16x4(a.x, wv.x, acc);
+      acc = mfma_f32_16x16x4(a.y, wv.y, acc);
+      acc = mfma_f32_16x16x4(a.z, wv.z, acc);
+      acc = mfma_f32_16x16x4(a.w, wv.w, acc);
+    }
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[r] + bv;
+        if (ACT == 1) v = fmaxf(v, 0.f);
+        Ys[(g * 4 + r) * ldy + n] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// zero the pad columns [E, Epad) of a [16][ld] tile
+__device__ __forceinline__ void wg_zero_pad(float* T, int ld, int E, int Epad) {
+  for (int i = threadIdx.x; i < DR * (Epad - E); i += blockDim.x) {
+    const int r = i / (Epad - E), c = E + i - r * (Epad - E);
+    T[r * ld + c] = 0.f;
+  }
+}
+
+// Y = LayerNorm(A + R) * gamma + beta over E columns, 16 threads per row (two-pass, like add_ln_fwd_kernel)
+__device__ __forceinline__ void wg_add_layernorm(const float* A, int lda, const float* R, int ldr, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* Y, int ldy, int E) {
+  const int r = threadIdx.x >> 4, s = threadIdx.x & 15;
+  float sum = 0.f;
+  for (int c = s; c < E; c += 16) sum += A[r * lda + c] + R[r * ldr + c];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)E;
+  float q = 0.f;
+  for (int c = s; c < E; c += 16) {
+    const float d = A[r * lda + c] + R[r * ldr + c] - mean;
+    q += d * d;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)E + 1e-5f);
+  __syncthreads();                                   // Y may alias A or R
+  float keep[8];
+  int i = 0;
+  for (int c = s; c < E; c += 16, ++i) keep[i] = (A[r * lda + c] + R[r * ldr + c] - mean) * rstd * gamma[c] + beta[c];
+  __syncthreads();
+  i = 0;
+  for (int c = s; c < E; c += 16, ++i) Y[r * ldy + c] = keep[i];
+  __syncthreads();
+}
+
+// Y = (X [+ sem]) * (1 + mod[c]) + mod[E + c]   (AdaLN, layers.py:273-290; mod == nullptr: plain X [+ sem])
+__device__ __forceinline__ void wg_adaln(const float* X, int ldx, const float* __restrict__ sem, const float* __restrict__ mod,
+                                         float* Y, int ldy, int L, int E) {
+  for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
+    const int r = i / E, c = i - r * E;
+    float v = X[r * ldx + c];
+    if (sem && r < L) v += sem[r * E + c];
+    if (mod) v = v * (1.0f + mod[c]) + mod[E + c];
+    Y[r * ldy + c] = v;
+  }
+  __syncthreads();
+}
+
+// in-place RoPE-3D of the E-wide blocks starting at columns col0, col0 + E, ... (nblk blocks) of T, by the rows' xyz
+__device__ __forceinline__ void wg_rope(float* T, int ld, int col0, int nblk, const float* __restrict__ xyz, int ldxyz,
+                                        const float* __restrict__ freq, int L, int E) {
+  const int half = E >> 1, third = E / 3;
+  for (int i = threadIdx.x; i < DR * half; i += blockDim.x) {
+    const int r = i / half, p = i - r * half;
+    if (r >= L) continue;
+    const int c = 2 * p;
+    const int axis = c / third;
+    const int k = (c - axis * third) >> 1;
+    const float th = xyz[r * ldxyz + axis] * freq[k];
+    float sn, cs;
+    sincosf(th, &sn, &cs);
+    for (int bk = 0; bk < nblk; ++bk) {
+      float* q = T + r * ld + col0 + bk * E + c;
+      const float y0 = q[0], y1 = q[1];
+      q[0] = y0 * cs - y1 * sn;
+      q[1] = y1 * cs + y0 * sn;
+    }
+  }
+  __syncthreads();
+}
+
+// O[l][h * 15 + d] = softmax_s(q_h[l] . k_h[s] + mask) v_h[s]; one thread per (row, head), keys in a loop (S is small: the
+// 53 instruction tokens or the <= 16 trajectory steps).  Q in LDS; K / V rows at stride ldk / ldv (global or LDS).
+__device__ __forceinline__ void wg_small_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                                   const unsigned char* __restrict__ kmask, int S, int H, float* O, int ldo) {
+  const int r = threadIdx.x >> 4, h = threadIdx.x & 15;
+  if (h < H) {
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = Q[r * ldq + h * HD + d]; acc[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int s = 0; s < S; ++s) {
+      if (kmask && kmask[s]) continue;
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sc += q[d] * K[(size_t)s * ldk + h * HD + d];
+      const float mn = fmaxf(m, sc);
+      const float a = __expf(m - mn), p = __expf(sc - mn);
+      l = l * a + p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * V[(size_t)s * ldv + h * HD + d];
+      m = mn;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) O[r * ldo + h * HD + d] = acc[d] * inv;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void wg_load_rows(const float* __restrict__ src, int E, int L, float* T, int ld, int Epad) {
+  for (int i = threadIdx.x; i < DR * Epad; i += blockDim.x) {
+    const int r = i / Epad, c = i - r * Epad;
+    T[r * ld + c] = (r < L && c < E) ? src[r * E + c] : 0.f;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ head
+__global__ __launch_bounds__(256) void dn_head_kernel(const float* __restrict__ traj, int D, a3d_dn_head_params p,
+                                                      float* __restrict__ x_out, int L, int E, int H) {
+  __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], As[DR * LDX], Ts[DR * LDX], Qs[DR * LDX];
+  const int b = blockIdx.x;
+  const int Epad = (E + 15) & ~15;
+  // trajectory rows (D = 9 channels) padded to one 16-channel block
+  for (int i = threadIdx.x; i < DR * 16; i += blockDim.x) {
+    const int r = i >> 4, c = i & 15;
+    As[r * LDX + c] = (r < L && c < D) ? traj[((size_t)b * L + r) * D + c] : 0.f;
+  }
+  wg_zero_pad(Ts, LDX, E, Epad);
+  wg_zero_pad(Xs, LDX, E, Epad);
+  wg_zero_pad(Qs, LDX, E, Epad);
+  __syncthreads();
+  wg_linear<1>(As, LDX, D, p.enc_w0, D, p.enc_b0, E, Ts, LDX);          // Linear(9, E) + ReLU
+  wg_linear<0>(Ts, LDX, E, p.enc_w1, E, p.enc_b1, E, Xs, LDX);          // Linear(E, E)         -> trajectory features
+  if (p.lang_kv) {
+    // traj_lang_attention: q = x + index embedding, keys = values = the instruction tokens, no positions, no AdaLN, no FFN
+    wg_zero_pad(As, LDX, E, Epad);
+    wg_adaln(Xs, LDX, p.sem, nullptr, As, LDX, L, E);
+    wg_linear<0>(As, LDX, E, p.q_w, E, p.q_b, E, Qs, LDX);
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int i = threadIdx.x; i < DR * E; i += blockDim.x) Qs[(i / E) * LDX + i % E] *= scale;
+    __syncthreads();
+    const float* kv = p.lang_kv + (size_t)b * p.S_lang * 2 * E;
+    wg_small_attention(Qs, LDX, kv, 2 * E, kv + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
+    wg_linear<0>(As, LDX, E, p.out_w, E, p.out_b, E, Ts, LDX);
+    wg_add_layernorm(Xs, LDX, Ts, LDX, p.ln_g, p.ln_b, Xs, LDX, E);
+  }
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
+}
+
+// ------------------------------------------------------------------------------------------------ cross attention
+// grid: (sample, head, key split) flattened XCD-aware; workspace Op [nsplit][B][H][16][16] (column 15 = sum_k p), Mp [..][16]
+__global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__ x, const float* __restrict__ traj, int D,
+                                                       a3d_dn_cross_params p, float* __restrict__ Op, float* __restrict__ Mp,
+                                                       int B, int L, int E, int H, int S, int Sp, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float As[DR * LDX];
+  __shared__ __attribute__((aligned(16))) float Pre[DR * 16];
+  __shared__ __attribute__((aligned(16))) float Qh[DR * 16];
+  __shared__ __attribute__((aligned(16))) float Cacc[4][16][16];
+  __shared__ float Cm[4][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  int group, sp;
+  if (!xcd_decode(nsplit, B * H, group, sp)) return;
+  const int b = group / H, h = group - b * H;
+  const size_t bh = (size_t)b * H + h;
+  // ---- q rows of this head: AdaLN(x + index embedding) W_q^T + b_q, scaled, rotated
+  for (int i = t; i < DR * E; i += blockDim.x) {
+    const int r = i / E, c = i - r * E;
+    float v = 0.f;
+    if (r < L) {
+      v = x[((size_t)b * L + r) * E + c] + (p.sem ? p.sem[r * E + c] : 0.f);
+      if (p.mod) v = v * (1.0f + p.mod[c]) + p.mod[E + c];
+    }
+    As[r * LDX + c] = v;
+  }
+  __syncthreads();
+  const int c_lo = (h * HD) & ~1;                     // 16-channel window holding the head's 15 channels and their RoPE partners
+  {
+    const int r = t >> 4, j = t & 15, c = c_lo + j;
+    float acc = 0.f;
+    if (c < E) {
+      const float* wrow = p.q_w + (size_t)c * E;
+      for (int k = 0; k < E; ++k) acc += As[r * LDX + k] * wrow[k];
+      acc = (acc + p.q_b[c]) * (1.0f / sqrtf((float)HD));
+    }
+    Pre[r * 16 + j] = acc;
+  }
+  __syncthreads();
+  if (p.freq && (t & 1) == 0) {
+    const int r = t >> 4, j = t & 15, c = c_lo + j;       // c even: pair (c, c + 1)
+    if (c + 1 < E && r < L) {
+      const int third = E / 3;
+      const int axis = c / third;
+      const int k = (c - axis * third) >> 1;
+      const float th = traj[((size_t)b * L + r) * D + axis] * p.freq[k];
+      float sn, cs;
+      sincosf(th, &sn, &cs);
+      const float y0 = Pre[r * 16 + j], y1 = Pre[r * 16 + j + 1];
+      Pre[r * 16 + j] = y0 * cs - y1 * sn;
+      Pre[r * 16 + j + 1] = y1 * cs + y0 * sn;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = t >> 4, d = t & 15;
+    Qh[r * 16 + d] = (d < HD && r < L) ? Pre[r * 16 + (h * HD - c_lo) + d] : 0.f;
+  }
+  __syncthreads();
+  const float4 qb = *reinterpret_cast<const float4*>(&Qh[li * 16 + 4 * g]);     // B operand: channel 4 g + j of query li
+
+  // ---- this wave's range of 32-key halves
+  const int NH = Sp >> 5;
+  const int parts = nsplit * 4, part = sp * 4 + wave;
+  const int h_beg = (int)((long long)NH * part / parts), h_end = (int)((long long)NH * (part + 1) / parts);
+  const float* Kb = p.Kf + bh * (size_t)Sp * 16;
+  const unsigned short* Vhi = p.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)Sp;
+  const unsigned short* Vlo = p.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)Sp;
+  const int krow_off[2] = {(li >> 2) * 8 + (li & 3), (li >> 2) * 8 + (li & 3) + 4};
+  struct Frag { float4 k0, k1; s16x8 vh, vl; };
+  auto load = [&](int hf) {
+    Frag f;
+    const int key0 = hf * 32;
+    f.k0 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g);
+    f.k1 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g);
+    f.vh = *reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8);
+    f.vl = *reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8);
+    return f;
+  };
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  float m_run = -INFINITY;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  Frag cur;
+  if (h_beg < h_end) cur = load(h_beg);
+  for (int hf = h_beg; hf < h_end; ++hf) {
+    Frag nxt = cur;
+    if (hf + 1 < h_end) nxt = load(hf + 1);
+    const int key0 = hf * 32;
+    f32x4 s[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < S) ? 0.f : -INFINITY;
+      const float4 kf = T ? cur.k1 : cur.k0;
+      s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
+      s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
+      s[T] = mfma_f32_16x16x4(kf.z, qb.z, s[T]);
+      s[T] = mfma_f32_16x16x4(kf.w, qb.w, s[T]);
+    }
+    const float mt = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    const float m_new = fmaxf(m_run, colmax4(mt));
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float nm = -m_use * LOG2E_F;
+    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));
+    unsigned int hw[4], lw[4];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr], LOG2E_F, nm)),
+                          __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr + 1], LOG2E_F, nm))};
+        const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
+        const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
+        hw[T * 2 + pr] = h2;
+        lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
+      }
+    }
+    const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+    const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+    const s16x8 vh = (li == 15) ? ones : cur.vh;        // pad channel 15 := 1: acc[15] = sum_k p on the MFMA pipe
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+    acc = mfma_bf16_16x16x32(vh, phi, acc);
+    acc = mfma_bf16_16x16x32(vh, plo, acc);
+    acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
+    cur = nxt;
+  }
+  // ---- combine the four waves (disjoint key ranges) and write this split's partial
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Cacc[wave][li][g * 4 + r] = acc[r];
+  if (g == 0) Cm[wave][li] = m_run;
+  __syncthreads();
+  {
+    const int q = t >> 4, d = t & 15;
+    const float m = fmaxf(fmaxf(Cm[0][q], Cm[1][q]), fmaxf(Cm[2][q], Cm[3][q]));
+    const float m_use = (m == -INFINITY) ? 0.f : m;
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o += __expf(Cm[w][q] - m_use) * Cacc[w][q][d];
+    const size_t row = (((size_t)sp * B + b) * H + h) * 16 + q;
+    Op[row * 16 + d] = o;
+    if (d == 0) Mp[row] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ rest of a layer
+__global__ __launch_bounds__(256) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
+                                                      const float* __restrict__ Op, const float* __restrict__ Mp,
+                                                      a3d_dn_rest_params p, float* __restrict__ x_out, int B, int L,
+                                                      int E, int H, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                       // [16][LDX]  residual stream
+  float* As = Xs + DR * LDX;              // [16][LDX]
+  float* Bs = As + DR * LDX;              // [16][LDX]
+  float* Ts = Bs + DR * LDX;              // [16][LDX]
+  float* QK = Ts + DR * LDX;              // [16][LDQK]
+  float* Hs = QK + DR * LDQK;             // [16][LDH]
+  const int b = blockIdx.x;
+  const int Epad = (E + 15) & ~15;
+  wg_load_rows(x_in + (size_t)b * L * E, E, L, Xs, LDX, Epad);
+  wg_zero_pad(As, LDX, E, Epad);
+  wg_zero_pad(Bs, LDX, E, Epad);
+  wg_zero_pad(Ts, LDX, E, Epad);
+  // ---- cross-attention output: combine the key splits
+  for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
+    const int r = i / E, c = i - r * E;
+    const int h = c / HD, d = c - h * HD;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, Mp[(((size_t)s * B + b) * H + h) * 16 + r]);
+    const float m_use = (m == -INFINITY) ? 0.f : m;
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const size_t row = (((size_t)s * B + b) * H + h) * 16 + r;
+      const float w = __expf(Mp[row] - m_use);
+      num += w * Op[row * 16 + d];
+      den += w * Op[row * 16 + 15];
+    }
+    As[r * LDX + c] = den > 0.f ? num / den : 0.f;
+  }
+  __syncthreads();
+  wg_linear<0>(As, LDX, E, p.c_out_w, E, p.c_out_b, E, Ts, LDX);
+  wg_add_layernorm(Xs, LDX, Ts, LDX, p.c_ln_g, p.c_ln_b, Xs, LDX, E);
+  if (p.s_in_w) {
+    // ---- self-attention: q = k = AdaLN(x + index embedding), v = AdaLN(x), RoPE by the steps' xyz, padded steps masked
+    wg_adaln(Xs, LDX, p.sem, p.s_mod, As, LDX, L, E);
+    wg_adaln(Xs, LDX, nullptr, p.s_mod, Bs, LDX, L, E);
+    wg_linear<0>(As, LDX, E, p.s_in_w, E, p.s_in_b, 2 * E, QK, LDQK);                      // [q | k]
+    wg_linear<0>(Bs, LDX, E, p.s_in_w + (size_t)2 * E * E, E, p.s_in_b + 2 * E, E, Hs, LDH);   // v
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int i = threadIdx.x; i < DR * E; i += blockDim.x) QK[(i / E) * LDQK + i % E] *= scale;
+    __syncthreads();
+    if (p.freq) wg_rope(QK, LDQK, 0, 2, traj + (size_t)b * L * D, D, p.freq, L, E);
+    wg_small_attention(QK, LDQK, QK + E, LDQK, Hs, LDH, p.kmask ? p.kmask + (size_t)b * L : nullptr, L, H, As, LDX);
+    wg_linear<0>(As, LDX, E, p.s_out_w, E, p.s_out_b, E, Ts, LDX);
+    wg_add_layernorm(Xs, LDX, Ts, LDX, p.s_ln_g, p.s_ln_b, Xs, LDX, E);
+  }
+  if (p.f_w1) {
+    // ---- FFN: y = AdaLN(x); x = LayerNorm(y + W2 relu(W1 y + b1) + b2)
+    wg_adaln(Xs, LDX, nullptr, p.f_mod, As, LDX, L, E);
+    for (int i = threadIdx.x; i < DR * (((p.F + 15) & ~15) - p.F); i += blockDim.x) {
+      const int padw = ((p.F + 15) & ~15) - p.F;
+      Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
+    }
+    __syncthreads();
+    wg_linear<1>(As, LDX, E, p.f_w1, E, p.f_b1, p.F, Hs, LDH);
+    wg_linear<0>(Hs, LDH, p.F, p.f_w2, p.F, p.f_b2, E, Ts, LDX);
+    wg_add_layernorm(As, LDX, Ts, LDX, p.f_ln_g, p.f_ln_b, Xs, LDX, E);
+  }
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
+}
+
+// ------------------------------------------------------------------------------------------------ tail
+__global__ __launch_bounds__(256) void dn_tail_kernel(const float* __restrict__ pos_feats, const float* __restrict__ rot_feats,
+                                                      const float* __restrict__ traj, int D, a3d_dn_tail_params p,
+                                                      float* __restrict__ traj_out, int L, int E, int t_step) {
+  __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], Ts[DR * LDX], Us[DR * 16];
+  const int b = blockIdx.x;
+  const int Epad = (E + 15) & ~15;
+  wg_zero_pad(Ts, LDX, E, Epad);
+  wg_load_rows(pos_feats + (size_t)b * L * E, E, L, Xs, LDX, Epad);
+  wg_linear<1>(Xs, LDX, E, p.pos_w0, E, p.pos_b0, E, Ts, LDX);
+  wg_linear<0>(Ts, LDX, E, p.pos_w1, E, p.pos_b1, 3, Us, 16);
+  wg_load_rows(rot_feats + (size_t)b * L * E, E, L, Xs, LDX, Epad);
+  wg_linear<1>(Xs, LDX, E, p.rot_w0, E, p.rot_b0, E, Ts, LDX);
+  wg_linear<0>(Ts, LDX, E, p.rot_w1, E, p.rot_b1, D - 3, Us + 3, 16);
+  // out = cat(traj_xyz + d_pos, rot); then the reverse step of diffusion_model.py:106-117 (see a3d_ddpm_step)
+  for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
+    const int r = i / D, c = i - r * D;
+    const size_t gi = ((size_t)b * L + r) * D + c;
+    float mo = Us[r * 16 + c] + (c < 3 ? traj[gi] : 0.f);
+    if (p.cond_mask && p.cond_mask[gi]) mo = p.cond_data[gi];
+    float out = mo;
+    if (t_step > 0) {
+      const float* cf = ((c < 3) ? p.coef_pos : p.coef_rot) + (size_t)t_step * 3;
+      const float x0 = fminf(fmaxf(mo, -1.0f), 1.0f);
+      out = cf[0] * x0 + cf[1] * traj[gi];
+      if (p.noise) out += cf[2] * p.noise[gi];
+    }
+    traj_out[gi] = out;
+  }
+}
+
+// rotated K rows in fp32: out[b][h][n][d] = rope(Y[b, n, :E] * scale)[h * 15 + d] (d < 15; column 15 and rows >= N zero)
+__global__ __launch_bounds__(256) void rope_rows_f32_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ xyz,
+                                                            const float* __restrict__ freq, float scale, float* __restrict__ out,
+                                                            int B, int N, int Npad, int E, int H) {
+  const size_t total = (size_t)B * H * Npad * 16;
+  const int third = E / 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i & 15);
+    const size_t row = i >> 4;
+    const int n = (int)(row % Npad);
+    const size_t bh = row / Npad;
+    const int h = (int)(bh % H), b = (int)(bh / H);
+    float v = 0.f;
+    if (d < HD && n < N) {
+      const int c = h * HD + d;
+      const size_t m = (size_t)b * N + n;
+      const float y = Y[m * ldy + c] * scale;
+      if (xyz) {
+        const int ce = c & ~1;
+        const int axis = ce / third;
+        const int k = (ce - axis * third) >> 1;
+        float sn, cs;
+        sincosf(xyz[m * 3 + axis] * freq[k], &sn, &cs);
+        const float yp = Y[m * ldy + (c ^ 1)] * scale;
+        v = (c & 1) ? (y * cs + yp * sn) : (y * cs - yp * sn);
+      } else {
+        v = y;
+      }
+    }
+    out[i] = v;
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+static int dn_check(const char* fn, int B, int L, int E, int H) {
+  if (B <= 0 || L <= 0 || L > DR || E <= 0 || E > 128 || (E % 6) != 0 || H * HD != E) {
+    set_error("%s: bad shape (B=%d L=%d E=%d H=%d; L <= 16, E = 15 H <= 128)", fn, B, L, E, H);
+    return A3D_ERR_ARG;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_dn_head(const float* traj, int D, const a3d_dn_head_params* p, float* x_out, int B, int L, int E, int H,
+                           void* stream) {
+  int rc = dn_check("a3d_dn_head", B, L, E, H);
+  if (rc) return rc;
+  if (!traj || !p || !x_out || D <= 0 || D > 16 || !p->enc_w0 || !p->enc_w1 ||
+      (p->lang_kv && (!p->q_w || !p->out_w || !p->ln_g || !p->sem || p->S_lang <= 0))) {
+    set_error("a3d_dn_head: bad argument");
+    return A3D_ERR_ARG;
+  }
+  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
+  return check_launch("a3d_dn_head");
+}
+
+extern "C" size_t a3d_dn_cross_ws_floats(int B, int H, int nsplit) { return (size_t)nsplit * B * H * 16 * 17; }
+
+extern "C" int a3d_dn_cross(const float* x, const float* traj, int D, const a3d_dn_cross_params* p, float* ws, int B, int L,
+                            int E, int H, int S, int Sp, int nsplit, void* stream) {
+  int rc = dn_check("a3d_dn_cross", B, L, E, H);
+  if (rc) return rc;
+  if (!x || !traj || !p || !ws || !p->q_w || !p->q_b || !p->Kf || !p->Vt || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 ||
+      nsplit > 64 || D < 3) {
+    set_error("a3d_dn_cross: bad argument (S=%d Sp=%d nsplit=%d)", S, Sp, nsplit);
+    return A3D_ERR_ARG;
+  }
+  float* Op = ws;
+  float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
+  hipLaunchKernelGGL(dn_cross_kernel, dim3(xcd_grid(B * H, nsplit)), dim3(256), 0, (hipStream_t)stream, x, traj, D, *p, Op, Mp,
+                     B, L, E, H, S, Sp, nsplit);
+  return check_launch("a3d_dn_cross");
+}
+
+extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const float* ws, const a3d_dn_rest_params* p,
+                           float* x_out, int B, int L, int E, int H, int nsplit, void* stream) {
+  int rc = dn_check("a3d_dn_rest", B, L, E, H);
+  if (rc) return rc;
+  if (!x_in || !traj || !ws || !p || !x_out || !p->c_out_w || !p->c_ln_g || nsplit < 1 || (p->f_w1 && (p->F <= 0 || p->F > 512)) ||
+      (p->s_in_w && (!p->s_out_w || !p->s_ln_g))) {
+    set_error("a3d_dn_rest: bad argument");
+    return A3D_ERR_ARG;
+  }
+  const size_t lds = (size_t)DR * (4 * LDX + LDQK + LDH) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dn_rest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  const float* Op = ws;
+  const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
+  hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E, H,
+                     nsplit);
+  return check_launch("a3d_dn_rest");
+}
+
+extern "C" int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D,
+                           const a3d_dn_tail_params* p, float* traj_out, int B, int L, int E, int t_step, void* stream) {
+  if (!pos_feats || !rot_feats || !traj || !p || !traj_out || B <= 0 || L <= 0 || L > DR || E <= 0 || E > 128 || D < 4 || D > 16 ||
+      t_step < 0 || !p->pos_w0 || !p->rot_w0 || !p->coef_pos || !p->coef_rot || (p->cond_mask && !p->cond_data)) {
+    set_error("a3d_dn_tail: bad argument");
+    return A3D_ERR_ARG;
+  }
+  hipLaunchKernelGGL(dn_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pos_feats, rot_feats, traj, D, *p, traj_out, L,
+                     E, t_step);
+  return check_launch("a3d_dn_tail");
+}
+
+extern "C" int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B,
+                                 int N, int Npad, int E, int H, void* stream) {
+  if (!Y || !out || (xyz && !freq) || B <= 0 || N <= 0 || Npad < N || E <= 0 || H * HD != E || ldy < E) {
+    set_error("a3d_rope_rows_f32: bad argument");
+    return A3D_ERR_ARG;
+  }
+  const size_t total = (size_t)B * H * Npad * 16;
+  hipLaunchKernelGGL(rope_rows_f32_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0,
+                     (hipStream_t)stream, Y, ldy, xyz, freq, scale, out, B, N, Npad, E, H);
+  return check_launch("a3d_rope_rows_f32");
+}

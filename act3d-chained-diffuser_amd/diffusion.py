@@ -21,6 +21,7 @@ distribution as the reference's torch generator, not the same draws.  The additi
 (default 0.1 = the reference) sets that probability; 0.0 disables it.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -263,6 +264,123 @@ class DiffusionHead(nn.Module):
         return O.TrajUpdateFn.apply(trajectory, upd)
 
 
+    # ---- inference, fused: 18 launches per network evaluation (csrc/denoise.hip)
+    @torch.no_grad()
+    def build_fused(self, ctx, ctx_xyz, instr, kmask, time_sin, Ln):
+        """Step-invariant state of the fused sampling path for one trajectory batch: the context K (fp32 rows) / V (bf16
+        planes) of every cross-attention layer, the instruction tokens through traj_lang_attention's k | v projection, and
+        the AdaLN modulation of every layer at every timestep (Linear(SiLU(sinusoidal(t))), layers.py:273-290).  Returns
+        {"tensors": [...]} -- the list is what a captured graph must refresh in place -- plus per-layer pointer tables."""
+        B, S, E = ctx.shape
+        H = self.num_attn_heads
+        dev = ctx.device
+        Sp = O.ceil_to(S, 64)
+        f4 = 4
+        freq = O.rope_freq(E, dev)
+        silu = F.silu(time_sin)                                         # (T, E)
+        st = {"S": S, "Sp": Sp, "layers": [], "tensors": [], "freq": freq, "sem": self._sem(Ln, E, dev), "kmask": kmask}
+        ctx = O._c(ctx)
+        xyz = O._c(ctx_xyz.float())
+        for lay in self._cross_layers():
+            mha = lay.cross_12
+            kv = O.linear_raw(ctx.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+                              mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
+            Kf = torch.empty((B, H, Sp, 16), device=dev, dtype=torch.float32)
+            Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.bfloat16)
+            O.L.call("a3d_rope_rows_f32", kv.data_ptr(), 2 * E, xyz.data_ptr(), freq.data_ptr(), 1.0, Kf.data_ptr(), B, S, Sp, E, H,
+                     O.L.stream())
+            O.L.call("a3d_split_vt", kv.data_ptr() + E * f4, 2 * E, Vt.data_ptr(), B, S, Sp, E, H, O.L.stream())
+            mods = [O.linear2d(silu, a.modulation[1].weight, a.modulation[1].bias) for a in (lay.adaln_12, lay.adaln_1, lay.adaln_ff1)]
+            st["layers"].append({"lay": lay, "Kf": Kf, "Vt": Vt, "mods": mods})
+            st["tensors"] += [Kf, Vt] + mods
+        st["lang_kv"] = None
+        if self.use_instruction:
+            mha = self.traj_lang_attention[0].layers[0].cross_12
+            instr = O._c(instr)
+            st["S_lang"] = instr.shape[1]
+            st["lang_kv"] = O.linear_raw(instr.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+                                         mha.in_proj_bias.data_ptr() + E * f4, B * instr.shape[1], 2 * E, E, dev)
+            st["tensors"].append(st["lang_kv"])
+        st["nsplit"] = max(1, min(8, Sp // 128, -(-1024 // (B * H))))
+        st["ws"] = torch.empty((O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"]),), device=dev, dtype=torch.float32)
+        return st
+
+    @torch.no_grad()
+    def fused_step(self, st, traj, t, noise, cond_data, cond_mask_u8, tb):
+        """One denoise step: network evaluation at timestep t + DDPM reverse step -> the next trajectory (B, L, D)."""
+        Lb = O.L
+        B, Ln, D = traj.shape
+        H = self.num_attn_heads
+        E = self.curr_gripper_embed.weight.shape[1]
+        dev = traj.device
+        f4 = 4
+        stream = Lb.stream()
+        nz = lambda x: None if x is None else x.data_ptr()
+        new = lambda: torch.empty((B, Ln, E), device=dev, dtype=torch.float32)
+        hp = Lb.DnHeadParams(enc_w0=self.traj_encoder[0].weight.data_ptr(), enc_b0=self.traj_encoder[0].bias.data_ptr(),
+                             enc_w1=self.traj_encoder[3].weight.data_ptr(), enc_b1=self.traj_encoder[3].bias.data_ptr(),
+                             sem=st["sem"].data_ptr(), lang_kv=nz(st["lang_kv"]), S_lang=st.get("S_lang", 0))
+        if st["lang_kv"] is not None:
+            ll = self.traj_lang_attention[0].layers[0]
+            hp.q_w, hp.q_b = ll.cross_12.in_proj_weight.data_ptr(), ll.cross_12.in_proj_bias.data_ptr()
+            hp.out_w, hp.out_b = ll.cross_12.out_proj.weight.data_ptr(), ll.cross_12.out_proj.bias.data_ptr()
+            hp.ln_g, hp.ln_b = ll.norm_12.weight.data_ptr(), ll.norm_12.bias.data_ptr()
+        x = new()
+        Lb.call("a3d_dn_head", traj.data_ptr(), D, C_byref(hp), x.data_ptr(), B, Ln, E, H, stream)
+
+        def run_layer(xin, rec):
+            lay = rec["lay"]
+            mo = [m.data_ptr() + t * 2 * E * f4 for m in rec["mods"]]
+            cp = Lb.DnCrossParams(sem=st["sem"].data_ptr(), mod=mo[0], q_w=lay.cross_12.in_proj_weight.data_ptr(),
+                                  q_b=lay.cross_12.in_proj_bias.data_ptr(), freq=st["freq"].data_ptr(), Kf=rec["Kf"].data_ptr(),
+                                  Vt=rec["Vt"].data_ptr())
+            Lb.call("a3d_dn_cross", xin.data_ptr(), traj.data_ptr(), D, C_byref(cp), st["ws"].data_ptr(), B, Ln, E, H, st["S"],
+                    st["Sp"], st["nsplit"], stream)
+            ff = lay.ffn_12
+            rp = Lb.DnRestParams(
+                c_out_w=lay.cross_12.out_proj.weight.data_ptr(), c_out_b=lay.cross_12.out_proj.bias.data_ptr(),
+                c_ln_g=lay.norm_12.weight.data_ptr(), c_ln_b=lay.norm_12.bias.data_ptr(), sem=st["sem"].data_ptr(),
+                s_mod=mo[1], s_in_w=lay.sa1.in_proj_weight.data_ptr(), s_in_b=lay.sa1.in_proj_bias.data_ptr(),
+                s_out_w=lay.sa1.out_proj.weight.data_ptr(), s_out_b=lay.sa1.out_proj.bias.data_ptr(),
+                s_ln_g=lay.norm_1.weight.data_ptr(), s_ln_b=lay.norm_1.bias.data_ptr(), freq=st["freq"].data_ptr(),
+                kmask=nz(st["kmask"]), f_mod=mo[2], f_w1=ff[0].weight.data_ptr(), f_b1=ff[0].bias.data_ptr(),
+                f_w2=ff[3].weight.data_ptr(), f_b2=ff[3].bias.data_ptr(), f_ln_g=lay.norm_122.weight.data_ptr(),
+                f_ln_b=lay.norm_122.bias.data_ptr(), F=ff[0].weight.shape[0])
+            xout = new()
+            Lb.call("a3d_dn_rest", xin.data_ptr(), traj.data_ptr(), D, st["ws"].data_ptr(), C_byref(rp), xout.data_ptr(), B, Ln,
+                    E, H, st["nsplit"], stream)
+            return xout
+
+        recs = st["layers"]
+        n_traj = len(self.traj_attention[0].layers)
+        n_pos = len(self.pos_attention[0].layers)
+        for rec in recs[:n_traj]:
+            x = run_layer(x, rec)
+        pf = x
+        for rec in recs[n_traj:n_traj + n_pos]:
+            pf = run_layer(pf, rec)
+        rf = x
+        for rec in recs[n_traj + n_pos:]:
+            rf = run_layer(rf, rec)
+        pr, rr = self.pos_regressor[0], self.rot_regressor[0]
+        tp = Lb.DnTailParams(pos_w0=pr[0].weight.data_ptr(), pos_b0=pr[0].bias.data_ptr(), pos_w1=pr[3].weight.data_ptr(),
+                             pos_b1=pr[3].bias.data_ptr(), rot_w0=rr[0].weight.data_ptr(), rot_b0=rr[0].bias.data_ptr(),
+                             rot_w1=rr[3].weight.data_ptr(), rot_b1=rr[3].bias.data_ptr(), noise=nz(noise),
+                             cond_data=cond_data.data_ptr(), cond_mask=cond_mask_u8.data_ptr(), coef_pos=tb.coef_pos.data_ptr(),
+                             coef_rot=tb.coef_rot.data_ptr())
+        out = torch.empty_like(traj)
+        Lb.call("a3d_dn_tail", pf.data_ptr(), rf.data_ptr(), traj.data_ptr(), D, C_byref(tp), out.data_ptr(), B, Ln, E, int(t), stream)
+        return out
+
+
+FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
+
+
+def C_byref(struct):
+    import ctypes
+    return ctypes.byref(struct)
+
+
 class DiffusionPlanner(nn.Module):
 
     def __init__(self, backbone="clip", image_size=(256, 256), embedding_dim=60, output_dim=7,
@@ -348,16 +466,16 @@ class DiffusionPlanner(nn.Module):
     @torch.no_grad()
     def compute_trajectory(self, trajectory_mask, rgb_obs, pcd_obs, instruction, curr_gripper, goal_gripper, *,
                            init_noise=None, step_noise=None, visual_tokens=None, use_graph=False, n_steps=None,
-                           return_trace=False):
+                           return_trace=False, fused=None):
         head = self.prediction_head
         dev = pcd_obs.device
         tb = self.tables(dev)
         B, Ln = trajectory_mask.shape
         tokens, ctx_xyz, cg, gg = self._prepare(rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens)
         ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
-        cache = head.build_kv_cache(ctx, ctx_xyz, instr)
         # conditioning: start pose at index 0, goal at L - pad - 1 and after (no host sync: index arithmetic on device)
         D = cg.shape[-1]
+        E = ctx.shape[-1]
         ar = torch.arange(Ln, device=dev)[None, :]
         cond_mask = (ar == 0)
         cond_data = torch.zeros((B, Ln, D), device=dev)
@@ -379,17 +497,32 @@ class DiffusionPlanner(nn.Module):
         traj = (init_noise.to(dev).float() + cond_data).contiguous()
         kmask = trajectory_mask.to(torch.uint8).contiguous()
         trace = []
+        # fused per-step kernels (csrc/denoise.hip) whenever the trajectory fits one 16-row tile; else the op-by-op path
+        fused = FUSED_DENOISE if fused is None else fused
+        fused = fused and Ln <= 16 and E <= 128 and D <= 16
+        if fused:
+            state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln)
+            static = state["tensors"]
+        else:
+            state = head.build_kv_cache(ctx, ctx_xyz, instr)
+            static = [c[k] for c in state["ctx"] for k in ("Ks", "Vt")] + \
+                ([state["lang"]["Ks"], state["lang"]["Vt"]] if "lang" in state else [])
+        static = static + [step_noise, cond_data, cond_mask_u8, kmask]
 
         def run_loop(x):
             for t in steps:
-                out = head.denoise_tokens_cached(x, kmask, t, cache, self._time_tables)
-                x = O.ddpm_step(out, x, step_noise[t] if t > 0 else None, cond_data, cond_mask_u8, tb.coef_pos, tb.coef_rot, t)
+                nz = step_noise[t] if t > 0 else None
+                if fused:
+                    x = head.fused_step(state, x, t, nz, cond_data, cond_mask_u8, tb)
+                else:
+                    out = head.denoise_tokens_cached(x, kmask, t, state, self._time_tables)
+                    x = O.ddpm_step(out, x, nz, cond_data, cond_mask_u8, tb.coef_pos, tb.coef_rot, t)
                 if return_trace:
                     trace.append(x)
             return x
 
         if use_graph and not return_trace:
-            key = (B, Ln, tuple(steps))
+            key = (B, Ln, tuple(steps), fused, tuple((tuple(t_.shape), t_.dtype) for t_ in static))
             if self._graph is None or self._graph["key"] != key:
                 static_in = traj.clone()
                 side = torch.cuda.Stream()
@@ -398,25 +531,16 @@ class DiffusionPlanner(nn.Module):
                     run_loop(static_in)                     # warm-up (allocator, lazy module state) outside capture
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                self._graph = {"key": key, "in": static_in, "cache": cache, "noise": step_noise, "cond": (cond_data, cond_mask_u8),
-                               "kmask": kmask}
+                self._graph = {"key": key, "in": static_in, "static": static}
                 with torch.cuda.graph(g):
                     self._graph["out"] = run_loop(static_in)
                 self._graph["g"] = g
             gr = self._graph
-            # refresh the captured buffers in place (same addresses)
+            # refresh the captured buffers in place (same addresses; the key pins every shape and dtype)
             gr["in"].copy_(traj)
-            for dst, src in zip(gr["cache"]["ctx"], cache["ctx"]):
+            for dst, src in zip(gr["static"], static):
                 if dst is not src:
-                    dst["Ks"].copy_(src["Ks"]); dst["Vt"].copy_(src["Vt"])
-            if "lang" in cache and gr["cache"]["lang"] is not cache["lang"]:
-                gr["cache"]["lang"]["Ks"].copy_(cache["lang"]["Ks"]); gr["cache"]["lang"]["Vt"].copy_(cache["lang"]["Vt"])
-            if gr["noise"] is not step_noise:
-                gr["noise"].copy_(step_noise)
-            if gr["cond"][0] is not cond_data:
-                gr["cond"][0].copy_(cond_data); gr["cond"][1].copy_(cond_mask_u8)
-            if gr["kmask"] is not kmask:
-                gr["kmask"].copy_(kmask)
+                    dst.copy_(src)
             gr["g"].replay()
             traj = gr["out"]
         else:

@@ -16,6 +16,23 @@ _f = C.c_float
 _z = C.c_size_t
 _u64 = C.c_ulonglong
 
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, t) for f, t in fields]})
+
+
+# parameter blocks of the fused denoise kernels (include/act3d_hip.h, same field order)
+DnHeadParams = _struct("DnHeadParams", [(n, _p) for n in ("enc_w0", "enc_b0", "enc_w1", "enc_b1", "sem", "lang_kv")] +
+                       [("S_lang", _i)] + [(n, _p) for n in ("q_w", "q_b", "out_w", "out_b", "ln_g", "ln_b")])
+DnCrossParams = _struct("DnCrossParams", [(n, _p) for n in ("sem", "mod", "q_w", "q_b", "freq", "Kf", "Vt")])
+DnRestParams = _struct("DnRestParams", [(n, _p) for n in (
+    "c_out_w", "c_out_b", "c_ln_g", "c_ln_b", "sem", "s_mod", "s_in_w", "s_in_b", "s_out_w", "s_out_b", "s_ln_g", "s_ln_b", "freq",
+    "kmask", "f_mod", "f_w1", "f_b1", "f_w2", "f_b2", "f_ln_g", "f_ln_b")] + [("F", _i)])
+DnTailParams = _struct("DnTailParams", [(n, _p) for n in (
+    "pos_w0", "pos_b0", "pos_w1", "pos_b1", "rot_w0", "rot_b0", "rot_w1", "rot_b1", "noise", "cond_data", "cond_mask", "coef_pos",
+    "coef_rot")])
+
 # name -> (restype, argtypes); mirrors include/act3d_hip.h one to one
 SIGNATURES = {
     "a3d_version": (_i, []),
@@ -40,6 +57,12 @@ SIGNATURES = {
     "a3d_traj_errors": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_keypose_errors": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "a3d_sym_quat_loss": (_i, [_p, _p, _i, _f, _p, _p, _i, _p]),
+    "a3d_dn_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_dn_cross_ws_floats": (_z, [_i, _i, _i]),
+    "a3d_dn_cross": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "a3d_dn_rest": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_dn_tail": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_rope_rows_f32": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
     "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),
     "a3d_attn_fwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_uint, _f, _p]),

@@ -215,6 +215,56 @@ int a3d_keypose_errors(const float* pos, const float* rot, const float* grip, co
 /* coeff * mean_b min(mse(q_b, g_b), mse(q_b, -g_b))  (symmetric_rotation_loss, main_keypose.py:370-376); grad optional [B][4]. */
 int a3d_sym_quat_loss(const float* q, const float* gt, int ldgt, float coeff, float* loss, float* grad, int B, void* stream);
 
+/* ---- fused denoising-network evaluation for the sampling loop (inference; diffusion_head.py:200-363 per step of
+ *      diffusion_model.py:86-119).  L <= 16 trajectory steps per sample, E = 15 H <= 128.  One step = a3d_dn_head, then per
+ *      ParallelAttentionLayer a3d_dn_cross + a3d_dn_rest, then a3d_dn_tail (18 launches instead of ~200).
+ *      Weights are the reference's tensors, row-major fp32 ([out][in]); every pointer is a device pointer. ------------- */
+typedef struct {
+  const float *enc_w0, *enc_b0, *enc_w1, *enc_b1;   /* traj_encoder: Linear(D, E) - ReLU - Linear(E, E)  (diffusion_head.py:41-46) */
+  const float* sem;                                 /* [L][E] sinusoidal step-index embedding (position_encodings.py:13-20) */
+  const float* lang_kv;                             /* [B][S_lang][2E] = instruction tokens through the packed k | v projection
+                                                       of traj_lang_attention; NULL: no instruction branch */
+  int S_lang;
+  const float *q_w, *q_b, *out_w, *out_b, *ln_g, *ln_b;   /* traj_lang_attention cross_12 (rows 0..E-1 of in_proj) / norm_12 */
+} a3d_dn_head_params;
+typedef struct {
+  const float* sem;          /* [L][E] or NULL */
+  const float* mod;          /* [2E] AdaLN (scale | shift) of this layer at this timestep, NULL: no AdaLN */
+  const float *q_w, *q_b;    /* rows 0..E-1 of cross_12.in_proj_weight / bias */
+  const float* freq;         /* E/6 RoPE frequencies, NULL: no rotation */
+  const float* Kf;           /* context keys, projected + rotated, fp32 rows [B][H][Sp][16] (a3d_rope_rows_f32) */
+  const unsigned short* Vt;  /* context values, bf16 hi / lo planes [B][H][2][16][Sp] (a3d_split_vt) */
+} a3d_dn_cross_params;
+typedef struct {
+  const float *c_out_w, *c_out_b, *c_ln_g, *c_ln_b;                       /* cross_12.out_proj, norm_12 */
+  const float* sem;
+  const float *s_mod, *s_in_w, *s_in_b, *s_out_w, *s_out_b, *s_ln_g, *s_ln_b;   /* adaln_1 (this step), sa1, norm_1; s_in_w NULL: none */
+  const float* freq;
+  const unsigned char* kmask;                                              /* [B][L] 1 = padded step, or NULL */
+  const float *f_mod, *f_w1, *f_b1, *f_w2, *f_b2, *f_ln_g, *f_ln_b;         /* adaln_ff1 (this step), ffn_12, norm_122; f_w1 NULL: none */
+  int F;                                                                   /* FFN hidden width (4E) */
+} a3d_dn_rest_params;
+typedef struct {
+  const float *pos_w0, *pos_b0, *pos_w1, *pos_b1, *rot_w0, *rot_b0, *rot_w1, *rot_b1;   /* regressors (diffusion_head.py:177-199) */
+  const float *noise, *cond_data;            /* [B][L][D]; noise NULL at t = 0 */
+  const unsigned char* cond_mask;            /* [B][L][D] or NULL */
+  const float *coef_pos, *coef_rot;          /* [T][3] posterior tables (see a3d_ddpm_step) */
+} a3d_dn_tail_params;
+int a3d_dn_head(const float* traj, int D, const a3d_dn_head_params* p, float* x_out, int B, int L, int E, int H, void* stream);
+size_t a3d_dn_cross_ws_floats(int B, int H, int nsplit);
+/* partial attention outputs of every (sample, head, key split) into ws (>= a3d_dn_cross_ws_floats floats) */
+int a3d_dn_cross(const float* x, const float* traj, int D, const a3d_dn_cross_params* p, float* ws, int B, int L, int E,
+                 int H, int S, int Sp, int nsplit, void* stream);
+/* combine + out-proj + LayerNorm, self-attention block, FFN block of one layer: x_in -> x_out ([B][L][E]) */
+int a3d_dn_rest(const float* x_in, const float* traj, int D, const float* ws, const a3d_dn_rest_params* p, float* x_out,
+                int B, int L, int E, int H, int nsplit, void* stream);
+/* regressors + trajectory update + DDPM reverse step t_step: traj ([B][L][D]) -> traj_out */
+int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D, const a3d_dn_tail_params* p,
+                float* traj_out, int B, int L, int E, int t_step, void* stream);
+/* out[b][h][n][16] fp32 = rope3d(Y[b, n, :E] * scale, xyz) split into heads (column 15 and rows >= N zero): the K cache */
+int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B, int N,
+                      int Npad, int E, int H, void* stream);
+
 /* ---- frozen-backbone BatchNorm (train-mode statistics) + ReLU + residual, bf16 NHWC -------------- */
 /* x, residual, y: bf16, `rows` = N*H*W rows of C channels (torch channels_last storage).  C = 8 * divisor of 256. */
 int a3d_bn_nslab(size_t rows, int C);

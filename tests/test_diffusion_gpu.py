@@ -140,3 +140,18 @@ def test_cfg3_full_shape_graph_vs_oracle(a3d, dev):
     scale_close("cfg3 sampled xyz", got[..., :3], ofinal[..., :3], 3e-4)
     sign = torch.sign((got[..., 3:] * ofinal[..., 3:]).sum(-1, keepdim=True))
     scale_close("cfg3 sampled quaternion", got[..., 3:] * sign, ofinal[..., 3:], 3e-4)
+
+
+def test_fused_denoise_step_equals_op_by_op_path(setup, dev):
+    """csrc/denoise.hip (18 launches per network evaluation: head, per-layer cross + rest, tail; fp32 K cache) against the
+    op-by-op path (AdaLN / projection / RoPE-split / attention / LayerNorm kernels, three-part bf16 K cache), state by state
+    over the first steps and at the end of the full loop, with padded trajectories and goal in-painting."""
+    r, cfg, m, inp = setup
+    m.eval()
+    kw = dict(init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=inp["tokens"], return_trace=True)
+    args = (inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"])
+    fa, ta = m.compute_trajectory(*args, fused=True, **kw)
+    fb, tb = m.compute_trajectory(*args, fused=False, **kw)
+    for i in (0, 1, 2, 50, 99):
+        scale_close(f"fused vs op-by-op state after step {i}", ta[i], tb[i], 2e-5)
+    scale_close("fused vs op-by-op final pose", fa, fb, 2e-5)
