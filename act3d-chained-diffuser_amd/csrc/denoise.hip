@@ -31,47 +31,79 @@ constexpr int LDQK = 260;         // [16][<=256]
 constexpr int LDH = 516;          // [16][<=512]
 
 // Y[16][N] = act(X[16][K] W[N][K]^T + bias), X / Y in LDS (X zero-padded to a multiple of 16 columns), W / bias in
-// global memory.  The four waves take the 16-column output tiles round-robin.  Contraction index permutation: MFMA j of a
-// 16-channel block contracts lane group g with channel 4 g + j, so that A and B are one float4 each per block.
+// global memory (L2-resident: every sample's workgroup reads the same weights).  The four waves take the 16-column output
+// tiles round-robin.  Contraction index permutation: MFMA j of a 16-channel block contracts lane group g with channel
+// 4 g + j, so that A and B are one float4 each per block.  The weight fragments of the NEXT (tile, 128-channel chunk) are
+// fetched into registers while the current chunk's 32 MFMAs issue (a load inside the MFMA loop would expose one L2 round
+// trip per 16 channels: measured 136 us for the layer remainder against ~20 us of MFMA issue); two accumulators per tile
+// keep the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 off the 32-cycle issue rate.
+constexpr int WCH = 8;            // 16-channel blocks per register chunk
+
 template <int ACT>
 __device__ __forceinline__ void wg_linear(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                           const float* __restrict__ bias, int N, float* Ys, int ldy) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const bool vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
-  const int ntile = (N + 15) >> 4;
-  for (int ct = wave; ct < ntile; ct += 4) {
+  const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
+  const int nchunk = (nblk + WCH - 1) / WCH;
+  auto loadw = [&](int ct, int c, float4 (&w)[WCH]) {
     const int n = ct * 16 + li;
     const float* wrow = W + (size_t)min(n, N - 1) * ldw;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < K; kk += 16) {
-      const int k0 = kk + 4 * g;
-      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + k0]);
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int k0 = (c * WCH + i) * 16 + 4 * g;
       float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) {
+      if (n < N && k0 < K) {
         if (vec && k0 + 3 < K) {
           wv = *reinterpret_cast<const float4*>(wrow + k0);
         } else {
-          if (k0 + 0 < K) wv.x = wrow[k0 + 0];
+          wv.x = wrow[k0];
           if (k0 + 1 < K) wv.y = wrow[k0 + 1];
           if (k0 + 2 < K) wv.z = wrow[k0 + 2];
           if (k0 + 3 < K) wv.w = wrow[k0 + 3];
         }
       }
-      acc = mfma_f32_16x16x4(a.x, wv.x, acc);
-      acc = mfma_f32_16x16x4(a.y, wv.y, acc);
-      acc = mfma_f32_16x16x4(a.z, wv.z, acc);
-      acc = mfma_f32_16x16x4(a.w, wv.w, acc);
+      w[i] = wv;
     }
-    if (n < N) {
-      const float bv = bias ? bias[n] : 0.f;
+  };
+  float4 wc[WCH], wn[WCH];
+  int ct = wave, c = 0;
+  if (ct < ntile) loadw(ct, 0, wc);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  while (ct < ntile) {
+    int nct = ct, nc = c + 1;
+    if (nc == nchunk) { nc = 0; nct = ct + 4; }
+    if (nct < ntile) loadw(nct, nc, wn);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[r] + bv;
-        if (ACT == 1) v = fmaxf(v, 0.f);
-        Ys[(g * 4 + r) * ldy + n] = v;
+    for (int i = 0; i < WCH; ++i) {
+      const int blk = c * WCH + i;
+      if (blk < nblk) {
+        const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
+        acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
+        acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
+        acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
+        acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
       }
     }
+    if (c == nchunk - 1) {
+      const int n = ct * 16 + li;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc0[r] + acc1[r] + bv;
+          if (ACT == 1) v = fmaxf(v, 0.f);
+          Ys[(g * 4 + r) * ldy + n] = v;
+        }
+      }
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wc[i] = wn[i];
+    ct = nct;
+    c = nc;
   }
   __syncthreads();
 }
@@ -188,6 +220,7 @@ __device__ __forceinline__ void wg_load_rows(const float* __restrict__ src, int 
 __global__ __launch_bounds__(256) void dn_head_kernel(const float* __restrict__ traj, int D, a3d_dn_head_params p,
                                                       float* __restrict__ x_out, int L, int E, int H) {
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], As[DR * LDX], Ts[DR * LDX], Qs[DR * LDX];
+  extern __shared__ __attribute__((aligned(16))) float kvS[];          // [S_lang][2E]: the instruction tokens' k | v rows
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
   // trajectory rows (D = 9 channels) padded to one 16-channel block
@@ -210,7 +243,9 @@ __global__ __launch_bounds__(256) void dn_head_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < DR * E; i += blockDim.x) Qs[(i / E) * LDX + i % E] *= scale;
     __syncthreads();
     const float* kv = p.lang_kv + (size_t)b * p.S_lang * 2 * E;
-    wg_small_attention(Qs, LDX, kv, 2 * E, kv + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
+    for (int i = threadIdx.x; i < p.S_lang * 2 * E; i += blockDim.x) kvS[i] = kv[i];    // coalesced; the key loop reads LDS
+    __syncthreads();
+    wg_small_attention(Qs, LDX, kvS, 2 * E, kvS + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
     wg_linear<0>(As, LDX, E, p.out_w, E, p.out_b, E, Ts, LDX);
     wg_add_layernorm(Xs, LDX, Ts, LDX, p.ln_g, p.ln_b, Xs, LDX, E);
   }
@@ -517,7 +552,17 @@ extern "C" int a3d_dn_head(const float* traj, int D, const a3d_dn_head_params* p
     set_error("a3d_dn_head: bad argument");
     return A3D_ERR_ARG;
   }
-  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
+  const size_t lds = p->lang_kv ? (size_t)p->S_lang * 2 * E * sizeof(float) : 0;
+  if (lds + 4 * DR * LDX * sizeof(float) > 150 * 1024) {
+    set_error("a3d_dn_head: %d instruction tokens do not fit the LDS staging", p->S_lang);
+    return A3D_ERR_ARG;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
   return check_launch("a3d_dn_head");
 }
 
