@@ -116,62 +116,81 @@ __device__ __forceinline__ void wg_zero_pad(float* T, int ld, int E, int Epad) {
   }
 }
 
-// Y = LayerNorm(A + R) * gamma + beta over E columns, 16 threads per row (two-pass, like add_ln_fwd_kernel)
+// Y = LayerNorm(A + R) * gamma + beta over E <= 128 columns, 16 threads per row (two-pass, like add_ln_fwd_kernel).  A thread
+// reads and writes the same (row, column) set and the row reductions are register shuffles, so Y may alias A or R and only
+// the trailing barrier is needed; gamma / beta are fetched up front (one L2 round trip, not one per element).
 __device__ __forceinline__ void wg_add_layernorm(const float* A, int lda, const float* R, int ldr, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float* Y, int ldy, int E) {
   const int r = threadIdx.x >> 4, s = threadIdx.x & 15;
+  float v[8], gm[8], bt[8];
   float sum = 0.f;
-  for (int c = s; c < E; c += 16) sum += A[r * lda + c] + R[r * ldr + c];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = s + 16 * i;
+    const bool ok = c < E;
+    gm[i] = ok ? gamma[c] : 0.f;
+    bt[i] = ok ? beta[c] : 0.f;
+    v[i] = ok ? A[r * lda + c] + R[r * ldr + c] : 0.f;
+    sum += v[i];
+  }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   const float mean = sum / (float)E;
   float q = 0.f;
-  for (int c = s; c < E; c += 16) {
-    const float d = A[r * lda + c] + R[r * ldr + c] - mean;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float d = (s + 16 * i < E) ? v[i] - mean : 0.f;
     q += d * d;
   }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q / (float)E + 1e-5f);
-  __syncthreads();                                   // Y may alias A or R
-  float keep[8];
-  int i = 0;
-  for (int c = s; c < E; c += 16, ++i) keep[i] = (A[r * lda + c] + R[r * ldr + c] - mean) * rstd * gamma[c] + beta[c];
-  __syncthreads();
-  i = 0;
-  for (int c = s; c < E; c += 16, ++i) Y[r * ldy + c] = keep[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = s + 16 * i;
+    if (c < E) Y[r * ldy + c] = (v[i] - mean) * rstd * gm[i] + bt[i];
+  }
   __syncthreads();
 }
 
-// Y = (X [+ sem]) * (1 + mod[c]) + mod[E + c]   (AdaLN, layers.py:273-290; mod == nullptr: plain X [+ sem])
+// Y = (X [+ sem]) * (1 + mod[c]) + mod[E + c]   (AdaLN, layers.py:273-290; mod == nullptr: plain X [+ sem]); optionally
+// Y2 = the same modulation of X without the index embedding (the value stream of the self-attention).  E <= 128.
 __device__ __forceinline__ void wg_adaln(const float* X, int ldx, const float* __restrict__ sem, const float* __restrict__ mod,
-                                         float* Y, int ldy, int L, int E) {
-  for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
-    const int r = i / E, c = i - r * E;
-    float v = X[r * ldx + c];
-    if (sem && r < L) v += sem[r * E + c];
-    if (mod) v = v * (1.0f + mod[c]) + mod[E + c];
-    Y[r * ldy + c] = v;
+                                         float* Y, int ldy, int L, int E, float* Y2 = nullptr, int ldy2 = 0) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < DR * E) {
+      const int r = i / E, c = i - r * E;
+      const float x0 = X[r * ldx + c];
+      const float sc = mod ? 1.0f + mod[c] : 1.0f, sh = mod ? mod[E + c] : 0.f;
+      const float se = (sem && r < L) ? sem[r * E + c] : 0.f;
+      Y[r * ldy + c] = (x0 + se) * sc + sh;
+      if (Y2) Y2[r * ldy2 + c] = x0 * sc + sh;
+    }
   }
   __syncthreads();
 }
 
 // in-place RoPE-3D of the E-wide blocks starting at columns col0, col0 + E, ... (nblk blocks) of T, by the rows' xyz
+// (block 0 is first multiplied by `scale0`: q = q * d^-1/2 before the rotation, multihead_custom_attention.py:325);
+// freq == nullptr: scaling only
 __device__ __forceinline__ void wg_rope(float* T, int ld, int col0, int nblk, const float* __restrict__ xyz, int ldxyz,
-                                        const float* __restrict__ freq, int L, int E) {
+                                        const float* __restrict__ freq, int L, int E, float scale0) {
   const int half = E >> 1, third = E / 3;
   for (int i = threadIdx.x; i < DR * half; i += blockDim.x) {
     const int r = i / half, p = i - r * half;
-    if (r >= L) continue;
     const int c = 2 * p;
-    const int axis = c / third;
-    const int k = (c - axis * third) >> 1;
-    const float th = xyz[r * ldxyz + axis] * freq[k];
-    float sn, cs;
-    sincosf(th, &sn, &cs);
+    float sn = 0.f, cs = 1.f;
+    if (freq && r < L) {
+      const int axis = c / third;
+      const int k = (c - axis * third) >> 1;
+      sincosf(xyz[r * ldxyz + axis] * freq[k], &sn, &cs);
+    }
     for (int bk = 0; bk < nblk; ++bk) {
       float* q = T + r * ld + col0 + bk * E + c;
-      const float y0 = q[0], y1 = q[1];
+      const float sc = bk == 0 ? scale0 : 1.0f;
+      const float y0 = q[0] * sc, y1 = q[1] * sc;
       q[0] = y0 * cs - y1 * sn;
       q[1] = y1 * cs + y0 * sn;
     }
@@ -420,6 +439,7 @@ __global__ __launch_bounds__(256) void dn_rest_kernel(const float* __restrict__ 
   wg_zero_pad(Bs, LDX, E, Epad);
   wg_zero_pad(Ts, LDX, E, Epad);
   // ---- cross-attention output: combine the key splits
+#pragma unroll 4
   for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
     const int r = i / E, c = i - r * E;
     const int h = c / HD, d = c - h * HD;
@@ -440,14 +460,10 @@ __global__ __launch_bounds__(256) void dn_rest_kernel(const float* __restrict__ 
   wg_add_layernorm(Xs, LDX, Ts, LDX, p.c_ln_g, p.c_ln_b, Xs, LDX, E);
   if (p.s_in_w) {
     // ---- self-attention: q = k = AdaLN(x + index embedding), v = AdaLN(x), RoPE by the steps' xyz, padded steps masked
-    wg_adaln(Xs, LDX, p.sem, p.s_mod, As, LDX, L, E);
-    wg_adaln(Xs, LDX, nullptr, p.s_mod, Bs, LDX, L, E);
+    wg_adaln(Xs, LDX, p.sem, p.s_mod, As, LDX, L, E, Bs, LDX);
     wg_linear<0>(As, LDX, E, p.s_in_w, E, p.s_in_b, 2 * E, QK, LDQK);                      // [q | k]
     wg_linear<0>(Bs, LDX, E, p.s_in_w + (size_t)2 * E * E, E, p.s_in_b + 2 * E, E, Hs, LDH);   // v
-    const float scale = 1.0f / sqrtf((float)HD);
-    for (int i = threadIdx.x; i < DR * E; i += blockDim.x) QK[(i / E) * LDQK + i % E] *= scale;
-    __syncthreads();
-    if (p.freq) wg_rope(QK, LDQK, 0, 2, traj + (size_t)b * L * D, D, p.freq, L, E);
+    wg_rope(QK, LDQK, 0, 2, traj + (size_t)b * L * D, D, p.freq, L, E, 1.0f / sqrtf((float)HD));
     wg_small_attention(QK, LDQK, QK + E, LDQK, Hs, LDH, p.kmask ? p.kmask + (size_t)b * L : nullptr, L, H, As, LDX);
     wg_linear<0>(As, LDX, E, p.s_out_w, E, p.s_out_b, E, Ts, LDX);
     wg_add_layernorm(Xs, LDX, Ts, LDX, p.s_ln_g, p.s_ln_b, Xs, LDX, E);

@@ -302,7 +302,9 @@ class DiffusionHead(nn.Module):
                                          mha.in_proj_bias.data_ptr() + E * f4, B * instr.shape[1], 2 * E, E, dev)
             st["tensors"].append(st["lang_kv"])
         st["nsplit"] = max(1, min(8, Sp // 128, -(-1024 // (B * H))))
-        st["ws"] = torch.empty((O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"]),), device=dev, dtype=torch.float32)
+        nws = O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"])
+        st["ws"] = torch.empty((nws,), device=dev, dtype=torch.float32)
+        st["ws_side"] = torch.empty((nws,), device=dev, dtype=torch.float32)     # the rotation branch runs concurrently
         return st
 
     @torch.no_grad()
@@ -314,7 +316,6 @@ class DiffusionHead(nn.Module):
         E = self.curr_gripper_embed.weight.shape[1]
         dev = traj.device
         f4 = 4
-        stream = Lb.stream()
         nz = lambda x: None if x is None else x.data_ptr()
         new = lambda: torch.empty((B, Ln, E), device=dev, dtype=torch.float32)
         hp = Lb.DnHeadParams(enc_w0=self.traj_encoder[0].weight.data_ptr(), enc_b0=self.traj_encoder[0].bias.data_ptr(),
@@ -326,15 +327,16 @@ class DiffusionHead(nn.Module):
             hp.out_w, hp.out_b = ll.cross_12.out_proj.weight.data_ptr(), ll.cross_12.out_proj.bias.data_ptr()
             hp.ln_g, hp.ln_b = ll.norm_12.weight.data_ptr(), ll.norm_12.bias.data_ptr()
         x = new()
-        Lb.call("a3d_dn_head", traj.data_ptr(), D, C_byref(hp), x.data_ptr(), B, Ln, E, H, stream)
+        Lb.call("a3d_dn_head", traj.data_ptr(), D, C_byref(hp), x.data_ptr(), B, Ln, E, H, Lb.stream())
 
-        def run_layer(xin, rec):
+        def run_layer(xin, rec, ws):
             lay = rec["lay"]
+            stream = Lb.stream()
             mo = [m.data_ptr() + t * 2 * E * f4 for m in rec["mods"]]
             cp = Lb.DnCrossParams(sem=st["sem"].data_ptr(), mod=mo[0], q_w=lay.cross_12.in_proj_weight.data_ptr(),
                                   q_b=lay.cross_12.in_proj_bias.data_ptr(), freq=st["freq"].data_ptr(), Kf=rec["Kf"].data_ptr(),
                                   Vt=rec["Vt"].data_ptr())
-            Lb.call("a3d_dn_cross", xin.data_ptr(), traj.data_ptr(), D, C_byref(cp), st["ws"].data_ptr(), B, Ln, E, H, st["S"],
+            Lb.call("a3d_dn_cross", xin.data_ptr(), traj.data_ptr(), D, C_byref(cp), ws.data_ptr(), B, Ln, E, H, st["S"],
                     st["Sp"], st["nsplit"], stream)
             ff = lay.ffn_12
             rp = Lb.DnRestParams(
@@ -347,7 +349,7 @@ class DiffusionHead(nn.Module):
                 f_w2=ff[3].weight.data_ptr(), f_b2=ff[3].bias.data_ptr(), f_ln_g=lay.norm_122.weight.data_ptr(),
                 f_ln_b=lay.norm_122.bias.data_ptr(), F=ff[0].weight.shape[0])
             xout = new()
-            Lb.call("a3d_dn_rest", xin.data_ptr(), traj.data_ptr(), D, st["ws"].data_ptr(), C_byref(rp), xout.data_ptr(), B, Ln,
+            Lb.call("a3d_dn_rest", xin.data_ptr(), traj.data_ptr(), D, ws.data_ptr(), C_byref(rp), xout.data_ptr(), B, Ln,
                     E, H, st["nsplit"], stream)
             return xout
 
@@ -355,13 +357,23 @@ class DiffusionHead(nn.Module):
         n_traj = len(self.traj_attention[0].layers)
         n_pos = len(self.pos_attention[0].layers)
         for rec in recs[:n_traj]:
-            x = run_layer(x, rec)
+            x = run_layer(x, rec, st["ws"])
+        # the position and rotation stacks (diffusion_head.py:343-357) both start from x and are independent: the rotation
+        # stack runs on a side stream (fork / join on events: capturable), its 64-workgroup per-sample kernels filling CUs
+        # the position stack leaves idle
+        cur = torch.cuda.current_stream(dev)
+        side = _dn_side_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            rf = x
+            for rec in recs[n_traj + n_pos:]:
+                rf = run_layer(rf, rec, st["ws_side"])
         pf = x
         for rec in recs[n_traj:n_traj + n_pos]:
-            pf = run_layer(pf, rec)
-        rf = x
-        for rec in recs[n_traj + n_pos:]:
-            rf = run_layer(rf, rec)
+            pf = run_layer(pf, rec, st["ws"])
+        cur.wait_stream(side)
+        rf.record_stream(cur)
+        stream = Lb.stream()
         pr, rr = self.pos_regressor[0], self.rot_regressor[0]
         tp = Lb.DnTailParams(pos_w0=pr[0].weight.data_ptr(), pos_b0=pr[0].bias.data_ptr(), pos_w1=pr[3].weight.data_ptr(),
                              pos_b1=pr[3].bias.data_ptr(), rot_w0=rr[0].weight.data_ptr(), rot_b0=rr[0].bias.data_ptr(),
@@ -374,6 +386,15 @@ class DiffusionHead(nn.Module):
 
 
 FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
+_DN_SIDE = {}
+
+
+def _dn_side_stream(dev):
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _DN_SIDE:
+        _DN_SIDE[key] = torch.cuda.Stream(device=dev)
+    return _DN_SIDE[key]
+
 
 
 def C_byref(struct):
