@@ -39,52 +39,57 @@ constexpr int LDH = 516;          // [16][<=512]
 // keep the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 off the 32-cycle issue rate.
 constexpr int WCH = 8;            // 16-channel blocks per register chunk
 
-template <int ACT>
-__device__ __forceinline__ void wg_linear(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
-                                          const float* __restrict__ bias, int N, float* Ys, int ldy) {
+// (The fragment loads are branch-free -- clamped addresses + selects: a per-lane guarded load compiles to one basic block
+// and one s_waitcnt vmcnt(0) per load, i.e. one exposed L2 round trip per 16 channels.)
+template <int ACT, bool VEC>
+__device__ __forceinline__ void wg_linear_impl(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
+                                               const float* __restrict__ bias, int N, float* Ys, int ldy) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const bool vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
   const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
   const int nchunk = (nblk + WCH - 1) / WCH;
   auto loadw = [&](int ct, int c, float4 (&w)[WCH]) {
     const int n = ct * 16 + li;
     const float* wrow = W + (size_t)min(n, N - 1) * ldw;
+    const bool row_ok = n < N;
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int k0 = (c * WCH + i) * 16 + 4 * g;
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && k0 < K) {
-        if (vec && k0 + 3 < K) {
-          wv = *reinterpret_cast<const float4*>(wrow + k0);
-        } else {
-          wv.x = wrow[k0];
-          if (k0 + 1 < K) wv.y = wrow[k0 + 1];
-          if (k0 + 2 < K) wv.z = wrow[k0 + 2];
-          if (k0 + 3 < K) wv.w = wrow[k0 + 3];
-        }
+      float4 wv;
+      if (VEC) {                                             // K % 4 == 0, rows 16-byte aligned
+        wv = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
+        if (!(row_ok && k0 < K)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        wv.x = wrow[min(k0 + 0, K - 1)];
+        wv.y = wrow[min(k0 + 1, K - 1)];
+        wv.z = wrow[min(k0 + 2, K - 1)];
+        wv.w = wrow[min(k0 + 3, K - 1)];
+        wv.x = (row_ok && k0 + 0 < K) ? wv.x : 0.f;
+        wv.y = (row_ok && k0 + 1 < K) ? wv.y : 0.f;
+        wv.z = (row_ok && k0 + 2 < K) ? wv.z : 0.f;
+        wv.w = (row_ok && k0 + 3 < K) ? wv.w : 0.f;
       }
       w[i] = wv;
     }
   };
   float4 wc[WCH], wn[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) wn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int ct = wave, c = 0;
   if (ct < ntile) loadw(ct, 0, wc);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   while (ct < ntile) {
     int nct = ct, nc = c + 1;
     if (nc == nchunk) { nc = 0; nct = ct + 4; }
-    if (nct < ntile) loadw(nct, nc, wn);
+    if (nct < ntile) loadw(nct, nc, wn);                     // wave-uniform condition
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-      const int blk = c * WCH + i;
-      if (blk < nblk) {
-        const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
-        acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
-        acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
-        acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
-        acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
-      }
+      const int blk = min(c * WCH + i, nblk - 1);            // blocks past the end multiply zero weights
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
+      acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
+      acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
+      acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
+      acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
     }
     if (c == nchunk - 1) {
       const int n = ct * 16 + li;
@@ -106,6 +111,14 @@ __device__ __forceinline__ void wg_linear(const float* Xs, int ldx, int K, const
     c = nc;
   }
   __syncthreads();
+}
+
+template <int ACT>
+__device__ __forceinline__ void wg_linear(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
+                                          const float* __restrict__ bias, int N, float* Ys, int ldy) {
+  const bool vec = ((ldw & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  if (vec) wg_linear_impl<ACT, true>(Xs, ldx, K, W, ldw, bias, N, Ys, ldy);
+  else wg_linear_impl<ACT, false>(Xs, ldx, K, W, ldw, bias, N, Ys, ldy);
 }
 
 // zero the pad columns [E, Epad) of a [16][ld] tile
