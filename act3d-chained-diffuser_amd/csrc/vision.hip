@@ -41,7 +41,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__
     };
     size_t r = r0 + rsub;
     const size_t step = (size_t)nsub;
-    // four independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+    // eight independent 16-byte loads in flight per thread (the loop is latency-bound otherwise: 3.1 TB/s with four)
+    for (; r + 7 * step < r1; r += 8 * step) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + u * step) * tpr + cp];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) accum(v[u]);
+    }
     for (; r + 3 * step < r1; r += 4 * step) {
       const uint4 v0 = x[r * tpr + cp];
       const uint4 v1 = x[(r + step) * tpr + cp];

@@ -176,7 +176,7 @@ def kernel_rooflines(a3d, device, B):
 def pmc_record(B):
     """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
     counters cannot be read from inside this process).  None when no record exists for this batch size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_B{B}.json")   # B = 16, 64
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_B{B}.json")   # B = 64 (round 2 kernels)
     try:
         with open(path) as fh:
             return json.load(fh)["kernels"]
@@ -326,7 +326,7 @@ def main():
             pmc = pmc_record(B) or {}
             r["traffic"] = pmc.get(dom, {}).get("hbm_bytes")
             if dom in pmc:
-                r["traffic_source"] = f"profiles/r01_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
+                r["traffic_source"] = f"profiles/r02_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
                 r["pmc"] = pmc[dom].get("pmc")
             res["roofline"] = r
             res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
