@@ -242,16 +242,24 @@ def test_data_parallel_two_ranks_equals_mean_of_rank_gradients(dev, overlap, gra
     """FlatDataParallel on the device: averaged 2-rank gradients == the mean of the two per-batch gradients (DDP's
     mean-of-means), with the hot-path segments reduced early on the side stream (overlap) or in one piece, eagerly and
     through the three-graph GraphedStep.  Reference semantics: DistributedDataParallel at engine.py:121-124."""
+    import socket
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + (2 if overlap else 0) + (1 if graphed else 0)
-    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, overlap, graphed, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
+    for attempt in range(2):                       # one retry if the rendezvous itself fails (port race on a shared box)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, overlap, graphed, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in range(2)]
+        for p in procs:
+            p.join(timeout=60)
+        errs = [r["error"] for r in res if "error" in r]
+        if not errs or attempt == 1 or not any(k in e for e in errs for k in ("Address already in use", "Connection", "timed out")):
+            break
+        print("[dp test] retrying after a rendezvous failure:", errs[0][-300:])
     for r in res:
         assert "error" not in r, r["error"]
         assert r["same_on_all_ranks"]
