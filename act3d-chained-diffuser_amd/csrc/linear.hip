@@ -422,6 +422,13 @@ extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, in
   return check_launch("a3d_linear_wgrad");
 }
 
+extern "C" int a3d_sq_wgrad_reduce(const float* partial, int nsplit, float* dW, int lddw, float* db, int E, void* stream) {
+  if (!partial || !dW || !db || nsplit < 1 || E <= 0) { set_error("a3d_sq_wgrad_reduce: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(E * (E + 1), 64)), dim3(1024), 0, (hipStream_t)stream, partial, nsplit, dW,
+                     lddw, db, E, E, E + 1);
+  return check_launch("a3d_sq_wgrad_reduce");
+}
+
 extern "C" int a3d_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
                                 float* db, int M, int N, int K, void* stream) {
   return a3d_linear_wgrad_ws(dY, lddy, X, ldx, dW, lddw, db, M, N, K, nullptr, 0, stream);

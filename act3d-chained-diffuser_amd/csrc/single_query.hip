@@ -1,0 +1,447 @@
+// Attention of ONE query per sample over the scene context -- Act3D's query stream (act3d.py:467-480: the learned query
+// token cross-attends to the level's context, RelativeCrossAttentionLayer layers.py:293-310) -- without ever materialising
+// the projected keys / values.
+//
+// With a single query the value projection commutes with the softmax-weighted sum,
+//     o_h = sum_k p_k (W_v,h x_k + b_v,h) = W_v,h (sum_k p_k x_k) + b_v,h          (sum_k p_k = 1),
+// so the forward needs, per head, only the p-weighted mean xbar_h of the RAW context rows; the key projection
+// (W_k x_k + b_k, rotated by the key's xyz) is recomputed per 64-key tile in LDS and consumed on the spot.  The general
+// path (rope.hip + attention*.hip) writes four operand formats of K and V (1152 B per key) for the forward and reads /
+// writes as much again in the backward, to serve 1 query: 2 x 6 blocks x ~0.33 ms per B = 64 step.  Here a block is one
+// pass over the context (240 B per key) forward, and one pass backward that recomputes the keys, forms
+//     ds_k,h = p_k,h (dxbar_h . x_k - dxbar_h . xbar_h),   dxbar_h = W_v,h^T dO_h,
+//     dX_k   = sum_h p_k,h dxbar_h  +  (R_k^T (ds_k (x) q)) W_k,
+//     dW_k  += (R_k^T (ds_k (x) q))^T X      (accumulated over the workgroup's tiles on the MFMA pipe, two-stage reduce),
+// and the rotated-query gradient dq_h = sum_k ds_k,h k_k,h.  All contractions use the exact-f32 MFMA (as linear.hip).
+// Restricted to E <= 64 channels, H <= 4 heads (Act3D: E = 60, H = 4), no key-padding mask (the query stream has none).
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int SQ_T = 64;       // keys per tile
+constexpr int SQ_LD = 68;      // LDS row stride (floats) of the [64][<=64] tiles
+constexpr int SQ_NT = 4;       // 16-column tiles of a row (E <= 64)
+
+// Xs[64][SQ_LD] <- context rows n0 .. n0+63 of sample b (zero beyond S / E); column E := 1 for valid rows if `ones`
+__device__ __forceinline__ void sq_stage_rows(float* Xs, const float* __restrict__ X, int b, int n0, int S, int E, bool ones) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + i * 256;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    const int n = n0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < S && c < E) v = *reinterpret_cast<const float4*>(X + ((size_t)b * S + n) * E + c);      // E % 4 == 0
+    if (ones && n < S) {
+      if (c + 0 == E) v.x = 1.f;
+      if (c + 1 == E) v.y = 1.f;
+      if (c + 2 == E) v.z = 1.f;
+      if (c + 3 == E) v.w = 1.f;
+    }
+    *reinterpret_cast<float4*>(&Xs[r * SQ_LD + c]) = v;
+  }
+}
+
+// Ws[64][SQ_LD] <- W[E][E] (zero padded); W may be only 4-byte aligned (flat parameter buffer)
+__device__ __forceinline__ void sq_stage_weight(float* Ws, const float* __restrict__ W, int ldw, int E) {
+  for (int idx = threadIdx.x; idx < SQ_T * 64; idx += blockDim.x) {
+    const int j = idx >> 6, c = idx & 63;
+    Ws[j * SQ_LD + c] = (j < E && c < E) ? W[(size_t)j * ldw + c] : 0.f;
+  }
+}
+
+// T[64][SQ_LD] = rope(Xs W^T + bias) for the tile's rows (rows >= S zero); Ws holds W (rows = output channels)
+__device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const float* Ws, const float* __restrict__ bias,
+                                                const float* __restrict__ xyz, const float* __restrict__ freq, int b, int n0,
+                                                int S, int E) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  f32x4 acc[SQ_NT];
+#pragma unroll
+  for (int i = 0; i < SQ_NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ksteps = (E + 3) >> 2;
+  for (int kk = 0; kk < ksteps; ++kk) {
+    const float a = Xs[(wave * 16 + li) * SQ_LD + kk * 4 + g];
+#pragma unroll
+    for (int nt = 0; nt < SQ_NT; ++nt) acc[nt] = mfma_f32_16x16x4(a, Ws[(nt * 16 + li) * SQ_LD + kk * 4 + g], acc[nt]);
+  }
+#pragma unroll
+  for (int nt = 0; nt < SQ_NT; ++nt) {
+    const int c = nt * 16 + li;
+    const float bv = (c < E && bias) ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + g * 4 + r;
+      T[row * SQ_LD + c] = (c < E && n0 + row < S) ? acc[nt][r] + bv : 0.f;
+    }
+  }
+  __syncthreads();
+  if (xyz) {
+    const int half = E >> 1, third = E / 3;
+    for (int idx = t; idx < SQ_T * half; idx += 256) {
+      const int r = idx / half, p = idx - r * half;
+      const int n = n0 + r;
+      if (n >= S) continue;
+      const int c = 2 * p;
+      const int axis = c / third;
+      const int kf = (c - axis * third) >> 1;
+      float sn, cs;
+      sincosf(xyz[((size_t)b * S + n) * 3 + axis] * freq[kf], &sn, &cs);
+      const float y0 = T[r * SQ_LD + c], y1 = T[r * SQ_LD + c + 1];
+      T[r * SQ_LD + c] = y0 * cs - y1 * sn;
+      T[r * SQ_LD + c + 1] = y1 * cs + y0 * sn;
+    }
+    __syncthreads();
+  }
+}
+
+// out[h][key] = sum_c A[key][c] M[h][c] for h < 4 via one 16-column MFMA tile; M in LDS as [16][SQ_LD] (rows >= H zero)
+__device__ __forceinline__ void sq_rows_times_heads(const float* A, const float* M, float* out /*[4][64]*/, int E) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int ksteps = (E + 3) >> 2;
+  for (int kk = 0; kk < ksteps; ++kk)
+    acc = mfma_f32_16x16x4(A[(wave * 16 + li) * SQ_LD + kk * 4 + g], M[li * SQ_LD + kk * 4 + g], acc);
+  if (li < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[li * SQ_T + wave * 16 + g * 4 + r] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (nsplit, B); partial [B][nsplit][H][E + 2] = {m, l, xbar[E]} per head
+__global__ __launch_bounds__(256) void sq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
+                                                     const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
+                                                     const float* __restrict__ qrot, const float* __restrict__ freq,
+                                                     float* __restrict__ part, int B, int S, int E, int H, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* Ws = Xs + SQ_T * SQ_LD;
+  float* T = Ws + SQ_T * SQ_LD;
+  float* Qm = T + SQ_T * SQ_LD;            // [16][SQ_LD]: row h = the head's rotated query in its channel range, else 0
+  float* sS = Qm + 16 * SQ_LD;             // [4][64]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  sq_stage_weight(Ws, Wk, ldw, E);
+  for (int idx = t; idx < 16 * SQ_LD; idx += 256) {
+    const int h = idx / SQ_LD, c = idx - h * SQ_LD;
+    const int d = c - h * HD;
+    Qm[idx] = (h < H && c < E && d >= 0 && d < HD) ? qrot[((size_t)b * H + h) * 16 + d] : 0.f;
+  }
+  const int ntile = (S + SQ_T - 1) / SQ_T;
+  const int t_beg = (int)((long long)ntile * sp / nsplit), t_end = (int)((long long)ntile * (sp + 1) / nsplit);
+  float m_run = -INFINITY, l_run = 0.f, xb = 0.f;      // wave = head; lane = channel of xbar
+  __syncthreads();
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int n0 = tile * SQ_T;
+    sq_stage_rows(Xs, X, b, n0, S, E, false);
+    __syncthreads();
+    sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
+    sq_rows_times_heads(T, Qm, sS, E);
+    __syncthreads();
+    float alpha = 1.f;
+    if (wave < H) {
+      const float s = (n0 + lane < S) ? sS[wave * SQ_T + lane] : -INFINITY;
+      const float m_new = fmaxf(m_run, wave_max(s));
+      const float p = (s == -INFINITY) ? 0.f : __expf(s - m_new);
+      alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+      l_run = l_run * alpha + wave_sum(p);
+      m_run = m_new;
+      sS[wave * SQ_T + lane] = p;            // own row, own element: no hazard with the other waves
+    }
+    __syncthreads();
+    if (wave < H && lane < E) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < SQ_T; ++k) a += sS[wave * SQ_T + k] * Xs[k * SQ_LD + lane];
+      xb = xb * alpha + a;
+    }
+    __syncthreads();
+  }
+  if (wave < H) {
+    float* o = part + (((size_t)b * nsplit + sp) * H + wave) * (E + 2);
+    if (lane == 0) { o[0] = m_run; o[1] = l_run; }
+    if (lane < E) o[2 + lane] = xb;
+  }
+}
+
+// xbar [B][H][E], lse [B][H] from the key-split partials
+__global__ __launch_bounds__(256) void sq_combine_kernel(const float* __restrict__ part, float* __restrict__ xbar,
+                                                         float* __restrict__ lse, int B, int H, int E, int nsplit) {
+  const int bh = blockIdx.x;                 // one workgroup per (b, h)
+  const int b = bh / H, h = bh - b * H;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part[(((size_t)b * nsplit + s) * H + h) * (E + 2)]);
+  const float m_use = (m == -INFINITY) ? 0.f : m;
+  float l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* p = part + (((size_t)b * nsplit + s) * H + h) * (E + 2);
+    l += p[1] * __expf(p[0] - m_use);
+  }
+  for (int c = threadIdx.x; c < E; c += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float* p = part + (((size_t)b * nsplit + s) * H + h) * (E + 2);
+      a += p[2 + c] * __expf(p[0] - m_use);
+    }
+    xbar[(size_t)bh * E + c] = l > 0.f ? a / l : 0.f;
+  }
+  if (threadIdx.x == 0) lse[bh] = l > 0.f ? m + logf(l) : -INFINITY;
+}
+
+// o[b][hd] = W_v[hd] . xbar[b][head(hd)] + b_v[hd]
+__global__ void sq_vproj_kernel(const float* __restrict__ xbar, const float* __restrict__ Wv, int ldw, const float* __restrict__ bv,
+                                float* __restrict__ o, int B, int H, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, hd = i - b * E, h = hd / HD;
+  const float* x = xbar + ((size_t)b * H + h) * E;
+  const float* w = Wv + (size_t)hd * ldw;
+  float a = bv ? bv[hd] : 0.f;
+  for (int c = 0; c < E; ++c) a += w[c] * x[c];
+  o[i] = a;
+}
+
+// dxbar[b][h][c] = sum_d dO[b][h*15+d] W_v[h*15+d][c];  cD[b][h] = dxbar . xbar
+// dW_v[hd][c] += sum_b dO[b][hd] xbar[b][h][c];  db_v[hd] += sum_b dO[b][hd]          (grid: B*H blocks, then E blocks)
+__global__ __launch_bounds__(64) void sq_vproj_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ xbar,
+                                                          const float* __restrict__ Wv, int ldw, float* __restrict__ dxbar,
+                                                          float* __restrict__ cD, float* __restrict__ dWv, int lddw,
+                                                          float* __restrict__ dbv, int B, int H, int E) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < B * H) {
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    float a = 0.f;
+    if (lane < E) {
+      for (int d = 0; d < HD; ++d) a += dO[(size_t)b * E + h * HD + d] * Wv[(size_t)(h * HD + d) * ldw + lane];
+      dxbar[(size_t)bh * E + lane] = a;
+    }
+    const float dot = wave_sum(lane < E ? a * xbar[(size_t)bh * E + lane] : 0.f);
+    if (lane == 0) cD[bh] = dot;
+  } else {
+    const int hd = blockIdx.x - B * H, h = hd / HD;
+    float a = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = dO[(size_t)b * E + hd];
+      sb += g;
+      if (lane < E) a += g * xbar[((size_t)b * H + h) * E + lane];
+    }
+    if (lane < E) dWv[(size_t)hd * lddw + lane] += a;
+    if (lane == 0 && dbv) dbv[hd] += sb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// grid (nsplit, B).  dX [B][S][E] (written, every row once); wpart [B * nsplit][E][E + 1] (dW_k | db_k partials);
+// dqp [nsplit][B][H][1][16] (rotated-query gradient partials, the layout a3d_rope_merge_bwd reads with Npad = 1)
+__global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
+                                                     const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
+                                                     const float* __restrict__ qrot, const float* __restrict__ freq,
+                                                     const float* __restrict__ lse, const float* __restrict__ dxbar,
+                                                     const float* __restrict__ cD, float* __restrict__ dX,
+                                                     float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E,
+                                                     int H, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* Ws = Xs + SQ_T * SQ_LD;
+  float* T = Ws + SQ_T * SQ_LD;            // rotated keys, then (in place) the gradient w.r.t. the un-rotated projection
+  float* Qm = T + SQ_T * SQ_LD;            // [16][SQ_LD]
+  float* Dm = Qm + 16 * SQ_LD;             // [16][SQ_LD]: row h = dxbar[b][h]
+  float* sS = Dm + 16 * SQ_LD;             // [4][64] scores -> p
+  float* dS = sS + 4 * SQ_T;               // [4][64] dp -> ds
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  sq_stage_weight(Ws, Wk, ldw, E);
+  for (int idx = t; idx < 16 * SQ_LD; idx += 256) {
+    const int h = idx / SQ_LD, c = idx - h * SQ_LD;
+    const int d = c - h * HD;
+    Qm[idx] = (h < H && c < E && d >= 0 && d < HD) ? qrot[((size_t)b * H + h) * 16 + d] : 0.f;
+    Dm[idx] = (h < H && c < E) ? dxbar[((size_t)b * H + h) * E + c] : 0.f;
+  }
+  const float lse_h = wave < H ? lse[(size_t)b * H + wave] : 0.f;
+  const float cd_h = wave < H ? cD[(size_t)b * H + wave] : 0.f;
+  const int ntile = (S + SQ_T - 1) / SQ_T;
+  const int t_beg = (int)((long long)ntile * sp / nsplit), t_end = (int)((long long)ntile * (sp + 1) / nsplit);
+  f32x4 wacc[SQ_NT];                        // dW_k rows n = wave*16 + g*4 + r, columns kt*16 + li (column E = db_k)
+#pragma unroll
+  for (int i = 0; i < SQ_NT; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dqa = 0.f;                          // wave = head, lane = channel d < 15
+  const int half = E >> 1, third = E / 3;
+  __syncthreads();
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int n0 = tile * SQ_T;
+    sq_stage_rows(Xs, X, b, n0, S, E, true);                 // column E = 1: the bias gradient rides in the weight gradient
+    __syncthreads();
+    sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
+    sq_rows_times_heads(T, Qm, sS, E);                       // scores
+    sq_rows_times_heads(Xs, Dm, dS, E);                      // dp = dxbar . x_k
+    __syncthreads();
+    if (wave < H) {
+      const bool ok = n0 + lane < S && lse_h != -INFINITY;
+      const float p = ok ? __expf(sS[wave * SQ_T + lane] - lse_h) : 0.f;
+      sS[wave * SQ_T + lane] = p;
+      dS[wave * SQ_T + lane] = p * (dS[wave * SQ_T + lane] - cd_h);
+    }
+    __syncthreads();
+    // rotated-query gradient: dq_h[d] += sum_k ds_k,h k_k[h*15 + d]   (T still holds the rotated keys)
+    if (wave < H && lane < HD) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < SQ_T; ++k) a += dS[wave * SQ_T + k] * T[k * SQ_LD + wave * HD + lane];
+      dqa += a;
+    }
+    __syncthreads();
+    // T <- R_k^T (ds_k (x) q): gradient w.r.t. the projected (un-rotated) key rows
+    for (int idx = t; idx < SQ_T * half; idx += 256) {
+      const int r = idx / half, p = idx - r * half;
+      const int c0 = 2 * p, c1 = c0 + 1;
+      const int h0 = c0 / HD, h1 = c1 / HD;
+      const float g0 = dS[h0 * SQ_T + r] * Qm[h0 * SQ_LD + c0];
+      const float g1 = dS[h1 * SQ_T + r] * Qm[h1 * SQ_LD + c1];
+      float y0 = g0, y1 = g1;
+      const int n = n0 + r;
+      if (xyz && n < S) {
+        const int axis = c0 / third;
+        const int kf = (c0 - axis * third) >> 1;
+        float sn, cs;
+        sincosf(xyz[((size_t)b * S + n) * 3 + axis] * freq[kf], &sn, &cs);
+        y0 = cs * g0 + sn * g1;
+        y1 = cs * g1 - sn * g0;
+      }
+      T[r * SQ_LD + c0] = y0;
+      T[r * SQ_LD + c1] = y1;
+    }
+    __syncthreads();
+    // dX tile = T W_k (dgrad, contraction over the projection's output channels) + sum_h p_h dxbar_h
+    {
+      f32x4 acc[SQ_NT];
+#pragma unroll
+      for (int i = 0; i < SQ_NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int ksteps = (E + 3) >> 2;
+      for (int kk = 0; kk < ksteps; ++kk) {
+        const float a = T[(wave * 16 + li) * SQ_LD + kk * 4 + g];
+#pragma unroll
+        for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(a, Ws[(kk * 4 + g) * SQ_LD + ct * 16 + li], acc[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < SQ_NT; ++ct) {
+        const int c = ct * 16 + li;
+        if (c >= E) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wave * 16 + g * 4 + r;
+          const int n = n0 + row;
+          if (n >= S) continue;
+          float v = acc[ct][r];
+          for (int h = 0; h < H; ++h) v += sS[h * SQ_T + row] * Dm[h * SQ_LD + c];
+          dX[((size_t)b * S + n) * E + c] = v;
+        }
+      }
+    }
+    // dW_k | db_k += T^T [Xs | 1]   (contraction over the tile's keys; wave -> output rows n = wave*16 .. +15)
+    for (int mm = 0; mm < 4; ++mm) {
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = T[(mm * 16 + g * 4 + j) * SQ_LD + wave * 16 + li];
+#pragma unroll
+      for (int kt = 0; kt < SQ_NT; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wacc[kt] = mfma_f32_16x16x4(a[j], Xs[(mm * 16 + g * 4 + j) * SQ_LD + kt * 16 + li], wacc[kt]);
+      }
+    }
+    __syncthreads();
+  }
+  const int KE = E + 1;
+  float* wp = wpart + ((size_t)b * nsplit + sp) * E * KE;
+#pragma unroll
+  for (int kt = 0; kt < SQ_NT; ++kt) {
+    const int k = kt * 16 + li;
+    if (k >= KE) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wave * 16 + g * 4 + r;
+      if (n < E) wp[(size_t)n * KE + k] = wacc[kt][r];
+    }
+  }
+  if (wave < H && lane < 16) dqp[(((size_t)sp * B + b) * H + wave) * 16 + lane] = lane < HD ? dqa : 0.f;
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+static int sq_check(const char* fn, int B, int S, int E, int H, int nsplit) {
+  if (B <= 0 || S <= 0 || E <= 0 || E > 60 || (E % 6) != 0 || (E % 4) != 0 || H <= 0 || H > 4 || H * HD != E || nsplit < 1 ||
+      nsplit > 256) {
+    set_error("%s: bad shape (B=%d S=%d E=%d H=%d nsplit=%d; E = 15 H <= 60, E %% 12 == 0)", fn, B, S, E, H, nsplit);
+    return A3D_ERR_ARG;
+  }
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_sq_fwd_ws_floats(int B, int H, int E, int nsplit) { return (size_t)B * nsplit * H * (E + 2); }
+
+extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                               int ldwv, const float* bv, const float* qrot, const float* freq, float* ws, float* xbar,
+                               float* lse, float* o, int B, int S, int E, int H, int nsplit, void* stream) {
+  int rc = sq_check("a3d_sq_attn_fwd", B, S, E, H, nsplit);
+  if (rc) return rc;
+  if (!X || !Wk || !Wv || !qrot || !ws || !xbar || !lse || !o || (xyz && !freq) || ((((uintptr_t)X) & 15) != 0)) {
+    set_error("a3d_sq_attn_fwd: null / misaligned pointer");
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 16 * SQ_LD + 4 * SQ_T) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sq_fwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
+  rc = check_launch("a3d_sq_attn_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sq_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, xbar, lse, B, H, E, nsplit);
+  rc = check_launch("a3d_sq_attn_fwd(combine)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sq_vproj_kernel, dim3(cdiv(B * E, 256)), dim3(256), 0, s, xbar, Wv, ldwv, bv, o, B, H, E);
+  return check_launch("a3d_sq_attn_fwd(vproj)");
+}
+
+extern "C" size_t a3d_sq_bwd_ws_floats(int B, int H, int E, int nsplit) {
+  return (size_t)B * H * E + (size_t)B * H + (size_t)B * nsplit * E * (E + 1);      // dxbar | cD | weight-gradient partials
+}
+
+extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                               int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                               const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
+                               int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
+  int rc = sq_check("a3d_sq_attn_bwd", B, S, E, H, nsplit);
+  if (rc) return rc;
+  if (!X || !Wk || !Wv || !qrot || !xbar || !lse || !dO || !ws || !dX || !dqp || !dWk || !dbk || !dWv || (xyz && !freq) ||
+      ((((uintptr_t)X) & 15) != 0)) {
+    set_error("a3d_sq_attn_bwd: null / misaligned pointer");
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dxbar = ws;
+  float* cD = dxbar + (size_t)B * H * E;
+  float* wpart = cD + (size_t)B * H;
+  hipLaunchKernelGGL(sq_vproj_bwd_kernel, dim3(B * H + E), dim3(64), 0, s, dO, xbar, Wv, ldwv, dxbar, cD, dWv, lddwv, dbv, B, H, E);
+  rc = check_launch("a3d_sq_attn_bwd(vproj)");
+  if (rc) return rc;
+  const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sq_bwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX, wpart,
+                     dqp, B, S, E, H, nsplit);
+  rc = check_launch("a3d_sq_attn_bwd");
+  if (rc) return rc;
+  return a3d_sq_wgrad_reduce(wpart, B * nsplit, dWk, lddwk, dbk, E, stream);
+}

@@ -57,6 +57,12 @@ SIGNATURES = {
     "a3d_traj_errors": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_keypose_errors": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "a3d_sym_quat_loss": (_i, [_p, _p, _i, _f, _p, _p, _i, _p]),
+    "a3d_sq_fwd_ws_floats": (_z, [_i, _i, _i, _i]),
+    "a3d_sq_attn_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_sq_bwd_ws_floats": (_z, [_i, _i, _i, _i]),
+    "a3d_sq_attn_bwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
+                             _i, _p]),
+    "a3d_sq_wgrad_reduce": (_i, [_p, _i, _p, _i, _p, _i, _p]),
     "a3d_dn_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "a3d_dn_cross_ws_floats": (_z, [_i, _i, _i]),
     "a3d_dn_cross": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -438,11 +438,90 @@ class AttnBlockFn(torch.autograd.Function):
         return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 13
 
 
+SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
+
+
+class SingleQueryAttnBlockFn(torch.autograd.Function):
+    """y = LayerNorm(resid + out_proj(MHA(q, ctx, ctx))) for ONE query per sample (Act3D's query stream, act3d.py:467-480)
+    on csrc/single_query.hip: the value projection commutes with the weighted sum for a single query, the key projection
+    is recomputed tile by tile -- no K / V operand tensors are written, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv_in, resid, q_xyz, k_xyz, in_w, in_b, out_w, out_b, ln_g, ln_b, H):
+        L.require_gpu(q_in, kv_in, resid)
+        q_in, kv_in, resid = _c(q_in), _c(kv_in), _c(resid)
+        B, _, E = q_in.shape
+        S = kv_in.shape[1]
+        dev = q_in.device
+        f4 = 4
+        if q_xyz is not None:
+            q_xyz, k_xyz = _c(q_xyz.to(F32)), _c(k_xyz.to(F32))
+        freq = rope_freq(E, dev)
+        scale = float(E // H) ** -0.5
+        wp, bp = in_w.data_ptr(), in_b.data_ptr()
+        nz = lambda t: None if t is None else t.data_ptr()
+        q_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B, E, E, dev)
+        qrot = torch.empty((B, H, 1, 16), device=dev, dtype=F32)
+        L.call("a3d_rope_rows_f32", q_pre.data_ptr(), E, nz(q_xyz), freq.data_ptr(), scale, qrot.data_ptr(), B, 1, 1, E, H, L.stream())
+        nsplit = max(1, min((S + 63) // 64, 1024 // B))
+        lib = L.load()
+        ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)
+        xbar = torch.empty((B, H, E), device=dev, dtype=F32)
+        lse = torch.empty((B, H), device=dev, dtype=F32)
+        o = torch.empty((B, E), device=dev, dtype=F32)
+        L.call("a3d_sq_attn_fwd", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, wp + 2 * E * E * f4, E,
+               bp + 2 * E * f4, qrot.data_ptr(), freq.data_ptr(), ws.data_ptr(), xbar.data_ptr(), lse.data_ptr(), o.data_ptr(), B, S, E,
+               H, nsplit, L.stream())
+        Y = linear2d(o, out_w, out_b)
+        y, mean, rstd = add_layernorm(resid.view(B, E), Y, ln_g, ln_b)
+        ctx.save_for_backward(q_in, kv_in, resid, Y, mean, rstd, qrot, xbar, lse, o,
+                              q_xyz if q_xyz is not None else torch.empty(0, device=dev),
+                              k_xyz if k_xyz is not None else torch.empty(0, device=dev))
+        ctx.params = (in_w, in_b, out_w, out_b, ln_g, ln_b)
+        ctx.meta = (B, S, E, H, scale, nsplit, q_xyz is not None)
+        return y.view(B, 1, E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        q_in, kv_in, resid, Y, mean, rstd, qrot, xbar, lse, o, q_xyz, k_xyz = ctx.saved_tensors
+        in_w, in_b, out_w, out_b, ln_g, ln_b = ctx.params
+        B, S, E, H, scale, nsplit, has_xyz = ctx.meta
+        dev = dy.device
+        f4 = 4
+        if not has_xyz:
+            q_xyz = k_xyz = None
+        freq = rope_freq(E, dev)
+        nz = lambda t: None if t is None else t.data_ptr()
+        dS = add_layernorm_bwd(resid.view(B, E), Y, ln_g, ln_b, mean, rstd, _c(dy).view(B, E))
+        dO = dgrad2d(dS, out_w)
+        wgrad2d(dS, o, out_w, out_b)
+        gW, gb = grad_buf(in_w), grad_buf(in_b)
+        wp, bp = in_w.data_ptr(), in_b.data_ptr()
+        lib = L.load()
+        ws = torch.empty((lib.a3d_sq_bwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)
+        dX = torch.empty((B, S, E), device=dev, dtype=F32)
+        dqp = torch.empty((nsplit, B, H, 1, 16), device=dev, dtype=F32)
+        L.call("a3d_sq_attn_bwd", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, wp + 2 * E * E * f4, E, qrot.data_ptr(),
+               freq.data_ptr(), xbar.data_ptr(), lse.data_ptr(), dO.data_ptr(), ws.data_ptr(), dX.data_ptr(), dqp.data_ptr(),
+               gW.data_ptr() + E * E * f4, E, gb.data_ptr() + E * f4, gW.data_ptr() + 2 * E * E * f4, E, gb.data_ptr() + 2 * E * f4,
+               B, S, E, H, nsplit, L.stream())
+        dq_pre = torch.empty((B, E), device=dev, dtype=F32)
+        rope_merge(dqp, nsplit, q_xyz, freq, scale, dq_pre.data_ptr(), E, B, 1, 1, E, H)
+        wgrad_raw(dq_pre.data_ptr(), E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(), B, E, E, dev)
+        d_q_in = dgrad2d(dq_pre, in_w[:E]).view(B, 1, E) if ctx.needs_input_grad[0] else None
+        return (d_q_in, dX if ctx.needs_input_grad[1] else None, dS.view(B, 1, E) if ctx.needs_input_grad[2] else None) + (None,) * 9
+
+
 def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=None, site=0):
     """mha: module with in_proj_weight/in_proj_bias/out_proj; norm: LayerNorm-like with weight/bias.
 
     The projection path is chosen structurally (which inputs are the same tensor), replacing the reference's
     data-dependent torch.equal checks (multihead_custom_attention.py:234-235) that force a host sync."""
+    E = q_in.shape[-1]
+    if (SINGLE_QUERY and k_in is v_in and q_in.shape[1] == 1 and kmask is None and E <= 60 and E % 12 == 0 and H <= 4
+            and (drop is None or drop.p <= 0) and k_in.dtype == F32 and q_in.is_cuda):
+        return SingleQueryAttnBlockFn.apply(q_in, k_in, resid, q_xyz, k_xyz, mha.in_proj_weight, mha.in_proj_bias,
+                                            mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H)
     if k_in is v_in:
         mode = "kv"
     elif q_in is k_in:

@@ -126,6 +126,25 @@ int a3d_attn_bwd_bf16_dropout(const void* Qs, const void* Qt, const void* Ks, co
                               int Sp, int nsplit, const unsigned long long* drop_state, unsigned int site, float p,
                               void* stream);
 
+/* ---- attention of ONE query per sample over the context (Act3D's query stream, act3d.py:467-480), keys / values never
+ *      materialised: o[b][h*15+d] = W_v[h*15+d] . xbar[b][h] + b_v with xbar = softmax-weighted mean of the raw context rows
+ *      X [B][S][E] (16-byte aligned); the key projection W_k x + b_k (rows E..2E of in_proj), rotated by xyz (NULL: none), is
+ *      recomputed per tile.  qrot: [B][H][16] rotated, scaled query (a3d_rope_rows_f32 with N = Npad = 1).  E = 15 H <= 60.
+ *      Outputs xbar [B][H][E], lse [B][H] (saved for backward), o [B][E].  ws >= a3d_sq_fwd_ws_floats floats. ------------- */
+size_t a3d_sq_fwd_ws_floats(int B, int H, int E, int nsplit);
+int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
+                    const float* bv, const float* qrot, const float* freq, float* ws, float* xbar, float* lse, float* o, int B,
+                    int S, int E, int H, int nsplit, void* stream);
+/* Backward: dX [B][S][E] (written), dqp [nsplit][B][H][16] (rotated-query gradient partials: a3d_rope_merge_bwd layout with
+ * Npad = 1), dWk / dbk / dWv / dbv accumulated (+=).  ws >= a3d_sq_bwd_ws_floats floats. */
+size_t a3d_sq_bwd_ws_floats(int B, int H, int E, int nsplit);
+int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
+                    const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
+                    float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv, int lddwv, float* dbv, int B, int S,
+                    int E, int H, int nsplit, void* stream);
+/* dW[n][k] += sum_z partial[z][n][k], db[n] += sum_z partial[z][n][E] for partial [nsplit][E][E + 1] (fixed order) */
+int a3d_sq_wgrad_reduce(const float* partial, int nsplit, float* dW, int lddw, float* db, int E, void* stream);
+
 /* ---- scene tokens --------------------------------------------------------------------------------------- */
 /* out[b][(cam*h + y)*w + x][:] = bilinear(pcd[(b,cam)], 1/factor)  (act3d.py:379-383, encoder.py:147-158) */
 int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C, int Hin, int Win, int factor, void* stream);

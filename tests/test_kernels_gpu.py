@@ -151,7 +151,9 @@ def _mk_modules(dev, in_w, in_b, out_w, out_b, ln_g, ln_b):
 @pytest.mark.parametrize("B,Lq,S,E,H,rope,masked,mode", [
     (2, 37, 131, 60, 4, True, False, "kv"),
     (2, 16, 70, 120, 8, True, True, "qk"),
-    (3, 1, 200, 60, 4, False, False, "kv"),
+    (3, 1, 200, 60, 4, False, False, "kv"),        # Lq = 1: the single-query kernels (csrc/single_query.hip), no RoPE (level 0)
+    (2, 1, 70, 60, 4, True, False, "kv"),           # ... with RoPE, one full + one partial 64-key tile
+    (2, 1, 4097, 60, 4, True, False, "kv"),         # ... the query stream at cfg-2's context length (key splits)
     (2, 333, 1025, 60, 4, True, False, "kv"),
     (2, 100, 53, 120, 8, False, False, "none"),
     (1, 130, 4097, 60, 4, True, False, "kv"),
