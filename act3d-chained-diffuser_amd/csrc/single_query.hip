@@ -23,8 +23,11 @@ constexpr int SQ_T = 64;       // keys per tile
 constexpr int SQ_LD = 68;      // LDS row stride (floats) of the [64][<=64] tiles
 constexpr int SQ_NT = 4;       // 16-column tiles of a row (E <= 64)
 
-// Xs[64][SQ_LD] <- context rows n0 .. n0+63 of sample b (zero beyond S / E); column E := 1 for valid rows if `ones`
-__device__ __forceinline__ void sq_stage_rows(float* Xs, const float* __restrict__ X, int b, int n0, int S, int E, bool ones) {
+// context rows n0 .. n0+63 of sample b (zero beyond S / E; column E := 1 for valid rows if `ones`): global -> registers
+// (issued one tile ahead, so the HBM round trip hides behind the previous tile's arithmetic) -> Xs[64][SQ_LD]
+struct SqRows { float4 v[4]; };
+__device__ __forceinline__ SqRows sq_load_rows(const float* __restrict__ X, int b, int n0, int S, int E, bool ones) {
+  SqRows s;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -39,7 +42,16 @@ __device__ __forceinline__ void sq_stage_rows(float* Xs, const float* __restrict
       if (c + 2 == E) v.z = 1.f;
       if (c + 3 == E) v.w = 1.f;
     }
-    *reinterpret_cast<float4*>(&Xs[r * SQ_LD + c]) = v;
+    s.v[i] = v;
+  }
+  return s;
+}
+__device__ __forceinline__ void sq_store_rows(float* Xs, const SqRows& s) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + i * 256;
+    *reinterpret_cast<float4*>(&Xs[(idx >> 4) * SQ_LD + (idx & 15) * 4]) = s.v[i];
   }
 }
 
@@ -60,8 +72,10 @@ __device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const
   f32x4 acc[SQ_NT];
 #pragma unroll
   for (int i = 0; i < SQ_NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ksteps = (E + 3) >> 2;
-  for (int kk = 0; kk < ksteps; ++kk) {
+  // 16 k-steps over the 64 staged columns (columns >= E are zero on at least one operand): a constant trip count lets the
+  // compiler hoist the LDS operand reads over the MFMAs
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
     const float a = Xs[(wave * 16 + li) * SQ_LD + kk * 4 + g];
 #pragma unroll
     for (int nt = 0; nt < SQ_NT; ++nt) acc[nt] = mfma_f32_16x16x4(a, Ws[(nt * 16 + li) * SQ_LD + kk * 4 + g], acc[nt]);
@@ -100,10 +114,14 @@ __device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const
 __device__ __forceinline__ void sq_rows_times_heads(const float* A, const float* M, float* out /*[4][64]*/, int E) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int ksteps = (E + 3) >> 2;
-  for (int kk = 0; kk < ksteps; ++kk)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 2) {          // M's columns >= E are zero
     acc = mfma_f32_16x16x4(A[(wave * 16 + li) * SQ_LD + kk * 4 + g], M[li * SQ_LD + kk * 4 + g], acc);
+    acc1 = mfma_f32_16x16x4(A[(wave * 16 + li) * SQ_LD + kk * 4 + 4 + g], M[li * SQ_LD + kk * 4 + 4 + g], acc1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
   if (li < 4) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[li * SQ_T + wave * 16 + g * 4 + r] = acc[r];
@@ -133,10 +151,13 @@ __global__ __launch_bounds__(256) void sq_fwd_kernel(const float* __restrict__ X
   const int ntile = (S + SQ_T - 1) / SQ_T;
   const int t_beg = (int)((long long)ntile * sp / nsplit), t_end = (int)((long long)ntile * (sp + 1) / nsplit);
   float m_run = -INFINITY, l_run = 0.f, xb = 0.f;      // wave = head; lane = channel of xbar
+  SqRows rows;
+  if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, false);
   __syncthreads();
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int n0 = tile * SQ_T;
-    sq_stage_rows(Xs, X, b, n0, S, E, false);
+    sq_store_rows(Xs, rows);
+    if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, false);
     __syncthreads();
     sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
     sq_rows_times_heads(T, Qm, sS, E);
@@ -270,10 +291,13 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   for (int i = 0; i < SQ_NT; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dqa = 0.f;                          // wave = head, lane = channel d < 15
   const int half = E >> 1, third = E / 3;
+  SqRows rows;
+  if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, true);     // column E = 1: the bias gradient rides in dW
   __syncthreads();
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int n0 = tile * SQ_T;
-    sq_stage_rows(Xs, X, b, n0, S, E, true);                 // column E = 1: the bias gradient rides in the weight gradient
+    sq_store_rows(Xs, rows);
+    if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, true);
     __syncthreads();
     sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
     sq_rows_times_heads(T, Qm, sS, E);                       // scores
@@ -320,8 +344,8 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       f32x4 acc[SQ_NT];
 #pragma unroll
       for (int i = 0; i < SQ_NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int ksteps = (E + 3) >> 2;
-      for (int kk = 0; kk < ksteps; ++kk) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {          // T's columns >= E and Ws's rows >= E are zero
         const float a = T[(wave * 16 + li) * SQ_LD + kk * 4 + g];
 #pragma unroll
         for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(a, Ws[(kk * 4 + g) * SQ_LD + ct * 16 + li], acc[ct]);
@@ -342,6 +366,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       }
     }
     // dW_k | db_k += T^T [Xs | 1]   (contraction over the tile's keys; wave -> output rows n = wave*16 .. +15)
+#pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
       float a[4];
 #pragma unroll
