@@ -158,8 +158,8 @@ class Act3D(nn.Module):
         B, ncam = visible_rgb.shape[:2]
         x = visible_rgb.flatten(0, 1)
         with torch.no_grad():
-            x = self.normalize(x).contiguous(memory_format=torch.channels_last)
-            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32)
+            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32,
+                                        normalize=self.normalize)
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):
                 # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row

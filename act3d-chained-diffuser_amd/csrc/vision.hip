@@ -138,6 +138,34 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector((f2){a, b}, b2));
 }
 
+// CLIP input normalisation (model/utils/clip.py:19, act3d.py:364) + NCHW fp32 -> NHWC bf16 in one pass: 4 pixels per thread.
+// y[n][h][w][c] = bf16((x[n][c][h][w] - mean[c]) / std[c])   (replaces sub, div, channels-last copy and cast: 4 passes)
+__global__ __launch_bounds__(256) void rgb_normalize_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ stdv, unsigned short* __restrict__ y,
+                                                            size_t N, size_t HW) {
+  const size_t quads = N * HW / 4;
+  const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = (i * 4) / HW, p = (i * 4) - n * HW;          // HW % 4 == 0: a quad never straddles images
+    const float* base = x + n * 3 * HW + p;
+    const float4 r = *reinterpret_cast<const float4*>(base);
+    const float4 g = *reinterpret_cast<const float4*>(base + HW);
+    const float4 b = *reinterpret_cast<const float4*>(base + 2 * HW);
+    const float rr[4] = {r.x, r.y, r.z, r.w}, gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+    unsigned short o[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[3 * j + 0] = f2bf((rr[j] - m0) / s0);
+      o[3 * j + 1] = f2bf((gg[j] - m1) / s1);
+      o[3 * j + 2] = f2bf((bb[j] - m2) / s2);
+    }
+    uint2* dst = reinterpret_cast<uint2*>(y + (n * HW + p) * 3);      // 24 bytes, 8-byte aligned (p % 4 == 0)
+    dst[0] = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    dst[1] = make_uint2(o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16));
+    dst[2] = make_uint2(o[8] | ((unsigned)o[9] << 16), o[10] | ((unsigned)o[11] << 16));
+  }
+}
+
 // 8 channels (16 B) per thread
 __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__ x, const uint4* __restrict__ res,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -363,4 +391,18 @@ extern "C" int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, i
   hipLaunchKernelGGL(upsample2_add_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint2*)dy, (uint2*)dtop,
                      N, H, W, C / 4);
   return check_launch("a3d_upsample2_add_bwd");
+}
+
+extern "C" int a3d_rgb_normalize_nhwc_bf16(const float* x, const float* mean, const float* stdv, void* y, size_t N, int H, int W,
+                                           void* stream) {
+  const size_t HW = (size_t)H * W;
+  if (!x || !mean || !stdv || !y || N == 0 || H <= 0 || W <= 0 || (HW % 4) != 0 || ((((uintptr_t)x) & 15) != 0) ||
+      ((((uintptr_t)y) & 7) != 0)) {
+    set_error("a3d_rgb_normalize_nhwc_bf16: bad argument (H * W must be a multiple of 4, x 16-byte aligned)");
+    return A3D_ERR_ARG;
+  }
+  const size_t quads = N * HW / 4;
+  hipLaunchKernelGGL(rgb_normalize_kernel, dim3((int)std::min<size_t>((quads + 255) / 256, 16384)), dim3(256), 0,
+                     (hipStream_t)stream, x, mean, stdv, (unsigned short*)y, N, HW);
+  return check_launch("a3d_rgb_normalize_nhwc_bf16");
 }

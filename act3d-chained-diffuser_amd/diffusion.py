@@ -159,8 +159,7 @@ class DiffusionHead(nn.Module):
         B, ncam = rgb.shape[:2]
         x = rgb.flatten(0, 1)
         with torch.no_grad():
-            x = self.normalize(x).contiguous(memory_format=torch.channels_last)
-            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype)
+            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, normalize=self.normalize)
         name = self.feature_map_pyramid[0]
         fm = self.feature_pyramid(feats, needed=[name])[name]
         n, E, h, w = fm.shape

@@ -413,11 +413,26 @@ def fused_frozen_backbone_forward(bb, x):
 FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
 
 
-def run_frozen_backbone(backbone, x, dtype, keep_dtype=False):
-    """Forward of the frozen backbone under no_grad.  For a reduced dtype the convolution weights are converted ONCE
+def normalize_to_nhwc_bf16(x, normalize):
+    """ClipNormalize + channels-last + bf16 cast of the raw images (N, 3, H, W) fp32 in one kernel (vision.hip)."""
+    x = x.float().contiguous()
+    N, _, H, W = x.shape
+    y = torch.empty((N, 3, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    O.L.call("a3d_rgb_normalize_nhwc_bf16", x.data_ptr(), normalize.mean.data_ptr(), normalize.std.data_ptr(), y.data_ptr(), N, H, W,
+             O.L.stream())
+    return y
+
+
+def run_frozen_backbone(backbone, x, dtype, keep_dtype=False, normalize=None):
+    """Forward of the frozen backbone under no_grad.  `normalize`: the ClipNormalize module when `x` are the RAW images
+    (None: already normalised).  For a reduced dtype the convolution weights are converted ONCE
     (the backbone is frozen, so there is no master copy to keep) instead of being re-cast by autocast at every step;
     BatchNorm keeps fp32 parameters / running statistics and, as in the reference's train() mode, batch statistics.
     On the GPU with bf16 the BatchNorm + ReLU + residual chain runs as the fused HIP kernels of vision.hip."""
+    fused = FUSED_BN and x.is_cuda and dtype == torch.bfloat16 and isinstance(backbone, SyntheticCLIPResNet50)
+    if normalize is not None and not (fused and isinstance(normalize, ClipNormalize) and (x.shape[-1] * x.shape[-2]) % 4 == 0):
+        x = normalize(x).contiguous(memory_format=torch.channels_last)
+        normalize = None
     if dtype == torch.float32:
         return backbone(x)
     if getattr(backbone, "_conv_dtype", None) != dtype:
@@ -426,9 +441,9 @@ def run_frozen_backbone(backbone, x, dtype, keep_dtype=False):
                 m.to(dtype)
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         backbone._conv_dtype = dtype
-    xb = x.to(dtype)
-    if FUSED_BN and x.is_cuda and dtype == torch.bfloat16 and isinstance(backbone, SyntheticCLIPResNet50):
-        feats = fused_frozen_backbone_forward(backbone, xb.contiguous(memory_format=torch.channels_last))
+    if fused:
+        xb = normalize_to_nhwc_bf16(x, normalize) if normalize is not None else x.to(dtype).contiguous(memory_format=torch.channels_last)
+        feats = fused_frozen_backbone_forward(backbone, xb)
     else:
-        feats = backbone(xb)
+        feats = backbone(x.to(dtype))
     return feats if keep_dtype else {k: v.float() for k, v in feats.items()}

@@ -306,6 +306,11 @@ int a3d_bn_apply_pool2(const void* x, const void* residual, const float* scale, 
 int a3d_upsample2_add_fwd(const void* lat, const void* top, void* y, int N, int H, int W, int C, void* stream);
 int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, int W, int C, void* stream);
 
+/* y (bf16, [N][H][W][3] = torch channels_last storage) = (x (fp32 [N][3][H][W]) - mean[c]) / std[c]: CLIP's input
+ * normalisation (model/utils/clip.py:19, act3d.py:364) fused with the layout change and the cast the bf16 backbone needs. */
+int a3d_rgb_normalize_nhwc_bf16(const float* x, const float* mean, const float* stdv, void* y, size_t N, int H, int W,
+                                void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------------- */
 int a3d_dbg_mfma_bf16(const void* A16x32, const void* B32x16, float* D16x16, void* stream);
 int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void* stream);

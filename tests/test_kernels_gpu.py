@@ -708,3 +708,14 @@ def test_pose_signal_kernels_vs_oracle_and_golden(a3d, dev):
     report("reference 6D", D.pose_to_signal(pose.to(dev))[:, 3:], r["o6"], 2e-6)
     sig = torch.cat([torch.zeros(6, 3), r["o6"]], dim=-1)
     report("reference quaternion", D.signal_to_pose(sig.to(dev))[:, 3:], r["q_back"], 2e-6)
+
+
+def test_rgb_normalize_kernel_matches_torch(a3d, dev):
+    """a3d_rgb_normalize_nhwc_bf16 == ClipNormalize -> channels_last -> bf16 cast, bit for bit"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(3, 3, 128, 128, generator=g).to(dev)
+    norm = a3d.nn.ClipNormalize().to(dev)
+    ref = norm(x).contiguous(memory_format=torch.channels_last).to(torch.bfloat16)
+    got = a3d.nn.normalize_to_nhwc_bf16(x, norm)
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == ref.shape
+    assert torch.equal(got, ref)
