@@ -86,9 +86,6 @@ class Act3D(nn.Module):
         assert image_size in [(128, 128), (256, 256)]
         assert rotation_parametrization in ["quat_from_top_ghost", "quat_from_query", "6D_from_top_ghost", "6D_from_query"]
         assert num_sampling_level in [1, 2, 3, 4]
-        if rotation_parametrization != "quat_from_query" or regress_position_offset or ins_pos_emb:
-            raise NotImplementedError("only rotation_parametrization='quat_from_query', regress_position_offset=False, "
-                                      "ins_pos_emb=False (the shipped training configuration) are implemented")
         assert ghost_sampler in ("philox", "numpy")
 
         self.image_size = image_size
@@ -138,11 +135,18 @@ class Act3D(nn.Module):
                 embedding_dim, num_attn_heads, num_vis_ins_attn_layers), weight_tying)
         self.query_cross_attn_pyramid = tied(lambda: RelativeCrossAttentionModule(
             embedding_dim, num_attn_heads, num_query_cross_attn_layers), weight_tying)
-        self.rotation_dim = 4
+        if regress_position_offset:
+            self.ghost_point_offset_predictor = nn.Sequential(nn.Linear(embedding_dim, embedding_dim), nn.ReLU(),
+                                                              nn.Linear(embedding_dim, 3))
+        self.rotation_dim = 4 if "quat" in rotation_parametrization else 6
         self.gripper_state_predictor = nn.Sequential(nn.Linear(embedding_dim, embedding_dim), nn.ReLU(),
                                                      nn.Linear(embedding_dim, self.rotation_dim + 1))
         if use_instruction:
             self.instruction_encoder = nn.Linear(512, embedding_dim)
+            if ins_pos_emb:
+                self._num_words = 53
+                self.instr_position_embedding = nn.Embedding(self._num_words, embedding_dim)
+                self.instr_position_norm = nn.LayerNorm(embedding_dim)
 
         # device-side sampler state {seed, call offset}; advanced by a kernel so that captured graphs draw fresh points
         self.register_buffer("_rng_state", torch.tensor([sampler_seed, 0], dtype=torch.int64), persistent=False)
@@ -236,6 +240,10 @@ class Act3D(nn.Module):
         instr = None
         if self.use_instruction:
             instr = O.linear(instruction.float(), self.instruction_encoder)
+            if self.ins_pos_emb:                        # act3d.py:201-209: + LayerNorm(position embedding), all 53 words
+                pe = O.LayerNormFn.apply(self.instr_position_embedding.weight, self.instr_position_norm.weight,
+                                         self.instr_position_norm.bias)
+                instr = O.AddRowsFn.apply(instr, pe)
             instr_xyz = torch.zeros((B, instr.shape[1], 3), device=device, dtype=torch.float32)
 
         grip_tok = broadcast_row(self.curr_gripper_embed.weight, B, 1)
@@ -295,17 +303,30 @@ class Act3D(nn.Module):
             ghost_features_pyramid.append(gfeat)
             prev_pos = pos_i if teacher_positions is None else teacher_positions[i].to(device=device, dtype=torch.float32)
 
-        pred = O.mlp(query[:, 0], self.gripper_state_predictor[0], self.gripper_state_predictor[2])
-        rotation, gripper = O.QuatSigmoidFn.apply(pred)
+        # ---- action (act3d.py:323-338, 507-535)
+        position = position_pyramid[-1][:, 0]
+        offsets = None
+        if self.regress_position_offset:
+            offsets = O.mlp(gfeat, self.ghost_point_offset_predictor[0], self.ghost_point_offset_predictor[2])   # (B, Ng, 3)
+            position = position + O.SelectRowFn.apply(offsets, top_idx)
+        if self.rotation_parametrization.endswith("from_top_ghost"):
+            features = O.SelectRowFn.apply(gfeat, top_idx)
+        else:
+            features = query[:, 0]
+        pred = O.mlp(features, self.gripper_state_predictor[0], self.gripper_state_predictor[2])
+        if self.rotation_dim == 4:
+            rotation, gripper = O.QuatSigmoidFn.apply(pred)
+        else:
+            rotation, gripper = O.Ortho6dSigmoidFn.apply(pred)
         return {
-            "position": position_pyramid[-1][:, 0],
+            "position": position,
             "rotation": rotation,
             "gripper": gripper,
             "position_pyramid": position_pyramid,
             "visible_rgb_mask_pyramid": [None] * L,
             "ghost_pcd_masks_pyramid": ghost_pcd_masks_pyramid,
             "ghost_pcd_pyramid": ghost_pcd_pyramid,
-            "fine_ghost_pcd_offsets": None,
+            "fine_ghost_pcd_offsets": None if offsets is None else offsets.transpose(1, 2),
             "visible_rgb_features_pyramid": feats,
             "visible_pcd_pyramid": pcd_pyramid,
             "query_features": query.transpose(0, 1),            # (1, B, E) as the reference returns it

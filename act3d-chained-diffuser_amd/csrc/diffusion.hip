@@ -115,6 +115,15 @@ __global__ void add_rows_kernel(const float* __restrict__ x, const float* __rest
     y[i] = x[i] + r[i % le];
 }
 
+// backward of the broadcast add w.r.t. the shared rows: dr[l][e] = sum_b dy[b][l][e]
+__global__ void add_rows_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dr, int B, int LE) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= LE) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += dy[(size_t)b * LE + i];
+  dr[i] = acc;
+}
+
 __global__ void traj_update_kernel(const float* __restrict__ traj, const float* __restrict__ upd, float* __restrict__ out,
                                    int rows, int D, int npos) {
   const size_t total = (size_t)rows * D;
@@ -290,6 +299,11 @@ extern "C" int a3d_add_rows(const float* x, const float* r, float* y, int B, int
   if (!x || !r || !y || B <= 0 || L <= 0 || E <= 0) { set_error("a3d_add_rows: bad argument"); return A3D_ERR_ARG; }
   hipLaunchKernelGGL(add_rows_kernel, dim3(gsz((size_t)B * L * E)), dim3(256), 0, (hipStream_t)stream, x, r, y, B, L, E);
   return check_launch("a3d_add_rows");
+}
+extern "C" int a3d_add_rows_bwd(const float* dy, float* dr, int B, int L, int E, void* stream) {
+  if (!dy || !dr || B <= 0 || L <= 0 || E <= 0) { set_error("a3d_add_rows_bwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(add_rows_bwd_kernel, dim3((L * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, dr, B, L * E);
+  return check_launch("a3d_add_rows_bwd");
 }
 extern "C" int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, int D, int npos, void* stream) {
   if (!traj || !upd || !out || rows <= 0 || D <= 0) { set_error("a3d_traj_update: bad argument"); return A3D_ERR_ARG; }

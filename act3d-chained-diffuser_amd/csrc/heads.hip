@@ -4,6 +4,8 @@
 //   a3d_argmax_gather           torch.max(mask).indices (first max) + coordinate gather   act3d.py:312-314, 512-513
 //   a3d_soft_ce_loss            label = softmax(-||ghost-gt||/spread); CE(logits, label)  main_keypose.py:382-405
 //   a3d_quat_sigmoid_{fwd,bwd}  normalise_quat + sigmoid of the 5-vector prediction        act3d.py:526-533, utils.py:51-52
+//   a3d_ortho6d_sigmoid_{fwd,bwd}  6D -> rotation matrix + sigmoid (the 6D_* heads)        act3d.py:529-533, utils.py:93-130
+//   a3d_select_row_{fwd,bwd}    row of the top-scoring ghost point (offset / feature)     act3d.py:513-522
 //   a3d_mse_loss / a3d_l1_loss  F.mse_loss / F.l1_loss (mean) with gradient               main_keypose.py:362-380, diffusion_model.py:315-323
 //   a3d_sample_ghost_points     Philox4x32-10 uniform cube / ball-rejection sampler        act3d.py:394-440, utils.py:68-84
 //   a3d_adamw_step              torch.optim.AdamW update on the flat parameter buffer      engine.py:89-102
@@ -220,6 +222,93 @@ __global__ void quat_sigmoid_bwd_kernel(const float* __restrict__ pred, const fl
   dpred[b * 5 + 4] = (dgrip ? dgrip[b] : 0.f) * sg * (1.f - sg);
 }
 
+// 6D head (act3d.py:529-531, model/utils/utils.py:93-130): pred [B][7] -> rot [B][3][3] with COLUMNS
+// x = a / |a|, y = z x x, z = (x x b) / |x x b|  (a = pred[0:3], b = pred[3:6]; |.| clamped at 1e-8), grip = sigmoid(pred[6]).
+__device__ __forceinline__ void cross3(const float* u, const float* v, float* o) {
+  o[0] = u[1] * v[2] - u[2] * v[1];
+  o[1] = u[2] * v[0] - u[0] * v[2];
+  o[2] = u[0] * v[1] - u[1] * v[0];
+}
+__global__ void ortho6d_sigmoid_fwd_kernel(const float* __restrict__ pred, float* __restrict__ rot,
+                                           float* __restrict__ grip, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + (size_t)b * 7;
+  float x[3], y[3], z[3];
+  const float na = fmaxf(sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]), 1e-8f);
+  for (int i = 0; i < 3; ++i) x[i] = p[i] / na;
+  cross3(x, p + 3, z);
+  const float nz = fmaxf(sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]), 1e-8f);
+  for (int i = 0; i < 3; ++i) z[i] /= nz;
+  cross3(z, x, y);
+  float* r = rot + (size_t)b * 9;
+  for (int i = 0; i < 3; ++i) { r[i * 3 + 0] = x[i]; r[i * 3 + 1] = y[i]; r[i * 3 + 2] = z[i]; }
+  grip[b] = 1.f / (1.f + expf(-p[6]));
+}
+// Reverse of the chain above.  u = v / max(|v|, eps): dv = (du - u (u.du)) / |v| on the unclamped branch, du / eps else.
+__global__ void ortho6d_sigmoid_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ drot,
+                                           const float* __restrict__ dgrip, float* __restrict__ dpred, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + (size_t)b * 7;
+  float x[3], z0[3], z[3], gx[3] = {0.f, 0.f, 0.f}, gy[3] = {0.f, 0.f, 0.f}, gz[3] = {0.f, 0.f, 0.f}, t[3];
+  const float ma = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const float na = fmaxf(ma, 1e-8f);
+  for (int i = 0; i < 3; ++i) x[i] = p[i] / na;
+  cross3(x, p + 3, z0);
+  const float mz = sqrtf(z0[0] * z0[0] + z0[1] * z0[1] + z0[2] * z0[2]);
+  const float nz = fmaxf(mz, 1e-8f);
+  for (int i = 0; i < 3; ++i) z[i] = z0[i] / nz;
+  if (drot) {
+    const float* g = drot + (size_t)b * 9;
+    for (int i = 0; i < 3; ++i) { gx[i] = g[i * 3 + 0]; gy[i] = g[i * 3 + 1]; gz[i] = g[i * 3 + 2]; }
+  }
+  // y = z x x
+  cross3(x, gy, t);
+  for (int i = 0; i < 3; ++i) gz[i] += t[i];
+  cross3(gy, z, t);
+  for (int i = 0; i < 3; ++i) gx[i] += t[i];
+  // z = z0 / max(|z0|, eps)
+  float gz0[3];
+  {
+    const float d = z[0] * gz[0] + z[1] * gz[1] + z[2] * gz[2];
+    for (int i = 0; i < 3; ++i) gz0[i] = (mz > 1e-8f) ? (gz[i] - z[i] * d) / nz : gz[i] / nz;
+  }
+  // z0 = x x b
+  cross3(p + 3, gz0, t);
+  for (int i = 0; i < 3; ++i) gx[i] += t[i];
+  cross3(gz0, x, t);
+  for (int i = 0; i < 3; ++i) dpred[(size_t)b * 7 + 3 + i] = t[i];
+  // x = a / max(|a|, eps)
+  {
+    const float d = x[0] * gx[0] + x[1] * gx[1] + x[2] * gx[2];
+    for (int i = 0; i < 3; ++i) dpred[(size_t)b * 7 + i] = (ma > 1e-8f) ? (gx[i] - x[i] * d) / na : gx[i] / na;
+  }
+  const float sg = 1.f / (1.f + expf(-p[6]));
+  dpred[(size_t)b * 7 + 6] = (dgrip ? dgrip[b] : 0.f) * sg * (1.f - sg);
+}
+
+// y[b][:] = x[b][idx[b]][:]   (act3d.py:513-522: the top ghost point's offset / feature row); the backward writes the whole
+// gradient map in one pass (zero except the selected row), so no memset precedes it.
+__global__ void select_row_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ idx, float* __restrict__ y,
+                                      int B, int N, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * W) return;
+  const int b = i / W, c = i - b * W;
+  y[i] = x[((size_t)b * N + idx[b]) * W + c];
+}
+__global__ void select_row_bwd_kernel(const float* __restrict__ dy, const long long* __restrict__ idx, float* __restrict__ dx,
+                                      int B, int N, int W) {
+  const size_t total = (size_t)B * N * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    const size_t bn = i / W;
+    const int b = (int)(bn / N);
+    const long long n = (long long)(bn - (size_t)b * N);
+    dx[i] = (n == idx[b]) ? dy[(size_t)b * W + c] : 0.f;
+  }
+}
+
 // Philox4x32-10 lives in a3d_common.h (shared with the dropout masks of attention.hip / dropout.hip)
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
@@ -398,6 +487,27 @@ extern "C" int a3d_quat_sigmoid_bwd(const float* pred, const float* drot, const 
   if (!pred || !dpred || B <= 0) { set_error("a3d_quat_sigmoid_bwd: bad argument"); return A3D_ERR_ARG; }
   hipLaunchKernelGGL(quat_sigmoid_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pred, drot, dgrip, dpred, B);
   return check_launch("a3d_quat_sigmoid_bwd");
+}
+extern "C" int a3d_ortho6d_sigmoid_fwd(const float* pred, float* rot, float* grip, int B, void* stream) {
+  if (!pred || !rot || !grip || B <= 0) { set_error("a3d_ortho6d_sigmoid_fwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(ortho6d_sigmoid_fwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pred, rot, grip, B);
+  return check_launch("a3d_ortho6d_sigmoid_fwd");
+}
+extern "C" int a3d_ortho6d_sigmoid_bwd(const float* pred, const float* drot, const float* dgrip, float* dpred, int B,
+                                       void* stream) {
+  if (!pred || !dpred || B <= 0) { set_error("a3d_ortho6d_sigmoid_bwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(ortho6d_sigmoid_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, pred, drot, dgrip, dpred, B);
+  return check_launch("a3d_ortho6d_sigmoid_bwd");
+}
+extern "C" int a3d_select_row_fwd(const float* x, const long long* idx, float* y, int B, int N, int W, void* stream) {
+  if (!x || !idx || !y || B <= 0 || N <= 0 || W <= 0) { set_error("a3d_select_row_fwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(select_row_fwd_kernel, dim3(cdiv(B * W, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, y, B, N, W);
+  return check_launch("a3d_select_row_fwd");
+}
+extern "C" int a3d_select_row_bwd(const float* dy, const long long* idx, float* dx, int B, int N, int W, void* stream) {
+  if (!dy || !idx || !dx || B <= 0 || N <= 0 || W <= 0) { set_error("a3d_select_row_bwd: bad argument"); return A3D_ERR_ARG; }
+  hipLaunchKernelGGL(select_row_bwd_kernel, dim3(grid_for((size_t)B * N * W)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, B, N, W);
+  return check_launch("a3d_select_row_bwd");
 }
 extern "C" int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds, const float* anchor,
                                        float radius, float* out, int B, int Ng, int level, int max_attempts,

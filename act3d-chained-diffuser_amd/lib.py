@@ -88,6 +88,10 @@ SIGNATURES = {
     "a3d_scale_by_scalar": (_i, [_p, _p, _p, _z, _p]),
     "a3d_quat_sigmoid_fwd": (_i, [_p, _p, _p, _i, _p]),
     "a3d_quat_sigmoid_bwd": (_i, [_p, _p, _p, _p, _i, _p]),
+    "a3d_ortho6d_sigmoid_fwd": (_i, [_p, _p, _p, _i, _p]),
+    "a3d_ortho6d_sigmoid_bwd": (_i, [_p, _p, _p, _p, _i, _p]),
+    "a3d_select_row_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_select_row_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_sample_ghost_points": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "a3d_rng_advance": (_i, [_p, _u64, _p]),
     "a3d_philox4x32_10_host": (None, [_p, _p, _p]),
@@ -112,6 +116,7 @@ SIGNATURES = {
     "a3d_silu_fwd": (_i, [_p, _p, _z, _p]),
     "a3d_silu_bwd": (_i, [_p, _p, _p, _z, _p]),
     "a3d_add_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "a3d_add_rows_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "a3d_traj_update": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }
 

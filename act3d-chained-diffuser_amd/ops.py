@@ -876,6 +876,52 @@ class QuatSigmoidFn(torch.autograd.Function):
         return dp
 
 
+class Ortho6dSigmoidFn(torch.autograd.Function):
+    """pred (B,7) -> compute_rotation_matrix_from_ortho6d(pred[:, :6]) (B,3,3), sigmoid(pred[:, 6:])   (act3d.py:529-533)"""
+
+    @staticmethod
+    def forward(ctx, pred):
+        pred = _c(pred)
+        B = pred.shape[0]
+        rot = torch.empty((B, 3, 3), device=pred.device, dtype=F32)
+        grip = torch.empty((B, 1), device=pred.device, dtype=F32)
+        L.call("a3d_ortho6d_sigmoid_fwd", pred.data_ptr(), rot.data_ptr(), grip.data_ptr(), B, L.stream())
+        ctx.save_for_backward(pred)
+        return rot, grip
+
+    @staticmethod
+    def backward(ctx, drot, dgrip):
+        (pred,) = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        drot = None if drot is None else _c(drot)
+        dgrip = None if dgrip is None else _c(dgrip)
+        L.call("a3d_ortho6d_sigmoid_bwd", pred.data_ptr(), None if drot is None else drot.data_ptr(),
+               None if dgrip is None else dgrip.data_ptr(), dp.data_ptr(), pred.shape[0], L.stream())
+        return dp
+
+
+class SelectRowFn(torch.autograd.Function):
+    """x (B, N, W), idx (B,) int64 -> x[b, idx[b]] (B, W): the top ghost point's offset / feature row (act3d.py:513-522)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        L.require_gpu(x, idx)
+        x, idx = _c(x), _c(idx)
+        B, N, W = x.shape
+        y = torch.empty((B, W), device=x.device, dtype=F32)
+        L.call("a3d_select_row_fwd", x.data_ptr(), idx.data_ptr(), y.data_ptr(), B, N, W, L.stream())
+        ctx.idx, ctx.shape = idx, (B, N, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, W = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty((B, N, W), device=dy.device, dtype=F32)
+        L.call("a3d_select_row_bwd", dy.data_ptr(), ctx.idx.data_ptr(), dx.data_ptr(), B, N, W, L.stream())
+        return dx, None
+
+
 def sample_ghost_points(state, bounds, anchor, radius, B, Ng, level, max_attempts=64):
     """Device Philox sampler (a-3 of SURVEY §8a).  state: uint64[2] device tensor {seed, offset}."""
     out = torch.empty((B, Ng, 3), device=state.device, dtype=F32)
@@ -934,7 +980,7 @@ def sinusoidal_emb(x, E):
 
 
 class AddRowsFn(torch.autograd.Function):
-    """x (B, L, E) + r (L, E) broadcast over the batch (r carries no gradient)."""
+    """x (B, L, E) + r (L, E) broadcast over the batch; r's gradient (the batch sum) is computed only when it needs one."""
 
     @staticmethod
     def forward(ctx, x, r):
@@ -946,7 +992,13 @@ class AddRowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, None
+        dr = None
+        if ctx.needs_input_grad[1]:
+            dy = _c(dy)
+            B, Ln, E = dy.shape
+            dr = torch.empty((Ln, E), device=dy.device, dtype=F32)
+            L.call("a3d_add_rows_bwd", dy.data_ptr(), dr.data_ptr(), B, Ln, E, L.stream())
+        return dy, dr
 
 
 class TrajUpdateFn(torch.autograd.Function):

@@ -184,6 +184,52 @@ def pmc_record(B):
         return None
 
 
+def joint_step_bench(a3d, device, B=16, steps=10, warmup=3):
+    """BASELINE configs[3] at its per-GPU shape (DP batch 128 over 8 GPUs = 16 per GPU): one joint iteration = one Act3D
+    keypose training step AND one trajectory-diffusion training step on B samples each (two models, two optimizers, as the
+    reference trains them: main_keypose.py / main_trajectory.py), each a hipGraph replay."""
+    import bench_denoise as BD
+    E = a3d.engine
+    model = build_model(a3d, device, torch.bfloat16)
+    crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    kb = synthetic_batch(B, 4, device, seed=77)
+
+    def kp_fwd_bwd(sample, on_hot_done=None):
+        return E.fwd_bwd_keypose(model, crit, sample, True, on_hot_done)
+
+    _, kopt = E.get_optimizer(model, lr=1e-4, active_names=E.discover_active_parameters(model, lambda: kp_fwd_bwd(kb)))
+    kstep = E.GraphedStep(kp_fwd_bwd, kopt, kb, warmup=2)
+
+    planner = BD.build_planner(a3d, device, train=True)
+    tb = BD.synthetic_inputs(B, 50, 3, device)
+    tcrit = a3d.TrajectoryCriterion()
+
+    def tr_fwd_bwd(sample):
+        loss = tcrit.compute_loss(planner(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
+                                          sample["instr"], sample["curr_gripper"], sample["action"]))
+        loss.backward()
+        return loss.detach()
+
+    _, topt = E.get_optimizer(planner, lr=1e-4, active_names=E.discover_active_parameters(planner, lambda: tr_fwd_bwd(tb)))
+    tstep = E.GraphedStep(tr_fwd_bwd, topt, tb, warmup=2)
+
+    for _ in range(warmup):
+        lk, lt = kstep(), tstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lk, lt = kstep(), tstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(lk).all() and torch.isfinite(lt).all()
+    return {"metric": "train samples/sec (keypose+diffusion fwd+bwd, joint iteration)", "value": B / dt, "unit": "samples/s",
+            "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "higher_is_better": True, "data": "synthetic",
+            "config": {"workload": f"per-GPU shape of BASELINE configs[3]: Act3D keypose step (B={B} keyframes, 4 cameras, 3 levels) "
+                                   f"+ DiffusionPlanner step (B={B} trajectories, horizon 50, 3 cameras, dropout 0.1), both with "
+                                   "backbone + FPN + AdamW, two hipGraph replays per iteration", "hipgraph": True,
+                       "final_losses": [float(lk.item()), float(lt.item())]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,7 +389,8 @@ def main():
             res["secondary"] = []
             for name, fn in (("diffusion_train_script_shape", lambda: BD.training_bench(a3d, device, 22, 50, 3, steps=10, warmup=3)),
                              ("diffusion_train_cfg3_shape", lambda: BD.training_bench(a3d, device, 64, 16, 3, steps=10, warmup=3)),
-                             ("diffusion_sampling_cfg3", lambda: BD.sampling_bench(a3d, device, 64, 16, 3, reps=3))):
+                             ("diffusion_sampling_cfg3", lambda: BD.sampling_bench(a3d, device, 64, 16, 3, reps=3)),
+                             ("joint_keypose_diffusion_cfg4_per_gpu_shape", lambda: joint_step_bench(a3d, device, 16))):
                 try:
                     r = fn()
                 except Exception as e:

@@ -184,6 +184,14 @@ int a3d_elem_loss(const float* pred, const float* target, int n, int kind, float
 int a3d_scale_by_scalar(const float* x, const float* scalar, float* y, size_t n, void* stream);
 int a3d_quat_sigmoid_fwd(const float* pred, float* rot, float* grip, int B, void* stream);
 int a3d_quat_sigmoid_bwd(const float* pred, const float* drot, const float* dgrip, float* dpred, int B, void* stream);
+/* The 6D_* rotation heads (act3d.py:529-533; compute_rotation_matrix_from_ortho6d, model/utils/utils.py:93-130):
+ * pred [B][7] -> rot [B][3][3] (columns x, y, z of the Gram-Schmidt frame), grip [B][1] = sigmoid(pred[6]). */
+int a3d_ortho6d_sigmoid_fwd(const float* pred, float* rot, float* grip, int B, void* stream);
+int a3d_ortho6d_sigmoid_bwd(const float* pred, const float* drot, const float* dgrip, float* dpred, int B, void* stream);
+/* y[b] = x[b][idx[b]] for x [B][N][W] (the top ghost point's offset / feature row, act3d.py:513-522); the backward
+ * writes the full [B][N][W] gradient (zero outside the selected rows). */
+int a3d_select_row_fwd(const float* x, const long long* idx, float* y, int B, int N, int W, void* stream);
+int a3d_select_row_bwd(const float* dy, const long long* idx, float* dx, int B, int N, int W, void* stream);
 /* state = {seed, offset} (2 x uint64, device).  anchor NULL: uniform box (utils.py:68-73); else ball rejection
  * inside the clipped box (utils.py:76-84, act3d.py:417-436) with a bounded number of attempts. */
 int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds, const float* anchor, float radius,
@@ -216,6 +224,8 @@ int a3d_silu_fwd(const float* x, float* y, size_t n, void* stream);
 int a3d_silu_bwd(const float* x, const float* dy, float* dx, size_t n, void* stream);
 /* y[b,l,:] = x[b,l,:] + r[l,:] */
 int a3d_add_rows(const float* x, const float* r, float* y, int B, int L, int E, void* stream);
+/* dr [L][E] = sum over the batch of dy [B][L][E] (gradient of the shared rows, e.g. instr_position_embedding, act3d.py:201-209) */
+int a3d_add_rows_bwd(const float* dy, float* dr, int B, int L, int E, void* stream);
 /* out = cat(traj[..., :npos] + upd[..., :npos], upd[..., npos:])  (diffusion_head.py:268-272) */
 int a3d_traj_update(const float* traj, const float* upd, float* out, int rows, int D, int npos, void* stream);
 

@@ -15,7 +15,8 @@ from . import sampling as OS
 
 def default_cfg(**kw):
     cfg = dict(E=60, H=4, levels=3, ncam=1, n_ghost_layers=2, n_query_layers=2, n_vis_ins_layers=2,
-               ball_diameter=0.16, use_instruction=False, knn_per_cam=1024,
+               ball_diameter=0.16, use_instruction=False, knn_per_cam=1024, rotation_parametrization="quat_from_query",
+               regress_position_offset=False, ins_pos_emb=False,
                bounds=np.array([[-0.1101, -0.5558, 0.7129], [0.6481, 0.5184, 1.5116]]))
     cfg.update(kw)
     return cfg
@@ -46,6 +47,10 @@ def act3d_forward(P, cfg, feats_pyramid, pcd_pyramid, curr_gripper, instruction=
     instr = None
     if cfg["use_instruction"]:
         instr = F.linear(instruction, P["instruction_encoder.weight"], P["instruction_encoder.bias"])   # :199
+        if cfg["ins_pos_emb"]:                                                                          # :201-209
+            pe = F.layer_norm(P["instr_position_embedding.weight"], (E,), P["instr_position_norm.weight"],
+                              P["instr_position_norm.bias"])
+            instr = instr + pe[None]
 
     grip_tok = P["curr_gripper_embed.weight"].expand(B, 1, E)                                             # :220
     out = dict(position_pyramid=[], ghost_pcd_pyramid=[], ghost_pcd_masks_pyramid=[], topk_indices=[],
@@ -99,17 +104,41 @@ def act3d_forward(P, cfg, feats_pyramid, pcd_pyramid, curr_gripper, instruction=
         out["ghost_features"].append(gfeat)
         out["query_features_pyramid"].append(query)
         prev_pos = pos_i.detach() if teacher_positions is None else teacher_positions[i]
-    # ---- action head (:507-535), rotation_parametrization="quat_from_query"
-    pred = OB.mlp2(query[:, 0], P, "gripper_state_predictor", "0", "2")
-    rot = pred[:, :4] / torch.clamp(pred[:, :4].square().sum(-1).sqrt().unsqueeze(-1), min=1e-10)
-    out.update(position=out["position_pyramid"][-1][:, 0], rotation=rot, gripper=torch.sigmoid(pred[:, 4:]),
-               query_features=query, pred_raw=pred)
+    # ---- offsets of the last level's ghost points (:323-327) and the action head (:507-535)
+    offsets = None
+    position = out["position_pyramid"][-1][:, 0]
+    ar = torch.arange(B)
+    if cfg["regress_position_offset"]:
+        offsets = OB.mlp2(gfeat, P, "ghost_point_offset_predictor", "0", "2")              # (B, Ng, 3)
+        position = position + offsets[ar, top_idx]
+    rp = cfg["rotation_parametrization"]
+    features = gfeat[ar, top_idx] if rp.endswith("from_top_ghost") else query[:, 0]
+    pred = OB.mlp2(features, P, "gripper_state_predictor", "0", "2")
+    if rp.startswith("quat"):
+        nrot = 4
+        rot = pred[:, :4] / torch.clamp(pred[:, :4].square().sum(-1).sqrt().unsqueeze(-1), min=1e-10)
+    else:
+        nrot = 6
+        rot = ortho6d_to_matrix(pred[:, :6])
+    out.update(position=position, rotation=rot, gripper=torch.sigmoid(pred[:, nrot:]), query_features=query, pred_raw=pred,
+               fine_ghost_pcd_offsets=None if offsets is None else offsets.transpose(1, 2))
     return out
 
 
+def ortho6d_to_matrix(d6):
+    """compute_rotation_matrix_from_ortho6d (model/utils/utils.py:93-130): Gram-Schmidt frame with columns x, y, z."""
+    def unit(v):
+        return v / torch.clamp(v.pow(2).sum(1).sqrt(), min=1e-8)[:, None]
+    x = unit(d6[:, 0:3])
+    z = unit(torch.cross(x, d6[:, 3:6], dim=1))
+    y = torch.cross(z, x, dim=1)
+    return torch.stack([x, y, z], dim=2)
+
+
 def keypose_loss(out, gt_action, spread=0.01, position_loss_coeff=1.0, rotation_loss_coeff=10.0,
-                 gripper_loss_coeff=1.0, label_smoothing=0.0):
-    """LossAndMetrics.compute_loss with position_loss="ce" (main_keypose.py:353-429)."""
+                 gripper_loss_coeff=1.0, label_smoothing=0.0, position_loss="ce", position_offset_loss_coeff=10000.0):
+    """LossAndMetrics.compute_loss with position_loss="ce" / "ce+mse" (main_keypose.py:353-429), incl. the supervised
+    offsets of regress_position_offset (:407-419)."""
     gt_pos = gt_action[:, :3]
     losses = {}
     L = len(out["ghost_pcd_masks_pyramid"])
@@ -118,6 +147,12 @@ def keypose_loss(out, gt_action, spread=0.01, position_loss_coeff=1.0, rotation_
         label = torch.softmax(-l2 / spread, dim=-1).detach()
         losses[f"position_ce_level{i}"] = F.cross_entropy(masks[-1], label, label_smoothing=label_smoothing).mean() \
             * position_loss_coeff / L
+    if out.get("fine_ghost_pcd_offsets") is not None:
+        pts = out["ghost_pcd_pyramid"][-1] + out["fine_ghost_pcd_offsets"]
+        losses["position_offset"] = F.mse_loss(pts, gt_pos.unsqueeze(-1).expand_as(pts)) \
+            * (position_offset_loss_coeff * position_loss_coeff)
+    if position_loss == "ce+mse":
+        losses["position_mse"] = F.mse_loss(out["position"], gt_pos) * position_loss_coeff
     losses["rotation"] = F.mse_loss(out["rotation"], gt_action[:, 3:7]) * rotation_loss_coeff
     losses["gripper"] = F.mse_loss(out["gripper"], gt_action[:, 7:8]) * gripper_loss_coeff
     return losses

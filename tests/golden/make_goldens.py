@@ -137,11 +137,11 @@ def golden_sampling():
 
 
 # ------------------------------------------------------------------------------------------------------ G6/G7: Act3D
-def build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=256, Ng_val=None):
+def build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=256, Ng_val=None, model_kw=None):
     m = R.act3d.Act3D(backbone="clip", image_size=(image, image), embedding_dim=E, num_attn_heads=4,
                       gripper_loc_bounds=C.PERACT_BOUNDS, num_ghost_points=Ng * levels,
                       num_ghost_points_val=(Ng * 2 if Ng_val is None else Ng_val) * levels, num_sampling_level=levels,
-                      weight_tying=True, gp_emb_tying=True, use_instruction=use_instruction)
+                      weight_tying=True, gp_emb_tying=True, use_instruction=use_instruction, **(model_kw or {}))
     if image == 128:
         # the reference's constructor names the attribute `coarse_feature_map` for 128x128 images but forward reads
         # `feature_map_pyramid` (act3d.py:81 vs :378); patch the instance as SURVEY App. B-5 does
@@ -169,10 +169,14 @@ def inject_features(m, inp, ncam):
     m._compute_visual_features = fake
 
 
-def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=1e-2, image=256, Ng_val=None):
+def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=1e-2, image=256, Ng_val=None,
+                   model_kw=None, loss_kw=None, probe=False):
+    """model_kw: non-default Act3D constructor options; loss_kw: LossAndMetrics options; probe=True replaces the loss by a
+    fixed linear functional of (rotation, gripper, position) -- used for the 6D heads, for which the reference has no loss."""
     for attempt in range(80):
         seed, gain = 100 + attempt, 3.0
-        m, sd = build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=image, Ng_val=Ng_val)
+        m, sd = build_ref_act3d(E, levels, ncam, Ng, use_instruction, seed, gain, image=image, Ng_val=Ng_val,
+                                model_kw=model_kw)
         inp = C.keypose_inputs(seed, B, ncam, E, levels, image=image)
         for f in inp["feats"]:
             f.requires_grad_(train)
@@ -197,7 +201,11 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
                masks=[[mm.detach() for mm in ms] for ms in out["ghost_pcd_masks_pyramid"]],
                positions=[p.detach()[:, 0] for p in out["position_pyramid"]],
                position=out["position"].detach(), rotation=out["rotation"].detach(), gripper=out["gripper"].detach(),
-               query_features=out["query_features"].detach()[0])
+               query_features=out["query_features"].detach()[0], model_kw=dict(model_kw or {}), loss_kw=dict(loss_kw or {}))
+    if model_kw:
+        rec["param_shapes"] = C.unique_param_shapes(m)[0]
+    if out["fine_ghost_pcd_offsets"] is not None:
+        rec["offsets"] = out["fine_ghost_pcd_offsets"].detach()
     idxs = [None]
     for i in range(1, levels):
         l2 = ((out["position_pyramid"][i - 1] - out["visible_pcd_pyramid"][i]) ** 2).sum(-1).sqrt()
@@ -206,10 +214,19 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
         rec.setdefault("topk_values", [None]).append(tk.values)
     rec["topk"] = idxs
     if train:
-        crit = R.main_keypose.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
-                                             ground_truth_gaussian_spread=0.01)
+        lk = dict(position_loss="ce", rotation_parametrization=(model_kw or {}).get("rotation_parametrization", "quat_from_query"),
+                  ground_truth_gaussian_spread=0.01)
+        lk.update(loss_kw or {})
+        crit = R.main_keypose.LossAndMetrics(**lk)
         sample = {"action": inp["action"], "task": ["t"] * B}
-        losses = crit.compute_loss(out, sample)
+        if probe:
+            g = torch.Generator().manual_seed(seed)
+            rec["probe"] = dict(rotation=torch.randn(out["rotation"].shape, generator=g),
+                                gripper=torch.randn(out["gripper"].shape, generator=g),
+                                position=torch.randn(out["position"].shape, generator=g))
+            losses = {k: (out[k] * w).sum() for k, w in rec["probe"].items()}
+        else:
+            losses = crit.compute_loss(out, sample)
         total = sum(losses.values())
         total.backward()
         rec["losses"] = {k: v.detach() for k, v in losses.items()}
@@ -219,7 +236,9 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
         keep = ["query_embed.weight", "curr_gripper_embed.weight", "ghost_points_embed_pyramid.0.weight",
                 "ghost_point_cross_attn_pyramid.0.attn_layers.0.multihead_attn.in_proj_weight",
                 "query_cross_attn_pyramid.0.attn_layers.1.multihead_attn.out_proj.weight",
-                "ghost_point_cross_attn_pyramid.0.ffw_layers.1.linear1.weight", "gripper_state_predictor.2.weight"]
+                "ghost_point_cross_attn_pyramid.0.ffw_layers.1.linear1.weight", "gripper_state_predictor.2.weight",
+                "gripper_state_predictor.0.weight", "ghost_point_offset_predictor.0.weight", "ghost_point_offset_predictor.2.bias",
+                "instr_position_embedding.weight", "instr_position_norm.weight", "instruction_encoder.weight"]
         rec["grads"] = {n: grads[n] for n in keep if n in grads}
         rec["feat_grad_norms"] = [None if f.grad is None else f.grad.norm().item() for f in inp["feats"][:2]]
         if levels == 1:
@@ -227,7 +246,9 @@ def run_act3d_case(tag, E, levels, ncam, Ng, use_instruction, B, train, min_gap=
         fg = inp["feats"][1].grad if levels > 1 else None
         if fg is not None:
             rec["feat1_grad_sample"] = C.tokens_from_maps(fg)[:, ::517].clone()
-        rec["metrics"] = {k: v.detach() for k, v in crit.compute_metrics(out, sample).items() if k.startswith("mean") or k == "gripper"}
+        if not probe:
+            rec["metrics"] = {k: v.detach() for k, v in crit.compute_metrics(out, sample).items()
+                              if k.startswith("mean") or k == "gripper"}
     return rec
 
 
@@ -248,6 +269,22 @@ def golden_act3d():
     save("act3d_manifest.pt", dict(named_parameters=man, named_parameters_instr=man2, state_dict_keys=sdk,
                                    n_trainable=sum(int(np.prod(s)) for s in man.values()),
                                    n_trainable_instr=sum(int(np.prod(s)) for s in man2.values())))
+
+
+def golden_act3d_options():
+    """The non-default Act3D options of act3d.py:30-39 (regress_position_offset, *_from_top_ghost, 6D_*, ins_pos_emb)."""
+    out = {
+        "offset_topghost_inspos": run_act3d_case(
+            "offset_topghost_inspos", 60, 2, 1, 64, True, 2, True,
+            model_kw=dict(regress_position_offset=True, rotation_parametrization="quat_from_top_ghost", ins_pos_emb=True),
+            loss_kw=dict(position_loss="ce+mse")),
+        "sixd_query": run_act3d_case("sixd_query", 60, 2, 1, 64, False, 2, True,
+                                     model_kw=dict(rotation_parametrization="6D_from_query"), probe=True),
+        "sixd_topghost_offset_eval": run_act3d_case(
+            "sixd_topghost_offset_eval", 60, 2, 1, 64, False, 2, False,
+            model_kw=dict(rotation_parametrization="6D_from_top_ghost", regress_position_offset=True)),
+    }
+    save("act3d_options.pt", out)
 
 
 def golden_act3d_cfg1():
@@ -410,6 +447,6 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "diffusion", "optimizer", "metrics"]
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "optimizer", "metrics"]
     for w in which:
         globals()["golden_" + w]()

@@ -82,6 +82,9 @@ def _check_golden_forward(tag, r, cfg, out):
     rel_close("rotation", out["rotation"], r["rotation"], 1e-3, 0)
     rel_close("gripper", out["gripper"], r["gripper"], 1e-3, 0)
     scale_close("query", out["query_features"][0], r["query_features"], 1e-3)
+    rel_close("position", out["position"], r["position"], 1e-3, 0)
+    if "offsets" in r:                                  # regress_position_offset (act3d.py:323-327)
+        scale_close("offsets", out["fine_ghost_pcd_offsets"], r["offsets"], 1e-3)
 
 
 def _check_golden_grads(r, cfg, m, fmaps):
@@ -111,7 +114,7 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
     batch 1, one 128x128 camera, one ghost-point level (1000 points in training, 10000 at evaluation)."""
     r, cfg, names = _act3d_case(tag)
     P = act3d_params(cfg, r["seed"], r["gain"], names)
-    m = build_model(a3d, dev, cfg, P, cfg["Ng"], cfg["train"])
+    m = build_model(a3d, dev, cfg, P, cfg["Ng"], cfg["train"], **r.get("model_kw", {}))
     inp, fmaps, feats = _golden_inputs(r, cfg, dev)
     out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev),
             gt_action=inp["action"].to(dev) if cfg["train"] else None,
@@ -119,17 +122,24 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
     _check_golden_forward(tag, r, cfg, out)
     if not cfg["train"]:
         return
-    crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
-                                     ground_truth_gaussian_spread=0.01)
     sample = {"action": inp["action"].to(dev), "task": ["t"] * cfg["B"]}
-    losses = crit.compute_loss(out, sample)
+    if "probe" in r:           # the 6D heads have no loss in the reference: a fixed linear functional of the outputs
+        losses = {k: (out[k] * w.to(dev)).sum() for k, w in r["probe"].items()}
+        crit = None
+    else:
+        lk = dict(position_loss="ce", ground_truth_gaussian_spread=0.01,
+                  rotation_parametrization=r.get("model_kw", {}).get("rotation_parametrization", "quat_from_query"))
+        lk.update(r.get("loss_kw", {}))
+        crit = a3d.losses.LossAndMetrics(**lk)
+        losses = crit.compute_loss(out, sample)
     for k, v in r["losses"].items():
         rel_close("loss " + k, losses[k], v, 1e-3, 1e-3)
     sum(losses.values()).backward()
     _check_golden_grads(r, cfg, m, fmaps)
-    met = crit.compute_metrics(out, sample)
-    for k, v in r["metrics"].items():
-        rel_close("metric " + k, met[k], v, 1e-3, 0)
+    if crit is not None:
+        met = crit.compute_metrics(out, sample)
+        for k, v in r["metrics"].items():
+            rel_close("metric " + k, met[k], v, 1e-3, 0)
 
 
 @pytest.mark.parametrize("tag", ["train_L3_C1_N64", "eval_L3_C1_N128", "train_128_L1_C1_N1000", "eval_128_L1_C1_N10000"])
