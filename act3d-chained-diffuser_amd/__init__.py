@@ -12,3 +12,5 @@ from .losses import LossAndMetrics, TrajectoryCriterion  # noqa: F401,E402
 from . import engine  # noqa: F401,E402
 from . import diffusion  # noqa: F401,E402
 from .diffusion import DiffusionPlanner, DiffusionHead  # noqa: F401,E402
+from . import data, trainers  # noqa: F401,E402
+from .trainers import BaseTrainTester, KeyposeTrainTester, TrajectoryTrainTester  # noqa: F401,E402

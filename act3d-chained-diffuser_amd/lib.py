@@ -117,6 +117,7 @@ SIGNATURES = {
     "a3d_silu_bwd": (_i, [_p, _p, _p, _z, _p]),
     "a3d_add_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_add_rows_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "a3d_resize_crop": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "a3d_traj_update": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }
 

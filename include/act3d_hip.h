@@ -327,6 +327,15 @@ int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void
 /* out[i] = v_cvt_pk_bf16_f32(in[2i], in[2i+1]) -- pins the rounding mode the attention kernel relies on (RNE). */
 int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream);
 
+/* ---- data plane ----------------------------------------------------------------------------------------
+ * The `Resize` augmentation of datasets/utils.py:40-100 (nearest resize by a random scale, reflect-pad right/bottom, random
+ * crop back to H x W; RGB and XYZ share the draws) as one gather pass over the collated batch on the device.
+ * src/dst [frames][planes][H][W] fp32 (planes = cameras x 3), params [frames][4] int32 = (resized_h, resized_w, crop_i,
+ * crop_j) per frame (host-sampled with the reference's RNG consumption, data.sample_resize_params);
+ * dst = src[map(y, x)] * scale + shift (scale = shift = 0.5 un-normalises RGB, dataset_engine.py:134-137). */
+int a3d_resize_crop(const float* src, float* dst, const int* params, int frames, int planes, int H, int W, float scale,
+                    float shift, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

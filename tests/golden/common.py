@@ -146,3 +146,52 @@ def metrics_inputs():
     kp["position"] = kp["position_pyramid"][-1][:, 0].clone()
     tasks = ["close_jar", "open_drawer", "close_jar", "stack_cups", "open_drawer", "close_jar"]
     return pred, gt, action, kp, tasks
+
+
+# ---------------------------------------------------------------------------------------------------- data plane fixtures
+DATASET_CAMERAS = ("wrist", "left_shoulder")
+DATASET_TASKVAR = [("task_a", 0), ("task_b", 0)]
+DATASET_IMAGE = 20
+
+
+def synthetic_episode(seed, T, ncam=2, H=DATASET_IMAGE):
+    """One episode in the on-disk layout of data_preprocessing/data_gen.py:122-132:
+    [frame_ids, obs (n_cam, 2, 3, H, W) per frame, actions (1, 8), camera dicts, grippers (1, 8), trajectories (N_i, 8)].
+    The camera dicts list the cameras in REVERSED order so that the dataset's camera re-mapping is exercised."""
+    rs = np.random.RandomState(seed)
+    frame_ids = list(range(T))
+    obs = [rs_tensor(rs, (ncam, 2, 3, H, H), kind="uniform") * 2 - 1 for _ in range(T)]
+
+    def pose():
+        p = rs_tensor(rs, (1, 8))
+        p[:, 3:7] = p[:, 3:7] / p[:, 3:7].norm(dim=-1, keepdim=True)
+        p[:, 7] = (p[:, 7] > 0).float()
+        return p
+    actions = [pose() for _ in range(T)]
+    cams = [{c: None for c in reversed(DATASET_CAMERAS)} for _ in range(T)]
+    grippers = [pose() for _ in range(T)]
+    trajs = []
+    for _ in range(T):
+        n = int(rs.randint(4, 9))
+        t = rs_tensor(rs, (n, 8))
+        t[:, 3:7] = t[:, 3:7] / t[:, 3:7].norm(dim=-1, keepdim=True)
+        t[:, 7] = (t[:, 7] > 0).float()
+        trajs.append(t)
+    return [frame_ids, obs, actions, cams, grippers, trajs]
+
+
+def write_synthetic_dataset(root):
+    """task_a+0/ep0.npy (7 frames: two chunks of <= 5) and task_b+0/ep0.pkl (3 frames); returns the instruction dict."""
+    import os
+    import pickle
+    os.makedirs(os.path.join(root, "task_a+0"), exist_ok=True)
+    os.makedirs(os.path.join(root, "task_b+0"), exist_ok=True)
+    ep = synthetic_episode(11, 7)
+    arr = np.empty(len(ep), dtype=object)
+    for i, e in enumerate(ep):
+        arr[i] = e
+    np.save(os.path.join(root, "task_a+0", "ep0.npy"), arr, allow_pickle=True)
+    with open(os.path.join(root, "task_b+0", "ep0.pkl"), "wb") as f:
+        pickle.dump(synthetic_episode(12, 3), f)
+    rs = np.random.RandomState(13)
+    return {"task_a": {0: rs_tensor(rs, (3, 53, 512))}, "task_b": {0: rs_tensor(rs, (2, 53, 512))}}

@@ -446,7 +446,88 @@ def golden_metrics():
     save("metrics.pt", out)
 
 
+def _import_reference_datasets():
+    """The reference's `datasets` package (datasets/dataset_engine.py, datasets/utils.py) under the alias `refdatasets` (the
+    name `datasets` is taken by an unrelated installed package and by refimport's inert stub).  torchvision / blosc are not
+    installed: `torchvision.transforms(.functional)` is stubbed by the torch operators torchvision 0.14 dispatches to for
+    float tensors -- resize(NEAREST) = F.interpolate(mode="nearest"), pad(reflect) = F.pad(mode="reflect"), crop = slice,
+    RandomCrop.get_params = two torch.randint draws unless the size already matches (third-party: parity unpinned there);
+    everything else that runs is the reference's own code."""
+    import importlib.util
+    import types
+
+    def resize(img, size, interpolation=None):
+        return F.interpolate(img, size=list(size), mode="nearest")
+
+    def pad(img, padding, padding_mode="constant"):
+        left, top, right, bottom = padding
+        return F.pad(img, [left, right, top, bottom], mode=padding_mode)
+
+    def crop(img, i, j, h, w):
+        return img[..., i:i + h, j:j + w]
+
+    class RandomCrop:
+        @staticmethod
+        def get_params(img, output_size):
+            h, w = img.shape[-2:]
+            th, tw = output_size
+            if h < th or w < tw:
+                raise ValueError("Required crop size is larger than input image size")
+            if w == tw and h == th:
+                return 0, 0, h, w
+            i = torch.randint(0, h - th + 1, size=(1,)).item()
+            j = torch.randint(0, w - tw + 1, size=(1,)).item()
+            return i, j, th, tw
+
+    tvt = sys.modules["torchvision.transforms"]
+    tvt.InterpolationMode = types.SimpleNamespace(NEAREST="nearest")
+    tvt.RandomCrop = RandomCrop
+    fmod = types.ModuleType("torchvision.transforms.functional")
+    fmod.resize, fmod.pad, fmod.crop = resize, pad, crop
+    sys.modules["torchvision.transforms.functional"] = fmod
+    tvt.functional = fmod
+    sys.modules.setdefault("blosc", types.ModuleType("blosc"))
+    spec = importlib.util.spec_from_file_location("refdatasets", "/root/reference/datasets/__init__.py",
+                                                  submodule_search_locations=["/root/reference/datasets"])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["refdatasets"] = pkg
+    spec.loader.exec_module(pkg)
+    import refdatasets.dataset_engine as de
+    return de
+
+
+def golden_dataset():
+    """Data plane: items of the reference's RLBenchDataset (training: with the Resize augmentation; evaluation)
+    on the synthetic episodes of common.write_synthetic_dataset, and the collated batches of the two main scripts."""
+    import random
+    import tempfile
+    de = _import_reference_datasets()
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        instr = C.write_synthetic_dataset(root)
+        for tag, training, traj in (("train_traj", True, True), ("eval_traj", False, True), ("train_keypose", True, False)):
+            random.seed(5)
+            np.random.seed(5)
+            torch.manual_seed(5)
+            ds = de.RLBenchDataset(root=root, instructions=instr, taskvar=C.DATASET_TASKVAR, max_episode_length=5, cache_size=0,
+                                   max_episodes_per_task=100, cameras=C.DATASET_CAMERAS, training=training,
+                                   gripper_loc_bounds=C.PERACT_BOUNDS, image_rescale=(0.75, 1.25),
+                                   point_cloud_rotate_yaw_range=0.0, return_low_lvl_trajectory=traj, dense_interpolation=traj,
+                                   interpolation_length=12, action_dim=8, predict_short=False)
+            items = [ds[i] for i in range(5)]
+            collate = R.main_trajectory.traj_collate_fn if traj else R.main_keypose.keypose_collate_fn
+            batch = collate(items)
+            rec = {k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in batch.items()}
+            rec["instr_sample"] = rec.pop("instr")[:, ::13, ::64].clone()          # (frames, 5, 8) of the (frames, 53, 512)
+            rec["frames_per_item"] = [len(it["task"]) for it in items]
+            rec["history"] = torch.cat([it["curr_gripper_history"] for it in items])
+            rec["len"] = len(ds)
+            out[tag] = rec
+            print(tag, {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in rec.items() if k != "task"})
+    save("dataset.pt", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "optimizer", "metrics"]
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "optimizer", "metrics", "dataset"]
     for w in which:
         globals()["golden_" + w]()

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import load_pkg
+from oracle import act3d as OA
 from oracle import blocks as OB
 
 pytestmark = pytest.mark.gpu
@@ -719,3 +720,47 @@ def test_rgb_normalize_kernel_matches_torch(a3d, dev):
     got = a3d.nn.normalize_to_nhwc_bf16(x, norm)
     assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == ref.shape
     assert torch.equal(got, ref)
+
+
+def test_option_head_kernels(a3d, dev):
+    """Kernels of Act3D's non-default options: 6D -> rotation matrix + sigmoid with its analytic backward
+    (act3d.py:529-533, utils.py:93-130), the top-ghost row selection (act3d.py:513-522) and the batch-sum backward of the
+    instruction position embedding (act3d.py:201-209), each against torch autograd of the oracle's restatement."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(7)
+    # ---- ortho6d + sigmoid
+    pred = torch.randn(9, 7, generator=g)
+    pred[3, :3] *= 1e-3                                        # a short first axis (normalisation well away from 1)
+    w_rot, w_grip = torch.randn(9, 3, 3, generator=g), torch.randn(9, 1, generator=g)
+    pc = pred.clone().requires_grad_()
+    rot_ref, grip_ref = OA.ortho6d_to_matrix(pc[:, :6]), torch.sigmoid(pc[:, 6:])
+    ((rot_ref * w_rot).sum() + (grip_ref * w_grip).sum()).backward()
+    pd = pred.to(dev).requires_grad_()
+    rot, grip = O.Ortho6dSigmoidFn.apply(pd)
+    ((rot * w_rot.to(dev)).sum() + (grip * w_grip.to(dev)).sum()).backward()
+    report("6D rotation", rot, rot_ref, 2e-6, 1e-6)
+    report("6D gripper", grip, grip_ref, 1e-6)
+    report("6D d pred", pd.grad, pc.grad, 2e-5, 1e-5)
+    eye = torch.eye(3).expand(9, 3, 3)
+    report("R^T R", rot.transpose(1, 2) @ rot, eye, 1e-5)
+    # ---- select row (W = 3 offsets, W = 60 features)
+    for W in (3, 60):
+        x = torch.randn(4, 37, W, generator=g)
+        idx = torch.tensor([0, 36, 5, 5])
+        dy = torch.randn(4, W, generator=g)
+        xd = x.to(dev).requires_grad_()
+        y = O.SelectRowFn.apply(xd, idx.to(dev))
+        y.backward(dy.to(dev))
+        assert torch.equal(y.cpu(), x[torch.arange(4), idx])
+        ref = torch.zeros_like(x)
+        ref[torch.arange(4), idx] = dy
+        assert torch.equal(xd.grad.cpu(), ref)
+    # ---- broadcast add of shared rows: gradient of the rows = sum over the batch
+    x, r = torch.randn(5, 53, 60, generator=g), torch.randn(53, 60, generator=g)
+    dy = torch.randn(5, 53, 60, generator=g)
+    xd, rd = x.to(dev).requires_grad_(), r.to(dev).requires_grad_()
+    y = O.AddRowsFn.apply(xd, rd)
+    y.backward(dy.to(dev))
+    assert torch.equal(y.cpu(), x + r[None])
+    assert torch.equal(xd.grad.cpu(), dy)
+    report("d rows", rd.grad, dy.sum(0), 1e-5, 1e-6)

@@ -345,3 +345,67 @@ def test_metrics_and_optional_losses():
         close("position mse", lo["position_mse"], r["losses"]["position_mse"], 1e-6)
         lo["rotation"].backward()
         close("d rotation", p["rotation"].grad, r["d_rotation"], 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ data plane
+def test_resize_restatement_equals_torch_operator_composition():
+    """oracle.data.resize_crop (explicit index map) == F.interpolate(nearest) -> F.pad(reflect) -> slice, the operators the
+    reference's torchvision calls resolve to; bit-exact, incl. the RNG consumption of the crop offsets."""
+    import torch.nn.functional as F
+    from oracle import data as OD
+    rs = np.random.RandomState(0)
+    seen = set()
+    for trial in range(60):
+        H = W = [256, 128, 64, 20][trial % 4]
+        x = torch.from_numpy(rs.standard_normal((3, 2, 3, H, W)).astype(np.float32))
+        np.random.seed(trial)
+        torch.manual_seed(trial)
+        rh, rw, i, j = OD.resize_params((0.75, 1.25), H, W)
+        seen.add((rh < H, rh == H, rh > H))
+        y = F.interpolate(x.flatten(0, 1), size=[rh, rw], mode="nearest")
+        if H > rh or W > rw:
+            y = F.pad(y, [0, max(W - rw, 0), 0, max(H - rh, 0)], mode="reflect")
+        y = y[..., i:i + H, j:j + W].reshape(x.shape)
+        assert np.array_equal(OD.resize_crop(x.numpy(), rh, rw, i, j), y.numpy()), (trial, rh, rw, i, j)
+    assert len(seen) >= 2                   # both the shrink (pad) and the grow (crop) branch ran
+
+
+@pytest.mark.parametrize("tag", ["train_traj", "eval_traj", "train_keypose"])
+def test_dataset_items_equal_reference(tag, tmp_path):
+    """The product's RLBenchDataset + collate (host logic) on the same synthetic episode files, same seeds, against the
+    REFERENCE's dataset output (tests/golden/dataset.pt): every key bit-exact; the deferred Resize draws applied with the
+    oracle's index map reproduce the reference's augmented RGB / XYZ bit for bit."""
+    import importlib
+    import random
+    from oracle import data as OD
+    a3d = importlib.import_module("act3d-chained-diffuser_amd")
+    r = load("dataset.pt")[tag]
+    instr = C.write_synthetic_dataset(str(tmp_path))
+    training, traj = tag.startswith("train"), tag.endswith("traj")
+    random.seed(5)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    ds = a3d.data.RLBenchDataset(root=str(tmp_path), instructions=instr, taskvar=C.DATASET_TASKVAR, max_episode_length=5,
+                                 cache_size=0, max_episodes_per_task=100, cameras=C.DATASET_CAMERAS, training=training,
+                                 gripper_loc_bounds=C.PERACT_BOUNDS, image_rescale=(0.75, 1.25),
+                                 point_cloud_rotate_yaw_range=0.0, return_low_lvl_trajectory=traj, dense_interpolation=traj,
+                                 interpolation_length=12, action_dim=8, predict_short=False)
+    assert len(ds) == r["len"]
+    items = [ds[i] for i in range(5)]
+    assert [len(it["task"]) for it in items] == r["frames_per_item"]
+    batch = (a3d.data.traj_collate_fn if traj else a3d.data.keypose_collate_fn)(items)
+    assert batch["task"] == r["task"]
+    keys = ["curr_gripper", "action"] + (["trajectory", "trajectory_mask"] if traj else [])
+    for k in keys:
+        assert batch[k].dtype == r[k].dtype and torch.equal(batch[k], r[k]), k
+    assert torch.equal(batch["instr"][:, ::13, ::64], r["instr_sample"])
+    assert torch.equal(torch.cat([it["curr_gripper_history"] for it in items]), r["history"])
+    p = batch["resize_params"]
+    assert p.dtype == torch.int32 and p.shape == (len(batch["task"]), 4)
+    if not training:
+        assert (p == torch.tensor([C.DATASET_IMAGE, C.DATASET_IMAGE, 0, 0], dtype=torch.int32)).all()
+    for k in ("rgbs", "pcds"):
+        aug = np.stack([OD.resize_crop(batch[k][f].numpy(), *[int(v) for v in p[f]]) for f in range(p.shape[0])])
+        assert np.array_equal(aug, r[k].numpy()), k
+    if training:
+        assert (p[:, 0] != C.DATASET_IMAGE).any()          # the augmentation actually did something
