@@ -298,3 +298,29 @@ def test_bf16_token_maps_gathered_in_place_equal_the_fp32_copy(a3d, dev):
         assert err <= 2 ** -7 * ref.abs().max().item(), err       # two bf16 roundings (one per fine level) at most
         same = ((a.grad == 0) == (ref == 0)).float().mean().item()
         assert same > 0.9999, same                                 # same sparsity: only gathered rows receive a gradient
+
+
+def test_hot_path_forward_is_run_to_run_deterministic(a3d, dev):
+    """Same visual tokens + same sampler state -> bit-identical free-running forward (ghost points, k-NN sets, mask logits,
+    argmax cascade, action): no forward kernel depends on atomics or launch timing.  (The convolutions in front of the hot
+    path are MIOpen's and may change algorithm between the first and later calls, which is why evaluation tests record the
+    forwards instead of repeating them.)"""
+    torch.manual_seed(0)
+    m = a3d.Act3D(image_size=(128, 128), gripper_loc_bounds=C.PERACT_BOUNDS, num_ghost_points=300, num_ghost_points_val=600,
+                  num_sampling_level=3, sampler_seed=5).to(dev).eval()
+    inp = C.keypose_inputs(61, 3, 2, 60, 3, image=128)
+    feats = [C.tokens_from_maps(f.to(dev)) for f in (inp["feats"][0], inp["feats"][1], inp["feats"][1])]
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):
+            m._rng_state.copy_(torch.tensor([5, 0]))
+            outs.append(m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev), gt_action=None,
+                          visual_features=feats))
+    for o in outs[1:]:
+        for i in range(3):
+            assert torch.equal(o["ghost_pcd_pyramid"][i], outs[0]["ghost_pcd_pyramid"][i]), f"ghost points level {i}"
+            assert torch.equal(o["ghost_pcd_masks_pyramid"][i][-1], outs[0]["ghost_pcd_masks_pyramid"][i][-1]), f"mask level {i}"
+            assert torch.equal(o["position_pyramid"][i], outs[0]["position_pyramid"][i])
+            if i > 0:
+                assert torch.equal(o["topk_indices_pyramid"][i], outs[0]["topk_indices_pyramid"][i])
+        assert torch.equal(o["rotation"], outs[0]["rotation"]) and torch.equal(o["gripper"], outs[0]["gripper"])
