@@ -57,21 +57,34 @@ __device__ __forceinline__ float l2_dist(float px, float py, float pz, const flo
   return sqrt_rn(s);
 }
 
+// distance of a scene point to the nearest of `npos` query positions (npos = 1: the Act3D k-NN centre, act3d.py:247-248;
+// npos = L: find_traj_nn of the multi-scale diffusion head, model/utils/utils.py:39-48, which ranks SQUARED distances)
+__device__ __forceinline__ float nn_dist(const float* __restrict__ pos, int npos, int squared, const float* q) {
+  float best = 0.f;
+  for (int l = 0; l < npos; ++l) {
+    const float dx = sub_rn(pos[l * 3 + 0], q[0]), dy = sub_rn(pos[l * 3 + 1], q[1]), dz = sub_rn(pos[l * 3 + 2], q[2]);
+    const float s = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+    const float d = squared ? s : sqrt_rn(s);
+    best = (l == 0) ? d : fminf(best, d);
+  }
+  return best;
+}
+
 constexpr int TK_THREADS = 1024;
 
 // One workgroup per sample.  dist_ws: [B][N] uint32 scratch.  keys: dynamic LDS, kpad uint64.
 __global__ __launch_bounds__(TK_THREADS) void knn_topk_kernel(
     const float* __restrict__ pos, const float* __restrict__ xyz, unsigned int* __restrict__ dist_ws,
-    long long* __restrict__ idx_out, float* __restrict__ dist_out, int N, int k, int kpad) {
+    long long* __restrict__ idx_out, float* __restrict__ dist_out, int N, int k, int kpad, int npos, int squared) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sh_prefix, sh_krem, sh_count, sh_neq;
   const int b = blockIdx.x, t = threadIdx.x;
-  const float px = pos[b * 3 + 0], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  const float* qp = pos + (size_t)b * npos * 3;
   const float* pts = xyz + (size_t)b * N * 3;
   unsigned int* dw = dist_ws + (size_t)b * N;
 
-  for (int i = t; i < N; i += TK_THREADS) dw[i] = __float_as_uint(l2_dist(px, py, pz, pts + (size_t)i * 3));
+  for (int i = t; i < N; i += TK_THREADS) dw[i] = __float_as_uint(nn_dist(qp, npos, squared, pts + (size_t)i * 3));
   if (t == 0) { sh_prefix = 0; sh_krem = (unsigned int)k; }
   __syncthreads();
 
@@ -187,19 +200,19 @@ __device__ __forceinline__ void hist_add_wave(unsigned int* hist, unsigned int b
 template <int ITEMS>
 __global__ __launch_bounds__(TK_THREADS) void knn_topk_reg_kernel(
     const float* __restrict__ pos, const float* __restrict__ xyz, long long* __restrict__ idx_out,
-    float* __restrict__ dist_out, int N, int k, int kpad) {
+    float* __restrict__ dist_out, int N, int k, int kpad, int npos, int squared) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sh_prefix, sh_krem, sh_count, sh_neq;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
-  const float px = pos[b * 3 + 0], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  const float* qp = pos + (size_t)b * npos * 3;
   const float* pts = xyz + (size_t)b * N * 3;
 
   unsigned int dv[ITEMS];     // element i of this thread is point t + i * 1024 (0xFFFFFFFF beyond N: never selected, k <= N)
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const int n = t + i * TK_THREADS;
-    dv[i] = (n < N) ? __float_as_uint(l2_dist(px, py, pz, pts + (size_t)n * 3)) : 0xFFFFFFFFu;
+    dv[i] = (n < N) ? __float_as_uint(nn_dist(qp, npos, squared, pts + (size_t)n * 3)) : 0xFFFFFFFFu;
   }
   if (t == 0) { sh_prefix = 0; sh_krem = (unsigned int)k; }
   __syncthreads();
@@ -448,10 +461,10 @@ extern "C" int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C
 
 extern "C" size_t a3d_knn_topk_ws_bytes(int B, int N) { return (size_t)B * N * sizeof(unsigned int); }
 
-extern "C" int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long long* idx_out, float* dist_out,
-                            int B, int N, int k, void* stream) {
-  if (!pos || !xyz || !ws || !idx_out || B <= 0 || N <= 0 || k <= 0 || k > N || k > 16384) {
-    set_error("a3d_knn_topk: bad argument (B=%d N=%d k=%d; need 0 < k <= min(N, 16384))", B, N, k);
+static int nn_topk_launch(const char* fn, const float* pos, int npos, int squared, const float* xyz, void* ws,
+                          long long* idx_out, float* dist_out, int B, int N, int k, void* stream) {
+  if (!pos || !xyz || !ws || !idx_out || B <= 0 || N <= 0 || k <= 0 || k > N || k > 16384 || npos <= 0) {
+    set_error("%s: bad argument (B=%d N=%d k=%d npos=%d; need 0 < k <= min(N, 16384))", fn, B, N, k, npos);
     return A3D_ERR_ARG;
   }
   int kpad = 2;
@@ -460,25 +473,31 @@ extern "C" int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long l
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    attr_set = true;
-  }
-  static bool attr2_set = false;
-  if (!attr2_set) {
     (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    attr2_set = true;
+    attr_set = true;
   }
   static const bool use_ws = getenv("A3D_KNN_WS") && atoi(getenv("A3D_KNN_WS")) != 0;   // A/B switch: scratch-based kernel
   if (!use_ws && N <= 16 * TK_THREADS)
     hipLaunchKernelGGL(knn_topk_reg_kernel<16>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
-                       dist_out, N, k, kpad);
+                       dist_out, N, k, kpad, npos, squared);
   else if (!use_ws && N <= 64 * TK_THREADS)
     hipLaunchKernelGGL(knn_topk_reg_kernel<64>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
-                       dist_out, N, k, kpad);
+                       dist_out, N, k, kpad, npos, squared);
   else
     hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz,
-                       (unsigned int*)ws, idx_out, dist_out, N, k, kpad);
-  return check_launch("a3d_knn_topk");
+                       (unsigned int*)ws, idx_out, dist_out, N, k, kpad, npos, squared);
+  return check_launch(fn);
+}
+
+extern "C" int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long long* idx_out, float* dist_out,
+                            int B, int N, int k, void* stream) {
+  return nn_topk_launch("a3d_knn_topk", pos, 1, 0, xyz, ws, idx_out, dist_out, B, N, k, stream);
+}
+
+extern "C" int a3d_traj_nn_topk(const float* traj_xyz, int L, const float* xyz, void* ws, long long* idx_out, float* dist_out,
+                                int B, int N, int k, void* stream) {
+  return nn_topk_launch("a3d_traj_nn_topk", traj_xyz, L, 1, xyz, ws, idx_out, dist_out, B, N, k, stream);
 }
 
 extern "C" int a3d_build_context(const float* feat, const long long* idx, const float* extra, float* ctx, int B,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "a3d_pcd_downsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_knn_topk_ws_bytes": (_z, [_i, _i]),
     "a3d_knn_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "a3d_traj_nn_topk": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_build_context": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_build_context_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_build_context_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

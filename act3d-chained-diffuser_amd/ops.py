@@ -667,6 +667,19 @@ def knn_topk(pos, xyz, k, return_dist=False):
     return (idx, dist) if return_dist else idx
 
 
+def traj_nn_topk(traj_xyz, xyz, k):
+    """find_traj_nn (model/utils/utils.py:39-48): indices (B, k) of the k scene points closest (squared distance) to ANY of
+    the trajectory points traj_xyz (B, L, 3), ascending (distance, index)."""
+    L.require_gpu(traj_xyz, xyz)
+    traj_xyz, xyz = _c(traj_xyz.detach().to(F32)), _c(xyz.to(F32))
+    B, N, _ = xyz.shape
+    ws = torch.empty((B * N,), device=xyz.device, dtype=torch.int32)
+    idx = torch.empty((B, k), device=xyz.device, dtype=torch.int64)
+    L.call("a3d_traj_nn_topk", traj_xyz.data_ptr(), traj_xyz.shape[1], xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(), None,
+           B, N, k, L.stream())
+    return idx
+
+
 def gather_rows(src, idx, extra=None):
     """[src[b][idx[b]] | extra[b]] without autograd (xyz rows)."""
     src = _c(src)

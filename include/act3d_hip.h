@@ -153,6 +153,10 @@ int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C, int Hin, 
 size_t a3d_knn_topk_ws_bytes(int B, int N);
 int a3d_knn_topk(const float* pos, const float* xyz, void* ws, long long* idx_out, float* dist_out, int B, int N,
                  int k, void* stream);
+/* find_traj_nn (model/utils/utils.py:39-48) of the multi-scale diffusion head: the k scene points with the smallest SQUARED
+ * distance to the nearest of the L trajectory points traj_xyz [B][L][3]; same (distance, index) order and workspace as above. */
+int a3d_traj_nn_topk(const float* traj_xyz, int L, const float* xyz, void* ws, long long* idx_out, float* dist_out, int B,
+                     int N, int k, void* stream);
 /* ctx[b] = [ feat[b][idx[b][0..k)] | extra[b][0..X) ], rows of W floats (idx NULL: identity, k == Npts)
  * (act3d.py:247-260). */
 int a3d_build_context(const float* feat, const long long* idx, const float* extra, float* ctx, int B, int Npts,

@@ -201,6 +201,58 @@ def head_forward(P, trajectory, traj_mask, timestep, ctx_feats, ctx_xyz, curr_gr
     return torch.cat([traj_xyz + upd[..., :3], upd[..., 3:]], dim=-1)
 
 
+def head_forward_multi(P, trajectory, traj_mask, timestep, ctx_feats_pyr, ctx_xyz_pyr, curr_gripper, goal_gripper, instruction,
+                       H, attn_rounds=1, feat_scales=1, use_goal=True, n_traj_layers=4, pre="prediction_head."):
+    """DiffusionHead.forward with attn_rounds / feat_scales_to_use > 1 (diffusion_head.py:249-275, eval mode / no dropout).
+    Every (round, scale) iteration l = round * feat_scales + scale evaluates its OWN module set `*.{l}` on the SAME
+    trajectory encoding and trajectory positions (the reference never feeds traj_feats / traj_pos forward, :286-288 are
+    locals of _one_attention_round); only the running `trajectory` chains: xyz accumulates the updates, the rotation
+    channels are replaced.  For scale > 0 with a goal the context is restricted to the nn_ * L fine tokens nearest to the
+    PREVIOUS iteration's predicted trajectory (find_traj_nn, nn_ = 64 at scale 1, 16 beyond).  Returns the list."""
+    from . import sampling as OS
+    E = ctx_feats_pyr[0].shape[-1]
+    B, Ln, _ = trajectory.shape
+    tf0 = OB.mlp2(trajectory, P, pre + "traj_encoder", "0", "3", name_root=pre)
+    traj_xyz = trajectory[..., :3]
+    time_feats = OB.sinusoidal(timestep, E)
+    instr = F.linear(instruction, P[pre + "instruction_encoder.weight"], P[pre + "instruction_encoder.bias"])
+    cg = F.linear(curr_gripper, P[pre + "curr_gripper_encoder.weight"], P[pre + "curr_gripper_encoder.bias"])[:, None] \
+        + P[pre + "curr_gripper_embed.weight"][None]
+    extra, extra_xyz = [cg], [curr_gripper[:, None, :3]]
+    if use_goal:
+        gg = F.linear(goal_gripper, P[pre + "goal_gripper_encoder.weight"], P[pre + "goal_gripper_encoder.bias"])[:, None] \
+            + P[pre + "goal_gripper_embed.weight"][None]
+        extra.append(gg)
+        extra_xyz.append(goal_gripper[:, None, :3])
+    sem = OB.sinusoidal(torch.arange(Ln, dtype=torch.float32), E)[None].expand(B, -1, -1)
+    outs, nn_indices = [], []
+    for rnd in range(attn_rounds):
+        for scale in range(feat_scales):
+            l = rnd * feat_scales + scale
+            feats, xyz = ctx_feats_pyr[scale], ctx_xyz_pyr[scale]
+            if use_goal and scale > 0:
+                idx_np, _ = OS.traj_nn_topk(outs[-1][..., :3].detach().numpy(), xyz.numpy(), (64 if scale == 1 else 16) * Ln)
+                idx = torch.from_numpy(idx_np)
+                nn_indices.append(idx)
+                feats = torch.gather(feats, 1, idx[..., None].expand(-1, -1, E))
+                xyz = torch.gather(xyz, 1, idx[..., None].expand(-1, -1, 3))
+            ctx = OB.parallel_attention(P, pre + f"vl_attention.{l}", 2, feats, None, instr, H, self_attn=False,
+                                        use_adaln=False, name_root=pre)
+            ctx = torch.cat([ctx] + extra, dim=1)
+            cxyz = torch.cat([xyz] + extra_xyz, dim=1)
+            tf = OB.parallel_attention(P, pre + f"traj_lang_attention.{l}", 1, tf0, traj_mask, instr, H, seq1_sem=sem,
+                                       self_attn=False, apply_ffn=False, use_adaln=False, name_root=pre)
+            kw = dict(seq1_xyz=traj_xyz, seq2_xyz=cxyz, seq1_sem=sem, ada=time_feats, name_root=pre)
+            tf = OB.parallel_attention(P, pre + f"traj_attention.{l}", n_traj_layers, tf, traj_mask, ctx, H, **kw)
+            pf = OB.parallel_attention(P, pre + f"pos_attention.{l}", 2, tf, traj_mask, ctx, H, **kw)
+            rf = OB.parallel_attention(P, pre + f"rot_attention.{l}", 2, tf, traj_mask, ctx, H, **kw)
+            upd = torch.cat([OB.mlp2(pf, P, pre + f"pos_regressor.{l}", "0", "3", name_root=pre),
+                             OB.mlp2(rf, P, pre + f"rot_regressor.{l}", "0", "3", name_root=pre)], dim=-1)
+            prev = trajectory if not outs else outs[-1]
+            outs.append(torch.cat([prev[..., :3] + upd[..., :3], upd[..., 3:]], dim=-1))
+    return outs, nn_indices
+
+
 def planner_loss(P, sched, gt_trajectory, traj_mask, ctx_feats, ctx_xyz_world, instruction, curr_gripper, goal_gripper,
                  bounds, noise, timesteps, H, ctx_xyz_norm=None, drop=None):
     """DiffusionPlanner.forward training branch (diffusion_model.py:253-324) with injected noise / timesteps.

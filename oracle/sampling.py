@@ -198,3 +198,16 @@ def knn_topk(pos, xyz, k):
     B, N = dist.shape
     order = np.lexsort((np.broadcast_to(np.arange(N), (B, N)), dist), axis=-1)[:, :k]
     return order.astype(np.int64), np.take_along_axis(dist, order, axis=1)
+
+
+def traj_nn_topk(traj_xyz, xyz, k):
+    """find_traj_nn (model/utils/utils.py:39-48): squared distance of every scene point to its nearest trajectory point,
+    then the k smallest; fp32, sum order (dx^2 + dy^2) + dz^2, ascending (distance, index) like knn_topk above."""
+    t = np.asarray(traj_xyz, dtype=np.float32)[:, :, None, :]          # (B, L, 1, 3)
+    x = np.asarray(xyz, dtype=np.float32)[:, None, :, :]               # (B, 1, N, 3)
+    d = t - x
+    d2 = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+    dist = d2.min(axis=1)
+    B, N = dist.shape
+    order = np.lexsort((np.broadcast_to(np.arange(N), (B, N)), dist), axis=-1)[:, :k]
+    return order.astype(np.int64), np.take_along_axis(dist, order, axis=1)

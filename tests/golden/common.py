@@ -128,6 +128,12 @@ def trajectory_inputs(seed, B, L, ncam, E, image=256, bounds=DIFFUSION_BOUNDS, p
                 init_noise=rs_tensor(rs, (B, L, 9)), step_noise=rs_tensor(rs, (100, B, L, 9)))
 
 
+def fine_feature_map(seed, B, ncam, E, image=256):
+    """Seeded stand-in for the FPN's res1 map (stride 2) used by the multi-scale diffusion fixtures."""
+    rs = np.random.RandomState(seed + 1000)
+    return rs_tensor(rs, (B, ncam, E, image // 2, image // 2))
+
+
 def metrics_inputs():
     """Seeded predictions / targets for the metric and optional-loss fixtures (shared with the tests)."""
     rs = np.random.RandomState(17)

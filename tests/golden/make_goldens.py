@@ -396,6 +396,102 @@ def golden_diffusion():
     save("diffusion.pt", rec)
 
 
+def golden_diffusion_multi():
+    """The multi-round / multi-scale head (diffusion_head.py:249-275): attn_rounds = 2, feat_scales_to_use = 2, untied
+    module sets, goal-conditioned (so that scale 1 attends to the find_traj_nn neighbourhood of the previous prediction).
+    Dropout is zeroed (p = 0 in every nn.Dropout / attention module) so that train-mode gradients are deterministic."""
+    E, B, Ln, ncam = 120, 2, 8, 1
+    m = R.dm.DiffusionPlanner(backbone="clip", image_size=(256, 256), embedding_dim=E, output_dim=7,
+                              num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6, use_instruction=True,
+                              use_goal=True, use_goal_at_test=True, feat_scales_to_use=2, attn_rounds=2,
+                              weight_tying=False, gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D",
+                              diffusion_timesteps=100)
+    shapes, alias = C.unique_param_shapes(m)
+    seed = 91
+    sd = C.expand_aliases(C.seeded_state_dict(shapes, seed, gain=1.5), alias)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+            mod.dropout = 0.0
+    inp = C.trajectory_inputs(seed, B, Ln, ncam, E, pad_last=2)
+    fine = C.fine_feature_map(seed, B, ncam, E)
+    head = m.prediction_head
+
+    def fake_encode_images(rgb, pcd):
+        import einops
+        out = []
+        for f in (8, 2):
+            p = einops.rearrange(pcd, "bt ncam c h w -> (bt ncam) c h w")
+            p = F.interpolate(p, scale_factor=1. / f, mode='bilinear')
+            out.append(einops.rearrange(p, "(bt ncam) c h w -> bt (ncam h w) c", ncam=ncam))
+        return [inp["fmap"], fine], out
+    head.encode_images = fake_encode_images
+    rgb = torch.zeros(B, ncam, 3, 256, 256)
+    rec = dict(cfg=dict(E=E, B=B, L=Ln, ncam=ncam, pad_last=2, attn_rounds=2, feat_scales=2), seed=seed, gain=1.5,
+               param_shapes=shapes, alias=alias)
+    m.train()
+    with patched_rng([inp["noise"]], inp["timesteps"]):
+        loss = m(inp["trajectory"], inp["mask"], rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"])
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None and "feature_pyramid" not in n}
+    rec["train_loss"] = loss.detach()
+    rec["grad_norms"] = {n: g.norm().item() for n, g in grads.items()}
+    keep = ["prediction_head.traj_encoder.0.weight", "prediction_head.traj_attention.3.layers.0.adaln_12.modulation.1.weight",
+            "prediction_head.pos_attention.1.layers.1.sa1.in_proj_weight", "prediction_head.pos_regressor.2.3.weight",
+            "prediction_head.vl_attention.1.layers.1.cross_12.in_proj_weight", "prediction_head.rot_regressor.3.0.weight"]
+    rec["grads"] = {n: grads[n].clone() for n in keep}
+    m.eval()
+    spy = {}
+    import model.trajectory_optimization.diffusion_head as dh
+    orig_nn = dh.find_traj_nn
+
+    def rec_nn(traj, pc, nn_=64):
+        out = orig_nn(traj, pc, nn_)
+        spy.setdefault("nn", []).append(out.clone())
+        return out
+    dh.find_traj_nn = rec_nn
+    with torch.no_grad():
+        tr9 = m.convert_rot(torch.cat([m.normalize_pos(inp["trajectory"][..., :3]), inp["trajectory"][..., 3:]], -1))
+        pcdn = torch.permute(m.normalize_pos(torch.permute(inp["pcd"], [0, 1, 3, 4, 2])), [0, 1, 4, 2, 3])
+        cg = inp["curr_gripper"].clone(); cg[:, :3] = m.normalize_pos(cg[:, :3]); cg = m.convert_rot(cg)
+        gg = inp["goal_gripper"].clone(); gg[:, :3] = m.normalize_pos(gg[:, :3]); gg = m.convert_rot(gg)
+        preds = head(tr9, inp["mask"], inp["timesteps"], rgb, pcdn, cg, gg, inp["instr"])
+    dh.find_traj_nn = orig_nn
+    rec["head_in"] = tr9
+    rec["head_outs"] = [p.clone() for p in preds]
+    rec["nn_indices"] = spy["nn"]
+    rec["conv"] = dict(curr9=cg, goal9=gg)
+    # a short sampling run (5 denoise steps) through the reference's own loop
+    sn = inp["step_noise"]
+    m.position_noise_scheduler.injected_noise = {t: sn[t][..., :3] for t in range(100)}
+    m.rotation_noise_scheduler.injected_noise = {t: sn[t][..., 3:] for t in range(100)}
+    trace = []
+    orig = m.policy_forward_pass
+    calls = {"n": 0}
+
+    class Stop(Exception):
+        pass
+
+    def limited(trajectory, timestep, fixed_inputs):
+        if calls["n"] == 5:
+            trace.append(trajectory.detach().clone())
+            raise Stop()
+        calls["n"] += 1
+        return orig(trajectory, timestep, fixed_inputs)
+    m.policy_forward_pass = limited
+    try:
+        with torch.no_grad(), patched_rng([inp["init_noise"]], inp["timesteps"]):
+            m(inp["trajectory"], inp["mask"], rgb, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+              run_inference=True)
+    except Stop:
+        pass
+    rec["sample_state_after_5_steps"] = trace[0]
+    save("diffusion_multi.pt", rec)
+
+
 def golden_optimizer():
     """G11: which names land in which AdamW group + one AdamW step on a toy module (engine.py:89-102)."""
     import types
@@ -528,6 +624,6 @@ def golden_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "optimizer", "metrics", "dataset"]
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "diffusion_multi", "optimizer", "metrics", "dataset"]
     for w in which:
         globals()["golden_" + w]()

@@ -6,6 +6,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
@@ -304,6 +305,52 @@ def test_diffusion_head_loss_and_sampling():
     q, qr = final[..., 3:], r["sample_final"][..., 3:]
     sign = torch.sign((q * qr).sum(-1, keepdim=True))
     close("sampled trajectory quat", q * sign, qr, 5e-3)
+
+
+def multi_head_inputs(r):
+    """Shared by the CPU and GPU tests of the multi-round / multi-scale head (tests/golden/diffusion_multi.pt)."""
+    cfg = r["cfg"]
+    inp = C.trajectory_inputs(r["seed"], cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"])
+    fine = C.fine_feature_map(r["seed"], cfg["B"], cfg["ncam"], cfg["E"])
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    xyz = [torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), f)) for f in (8, 2)]
+    feats = [C.tokens_from_maps(inp["fmap"]), C.tokens_from_maps(fine)]
+    P = C.expand_aliases(C.seeded_state_dict(r["param_shapes"], r["seed"], r["gain"]), r["alias"])
+    return inp, feats, xyz, P, bounds
+
+
+def test_diffusion_multi_round_multi_scale_head():
+    """attn_rounds = 2 x feat_scales_to_use = 2 (diffusion_head.py:249-275): the four chained predictions, the find_traj_nn
+    neighbourhoods, the training loss summed over all four and its gradients, against the reference."""
+    r = load("diffusion_multi.pt")
+    inp, feats, xyz, Pc, bounds = multi_head_inputs(r)
+    P = {n: t.clone().requires_grad_() for n, t in Pc.items()}
+    H = 8
+    cg, gg = r["conv"]["curr9"], r["conv"]["goal9"]
+    with torch.no_grad():
+        outs, nn_idx = OD.head_forward_multi(P, r["head_in"], inp["mask"], inp["timesteps"], feats, xyz, cg, gg, inp["instr"],
+                                             H, attn_rounds=2, feat_scales=2)
+    assert len(outs) == 4 and len(nn_idx) == 2
+    for i, (o, ref) in enumerate(zip(outs, r["head_outs"])):
+        close(f"prediction {i}", o, ref, 2e-4)
+    for i, (a, b) in enumerate(zip(nn_idx, r["nn_indices"])):
+        assert a.shape == b.shape == (2, 64 * 8)
+        assert torch.equal(a.sort(-1).values, b.sort(-1).values), f"find_traj_nn set {i}"
+    sched = OD.DDPMSchedules(100)
+    gt = inp["trajectory"].clone()
+    gt[..., :3] = OD.normalize_pos(gt[..., :3], bounds)
+    gt = OD.convert_rot(gt)
+    noisy = sched.add_noise(gt, inp["noise"], inp["timesteps"])
+    preds, _ = OD.head_forward_multi(P, noisy, inp["mask"], inp["timesteps"], feats, xyz, cg, gg, inp["instr"], H,
+                                     attn_rounds=2, feat_scales=2)
+    loss = sum(100 * F.l1_loss(p_[..., :3], gt[..., :3]) + 10 * F.l1_loss(p_[..., 3:9], gt[..., 3:9]) for p_ in preds)
+    close("train loss", loss, r["train_loss"], 2e-4, 1e-5)
+    loss.backward()
+    for n, gref in r["grads"].items():
+        close("grad " + n, P[n].grad, gref, 5e-4, 2e-3)
+    for n, nr in r["grad_norms"].items():
+        assert abs(P[n].grad.norm().item() - nr) <= 3e-3 * nr + 1e-5, n
 
 
 def test_optimizer_grouping_and_step():
