@@ -95,9 +95,12 @@ class DiffusionHead(nn.Module):
                  use_sigma=False, feat_scales_to_use=1, attn_rounds=1, weight_tying=False,
                  rotation_parametrization='quat', dropout=0.1, dropout_seed=0):
         super().__init__()
-        if feat_scales_to_use != 1 or attn_rounds != 1 or use_sigma:
-            raise NotImplementedError("only feat_scales_to_use=1, attn_rounds=1, use_sigma=False (the shipped "
-                                      "configuration, scripts/train_trajectory.sh) are implemented")
+        if use_sigma:
+            # DiffusionPlanner never forwards use_sigma (diffusion_model.py:37-50): unreachable through the model API
+            raise NotImplementedError("use_sigma=True (a learned time embedding, encoder.py:68-76) is not implemented")
+        assert feat_scales_to_use in (1, 2, 3, 4) and attn_rounds >= 1
+        self.attn_rounds, self.feat_scales = attn_rounds, feat_scales_to_use
+        R = attn_rounds * feat_scales_to_use        # one module set per (round, scale) iteration, diffusion_head.py:53-199
         self.image_size = tuple(image_size)
         self.use_instruction, self.use_goal = use_instruction, use_goal
         self.rotation_parametrization = rotation_parametrization
@@ -124,24 +127,33 @@ class DiffusionHead(nn.Module):
             self.goal_gripper_encoder = nn.Linear(output_dim, E)
         common = dict(d_model=E, n_heads=num_attn_heads, dropout=dropout, self_attention2=False, cross_attention1=True,
                       cross_attention2=False)
+        def stack(make):                      # the reference shares ONE module across all iterations iff weight_tying
+            if weight_tying:
+                m = make()
+                return nn.ModuleList([m for _ in range(R)])
+            return nn.ModuleList([make() for _ in range(R)])
+
         if use_instruction:
-            self.vl_attention = nn.ModuleList([ParallelAttention(num_layers=num_vis_ins_attn_layers, self_attention1=False, **common)])
-        self.traj_lang_attention = nn.ModuleList([ParallelAttention(num_layers=1, self_attention1=False, rotary_pe=False,
-                                                                    apply_ffn=False, **common)])
-        self.traj_attention = nn.ModuleList([ParallelAttention(num_layers=num_query_cross_attn_layers - 2, self_attention1=True,
-                                                               rotary_pe=True, use_adaln=True, **common)])
-        self.pos_attention = nn.ModuleList([ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
-                                                              use_adaln=True, **common)])
-        self.rot_attention = nn.ModuleList([ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
-                                                              use_adaln=True, **common)])
-        self.pos_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, 3))])
-        self.rot_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, output_dim - 3))])
+            self.vl_attention = stack(lambda: ParallelAttention(num_layers=num_vis_ins_attn_layers, self_attention1=False, **common))
+        self.traj_lang_attention = stack(lambda: ParallelAttention(num_layers=1, self_attention1=False, rotary_pe=False,
+                                                                   apply_ffn=False, **common))
+        self.traj_attention = stack(lambda: ParallelAttention(num_layers=num_query_cross_attn_layers - 2, self_attention1=True,
+                                                              rotary_pe=True, use_adaln=True, **common))
+        self.pos_attention = stack(lambda: ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
+                                                             use_adaln=True, **common))
+        self.rot_attention = stack(lambda: ParallelAttention(num_layers=2, self_attention1=True, rotary_pe=True,
+                                                             use_adaln=True, **common))
+        self.pos_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout), nn.Linear(E, 3))
+                                            for _ in range(R)])
+        self.rot_regressor = nn.ModuleList([nn.Sequential(nn.Linear(E, E), nn.ReLU(), nn.Dropout(dropout),
+                                                          nn.Linear(E, output_dim - 3)) for _ in range(R)])
         self._sem_cache = {}
         # dropout sites are named after the modules (ops.site_id); generator state {seed, forward-pass counter} on the device
         for name, mod in self.named_modules():
             if hasattr(mod, "site_base"):
                 mod.site_base = O.site_id(name)
-        self._mlp_sites = {n: O.site_id(n, 4) for n in ("traj_encoder", "pos_regressor.0", "rot_regressor.0")}
+        self._mlp_sites = {n: O.site_id(n, 4) for n in ["traj_encoder"] + [f"{k}_regressor.{l}" for k in ("pos", "rot")
+                                                                          for l in range(R)]}
         self.register_buffer("_drop_state", torch.tensor([dropout_seed, 0], dtype=torch.int64), persistent=False)
 
     def begin_dropout(self):
@@ -155,15 +167,21 @@ class DiffusionHead(nn.Module):
 
     # ---- vision (adjacent): one scale
     def encode_images(self, rgb, pcd_norm):
-        """encoder.py:115-167 for one scale: tokens (B, ncam*h*w, E) and down-sampled (already normalised) coordinates."""
+        """encoder.py:115-167: FPN tokens (B, ncam*h*w, E) of the scales the head uses -- one tensor for
+        feat_scales_to_use = 1 (the res3 map at 1/8), a list [res3 @ 1/8, res1 @ 1/2, ...] otherwise."""
         B, ncam = rgb.shape[:2]
         x = rgb.flatten(0, 1)
         with torch.no_grad():
             feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, normalize=self.normalize)
-        name = self.feature_map_pyramid[0]
-        fm = self.feature_pyramid(feats, needed=[name])[name]
-        n, E, h, w = fm.shape
-        return fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+        names = self.feature_map_pyramid[:self.feat_scales]
+        pyr = self.feature_pyramid(feats, needed=sorted(set(names)))
+        toks = {}
+        for name in set(names):
+            fm = pyr[name]
+            n, E, h, w = fm.shape
+            toks[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+        out = [toks[n] for n in names]
+        return out[0] if self.feat_scales == 1 else out
 
     def _sem(self, Ln, E, device):
         key = (Ln, E, str(device))
@@ -210,6 +228,64 @@ class DiffusionHead(nn.Module):
                          O.mlp(rot_feats, self.rot_regressor[0][0], self.rot_regressor[0][3], drop=drop,
                                site_hidden=ms["rot_regressor.0"])], dim=-1)
         return O.TrajUpdateFn.apply(trajectory, upd)
+
+    def forward_multi(self, trajectory, trajectory_mask, timestep, tokens, xyzs, instruction, curr_gripper, goal_gripper,
+                      new_drop=None):
+        """DiffusionHead.forward for attn_rounds x feat_scales_to_use > 1 (diffusion_head.py:249-275).  Iteration
+        l = round * feat_scales + scale runs module set l on the SAME trajectory encoding / positions (the reference never
+        carries traj_feats over, :286-288); only the prediction chains (xyz accumulates, rotation is replaced).  With a goal,
+        scales > 0 attend to the (64 | 16) * L fine tokens nearest to the previous prediction (find_traj_nn ->
+        a3d_traj_nn_topk).  tokens / xyzs: per-scale visual tokens (B, N_s, E) and normalised coordinates (B, N_s, 3).
+        new_drop: callable returning a fresh DropCtx per iteration (None: no dropout).  Returns the list of predictions."""
+        B, Ln, _ = trajectory.shape
+        E = self.curr_gripper_embed.weight.shape[1]
+        trajectory = trajectory.contiguous()
+        ms = self._mlp_sites
+        drop = new_drop() if new_drop is not None else None
+        traj_feats0 = O.mlp(trajectory, self.traj_encoder[0], self.traj_encoder[3], drop=drop, site_hidden=ms["traj_encoder"])
+        traj_xyz = trajectory[..., :3].contiguous()
+        silu_t = O.SiLUFn.apply(O.sinusoidal_emb(timestep.float(), E))
+        sem = self._sem(Ln, E, trajectory.device)
+        instr = O.linear(instruction.float(), self.instruction_encoder) if self.use_instruction else None
+        cg = O.linear(curr_gripper, self.curr_gripper_encoder)[:, None] + broadcast_row(self.curr_gripper_embed.weight, B, 1)
+        extra, extra_xyz = [cg], [curr_gripper[:, None, :3]]
+        if self.use_goal:
+            gg = O.linear(goal_gripper, self.goal_gripper_encoder)[:, None] + broadcast_row(self.goal_gripper_embed.weight, B, 1)
+            extra.append(gg)
+            extra_xyz.append(goal_gripper[:, None, :3])
+        extra, extra_xyz = torch.cat(extra, dim=1), torch.cat(extra_xyz, dim=1).contiguous()
+        none = torch.empty((B, 0, E), device=trajectory.device, dtype=torch.float32)
+        outs, prev = [], trajectory
+        for rnd in range(self.attn_rounds):
+            for scale in range(self.feat_scales):
+                l = rnd * self.feat_scales + scale
+                if l > 0 and new_drop is not None:
+                    drop = new_drop()
+                feats, xyz = tokens[scale], xyzs[scale]
+                idx = None
+                if self.use_goal and scale > 0:
+                    idx = O.traj_nn_topk(outs[-1][..., :3], xyz, (64 if scale == 1 else 16) * Ln)
+                if self.use_instruction:
+                    ctx = O.BuildContextFn.apply(feats, idx, none) if idx is not None else feats
+                    ctx = self.vl_attention[l](ctx, None, instr, drop=drop)
+                    ctx = O.BuildContextFn.apply(ctx, None, extra)
+                else:
+                    ctx = O.BuildContextFn.apply(feats, idx, extra)
+                ctx_xyz = O.gather_rows(xyz, idx, extra_xyz)
+                tf = traj_feats0
+                if self.use_instruction:
+                    tf = self.traj_lang_attention[l](tf, trajectory_mask, instr, seq1_sem_pos=sem, drop=drop)
+                kw = dict(seq1_xyz=traj_xyz, seq2_xyz=ctx_xyz, seq1_sem_pos=sem, silu_t=silu_t, drop=drop)
+                tf = self.traj_attention[l](tf, trajectory_mask, ctx, **kw)
+                pf = self.pos_attention[l](tf, trajectory_mask, ctx, **kw)
+                rf = self.rot_attention[l](tf, trajectory_mask, ctx, **kw)
+                upd = torch.cat([O.mlp(pf, self.pos_regressor[l][0], self.pos_regressor[l][3], drop=drop,
+                                       site_hidden=ms[f"pos_regressor.{l}"]),
+                                 O.mlp(rf, self.rot_regressor[l][0], self.rot_regressor[l][3], drop=drop,
+                                       site_hidden=ms[f"rot_regressor.{l}"])], dim=-1)
+                prev = O.TrajUpdateFn.apply(prev, upd)
+                outs.append(prev)
+        return outs
 
     # ---- inference with cached K/V
     def _cross_layers(self):
@@ -448,14 +524,21 @@ class DiffusionPlanner(nn.Module):
         return signal_to_pose(signal)
 
     def _prepare(self, rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens):
-        """Normalised, converted conditioning + visual tokens and their (normalised, down-sampled) coordinates."""
+        """Normalised, converted conditioning + visual tokens and their (normalised, down-sampled) coordinates
+        (one tensor each, or one per scale for a multi-scale head)."""
         head = self.prediction_head
         with torch.no_grad():
             pcd_n = self.normalize_pos(pcd_obs.float().permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3).contiguous()
-            ctx_xyz = O.pcd_downsample(pcd_n, head.downscaling_factor_pyramid[0])
+            by_factor = {}
+            for f in head.downscaling_factor_pyramid[:head.feat_scales]:
+                if f not in by_factor:
+                    by_factor[f] = O.pcd_downsample(pcd_n, f)
+            ctx_xyz = [by_factor[f] for f in head.downscaling_factor_pyramid[:head.feat_scales]]
             cg = pose_to_signal(curr_gripper, self.gripper_loc_bounds)
             gg = pose_to_signal(goal_gripper, self.gripper_loc_bounds)
         tokens = visual_tokens if visual_tokens is not None else head.encode_images(rgb_obs, pcd_n)
+        if head.feat_scales == 1:
+            ctx_xyz = ctx_xyz[0]
         return tokens, ctx_xyz, cg, gg
 
     # ---- training (diffusion_model.py:253-324)
@@ -476,6 +559,15 @@ class DiffusionPlanner(nn.Module):
                 timesteps = torch.randint(0, self.n_steps, (gt.shape[0],), device=dev).long()
             gt = gt[..., :9].contiguous()               # the reference rebuilds the 9 pose channels (diffusion_model.py:296-305)
             noisy = O.ddpm_add_noise(gt, noise.to(dev).float()[..., :9].contiguous(), timesteps.to(dev), tb.acp_pos, tb.acp_rot)
+        if head.attn_rounds * head.feat_scales > 1:
+            # every iteration's prediction is supervised (diffusion_model.py:313-323)
+            toks = tokens if isinstance(tokens, (list, tuple)) else [tokens]
+            xyzs = ctx_xyz if isinstance(ctx_xyz, (list, tuple)) else [ctx_xyz]
+            preds = head.forward_multi(noisy, trajectory_mask, timesteps.to(dev), toks, xyzs, instruction, cg, gg,
+                                       head.begin_dropout if (head.training and head.dropout_p > 0) else None)
+            loss = sum(O.ElemLossFn.apply(p_[..., :3], gt[..., :3], 1, 100.0) + O.ElemLossFn.apply(p_[..., 3:9], gt[..., 3:9], 1, 10.0)
+                       for p_ in preds)
+            return (loss, preds, gt) if return_pred else loss
         drop = head.begin_dropout()
         ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg, drop=drop)
         pred = head.forward_tokens(noisy, trajectory_mask, timesteps.to(dev), ctx, ctx_xyz, instr, drop=drop)
@@ -492,10 +584,12 @@ class DiffusionPlanner(nn.Module):
         tb = self.tables(dev)
         B, Ln = trajectory_mask.shape
         tokens, ctx_xyz, cg, gg = self._prepare(rgb_obs, pcd_obs, curr_gripper, goal_gripper, visual_tokens)
-        ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
+        multi = head.attn_rounds * head.feat_scales > 1
+        if not multi:
+            ctx, ctx_xyz, instr = head.encode_context(tokens, ctx_xyz, instruction, cg, gg)
         # conditioning: start pose at index 0, goal at L - pad - 1 and after (no host sync: index arithmetic on device)
         D = cg.shape[-1]
-        E = ctx.shape[-1]
+        E = head.curr_gripper_embed.weight.shape[1]
         ar = torch.arange(Ln, device=dev)[None, :]
         cond_mask = (ar == 0)
         cond_data = torch.zeros((B, Ln, D), device=dev)
@@ -519,8 +613,15 @@ class DiffusionPlanner(nn.Module):
         trace = []
         # fused per-step kernels (csrc/denoise.hip) whenever the trajectory fits one 16-row tile; else the op-by-op path
         fused = FUSED_DENOISE if fused is None else fused
-        fused = fused and Ln <= 16 and E <= 128 and D <= 16
-        if fused:
+        fused = fused and Ln <= 16 and E <= 128 and D <= 16 and not multi
+        if multi:
+            # multi-round / multi-scale heads: the fine-scale context follows the previous prediction, so nothing but the
+            # image encoding is step-invariant -- every step evaluates the full head (no K/V cache, no fused kernels)
+            toks = tokens if isinstance(tokens, (list, tuple)) else [tokens]
+            xyzs = ctx_xyz if isinstance(ctx_xyz, (list, tuple)) else [ctx_xyz]
+            state, static = None, list(toks) + list(xyzs) + [instruction, cg, gg]
+            tmask = trajectory_mask.bool()
+        elif fused:
             state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln)
             static = state["tensors"]
         else:
@@ -532,7 +633,11 @@ class DiffusionPlanner(nn.Module):
         def run_loop(x):
             for t in steps:
                 nz = step_noise[t] if t > 0 else None
-                if fused:
+                if multi:
+                    tt = torch.full((B,), t, device=dev, dtype=torch.long)
+                    out = head.forward_multi(x, tmask, tt, toks, xyzs, instruction, cg, gg)[-1]
+                    x = O.ddpm_step(out, x, nz, cond_data, cond_mask_u8, tb.coef_pos, tb.coef_rot, t)
+                elif fused:
                     x = head.fused_step(state, x, t, nz, cond_data, cond_mask_u8, tb)
                 else:
                     out = head.denoise_tokens_cached(x, kmask, t, state, self._time_tables)

@@ -292,12 +292,14 @@ def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=
 def fwd_bwd_trajectory(model, criterion, sample, on_hot_done=None):
     """forward + loss + backward of main_trajectory.py:177-195 with the backward split at the FPN tokens"""
     tokens = model.prediction_head.encode_images(sample["rgbs"], None)
+    multi = isinstance(tokens, (list, tuple))                  # one token tensor per scale for a multi-scale head
 
     def hot(leaves):
         return criterion.compute_loss(model(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
-                                            sample["instr"], sample["curr_gripper"], sample["action"], visual_tokens=leaves[0]))
+                                            sample["instr"], sample["curr_gripper"], sample["action"],
+                                            visual_tokens=list(leaves) if multi else leaves[0]))
 
-    return _split_backward([tokens], hot, on_hot_done)
+    return _split_backward(list(tokens) if multi else [tokens], hot, on_hot_done)
 
 
 def _finish_step(optimizer, ddp, step_id, accumulate_grad_batches):

@@ -1015,7 +1015,8 @@ class AddRowsFn(torch.autograd.Function):
 
 
 class TrajUpdateFn(torch.autograd.Function):
-    """cat(traj[..., :3] + upd[..., :3], upd[..., 3:])   (diffusion_head.py:268-272); gradient flows to `upd` only."""
+    """cat(traj[..., :3] + upd[..., :3], upd[..., 3:])   (diffusion_head.py:268-272).  `traj` needs a gradient only when it
+    is a previous iteration's prediction (multi-round / multi-scale heads): d traj = [dy_xyz | 0]."""
 
     @staticmethod
     def forward(ctx, traj, upd):
@@ -1027,7 +1028,11 @@ class TrajUpdateFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return None, dy
+        dtraj = None
+        if ctx.needs_input_grad[0]:
+            dtraj = torch.zeros_like(dy)
+            dtraj[..., :3] = dy[..., :3]
+        return dtraj, dy
 
 
 def ddpm_add_noise(x0, noise, t, acp_pos, acp_rot):

@@ -155,3 +155,57 @@ def test_fused_denoise_step_equals_op_by_op_path(setup, dev):
     for i in (0, 1, 2, 50, 99):
         scale_close(f"fused vs op-by-op state after step {i}", ta[i], tb[i], 2e-5)
     scale_close("fused vs op-by-op final pose", fa, fb, 2e-5)
+
+
+def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
+    """attn_rounds = 2 x feat_scales_to_use = 2, untied module sets, goal-conditioned (diffusion_head.py:249-275) against
+    tests/golden/diffusion_multi.pt: the four chained predictions, the find_traj_nn neighbourhoods (a3d_traj_nn_topk), the
+    training loss summed over all four with its gradients, and the state after 5 sampling steps."""
+    from test_oracle_golden import multi_head_inputs
+    r = load("diffusion_multi.pt")
+    cfg = r["cfg"]
+    inp, feats, xyz, P, bounds = multi_head_inputs(r)
+    m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, feat_scales_to_use=2, attn_rounds=2,
+                             weight_tying=False, gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D",
+                             diffusion_timesteps=100, dropout=0.0)
+    res = m.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys
+    assert all(".backbone." in k or "feature_pyramid" in k for k in res.missing_keys), res.missing_keys
+    m.to(dev)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    toks = [f.to(dev) for f in feats]
+    head = m.prediction_head
+    # ---- k-NN kernel against the oracle's restatement on the reference's own query (bit-exact sets and order)
+    from oracle import sampling as OS
+    prev = r["head_outs"][0][..., :3]
+    idx_ref, _ = OS.traj_nn_topk(prev.numpy(), xyz[1].numpy(), 64 * cfg["L"])
+    idx = a3d.ops.traj_nn_topk(prev.to(dev), xyz[1].to(dev), 64 * cfg["L"])
+    assert torch.equal(idx.cpu(), torch.from_numpy(idx_ref))
+    # ---- eval forward: the chained predictions
+    m.eval()
+    with torch.no_grad():
+        tokens, ctx_xyz, cg, gg = m._prepare(None, inp["pcd"], inp["curr_gripper"], inp["goal_gripper"], toks)
+        for a, b in zip(ctx_xyz, xyz):
+            assert torch.equal(a.cpu(), b)
+        preds = head.forward_multi(r["head_in"].to(dev), inp["mask"], inp["timesteps"], tokens, ctx_xyz, inp["instr"], cg, gg)
+    assert len(preds) == 4
+    for i, (p_, ref) in enumerate(zip(preds, r["head_outs"])):
+        scale_close(f"prediction {i}", p_, ref)
+    # ---- training loss over all four predictions + gradients
+    m.train()
+    loss = m(inp["trajectory"], inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+             noise=inp["noise"], timesteps=inp["timesteps"], visual_tokens=toks)
+    scale_close("train loss", loss, r["train_loss"], 1e-3)
+    loss.backward()
+    named = dict(m.named_parameters())
+    for n, gref in r["grads"].items():
+        scale_close("grad " + n, named[n].grad, gref, 1.5e-3, floor=1e-3)
+    for n, nr in r["grad_norms"].items():
+        assert abs(named[n].grad.norm().item() - nr) <= 3e-3 * nr + 1e-4, f"grad norm {n}"
+    # ---- 5 steps of the sampling loop (no K/V cache: the fine-scale context follows the prediction)
+    m.eval()
+    _, trace = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
+                                    init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=toks, n_steps=5,
+                                    return_trace=True)
+    scale_close("state after 5 steps", trace[-1], r["sample_state_after_5_steps"], 2e-3)
