@@ -201,8 +201,14 @@ def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
     named = dict(m.named_parameters())
     for n, gref in r["grads"].items():
         scale_close("grad " + n, named[n].grad, gref, 1.5e-3, floor=1e-3)
+    worst = 0.0
     for n, nr in r["grad_norms"].items():
-        assert abs(named[n].grad.norm().item() - nr) <= 3e-3 * nr + 1e-4, f"grad norm {n}"
+        # norms of all 900+ gradient tensors (only six are stored in full): 5e-3 -- the sum of four L1 losses back-propagates
+        # through four chained predictions, and sign(pred - gt) is discontinuous where a prediction error crosses zero
+        rel = abs(named[n].grad.norm().item() - nr) / (nr + 1e-4)
+        worst = max(worst, rel)
+        assert rel <= 5e-3, f"grad norm {n}: {named[n].grad.norm().item()} vs {nr}"
+    print(f"[parity] worst relative gradient-norm deviation over {len(r['grad_norms'])} tensors: {worst:.2e}")
     # ---- 5 steps of the sampling loop (no K/V cache: the fine-scale context follows the prediction)
     m.eval()
     _, trace = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
