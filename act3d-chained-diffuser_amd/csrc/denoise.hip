@@ -31,8 +31,9 @@ constexpr int LDQK = 260;         // [16][<=256]
 constexpr int LDH = 516;          // [16][<=512]
 
 // Y[16][N] = act(X[16][K] W[N][K]^T + bias), X / Y in LDS (X zero-padded to a multiple of 16 columns), W / bias in
-// global memory (L2-resident: every sample's workgroup reads the same weights).  The four waves take the 16-column output
-// tiles round-robin.  Contraction index permutation: MFMA j of a 16-channel block contracts lane group g with channel
+// global memory (L2-resident: every sample's workgroup reads the same weights).  The workgroup's waves (4 or 8) take the
+// 16-column output tiles round-robin: the more waves, the more weight fragments are in flight per CU -- the per-sample
+// kernels are bound by that (PMC: MfmaUtil 2.5 %, VALUBusy 3.3 %, 8.6 MB of HBM fetch per 103 us launch).  Contraction index permutation: MFMA j of a 16-channel block contracts lane group g with channel
 // 4 g + j, so that A and B are one float4 each per block.  The weight fragments of the NEXT (tile, 128-channel chunk) are
 // fetched into registers while the current chunk's 32 MFMAs issue (a load inside the MFMA loop would expose one L2 round
 // trip per 16 channels: measured 136 us for the layer remainder against ~20 us of MFMA issue); two accumulators per tile
@@ -44,7 +45,7 @@ constexpr int WCH = 8;            // 16-channel blocks per register chunk
 template <int ACT, bool VEC>
 __device__ __forceinline__ void wg_linear_impl(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                                const float* __restrict__ bias, int N, float* Ys, int ldy) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
   const int nchunk = (nblk + WCH - 1) / WCH;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void wg_linear_impl(const float* Xs, int ldx, int K, 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   while (ct < ntile) {
     int nct = ct, nc = c + 1;
-    if (nc == nchunk) { nc = 0; nct = ct + 4; }
+    if (nc == nchunk) { nc = 0; nct = ct + nwave; }
     if (nct < ntile) loadw(nct, nc, wn);                     // wave-uniform condition
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
@@ -134,13 +135,14 @@ __device__ __forceinline__ void wg_zero_pad(float* T, int ld, int E, int Epad) {
 // the trailing barrier is needed; gamma / beta are fetched up front (one L2 round trip, not one per element).
 __device__ __forceinline__ void wg_add_layernorm(const float* A, int lda, const float* R, int ldr, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float* Y, int ldy, int E) {
-  const int r = threadIdx.x >> 4, s = threadIdx.x & 15;
+  const int r = (threadIdx.x >> 4) & 15, s = threadIdx.x & 15;
+  const bool worker = threadIdx.x < 256;                  // 16 rows x 16 threads; further waves only join the barrier
   float v[8], gm[8], bt[8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = s + 16 * i;
-    const bool ok = c < E;
+    const bool ok = worker && c < E;
     gm[i] = ok ? gamma[c] : 0.f;
     bt[i] = ok ? beta[c] : 0.f;
     v[i] = ok ? A[r * lda + c] + R[r * ldr + c] : 0.f;
@@ -161,7 +163,7 @@ __device__ __forceinline__ void wg_add_layernorm(const float* A, int lda, const 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = s + 16 * i;
-    if (c < E) Y[r * ldy + c] = (v[i] - mean) * rstd * gm[i] + bt[i];
+    if (worker && c < E) Y[r * ldy + c] = (v[i] - mean) * rstd * gm[i] + bt[i];
   }
   __syncthreads();
 }
@@ -171,8 +173,8 @@ __device__ __forceinline__ void wg_add_layernorm(const float* A, int lda, const 
 __device__ __forceinline__ void wg_adaln(const float* X, int ldx, const float* __restrict__ sem, const float* __restrict__ mod,
                                          float* Y, int ldy, int L, int E, float* Y2 = nullptr, int ldy2 = 0) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = threadIdx.x + j * 256;
+  for (int j = 0; j < 8; ++j) {                            // DR * E <= 2048 = 8 x 256: predicated, all loads issued up front
+    const int i = threadIdx.x + j * blockDim.x;
     if (i < DR * E) {
       const int r = i / E, c = i - r * E;
       const float x0 = X[r * ldx + c];
@@ -215,8 +217,8 @@ __device__ __forceinline__ void wg_rope(float* T, int ld, int col0, int nblk, co
 // 53 instruction tokens or the <= 16 trajectory steps).  Q in LDS; K / V rows at stride ldk / ldv (global or LDS).
 __device__ __forceinline__ void wg_small_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                                                    const unsigned char* __restrict__ kmask, int S, int H, float* O, int ldo) {
-  const int r = threadIdx.x >> 4, h = threadIdx.x & 15;
-  if (h < H) {
+  const int r = (threadIdx.x >> 4) & 15, h = threadIdx.x & 15;
+  if (threadIdx.x < 256 && h < H) {
     float q[HD], acc[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) { q[d] = Q[r * ldq + h * HD + d]; acc[d] = 0.f; }
@@ -249,7 +251,7 @@ __device__ __forceinline__ void wg_load_rows(const float* __restrict__ src, int 
 }
 
 // ------------------------------------------------------------------------------------------------ head
-__global__ __launch_bounds__(256) void dn_head_kernel(const float* __restrict__ traj, int D, a3d_dn_head_params p,
+__global__ __launch_bounds__(512) void dn_head_kernel(const float* __restrict__ traj, int D, a3d_dn_head_params p,
                                                       float* __restrict__ x_out, int L, int E, int H) {
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], As[DR * LDX], Ts[DR * LDX], Qs[DR * LDX];
   extern __shared__ __attribute__((aligned(16))) float kvS[];          // [S_lang][2E]: the instruction tokens' k | v rows
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ rest of a layer
-__global__ __launch_bounds__(256) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
+__global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
                                                       const float* __restrict__ Op, const float* __restrict__ Mp,
                                                       a3d_dn_rest_params p, float* __restrict__ x_out, int B, int L,
                                                       int E, int H, int nsplit) {
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void dn_rest_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ tail
-__global__ __launch_bounds__(256) void dn_tail_kernel(const float* __restrict__ pos_feats, const float* __restrict__ rot_feats,
+__global__ __launch_bounds__(512) void dn_tail_kernel(const float* __restrict__ pos_feats, const float* __restrict__ rot_feats,
                                                       const float* __restrict__ traj, int D, a3d_dn_tail_params p,
                                                       float* __restrict__ traj_out, int L, int E, int t_step) {
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], Ts[DR * LDX], Us[DR * 16];
@@ -564,6 +566,13 @@ __global__ __launch_bounds__(256) void rope_rows_f32_kernel(const float* __restr
 
 using namespace a3d;
 
+// threads per sample-workgroup of the per-sample kernels: 512 (8 waves) by default, A3D_DN_THREADS=256 for the A/B run
+// (measured on MI355X, cfg-3: 1.125 -> 0.955 ms per denoise step; 16 waves gave nothing more: 0.949)
+static int dn_threads() {
+  static const int n = (getenv("A3D_DN_THREADS") && atoi(getenv("A3D_DN_THREADS")) == 256) ? 256 : 512;
+  return n;
+}
+
 static int dn_check(const char* fn, int B, int L, int E, int H) {
   if (B <= 0 || L <= 0 || L > DR || E <= 0 || E > 128 || (E % 6) != 0 || H * HD != E) {
     set_error("%s: bad shape (B=%d L=%d E=%d H=%d; L <= 16, E = 15 H <= 128)", fn, B, L, E, H);
@@ -591,7 +600,7 @@ extern "C" int a3d_dn_head(const float* traj, int D, const a3d_dn_head_params* p
     (void)hipFuncSetAttribute((const void*)dn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
+  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
   return check_launch("a3d_dn_head");
 }
 
@@ -630,7 +639,7 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
   }
   const float* Op = ws;
   const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
-  hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E, H,
+  hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E, H,
                      nsplit);
   return check_launch("a3d_dn_rest");
 }
@@ -642,7 +651,7 @@ extern "C" int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const
     set_error("a3d_dn_tail: bad argument");
     return A3D_ERR_ARG;
   }
-  hipLaunchKernelGGL(dn_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pos_feats, rot_feats, traj, D, *p, traj_out, L,
+  hipLaunchKernelGGL(dn_tail_kernel, dim3(B), dim3(dn_threads()), 0, (hipStream_t)stream, pos_feats, rot_feats, traj, D, *p, traj_out, L,
                      E, t_step);
   return check_launch("a3d_dn_tail");
 }
