@@ -73,6 +73,11 @@ def _time(fn, iters):
     return st.elapsed_time(en) / iters * 1e-3
 
 
+# HBM bytes per a3d_dn_cross launch at cfg-3 from the committed counter passes: FETCH_SIZE 111215.5 KiB x 2 (gfx950 wide-read
+# correction) + WRITE_SIZE 1088 KiB
+PMC_DN_CROSS_BYTES = (111215.5 * 2 + 1088.0) * 1024
+
+
 def cached_attention_roofline(a3d, B, Ln, S, dev):
     """One a3d_dn_cross launch (AdaLN + q-projection + RoPE + the L-query flash attention against the cached context) at
     the sampling shapes, timed with events on the launch stream.  ALGORITHMIC bytes: a 16-channel bf16 K row and
@@ -89,7 +94,7 @@ def cached_attention_roofline(a3d, B, Ln, S, dev):
     qw, qb = (torch.randn(E, E, generator=g) / 11).to(dev), torch.randn(E, generator=g).to(dev)
     mod, sem = (torch.randn(2 * E, generator=g) * 0.1).to(dev), torch.randn(Ln, E, generator=g).to(dev)
     freq = a3d.ops.rope_freq(E, dev)
-    ns = max(1, min(8, Sp // 128, -(-1024 // (B * H))))
+    ns = max(1, min(8, Sp // 128, -(-a3d.diffusion.DN_TARGET_WGS // (B * H))))       # the split the sampling loop uses
     ws = torch.empty((Lb.load().a3d_dn_cross_ws_floats(B, H, ns),), device=dev)
     cp = Lb.DnCrossParams(sem=sem.data_ptr(), mod=mod.data_ptr(), q_w=qw.data_ptr(), q_b=qb.data_ptr(), freq=freq.data_ptr(),
                           Kf=Kf.data_ptr(), Vt=Vt.data_ptr())
@@ -99,7 +104,9 @@ def cached_attention_roofline(a3d, B, Ln, S, dev):
     stored = B * H * Sp * 128.0
     return {"bound": "hbm", "kernel": "dn_cross (trajectory -> context cross-attention against the fp32-K / bf16-V cache)",
             "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0, "ms": t * 1e3,
-            "traffic": None, "algorithmic_bytes_per_launch": alg, "stored_bytes_per_launch": stored,
+            "traffic": PMC_DN_CROSS_BYTES if (B, Ln, S) == (64, 16, 3074) else None,
+            "traffic_source": "profiles/r02_pmc_denoise_summary.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, nsplit 2)",
+            "algorithmic_bytes_per_launch": alg, "stored_bytes_per_launch": stored,
             "stored_bytes_rate_GBps": stored / t / 1e9, "launches_per_denoise_step": 8, "nsplit": ns}
 
 
