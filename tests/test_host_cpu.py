@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import sys
+import types
 
 import numpy as np
 import pytest
@@ -312,3 +313,61 @@ def test_dropout_twin_statistics_and_site_ids():
     a = t.attn(3, 2, 8, 16, 70) > 0
     assert a.shape == (2, 8, 16, 70) and abs(a.mean() - 0.9) < 2e-2
     assert (DropoutTwin(11, 0, 0.0).flat(1, (100,)) == 1.0).all()
+
+
+# ------------------------------------------------------------------------------------------------ drivers: host helpers
+def test_driver_helpers(tmp_path):
+    """utils_without_rlbench.py:54-98 restated in trainers.py: workspace bounds (one task / union, with buffer) and the
+    instruction filter."""
+    import json
+    import pickle
+    a3d = load_pkg()
+    T = a3d.trainers
+    bounds = {"close_jar": [[0.0, -0.5, 0.7], [0.5, 0.5, 1.5]], "open_drawer": [[-0.1, -0.2, 0.8], [0.3, 0.6, 1.2]]}
+    p = tmp_path / "bounds.json"
+    p.write_text(json.dumps(bounds))
+    one = T.get_gripper_loc_bounds(str(p), buffer=0.04, task="close_jar")
+    assert np.allclose(one, [[-0.04, -0.54, 0.66], [0.54, 0.54, 1.54]])
+    union = T.get_gripper_loc_bounds(str(p), buffer=0.04)
+    assert np.allclose(union, [[-0.14, -0.54, 0.66], [0.54, 0.64, 1.54]])
+    assert np.allclose(T.get_gripper_loc_bounds(str(p), buffer=0.0, task="not_a_task"), [[-0.1, -0.5, 0.7], [0.5, 0.6, 1.5]])
+    instr = {"close_jar": {0: torch.zeros(2, 53, 512), 1: torch.ones(1, 53, 512)}, "open_drawer": {0: torch.ones(3, 53, 512)}}
+    ip = tmp_path / "instructions.pkl"
+    with open(ip, "wb") as f:
+        pickle.dump(instr, f)
+    got = T.load_instructions(str(ip), tasks=("close_jar",), variations=(1,))
+    assert list(got) == ["close_jar"] and list(got["close_jar"]) == [1]
+    assert T.load_instructions(None) is None
+    assert T.all_gather({"a": 1}) == [{"a": 1}]                  # no process group: identity
+    tt = T.BaseTrainTester(types.SimpleNamespace(log_dir=None))
+    merged = tt.synchronize_between_processes({"k": torch.tensor([1.0, 2.0])})
+    assert torch.equal(merged["k"], torch.tensor([1.0, 2.0]))
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    a3d = load_pkg()
+    tt = a3d.trainers.BaseTrainTester(types.SimpleNamespace(log_dir=None))
+    vals = {"val-losses/x": torch.tensor([1.0 + rank, 3.0 + rank])}
+    if rank == 1:
+        vals["val-loss/only_rank1/x"] = torch.tensor([7.0])
+    merged = tt.synchronize_between_processes(vals)            # engine.py:232-245: rank 0 gets the concatenation
+    q.put((rank, {k: v.tolist() for k, v in merged.items()}))
+    dist.destroy_process_group()
+
+
+def test_evaluation_statistics_gathered_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == {"val-losses/x": [1.0, 3.0, 2.0, 4.0]}    # keys of rank 0, every rank's entries, in rank order
+    assert res[1]["val-losses/x"] == [2.0, 4.0]                # other ranks keep their own dictionary, as in the reference
