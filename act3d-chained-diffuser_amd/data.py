@@ -106,153 +106,159 @@ class TrajectoryInterpolator:
 
 
 class RLBenchDataset(Dataset):
-    """datasets/dataset_engine.py:14-258, same constructor and item dictionary.  One difference, by design: in training
-    mode the item carries the UN-augmented `rgbs` / `pcds` plus `resize_params` (n_frames, 4) int32 -- the draws of the
-    `Resize` augmentation -- and `DeviceLoader` applies them on the GPU.  Everything else (episode chunking, camera
-    re-mapping, RGB rescale to [0, 1], instruction choice, gripper history, trajectory interpolation / padding) follows
-    the reference, consuming `random` / numpy / torch RNG in the same order."""
+    """Episode files -> per-chunk training items; constructor and item dictionary of datasets/dataset_engine.py:14-258.
+
+    On-disk episode (data_preprocessing/data_gen.py:122-132), indexed by frame id:
+      [0] frame ids  [1] observations (n_cam, 2 = rgb | xyz, 3, H, W)  [2] actions (1, 8)  [3] camera dicts
+      [4] gripper poses (1, 8)  [5] low-level trajectories (N_i, 8)
+    One difference from the reference, by design: in training mode the item carries the UN-augmented `rgbs` / `pcds` plus
+    `resize_params` (n_frames, 4) int32 -- the draws of the `Resize` augmentation -- and `DeviceLoader` applies them on the
+    GPU.  The host-side RNG streams (`random` for the chunk and the instruction, numpy / torch for the augmentation) are
+    consumed in the reference's order, so seeded runs pick the same chunks, instructions and crops."""
+
+    _EPISODE_PATTERNS = ("*.npy", "*.dat", "*.pkl")        # the reference's listing order (dataset_engine.py:94-97)
 
     def __init__(self, root, instructions=None, taskvar=[('close_door', 0)], max_episode_length=5, cache_size=0,
                  max_episodes_per_task=100, num_iters=None, cameras=("wrist", "left_shoulder", "right_shoulder"),
                  training=True, gripper_loc_bounds=None, image_rescale=(1.0, 1.0), point_cloud_rotate_yaw_range=0.0,
                  return_low_lvl_trajectory=False, dense_interpolation=False, interpolation_length=100, action_dim=8,
                  predict_short=None):
-        self._cache = {}
-        self._cache_size = cache_size
+        self._cache, self._cache_size = {}, cache_size
         self._cameras = cameras
         self._max_episode_length = max_episode_length
         self._num_iters = num_iters
         self._training = training
         self._taskvar = taskvar
-        self._return_low_lvl_trajectory = return_low_lvl_trajectory
         self._action_dim = action_dim
-        if isinstance(root, (Path, str)):
-            root = [Path(root)]
-        self._root = [Path(r).expanduser() for r in root]
         self._predict_short = predict_short
+        self._root = [Path(r).expanduser() for r in ([root] if isinstance(root, (Path, str)) else root)]
+        self._return_low_lvl_trajectory = return_low_lvl_trajectory
         if return_low_lvl_trajectory:
-            assert dense_interpolation or self._predict_short
+            assert dense_interpolation or predict_short
             self._interpolate_traj = TrajectoryInterpolator(use=dense_interpolation, interpolation_length=interpolation_length)
-
-        self._instructions = defaultdict(dict)
-        self._num_vars = Counter()
-        for r, (task, var) in itertools.product(self._root, taskvar):
-            if (r / f"{task}+{var}").is_dir():
-                if instructions is not None:
-                    self._instructions[task][var] = instructions[task][var]
-                self._num_vars[task] += 1
-
-        if self._training:
+        if training:
             self._image_rescale = tuple(image_rescale)
             self._rotate = Rotate(gripper_loc_bounds=gripper_loc_bounds, yaw_range=point_cloud_rotate_yaw_range)
-
-        self._data_dirs = []
-        episodes_by_task = defaultdict(list)
-        for r, (task, var) in itertools.product(self._root, taskvar):
-            data_dir = r / f"{task}+{var}"
-            if not data_dir.is_dir():
-                print(f"Can't find dataset folder {data_dir}")
-                continue
-            episodes = [(task, var, ep) for pat in ("*.npy", "*.dat", "*.pkl") for ep in data_dir.glob(pat)]
-            if max_episodes_per_task > -1:
-                episodes = episodes[:max_episodes_per_task // self._num_vars[task] + 1]
-            if len(episodes) == 0:
-                print(f"Can't find episodes at folder {data_dir}")
-                continue
-            self._data_dirs.append(data_dir)
-            episodes_by_task[task] += episodes
-
-        self._episodes = []
-        self._num_episodes = 0
-        for task, eps in episodes_by_task.items():
-            if len(eps) > max_episodes_per_task and max_episodes_per_task > -1:
-                eps = random.sample(eps, max_episodes_per_task)
-            self._episodes += eps
-            self._num_episodes += len(eps)
+        self._instructions, self._num_vars = self._collect_instructions(instructions)
+        self._data_dirs, self._episodes = self._index_episodes(max_episodes_per_task)
+        self._num_episodes = len(self._episodes)
         print(f"Created dataset from {self._root} with {self._num_episodes}")
 
+    # ---- construction
+    def _task_dirs(self):
+        for r, (task, var) in itertools.product(self._root, self._taskvar):
+            yield task, var, r / f"{task}+{var}"
+
+    def _collect_instructions(self, instructions):
+        """Only the instructions of (task, variation) folders that exist; variations counted per task (:62-70)."""
+        kept, num_vars = defaultdict(dict), Counter()
+        for task, var, d in self._task_dirs():
+            if d.is_dir():
+                if instructions is not None:
+                    kept[task][var] = instructions[task][var]
+                num_vars[task] += 1
+        return kept, num_vars
+
+    def _index_episodes(self, max_per_task):
+        """(task, variation, file) per episode: an equal share per variation, then at most max_per_task per task (:84-117)."""
+        dirs, by_task = [], defaultdict(list)
+        for task, var, d in self._task_dirs():
+            if not d.is_dir():
+                print(f"Can't find dataset folder {d}")
+                continue
+            files = [(task, var, ep) for pat in self._EPISODE_PATTERNS for ep in d.glob(pat)]
+            if max_per_task > -1:
+                files = files[:max_per_task // self._num_vars[task] + 1]
+            if not files:
+                print(f"Can't find episodes at folder {d}")
+                continue
+            dirs.append(d)
+            by_task[task] += files
+        episodes = []
+        for task, eps in by_task.items():
+            if -1 < max_per_task < len(eps):
+                eps = random.sample(eps, max_per_task)
+            episodes += eps
+        return dirs, episodes
+
     def read_from_cache(self, args):
+        """Bounded episode cache with the reference's time-based eviction (:119-137)."""
         if self._cache_size == 0:
             return loader(args)
-        if args in self._cache:
-            return self._cache[args]
-        value = loader(args)
-        if len(self._cache) == self._cache_size:
-            del self._cache[list(self._cache.keys())[int(time()) % self._cache_size]]
-        if len(self._cache) < self._cache_size:
+        if args not in self._cache:
+            value = loader(args)
+            if len(self._cache) == self._cache_size:
+                del self._cache[list(self._cache.keys())[int(time()) % self._cache_size]]
+            if len(self._cache) >= self._cache_size:
+                return value
             self._cache[args] = value
-        return value
+        return self._cache[args]
 
     @staticmethod
     def _unnormalize_rgb(rgb):
         return rgb / 2 + 0.5
 
+    # ---- one item
+    def _observations(self, episode, frame_ids):
+        """(rgb in [0, 1], xyz), each (n_frames, n_cam, 3, H, W), cameras in the order the dataset was asked for."""
+        frames = [episode[1][i] for i in frame_ids]
+        states = torch.stack([f if isinstance(f, torch.Tensor) else torch.from_numpy(f) for f in frames])
+        if episode[3]:
+            stored = list(episode[3][0].keys())
+            assert all(c in stored for c in self._cameras)
+            states = states[:, torch.tensor([stored.index(c) for c in self._cameras])]
+        return self._unnormalize_rgb(states[:, :, 0]), states[:, :, 1]
+
+    def _trajectories(self, episode, frame_ids):
+        """Zero-padded (n_frames, T_max, 8) low-level trajectories, their lengths and the padding mask (1 = padded)."""
+        items = [self._interpolate_traj(episode[5][i]) for i in frame_ids]
+        lens = torch.as_tensor([len(it) for it in items])
+        traj = torch.zeros(len(items), int(lens.max()), 8)
+        mask = torch.zeros(traj.shape[:-1])
+        for k, it in enumerate(items):
+            traj[k, :len(it)] = it
+            mask[k, len(it):] = 1
+        return traj, lens, mask
+
     def __getitem__(self, episode_id):
-        """episode = [frame_ids, obs tensors (n_cam, 2, 3, H, W), action tensors (1, 8), camera dicts, gripper tensors
-        (1, 8), trajectories (N_i, 8)]  (data_preprocessing/data_gen.py:122-132)."""
-        episode_id %= self._num_episodes
-        task, variation, file = self._episodes[episode_id]
+        task, variation, file = self._episodes[episode_id % self._num_episodes]
         episode = self.read_from_cache(file)
         if episode is None:
             return None
-
-        chunk = random.randint(0, math.ceil(len(episode[0]) / self._max_episode_length) - 1)
+        # one random chunk of at most max_episode_length keyframes (dynamic chunking, :153-162)
+        n_chunks = math.ceil(len(episode[0]) / self._max_episode_length)
+        chunk = random.randint(0, n_chunks - 1)
         frame_ids = episode[0][chunk * self._max_episode_length:(chunk + 1) * self._max_episode_length]
-        states = torch.stack([episode[1][i] if isinstance(episode[1][i], torch.Tensor) else torch.from_numpy(episode[1][i])
-                              for i in frame_ids])
-        if episode[3]:
-            cameras = list(episode[3][0].keys())
-            assert all(c in cameras for c in self._cameras)
-            states = states[:, torch.tensor([cameras.index(c) for c in self._cameras])]
-        rgbs = self._unnormalize_rgb(states[:, :, 0])
-        pcds = states[:, :, 1]
+        rgbs, pcds = self._observations(episode, frame_ids)
+        n = len(rgbs)
         action = torch.cat([episode[2][i] for i in frame_ids])
-
         if self._instructions:
-            instr = random.choice(self._instructions[task][variation])
-            instr = instr[None].repeat(len(rgbs), 1, 1)
+            instr = random.choice(self._instructions[task][variation])[None].repeat(n, 1, 1)
         else:
-            instr = torch.zeros((rgbs.shape[0], 53, 512))
-
-        gripper = torch.cat([episode[4][i] for i in frame_ids])
-        gripper_history = torch.stack([torch.cat([episode[4][max(0, i - 2)] for i in frame_ids]),
-                                       torch.cat([episode[4][max(0, i - 1)] for i in frame_ids]), gripper], dim=1)
-
-        traj, traj_lens = None, 0
+            instr = torch.zeros((n, 53, 512))
+        poses = episode[4]
+        gripper = torch.cat([poses[i] for i in frame_ids])
+        history = torch.stack([torch.cat([poses[max(0, i - back)] for i in frame_ids]) for back in (2, 1)] + [gripper], dim=1)
+        traj = traj_mask = None
         if self._return_low_lvl_trajectory:
-            items = [self._interpolate_traj(episode[5][i]) for i in frame_ids]
-            max_l = max(len(item) for item in items)
-            traj = torch.zeros(len(items), max_l, 8)
-            traj_lens = torch.as_tensor([len(item) for item in items])
-            for i, item in enumerate(items):
-                traj[i, :len(item)] = item
-            traj_mask = torch.zeros(traj.shape[:-1])
-            for i, len_ in enumerate(traj_lens.long()):
-                traj_mask[i, len_:] = 1
+            traj, traj_lens, traj_mask = self._trajectories(episode, frame_ids)
 
         H, W = rgbs.shape[-2:]
-        params = torch.tensor([[H, W, 0, 0]], dtype=torch.int32).repeat(len(rgbs), 1)          # identity map
+        draws = (H, W, 0, 0)                                   # identity: evaluation items are not augmented
         if self._training:
             pcds, gripper, action, traj = self._rotate(pcds, gripper, action, None, traj)
             if traj is not None:
-                for t, tlen in enumerate(traj_lens):
-                    traj[t, tlen:] = 0
+                for k, tlen in enumerate(traj_lens):
+                    traj[k, tlen:] = 0
             # the Resize draws (one set per item, shared by its frames and by RGB / XYZ); applied by DeviceLoader
-            params = torch.tensor([sample_resize_params(self._image_rescale, H, W)], dtype=torch.int32).repeat(len(rgbs), 1)
-
-        ret = {
-            "task": [task for _ in frame_ids],
-            "rgbs": rgbs,
-            "pcds": pcds,
-            "action": action[..., :self._action_dim],
-            "instr": instr,
-            "curr_gripper": gripper[..., :self._action_dim],
-            "curr_gripper_history": gripper_history[..., :self._action_dim],
-            "resize_params": params,
-        }
-        if self._return_low_lvl_trajectory:
-            ret.update({"trajectory": traj[..., :self._action_dim], "trajectory_mask": traj_mask.bool()})
-        return ret
+            draws = sample_resize_params(self._image_rescale, H, W)
+        d = self._action_dim
+        item = {"task": [task] * n, "rgbs": rgbs, "pcds": pcds, "action": action[..., :d], "instr": instr,
+                "curr_gripper": gripper[..., :d], "curr_gripper_history": history[..., :d],
+                "resize_params": torch.tensor([draws], dtype=torch.int32).repeat(n, 1)}
+        if traj is not None:
+            item["trajectory"], item["trajectory_mask"] = traj[..., :d], traj_mask.bool()
+        return item
 
     def __len__(self):
         return self._num_iters if self._num_iters is not None else self._num_episodes
