@@ -1,0 +1,198 @@
+// 1x1 convolutions of the frozen backbone as a bf16 MFMA GEMM with the neighbouring BatchNorm work folded in
+// (CLIP ModifiedResNet bottleneck, model/utils/clip.py:28-43: conv1 / conv3 / downsample are 1x1).
+//   y[m][n] = sum_k f(x[m][k]) * w[n][k],   f(x) = relu?(x * in_scale[k] + in_shift[k])  (identity when in_scale == NULL)
+//   x [M][K] bf16 (NHWC rows, M = images * H * W), w [N][K] bf16, y [M][N] bf16 (fp32 accumulation, one rounding);
+//   optional epilogue: per-workgroup partial (sum, sum of squares) of the ROUNDED outputs per channel, in the layout
+//   a3d_bn_finalize reduces ([slab][2][N]) -- the statistics pass of the BatchNorm that follows the convolution.
+// Folding BatchNorm-apply + ReLU of the PRODUCER into the A-operand load and the statistics of the CONSUMER's BatchNorm
+// into the epilogue removes one read + one write and one read of the activation per fused layer; the GEMM itself is
+// HBM-bound (K, N <= 2048: 2 (M K + M N) bytes for 2 M N K FLOP).
+// Tiling: 256 threads = 4 waves in a WM x WN grid, 64 x 64 outputs per wave (16 MFMA 16x16x32 tiles, computed TRANSPOSED --
+// A operand = w rows, B operand = x rows -- so that a lane owns 4 consecutive channels of one row: 8-byte stores, full
+// 32-byte sectors).  32-channel K steps staged through LDS (swizzled [rows][32] tiles, a3d_common.h plane_off),
+// register-prefetched one step ahead; workgroups walk the M tiles persistently so that there are few statistic slabs.
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int C1_BK = 32;
+
+template <int WN>     // waves along N (1, 2 or 4); WM = 4 / WN waves along M
+__global__ __launch_bounds__(256) void conv1x1_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                      const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                      int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial,
+                                                      long long M, int K, int N) {
+  constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int XL = BM * 4 / 256, WL = BN * 4 / 256;            // 16-byte segments each thread stages per K step
+  __shared__ __attribute__((aligned(16))) unsigned short Xs[2][BM * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[2][BN * 32];
+  __shared__ float redS[4][64], redQ[4][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.y * BN;
+  const long long mtiles = (M + BM - 1) / BM;
+  const int ksteps = K / C1_BK;
+  float ssum[4][4], ssq[4][4];                                    // [tn][r]: channel n0 + wn * 64 + tn * 16 + g * 4 + r
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
+
+  for (long long mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+    const long long m0 = mt * BM;
+    uint4 xr[XL], wr[WL];
+    auto load = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+        const long long m = m0 + row < M ? m0 + row : M - 1;                   // clamped: tail rows are masked at the store
+        xr[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks * C1_BK + seg * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < WL; ++i) {
+        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+        wr[i] = *reinterpret_cast<const uint4*>(w + (size_t)(n0 + row) * K + ks * C1_BK + seg * 8);
+      }
+    };
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+        uint4 v = xr[i];
+        if (in_scale) {
+          // producer's BatchNorm-apply (+ ReLU) on the 8 channels of this segment, rounded back to bf16 like the
+          // activation the unfused path materialises
+          const int k0 = ks * C1_BK + seg * 8;
+          const float4 s0 = *reinterpret_cast<const float4*>(in_scale + k0), s1 = *reinterpret_cast<const float4*>(in_scale + k0 + 4);
+          const float4 h0 = *reinterpret_cast<const float4*>(in_shift + k0), h1 = *reinterpret_cast<const float4*>(in_shift + k0 + 4);
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
+            float b = __uint_as_float(u[j] & 0xFFFF0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+            if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+            u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+          }
+          v = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        *reinterpret_cast<uint4*>(&Xs[buf][plane_off(row, seg)]) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < WL; ++i) {
+        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+        *reinterpret_cast<uint4*>(&Ws[buf][plane_off(row, seg)]) = wr[i];
+      }
+    };
+
+    f32x4 acc[4][4];                                              // [tn][tm]: D[n = g * 4 + r][m = li]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load(0);
+    __syncthreads();                                              // previous tile's LDS reads are done
+    stage(0, 0);
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int buf = ks & 1;
+      if (ks + 1 < ksteps) load(ks + 1);
+      __syncthreads();                                            // stage(buf) visible; reads of buf ^ 1 (step ks - 1) done
+      s16x8 xa[4], wb[4];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+        xa[tm] = *reinterpret_cast<const s16x8*>(&Xs[buf][plane_off(wm * 64 + tm * 16 + li, g)]);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[buf][plane_off(wn * 64 + tn * 16 + li, g)]);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
+      if (ks + 1 < ksteps) stage(buf ^ 1, ks + 1);
+    }
+    // ---- epilogue: round once, 8-byte stores (4 consecutive channels of one row), statistics of the rounded values
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const long long m = m0 + wm * 64 + tm * 16 + li;
+      const bool ok = m < M;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = f2bf(acc[tn][tm][r]);
+          if (ok) {
+            const float v = bf2f(h[r]);
+            ssum[tn][r] += v;
+            ssq[tn][r] += v * v;
+          }
+        }
+        if (ok) {
+          const uint2 pk = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
+          *reinterpret_cast<uint2*>(y + (size_t)m * N + n0 + wn * 64 + tn * 16 + g * 4) = pk;
+        }
+      }
+    }
+  }
+  if (!partial) return;
+  // ---- per-workgroup partial statistics: sum over the 16 rows a lane group holds, then over the WM waves along M
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = ssum[tn][r], q = ssq[tn][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+      if (li == 0) { redS[wave][tn * 16 + g * 4 + r] = s; redQ[wave][tn * 16 + g * 4 + r] = q; }
+    }
+  __syncthreads();
+  for (int i = t; i < BN; i += 256) {
+    const int wn_i = i >> 6, c = i & 63;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < WM; ++j) { s += redS[j * WN + wn_i][c]; q += redQ[j * WN + wn_i][c]; }
+    float* p = partial + (size_t)blockIdx.x * 2 * N;
+    p[n0 + i] = s;
+    p[N + n0 + i] = q;
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+static int c1_slabs(size_t M, int N) {
+  const int wn = N >= 256 ? 4 : (N >= 128 ? 2 : 1);
+  const int bm = 64 * (4 / wn);
+  const size_t mtiles = (M + bm - 1) / bm;
+  const int ntiles = N / (64 * wn);
+  size_t cap = (size_t)std::max(1, 2048 / ntiles);               // ~8 workgroups per CU over the whole grid
+  return (int)std::min(mtiles, cap);
+}
+
+extern "C" int a3d_conv1x1_nslab(size_t M, int N) { return (M == 0 || N <= 0) ? 0 : c1_slabs(M, N); }
+
+extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu,
+                                  void* y, float* partial, size_t M, int K, int N, void* stream) {
+  if (!x || !w || !y || M == 0 || K <= 0 || N <= 0 || (K % 32) != 0 || (N % 64) != 0 || (N >= 256 && (N % 256) != 0) ||
+      (in_scale && !in_shift) || ((((uintptr_t)x | (uintptr_t)w) & 15) != 0) || (((uintptr_t)y) & 7) != 0 ||
+      (in_scale && ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0))) {
+    set_error("a3d_conv1x1_bn_fwd: bad argument (M=%zu K=%d N=%d; K %% 32 == 0, N in {64, 128, 256 j}, 16-byte aligned operands)", M, K, N);
+    return A3D_ERR_ARG;
+  }
+  const int slabs = c1_slabs(M, N);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* xs = (const unsigned short*)x;
+  const unsigned short* ws = (const unsigned short*)w;
+  unsigned short* ys = (unsigned short*)y;
+  if (N >= 256)
+    hipLaunchKernelGGL(conv1x1_kernel<4>, dim3(slabs, N / 256), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
+  else if (N == 128)
+    hipLaunchKernelGGL(conv1x1_kernel<2>, dim3(slabs, 1), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
+  else
+    hipLaunchKernelGGL(conv1x1_kernel<1>, dim3(slabs, 1), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
+  return check_launch("a3d_conv1x1_bn_fwd");
+}

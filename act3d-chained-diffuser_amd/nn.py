@@ -312,11 +312,55 @@ def load_synthetic_clip():
     return SyntheticCLIPResNet50(), ClipNormalize()
 
 
-def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True):
+def bn_scale_shift(x, bn, partial=None):
+    """(2, C) fp32 [scale | shift] of BatchNorm2d `bn` for the bf16 channels_last activation x: batch statistics when
+    bn.training (one read of x -- or none, when the producing a3d_conv1x1_bn_fwd already left its `partial` sums), running
+    statistics otherwise; the finalize kernel also applies the running-stat update."""
+    N, C, H, W = x.shape
+    rows = N * H * W
+    dev = x.device
+    st = O.L.stream()
+    scale = torch.empty((2, C), device=dev, dtype=torch.float32)
+    train = 1 if bn.training else 0
+    nslab = 1
+    if train and partial is None:
+        nslab = O.L.load().a3d_bn_nslab(rows, C)
+        partial = torch.empty((nslab, 2, C), device=dev, dtype=torch.float32)
+        O.L.call("a3d_bn_stats", x.data_ptr(), partial.data_ptr(), rows, C, nslab, st)
+    elif train:
+        nslab = partial.shape[0]
+    O.L.call("a3d_bn_finalize", None if not train else partial.data_ptr(), nslab, rows, C, float(bn.eps),
+             float(bn.momentum if bn.momentum is not None else 0.1), bn.weight.data_ptr(), bn.bias.data_ptr(),
+             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale[0].data_ptr(), scale[1].data_ptr(), train, st)
+    return scale
+
+
+def conv1x1_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
+    """1x1 stride-1 convolution of a bf16 channels_last activation as the fused GEMM of csrc/conv1x1.hip: optional
+    BatchNorm-apply (+ ReLU) of the producer on the input (`in_scale` = bn_scale_shift of that layer), and the partial
+    statistics of the output for the BatchNorm that follows.  Returns (y, partial or None)."""
+    N, K, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.bias is None and conv.weight.dtype == torch.bfloat16
+    M = N * H * W
+    w2 = conv.weight.reshape(Cout, K)
+    assert w2.is_contiguous()
+    y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    partial = None
+    if want_stats:
+        partial = torch.empty((O.L.load().a3d_conv1x1_nslab(M, Cout), 2, Cout), device=x.device, dtype=torch.float32)
+    O.L.call("a3d_conv1x1_bn_fwd", x.data_ptr(), w2.data_ptr(), None if in_scale is None else in_scale[0].data_ptr(),
+             None if in_scale is None else in_scale[1].data_ptr(), 1 if in_relu else 0, y.data_ptr(),
+             None if partial is None else partial.data_ptr(), M, K, Cout, O.L.stream())
+    return y, partial
+
+
+def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
-    bf16 channels_last activation (vision.hip).  Three launches: stats, finalize, apply.  pool=True also applies the
-    nn.AvgPool2d(2) that follows in the CLIP ResNet inside the apply kernel and returns (full, pooled); full is None
-    when keep_full=False.  bn=None: no normalisation (plain 2x2 average pool of x)."""
+    bf16 channels_last activation (vision.hip).  Three launches: stats (skipped when the producer left `partial` sums),
+    finalize, apply.  pool=True also applies the nn.AvgPool2d(2) that follows in the CLIP ResNet inside the apply kernel and
+    returns (full, pooled); full is None when keep_full=False.  bn=None: no normalisation (plain 2x2 average pool of x)."""
     N, C, H, W = x.shape
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
     if residual is not None:
@@ -327,16 +371,7 @@ def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True):
     st = O.L.stream()
     sc_ptr = sh_ptr = None
     if bn is not None:
-        scale = torch.empty((2, C), device=dev, dtype=torch.float32)
-        train = 1 if bn.training else 0
-        partial, nslab = None, 1
-        if train:
-            nslab = O.L.load().a3d_bn_nslab(rows, C)
-            partial = torch.empty((nslab, 2, C), device=dev, dtype=torch.float32)
-            O.L.call("a3d_bn_stats", x.data_ptr(), partial.data_ptr(), rows, C, nslab, st)
-        O.L.call("a3d_bn_finalize", None if partial is None else partial.data_ptr(), nslab, rows, C, float(bn.eps),
-                 float(bn.momentum if bn.momentum is not None else 0.1), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale[0].data_ptr(), scale[1].data_ptr(), train, st)
+        scale = bn_scale_shift(x, bn, partial)
         sc_ptr, sh_ptr = scale[0].data_ptr(), scale[1].data_ptr()
     res_ptr = None if residual is None else residual.data_ptr()
     if not pool:
@@ -374,14 +409,29 @@ def fused_frozen_backbone_forward(bb, x):
     blocks = [blk for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for blk in layer]
     last_of_layer = {id(layer[-1]) for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4)}
     x_pooled = None                                    # AvgPool2d(2)(x), when the producer of x already emitted it
+    fuse = FUSED_CONV1X1
+
+    def conv1(m, t, **kw):
+        """1x1 convolution + the partial statistics of its output (None on the MIOpen path)"""
+        if fuse and m.kernel_size == (1, 1) and m.stride == (1, 1) and t.shape[1] % 32 == 0 and m.weight.shape[0] % 64 == 0 \
+                and (m.weight.shape[0] < 256 or m.weight.shape[0] % 256 == 0):
+            return conv1x1_bn(t, m, **kw)
+        return conv(m, t), None
+
     for bi, blk in enumerate(blocks):
-        out = bn_act(conv(blk.conv1, x), blk.bn1)
+        c1, p1 = conv1(blk.conv1, x, want_stats=blk.bn1.training)
+        out = bn_act(c1, blk.bn1, partial=p1)
         c2 = conv(blk.conv2, out)
-        if _pool2_ok(blk.avgpool, c2):
-            out = bn_act(c2, blk.bn2, pool=True, keep_full=False)[1]
+        no_pool = isinstance(blk.avgpool, nn.Identity) or (isinstance(blk.avgpool, nn.AvgPool2d) and blk.avgpool.kernel_size in (1, (1, 1)))
+        if fuse and no_pool and blk.conv3.weight.shape[0] % 256 == 0:
+            # BatchNorm-apply + ReLU of bn2 ride on conv3's operand load: c2 is never rewritten
+            o3, p3 = conv1x1_bn(c2, blk.conv3, in_scale=bn_scale_shift(c2, blk.bn2), in_relu=True, want_stats=blk.bn3.training)
         else:
-            out = blk.avgpool(bn_act(c2, blk.bn2))
-        o3 = conv(blk.conv3, out)
+            if _pool2_ok(blk.avgpool, c2):
+                out = bn_act(c2, blk.bn2, pool=True, keep_full=False)[1]
+            else:
+                out = blk.avgpool(bn_act(c2, blk.bn2))
+            o3, p3 = conv1(blk.conv3, out, want_stats=blk.bn3.training)
         if blk.downsample is not None:
             dpool = blk.downsample[0]
             if x_pooled is not None:
@@ -392,16 +442,17 @@ def fused_frozen_backbone_forward(bb, x):
                 xin = x                                # AvgPool2d(1) is the identity
             else:
                 xin = dpool(x)
-            idn = bn_act(conv(blk.downsample[1], xin), blk.downsample[2], relu=False)
+            cd, pd = conv1(blk.downsample[1], xin, want_stats=blk.downsample[2].training)
+            idn = bn_act(cd, blk.downsample[2], relu=False, partial=pd)
             bns.append(blk.downsample[2])
         else:
             idn = x
         nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
         want_pooled = nxt is not None and nxt.downsample is not None and _pool2_ok(nxt.downsample[0], o3)
         if want_pooled:
-            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True)
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True, partial=p3)
         else:
-            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn), None
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, partial=p3), None
         bns += [blk.bn1, blk.bn2, blk.bn3]
         if id(blk) in last_of_layer:
             outs.append(x)
@@ -411,6 +462,9 @@ def fused_frozen_backbone_forward(bb, x):
 
 
 FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
+# opt-in (round 2: correctness-tested, not yet timed inside the step): the backbone's 1x1 convolutions through
+# a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the consumer folded into the GEMM
+FUSED_CONV1X1 = os.environ.get("A3D_FUSED_CONV1X1", "0") == "1"
 
 
 def normalize_to_nhwc_bf16(x, normalize):

@@ -331,6 +331,15 @@ int a3d_dbg_mfma_f32(const float* A16x4, const float* B4x16, float* D16x16, void
 /* out[i] = v_cvt_pk_bf16_f32(in[2i], in[2i+1]) -- pins the rounding mode the attention kernel relies on (RNE). */
 int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream);
 
+/* ---- frozen backbone: 1x1 convolutions as a bf16 MFMA GEMM with the neighbouring BatchNorm work folded in ---------------
+ * (CLIP ModifiedResNet bottleneck conv1 / conv3 / downsample, model/utils/clip.py:28-43.)
+ * y [M][N] bf16 = f(x [M][K] bf16) w[N][K]^T with f(x) = relu?(x * in_scale[k] + in_shift[k]) (the producer's BatchNorm-apply;
+ * in_scale NULL: identity); partial (or NULL): [a3d_conv1x1_nslab(M, N)][2][N] per-workgroup (sum, sum of squares) of the
+ * rounded outputs = the input a3d_bn_finalize expects for the BatchNorm that follows.  K % 32 == 0, N in {64, 128, 256 j}. */
+int a3d_conv1x1_nslab(size_t M, int N);
+int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
+                       float* partial, size_t M, int K, int N, void* stream);
+
 /* ---- data plane ----------------------------------------------------------------------------------------
  * The `Resize` augmentation of datasets/utils.py:40-100 (nearest resize by a random scale, reflect-pad right/bottom, random
  * crop back to H x W; RGB and XYZ share the draws) as one gather pass over the collated batch on the device.

@@ -764,3 +764,66 @@ def test_option_head_kernels(a3d, dev):
     assert torch.equal(y.cpu(), x + r[None])
     assert torch.equal(xd.grad.cpu(), dy)
     report("d rows", rd.grad, dy.sum(0), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("M,K,N,pro", [(1000, 256, 64, True), (4096, 64, 256, False), (777, 512, 128, True),
+                                       (2048, 1024, 512, True), (64, 2048, 1024, False), (16, 128, 256, True)])
+def test_conv1x1_gemm_with_folded_batchnorm(a3d, dev, M, K, N, pro):
+    """a3d_conv1x1_bn_fwd: y = bf16(f(x) w^T) with f = the producer's BatchNorm-apply + ReLU (rounded to bf16 as the unfused
+    path materialises it), fp32 accumulation, and the per-slab (sum, sum of squares) of the rounded outputs."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc = (1.0 + 0.3 * torch.randn(K, generator=g)) if pro else None
+    sh = (0.2 * torch.randn(K, generator=g)) if pro else None
+    xd, wd = x.to(dev), w.to(dev)
+    y = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    nslab = a3d.lib.load().a3d_conv1x1_nslab(M, N)
+    part = torch.zeros((nslab, 2, N), device=dev, dtype=torch.float32)
+    scd = None if sc is None else sc.to(dev).contiguous()
+    shd = None if sh is None else sh.to(dev).contiguous()
+    a3d.lib.call("a3d_conv1x1_bn_fwd", xd.data_ptr(), wd.data_ptr(), None if scd is None else scd.data_ptr(),
+                 None if shd is None else shd.data_ptr(), 1 if pro else 0, y.data_ptr(), part.data_ptr(), M, K, N, a3d.lib.stream())
+    torch.cuda.synchronize()
+    xf = x.float()
+    if pro:
+        xf = torch.relu(xf * sc + sh).to(torch.bfloat16).float()
+    ref = xf.double() @ w.double().t()
+    got = y.float().cpu()
+    # one bf16 rounding of an fp32-accumulated sum: half an ulp (2^-9 relative) plus accumulation noise
+    err = (got.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-3
+    assert torch.isfinite(got).all()
+    assert (err <= tol).all(), f"max err {err.max().item():.3e} at {torch.nonzero(err > tol)[:3].tolist()}"
+    s = part.sum(0).cpu()
+    report("sum", s[0], got.sum(0), 1e-2, 1e-4)
+    report("sum of squares", s[1], (got * got).sum(0), 1e-2, 1e-4)
+
+
+def test_backbone_with_fused_1x1_convolutions_matches_miopen_path(a3d, dev):
+    """The opt-in backbone path (1x1 convolutions through a3d_conv1x1_bn_fwd, bn2-apply folded into conv3's operand load,
+    output statistics from the GEMM epilogue) against the default path (MIOpen convolutions + separate BatchNorm kernels):
+    same feature maps to bf16 accuracy, same running statistics."""
+    import copy
+    torch.manual_seed(0)
+    bb = a3d.nn.SyntheticCLIPResNet50().to(dev).train()
+    x = torch.rand(3, 3, 128, 128, device=dev)
+    bb2 = copy.deepcopy(bb)
+    outs = {}
+    for flag, net in ((False, bb), (True, bb2)):
+        a3d.nn.FUSED_CONV1X1 = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = a3d.nn.run_frozen_backbone(net, x.clone(), torch.bfloat16)
+        finally:
+            a3d.nn.FUSED_CONV1X1 = False
+    for k in outs[False]:
+        a, b = outs[False][k].float(), outs[True][k].float()
+        rel = ((a - b).norm() / a.norm()).item()
+        print(f"[parity] backbone {k}: relative L2 difference fused-1x1 vs MIOpen {rel:.3e}")
+        assert torch.isfinite(b).all() and rel < 2e-2, (k, rel)
+    for (n, p), (_, q) in zip(bb.named_buffers(), bb2.named_buffers()):
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            assert torch.allclose(p, q, rtol=2e-2, atol=2e-3), n
+        elif n.endswith("num_batches_tracked"):
+            assert torch.equal(p, q), n
