@@ -371,3 +371,42 @@ def test_evaluation_statistics_gathered_over_ranks():
         p.join(timeout=60)
     assert res[0] == {"val-losses/x": [1.0, 3.0, 2.0, 4.0]}    # keys of rank 0, every rank's entries, in rank order
     assert res[1]["val-losses/x"] == [2.0, 4.0]                # other ranks keep their own dictionary, as in the reference
+
+
+def test_ctypes_signatures_match_the_header_arity():
+    """Every prototype of include/act3d_hip.h has as many parameters as its ctypes signature in lib.py (a mismatch would
+    only show up as a crash or a silently shifted argument on the GPU box)."""
+    a3d = load_pkg()
+    header = open(os.path.join(ROOT, "include", "act3d_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|void|const char\*)\s+(a3d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) >= 80
+    seen = set()
+    for name, args in protos:
+        args = args.strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        assert name in a3d.lib.SIGNATURES, name
+        assert len(a3d.lib.SIGNATURES[name][1]) == n, f"{name}: header has {n} parameters, lib.py {len(a3d.lib.SIGNATURES[name][1])}"
+        seen.add(name)
+    assert seen == set(a3d.lib.SIGNATURES), sorted(set(a3d.lib.SIGNATURES) ^ seen)
+
+
+def test_round2_entry_points_validate_arguments_without_gpu():
+    a3d = load_pkg()
+    lib = a3d.lib.load()
+    dummy = ctypes.c_void_p(64)
+    assert lib.a3d_resize_crop(dummy, dummy, dummy, 4, 3, 8, 8, 1.0, 0.0, None) == -22            # in place
+    assert lib.a3d_resize_crop(dummy, ctypes.c_void_p(128), None, 4, 3, 8, 8, 1.0, 0.0, None) == -22
+    assert lib.a3d_traj_nn_topk(dummy, 0, dummy, dummy, dummy, None, 1, 100, 10, None) == -22      # no trajectory points
+    assert lib.a3d_traj_nn_topk(dummy, 8, dummy, dummy, dummy, None, 1, 100, 101, None) == -22     # k > N
+    assert lib.a3d_select_row_fwd(dummy, None, dummy, 2, 5, 3, None) == -22
+    assert lib.a3d_ortho6d_sigmoid_fwd(dummy, dummy, None, 2, None) == -22
+    assert lib.a3d_add_rows_bwd(dummy, None, 2, 53, 60, None) == -22
+    assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 48, 64, None) == -22      # K % 32
+    assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 64, 320, None) == -22     # N not 256 j
+    assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, None, 1, dummy, None, 128, 64, 64, None) == -22     # scale without shift
+    assert b"a3d_conv1x1_bn_fwd" in lib.a3d_last_error_string()
+    # slab planning is pure host code and consistent with the tile table (64 / 128 / >= 256 output channels)
+    assert lib.a3d_conv1x1_nslab(1 << 20, 64) == 2048 and lib.a3d_conv1x1_nslab(1000, 64) == 4
+    assert lib.a3d_conv1x1_nslab(1 << 20, 1024) == 512 and lib.a3d_conv1x1_nslab(100, 256) == 2
+    assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
