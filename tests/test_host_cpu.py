@@ -127,6 +127,68 @@ def test_ddpm_closed_form_identities():
     assert torch.equal(out, x0 * 3)                     # last step: un-clipped network output, no noise
 
 
+# Known answers of diffusers' DDPMScheduler arithmetic (third-party; not vendored in the reference).  The numbers below were
+# computed in float64 with plain Python `math` from the PUBLISHED algorithm -- betas: "scaled_linear" =
+# linspace(sqrt(1e-4), sqrt(0.02), T)^2, "squaredcos_cap_v2" = min(1 - ab((i+1)/T) / ab(i/T), 0.999) with
+# ab(s) = cos((s + 0.008) / 1.008 * pi / 2)^2; step(): x0-prediction clipped to +-1, posterior-mean coefficients
+# sqrt(acp_prev) * beta_t / (1 - acp_t) and sqrt(alpha_t) * (1 - acp_prev) / (1 - acp_t), variance "fixed_small" =
+# (1 - acp_prev) / (1 - acp_t) * beta_t clamped at 1e-20 -- independently of oracle/diffusion.py and of the product's tables.
+DDPM_KNOWN = {
+    "pos": {"acp": {0: 9.999000000000e-01, 1: 9.997717008367e-01, 50: 8.915449517724e-01, 99: 4.845898112468e-01},
+            "coef": {1: (5.620063468074e-01, 4.379936515885e-01, 7.496895685765e-03),
+                     50: (5.093168771788e-02, 9.489886642540e-01, 7.450983827886e-02),
+                     99: (2.728670511889e-02, 9.709545400659e-01, 1.400580022199e-01)}},
+    "rot": {"acp": {0: 9.993687184017e-01, 1: 9.982524864661e-01, 50: 4.782646329455e-01, 99: 2.428572279350e-07},
+            "coef": {1: (6.389560991243e-01, 3.610438126609e-01, 2.008702579022e-02),
+                     50: (4.249065288959e-02, 9.547153075244e-01, 1.749410452965e-01),
+                     99: (1.556829708285e-02, 3.161510445978e-02, 9.993786210365e-01)}},
+}
+
+
+def _check_ddpm_tables(acp_pos, acp_rot, coef_pos, coef_rot):
+    for tag, acp, cf in (("pos", acp_pos, coef_pos), ("rot", acp_rot, coef_rot)):
+        for t, want in DDPM_KNOWN[tag]["acp"].items():
+            # fp32 cumulative products: relative 2e-5 covers 100 roundings; the last cosine entry (2.4e-7) is a difference of
+            # nearly equal cosines and gets an absolute bound
+            assert abs(float(acp[t]) - want) <= 2e-5 * want + 2e-9, (tag, t, float(acp[t]), want)
+        for t, want in DDPM_KNOWN[tag]["coef"].items():
+            for j in range(3):
+                # 1 - acp_t cancels in fp32 at small t (acp ~ 0.9998): 2e-4 relative there, as diffusers' own fp32 tables
+                assert abs(float(cf[t, j]) - want[j]) <= 3e-4 * abs(want[j]) + 1e-7, (tag, t, j, float(cf[t, j]), want[j])
+
+
+def test_ddpm_known_answers_oracle_and_product_tables():
+    """Pins the DDPM schedule arithmetic of the oracle AND of the product's device tables (built on CPU here) against
+    hard-coded values of the published formulas at T = 100 (reference constructor arguments: diffusion_model.py:51-60)."""
+    from oracle.diffusion import DDPMSchedules
+    s = DDPMSchedules(100)
+    _check_ddpm_tables(s.acp_pos, s.acp_rot, s.coef_pos, s.coef_rot)
+    a3d = load_pkg()
+    tb = a3d.diffusion.DDPMTables(100, torch.device("cpu"))
+    _check_ddpm_tables(tb.acp_pos, tb.acp_rot, tb.coef_pos, tb.coef_rot)
+    assert torch.equal(tb.acp_pos, s.acp_pos) and torch.equal(tb.coef_rot, s.coef_rot)
+
+
+def test_ddpm_step_known_answer_with_clipping_active():
+    """One DDPMScheduler.step() with clip_sample active (|x0 prediction| > 1), both schedules, against the float64 hand
+    computation: prev = c_x0 * clip(x0) + c_xt * x_t + sigma * noise."""
+    from oracle.diffusion import DDPMSchedules
+    s = DDPMSchedules(100)
+    t = 50
+    model_out = torch.tensor([[[1.7, -0.25, -3.0, 0.5, 2.0, -1.5, 0.1, 0.9, -0.7]]])
+    sample = torch.tensor([[[0.3, -0.6, 0.9, -1.2, 0.4, 0.8, -0.1, 0.2, 1.1]]])
+    noise = torch.tensor([[[0.5, -1.0, 0.25, 2.0, -0.5, 1.5, -2.0, 0.75, 0.1]]])
+    got = s.step(model_out, sample, noise, t)[0, 0]
+    for ch in range(9):
+        c0, c1, sg = DDPM_KNOWN["pos" if ch < 3 else "rot"]["coef"][t]
+        x0 = min(1.0, max(-1.0, float(model_out[0, 0, ch])))
+        want = c0 * x0 + c1 * float(sample[0, 0, ch]) + sg * float(noise[0, 0, ch])
+        assert abs(float(got[ch]) - want) < 2e-6 * max(1.0, abs(want)), (ch, float(got[ch]), want)
+    # t = 0 of the loop body: the inpainted network output is returned un-clipped, without noise (diffusion_model.py:106-117)
+    out = s.step_with_inpaint(model_out, sample, noise, sample, torch.zeros(1, 1, 9, dtype=torch.bool), 0)
+    assert torch.equal(out, model_out)
+
+
 def test_optimizer_grouping_rule():
     a3d = load_pkg()
     E = a3d.engine
