@@ -104,17 +104,69 @@ __device__ __forceinline__ void write_operand_formats(const float* T, int ldt, u
   }
 }
 
+// The "16" formats of attention16.hip: rows16 [B][H][Npad][32] fp16 = hi(16) | lo(16) (x = hi + lo, 22 mantissa bits; the
+// lo part may be an fp16 subnormal, which the MFMA honours), planes16 [B][H][parts][16][Npad] = fp16 hi (and lo when parts == 2) planes, transposed.
+typedef __attribute__((ext_vector_type(2))) _Float16 rh16x2;
+typedef __attribute__((ext_vector_type(2))) float rf32x2;
+__device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+__device__ __forceinline__ void write_operand_formats16(const float* T, int ldt, unsigned short* __restrict__ rows_out,
+                                                        unsigned short* __restrict__ planes_out, int plane_parts, int b,
+                                                        int n0, int Npad, int H) {
+  if (rows_out) {
+    for (int idx = threadIdx.x; idx < RT_ROWS * H * 2; idx += blockDim.x) {
+      const int half = idx & 1;
+      const int r = (idx >> 1) % RT_ROWS;
+      const int h = (idx >> 1) / RT_ROWS;
+      const int n = n0 + r;
+      if (n >= Npad) continue;
+      s16x8 ohi, olo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = half * 8 + j;
+        const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
+        const unsigned short hi = f2h(v);
+        ohi[j] = (short)hi;
+        olo[j] = (short)f2h(v - h2f(hi));
+      }
+      unsigned short* dst = rows_out + (((size_t)b * H + h) * Npad + n) * 32 + half * 8;
+      *reinterpret_cast<s16x8*>(dst) = ohi;
+      *reinterpret_cast<s16x8*>(dst + 16) = olo;
+    }
+  }
+  if (planes_out) {
+    for (int idx = threadIdx.x; idx < H * 16 * 8; idx += blockDim.x) {
+      const int seg = idx & 7;
+      const int d = (idx >> 3) & 15;
+      const int h = idx >> 7;
+      s16x8 o, o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = (d < HD) ? T[(seg * 8 + j) * ldt + h * HD + d] : 0.f;
+        const unsigned short hi = f2h(v);
+        o[j] = (short)hi;
+        o2[j] = (short)f2h(v - h2f(hi));
+      }
+      unsigned short* dst = planes_out + ((((size_t)b * H + h) * plane_parts) * 16 + d) * Npad + n0 + seg * 8;
+      *reinterpret_cast<s16x8*>(dst) = o;
+      if (plane_parts == 2) *reinterpret_cast<s16x8*>(dst + (size_t)16 * Npad) = o2;
+    }
+  }
+}
+
 // Writes the rotated, scaled rows in rows format (rows_out) and / or planes format (planes_out); either may be null.
 __global__ __launch_bounds__(256) void rope_split_kernel(
     const float* __restrict__ Y, int ldy, const float* __restrict__ xyz, const float* __restrict__ freq,
     float scale, unsigned short* __restrict__ rows_out, int rows_width, unsigned short* __restrict__ planes_out, int B,
-    int N, int Npad, int E, int H) {
+    int N, int Npad, int E, int H, int fmt16) {
   extern __shared__ __attribute__((aligned(16))) float T[];
   const int ldt = E + 1;
   const int b = blockIdx.y, n0 = blockIdx.x * RT_ROWS;
   rope_tile_to_lds(T, ldt, Y, ldy, xyz, freq, scale, b, n0, N, E);
   __syncthreads();
-  write_operand_formats(T, ldt, rows_out, rows_width, planes_out, b, n0, Npad, H);
+  if (fmt16) write_operand_formats16(T, ldt, rows_out, planes_out, rows_width, b, n0, Npad, H);   // rows_width = plane parts
+  else write_operand_formats(T, ldt, rows_out, rows_width, planes_out, b, n0, Npad, H);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -136,7 +188,7 @@ constexpr int PR_LD = 68;    // padded LDS row stride (floats)
 template <int NT>   // 16-column output tiles: 4 (E <= 64) or 8 (E <= 128)
 __global__ __launch_bounds__(256) void proj_rope_split_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ bias, int K,
-    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E, int H) {
+    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E, int H, int fmt16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                          // [64][PR_LD]
   float* Ws = smem + RT_ROWS * PR_LD;        // [NT * 16][PR_LD]
@@ -217,7 +269,8 @@ __global__ __launch_bounds__(256) void proj_rope_split_kernel(
     }
     __syncthreads();
   }
-  write_operand_formats(T, ldt, blk.rows, blk.rows_width, blk.planes, b, n0, Npad, H);
+  if (fmt16) write_operand_formats16(T, ldt, blk.rows, blk.planes, blk.rows_width, b, n0, Npad, H);   // rows_width = plane parts
+  else write_operand_formats(T, ldt, blk.rows, blk.rows_width, blk.planes, b, n0, Npad, H);
 }
 
 // dY[m][c] = scale * R(xyz)^T * sum_s dR[s][b][h][n][d]   (R^T = inverse rotation; identity when xyz == null)
@@ -271,21 +324,35 @@ static int check_rope_args(const char* fn, int B, int N, int Npad, int E, int H)
   return A3D_OK;
 }
 
-extern "C" int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
-                              void* rows_out, int rows_width, void* planes_out, int B, int N, int Npad, int E, int H,
-                              void* stream) {
-  int rc = check_rope_args("a3d_rope_split", B, N, Npad, E, H);
+static int rope_split_launch(const char* fn, const float* Y, int ldy, const float* xyz, const float* freq, float scale,
+                             void* rows_out, int rows_width, void* planes_out, int B, int N, int Npad, int E, int H,
+                             int fmt16, void* stream) {
+  int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
-  if (rows_out && rows_width != VRW && rows_width != QKW) {
-    set_error("a3d_rope_split: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", rows_width);
+  if (fmt16 ? (rows_width != 1 && rows_width != 2) : (rows_out && rows_width != VRW && rows_width != QKW)) {
+    set_error(fmt16 ? "%s: plane parts must be 1 or 2, got %d" : "%s: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", fn,
+              rows_width);
     return A3D_ERR_ARG;
   }
-  if (!Y || (!rows_out && !planes_out) || (xyz && !freq)) { set_error("a3d_rope_split: null pointer"); return A3D_ERR_ARG; }
+  if (!Y || (!rows_out && !planes_out) || (xyz && !freq)) { set_error("%s: null pointer", fn); return A3D_ERR_ARG; }
   dim3 grid(Npad / RT_ROWS, B);
   const size_t lds = (size_t)RT_ROWS * (E + 1) * sizeof(float);
   hipLaunchKernelGGL(rope_split_kernel, grid, dim3(256), lds, (hipStream_t)stream, Y, ldy, xyz, freq, scale,
-                     (unsigned short*)rows_out, rows_width, (unsigned short*)planes_out, B, N, Npad, E, H);
-  return check_launch("a3d_rope_split");
+                     (unsigned short*)rows_out, rows_width, (unsigned short*)planes_out, B, N, Npad, E, H, fmt16);
+  return check_launch(fn);
+}
+
+extern "C" int a3d_rope_split(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
+                              void* rows_out, int rows_width, void* planes_out, int B, int N, int Npad, int E, int H,
+                              void* stream) {
+  return rope_split_launch("a3d_rope_split", Y, ldy, xyz, freq, scale, rows_out, rows_width, planes_out, B, N, Npad, E, H, 0,
+                           stream);
+}
+
+extern "C" int a3d_rope_split16(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
+                                void* planes_out, int plane_parts, int B, int N, int Npad, int E, int H, void* stream) {
+  return rope_split_launch("a3d_rope_split16", Y, ldy, xyz, freq, scale, rows_out, plane_parts, planes_out, B, N, Npad, E, H,
+                           1, stream);
 }
 
 extern "C" int a3d_rope_split_qk(const float* Y, int ldy, const float* xyz, const float* freq, float scale,
@@ -313,18 +380,19 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
   return check_launch("a3d_rope_merge_bwd");
 }
 
-extern "C" int a3d_proj_rope_split(const float* X, int ldx, const float* W, int ldw, const float* bias, int K,
-                                   const float* xyz0, float scale0, void* rows0, int rows0_width, void* planes0,
-                                   const float* xyz1, float scale1, void* rows1, int rows1_width, void* planes1,
-                                   const float* freq, int B, int N, int Npad, int E, int H, void* stream) {
-  int rc = check_rope_args("a3d_proj_rope_split", B, N, Npad, E, H);
+static int proj_rope_split_launch(const char* fn, const float* X, int ldx, const float* W, int ldw, const float* bias, int K,
+                                  const float* xyz0, float scale0, void* rows0, int rows0_width, void* planes0,
+                                  const float* xyz1, float scale1, void* rows1, int rows1_width, void* planes1,
+                                  const float* freq, int B, int N, int Npad, int E, int H, int fmt16, void* stream) {
+  int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
   const bool two = rows1 || planes1;
+  const bool w0_ok = fmt16 ? (rows0_width == 1 || rows0_width == 2) : (!rows0 || rows0_width == VRW || rows0_width == QKW);
+  const bool w1_ok = fmt16 ? (!two || rows1_width == 1 || rows1_width == 2) : (!rows1 || rows1_width == VRW || rows1_width == QKW);
   if (!X || !W || K <= 0 || (K & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || E > 128 ||
-      (!rows0 && !planes0) || ((xyz0 || xyz1) && !freq) || (rows0 && rows0_width != VRW && rows0_width != QKW) ||
-      (rows1 && rows1_width != VRW && rows1_width != QKW)) {
-    set_error("a3d_proj_rope_split: bad argument (K=%d ldx=%d must be multiples of 4, X 16-byte aligned, E=%d <= 128, "
-              "rows widths 32 or 48)", K, ldx, E);
+      (!rows0 && !planes0) || ((xyz0 || xyz1) && !freq) || !w0_ok || !w1_ok) {
+    set_error("%s: bad argument (K=%d ldx=%d must be multiples of 4, X 16-byte aligned, E=%d <= 128, %s)", fn, K, ldx, E,
+              fmt16 ? "plane parts 1 or 2" : "rows widths 32 or 48");
     return A3D_ERR_ARG;
   }
   ProjBlock b0{xyz0, scale0, (unsigned short*)rows0, rows0_width, (unsigned short*)planes0};
@@ -339,9 +407,25 @@ extern "C" int a3d_proj_rope_split(const float* X, int ldx, const float* W, int 
   }
   if (NT == 4)
     hipLaunchKernelGGL(proj_rope_split_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
-                       freq, B, N, Npad, E, H);
+                       freq, B, N, Npad, E, H, fmt16);
   else
     hipLaunchKernelGGL(proj_rope_split_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
-                       freq, B, N, Npad, E, H);
-  return check_launch("a3d_proj_rope_split");
+                       freq, B, N, Npad, E, H, fmt16);
+  return check_launch(fn);
+}
+
+extern "C" int a3d_proj_rope_split(const float* X, int ldx, const float* W, int ldw, const float* bias, int K,
+                                   const float* xyz0, float scale0, void* rows0, int rows0_width, void* planes0,
+                                   const float* xyz1, float scale1, void* rows1, int rows1_width, void* planes1,
+                                   const float* freq, int B, int N, int Npad, int E, int H, void* stream) {
+  return proj_rope_split_launch("a3d_proj_rope_split", X, ldx, W, ldw, bias, K, xyz0, scale0, rows0, rows0_width, planes0,
+                                xyz1, scale1, rows1, rows1_width, planes1, freq, B, N, Npad, E, H, 0, stream);
+}
+
+extern "C" int a3d_proj_rope_split16(const float* X, int ldx, const float* W, int ldw, const float* bias, int K,
+                                     const float* xyz0, float scale0, void* rows0, void* planes0, int parts0,
+                                     const float* xyz1, float scale1, void* rows1, void* planes1, int parts1,
+                                     const float* freq, int B, int N, int Npad, int E, int H, void* stream) {
+  return proj_rope_split_launch("a3d_proj_rope_split16", X, ldx, W, ldw, bias, K, xyz0, scale0, rows0, parts0, planes0, xyz1,
+                                scale1, rows1, parts1, planes1, freq, B, N, Npad, E, H, 1, stream);
 }

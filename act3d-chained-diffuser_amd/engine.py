@@ -92,11 +92,22 @@ class FlatAdamW:
     """torch.optim.AdamW semantics (lr, betas, eps, two weight-decay groups) as one fused kernel over FlatParams."""
 
     def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
-        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = torch.zeros(1, device=flat.flat.device, dtype=torch.float32)
         self.param_groups = [{"lr": lr, "weight_decay": 0.0}, {"lr": lr, "weight_decay": weight_decay}]
+
+    @property
+    def lr(self):
+        """The learning rate the fused kernel uses: ONE value for both groups (the reference builds both groups with
+        args.lr and resets every group to it on resume, engine.py:89-102,200-201)."""
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        for g in self.param_groups:
+            g["lr"] = float(value)
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -104,7 +115,7 @@ class FlatAdamW:
     def step(self, grad_scale=1.0):
         f = self.flat
         L.call("a3d_adamw_step", f.flat.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
-               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), f.n, f.n_nodecay, float(self.param_groups[0]["lr"]),
+               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), f.n, f.n_nodecay, float(self.lr),
                self.betas[0], self.betas[1], self.eps, 0.0, float(self.weight_decay), float(grad_scale), L.stream())
 
     def state_dict(self):
@@ -116,13 +127,18 @@ class FlatAdamW:
         state = {}
         step = self.step_count.detach().cpu().reshape(()).clone()
         if float(step) > 0:
-            for n, p in f.order:
+            # a parameter whose second moment is still all zero has never received a gradient: torch writes no state for it
+            touched = torch.stack([self.exp_avg_sq[a:b].abs().max() if b > a else self.exp_avg_sq.new_zeros(())
+                                   for a, b in (f.slices[n] for n, _ in f.order)]).cpu() > 0
+            for (n, p), used in zip(f.order, touched.tolist()):
+                if not used:
+                    continue
                 a, b = f.slices[n]
                 state[f.torch_index[n]] = {"step": step.clone(), "exp_avg": self.exp_avg[a:b].detach().clone().view(p.shape),
                                            "exp_avg_sq": self.exp_avg_sq[a:b].detach().clone().view(p.shape)}
         groups, off = [], 0
         for names, wd in zip(f.torch_groups, (0.0, self.weight_decay)):
-            groups.append({"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd,
+            groups.append({"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd,
                            "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                            "differentiable": False, "fused": None, "decoupled_weight_decay": True,
                            "params": list(range(off, off + len(names)))})
@@ -131,7 +147,10 @@ class FlatAdamW:
 
     def load_state_dict(self, sd):
         """Accepts the torch.optim.AdamW layout (a reference checkpoint's "optimizer" entry).  Raises on a layout that does
-        not describe this model's parameters instead of silently resuming with zeroed moments."""
+        not describe this model's parameters (unknown indices, size mismatches, different group sizes).  Parameters WITHOUT
+        an entry are legal: torch.optim.AdamW writes no state for parameters whose .grad stayed None (the FPN blocks of maps
+        a configuration never reads, find_unused_parameters=True in engine.py:121-124); their moments stay zero, which the
+        fused kernel leaves alone until the first gradient arrives."""
         f = self.flat
         if not isinstance(sd, dict) or "state" not in sd or "param_groups" not in sd:
             raise ValueError("optimizer state: expected torch.optim.AdamW's {'state', 'param_groups'} layout")
@@ -156,16 +175,18 @@ class FlatAdamW:
             steps.append(float(st["step"]))
             seen.add(n)
         if steps:
-            missing = [n for n, _ in f.order if n not in seen]
-            if missing:
-                raise ValueError("optimizer state lacks %d trained parameters (e.g. %s)" % (len(missing), missing[:3]))
+            for n, _ in f.order:
+                if n not in seen:                      # state-less (never-used) parameter: zero moments
+                    a, b = f.slices[n]
+                    self.exp_avg[a:b].zero_()
+                    self.exp_avg_sq[a:b].zero_()
             if max(steps) != min(steps):
                 raise ValueError("optimizer state: per-parameter steps differ (%g .. %g); the flat optimizer keeps one"
                                  % (min(steps), max(steps)))
             self.step_count.fill_(steps[0])
         else:
             self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
-        self.param_groups[0]["lr"] = self.param_groups[1]["lr"] = sd["param_groups"][0].get("lr", self.lr)
+        self.lr = sd["param_groups"][0].get("lr", self.lr)
 
 
 def get_optimizer(model, lr=1e-4, active_names=None):

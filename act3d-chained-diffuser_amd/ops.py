@@ -121,6 +121,82 @@ def pick_nsplit(B, H, Lqp, Sp):
     return ns
 
 
+ATTN_MODE = os.environ.get("A3D_ATTN_MODE", "f16")      # "f16": split-fp16 kernels (attention16.hip); "bf16x3": attention.hip
+LOG2E = 1.4426950408889634
+
+
+def _use16(drop):
+    """The split-fp16 attention core is the default; its backward has no attention-weight dropout yet, so a pass with
+    dropout (diffusion training) runs on the split-bf16 kernels."""
+    return ATTN_MODE == "f16" and (drop is None or drop.p <= 0)
+
+
+PLANE_PARTS = int(os.environ.get("A3D_ATTN16_PLANES", "2"))   # parts of the q / k planes the fp16 backward contracts with dS
+
+
+def _alloc16(B, H, Lqp, Sp, device, need_bwd):
+    hf = torch.float16
+    Qr = torch.empty((B, H, Lqp, 32), device=device, dtype=hf)       # rows16: hi | lo
+    Kr = torch.empty((B, H, Sp, 32), device=device, dtype=hf)
+    Vp = torch.empty((B, H, 2, 16, Sp), device=device, dtype=hf)     # planes16: hi and lo planes, transposed
+    Qp = Kp = Vr = None
+    if need_bwd:
+        Qp = torch.empty((B, H, PLANE_PARTS, 16, Lqp), device=device, dtype=hf)
+        Kp = torch.empty((B, H, PLANE_PARTS, 16, Sp), device=device, dtype=hf)
+        Vr = torch.empty((B, H, Sp, 32), device=device, dtype=hf)
+    return Qr, Kr, Vp, Qp, Kp, Vr
+
+
+def attn_operands16(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
+    """attn_operands for the split-fp16 kernels: q carries scale * log2(e) (scores in log2 units); returns the same tuple
+    shape, `scale` being the factor a3d_rope_merge_bwd must apply to the q gradient."""
+    Lqp, Sp = ceil_to(Lq, 64), ceil_to(S, 64)
+    scale = float(E // H) ** -0.5 * LOG2E
+    freq = rope_freq(E, device)
+    Qr, Kr, Vp, Qp, Kp, Vr = _alloc16(B, H, Lqp, Sp, device, need_bwd)
+    st = L.stream()
+    qx = None if q_xyz is None else q_xyz.data_ptr()
+    kx = None if k_xyz is None else k_xyz.data_ptr()
+    nz = lambda t: None if t is None else t.data_ptr()
+    L.call("a3d_rope_split16", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS, B, Lq, Lqp, E, H, st)
+    L.call("a3d_rope_split16", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS, B, S, Sp, E, H, st)
+    L.call("a3d_rope_split16", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vr), Vp.data_ptr(), 2, B, S, Sp, E, H, st)
+    return Qr, Kr, Vp, Lqp, Sp, scale, freq, (Qp, Kp, Vr)
+
+
+def attn_operands_fused16(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
+    """attn_operands_fused for the split-fp16 kernels (a3d_proj_rope_split16)."""
+    Lqp, Sp = ceil_to(Lq, 64), ceil_to(S, 64)
+    scale = float(E // H) ** -0.5 * LOG2E
+    freq = rope_freq(E, device)
+    Qr, Kr, Vp, Qp, Kp, Vr = _alloc16(B, H, Lqp, Sp, device, need_bwd)
+    st = L.stream()
+    f4 = 4
+    qx = None if q_xyz is None else q_xyz.data_ptr()
+    kx = None if k_xyz is None else k_xyz.data_ptr()
+    nz = lambda t: None if t is None else t.data_ptr()
+    fp = freq.data_ptr()
+
+    def proj(x, w_off, blk0, blk1, N, Npad):
+        L.call("a3d_proj_rope_split16", x.data_ptr(), E, wp + w_off * E * f4, E, bp + w_off * f4, E,
+               *blk0, *(blk1 if blk1 is not None else (None, 1.0, None, None, 1)), fp, B, N, Npad, E, H, st)
+
+    qb = (qx, scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS)
+    kb = (kx, 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS)
+    vb = (None, 1.0, nz(Vr), Vp.data_ptr(), 2)
+    if mode == "qk":
+        proj(q_in, 0, qb, kb, Lq, Lqp)
+        proj(v_in, 2 * E, vb, None, S, Sp)
+    else:
+        proj(q_in, 0, qb, None, Lq, Lqp)
+        if mode == "kv":
+            proj(k_in, E, kb, vb, S, Sp)
+        else:
+            proj(k_in, E, kb, None, S, Sp)
+            proj(v_in, 2 * E, vb, None, S, Sp)
+    return Qr, Kr, Vp, Lqp, Sp, scale, freq, (Qp, Kp, Vr)
+
+
 def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
     """rope + split the three projected row sets into the attention operand formats.  The forward reads q and k in the
     rows (QK) format and v in the planes (VT) format; the bf16 backward additionally needs the other format of each
@@ -236,6 +312,8 @@ def dropout_mask(drop, site, n, bh=None, q=None):
 
 
 def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0):
+    """Attention core on pre-formatted operands; the operand dtype selects the kernel family (fp16: attention16.hip, whose
+    LSE is in log2 units; bf16: attention.hip)."""
     dev = Qs.device
     E = H * 15
     O = torch.empty((B, Lq, E), device=dev, dtype=F32)
@@ -243,6 +321,12 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, si
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit * B * H * Lqp * 18,), device=dev, dtype=F32)
+    if Qs.dtype == torch.float16:
+        dropping = drop is not None and drop.p > 0
+        L.call("a3d_attn16_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
+               O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
+               drop.state.data_ptr() if dropping else None, int(site), drop.p if dropping else 0.0, L.stream())
+        return O, LSE
     args = (Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
             O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit)
     if drop is not None and drop.p > 0:
@@ -263,6 +347,16 @@ def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, e
     dK = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     dV = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     km = None if kmask is None else kmask.data_ptr()
+    if Qs.dtype == torch.float16:
+        Qp, Kp, Vr = extra
+        dOr = torch.empty((B, H, Lqp, 16), device=dev, dtype=torch.float16)
+        dOp = torch.empty((B, H, 16, Lqp), device=dev, dtype=torch.float16)
+        rexp = torch.empty((B, H, Lqp), device=dev, dtype=torch.int32)
+        L.call("a3d_attn16_bwd", Qs.data_ptr(), Qp.data_ptr(), Ks.data_ptr(), Kp.data_ptr(), Qp.shape[2], Vr.data_ptr(), km, O.data_ptr(),
+               dO.data_ptr(), LSE.data_ptr(), dOr.data_ptr(), dOp.data_ptr(), D.data_ptr(), rexp.data_ptr(), dQp.data_ptr(),
+               dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, drop.state.data_ptr() if dropping else None,
+               int(site), drop.p if dropping else 0.0, L.stream())
+        return dQp, dK, dV
     if extra is None or extra[0] is None or BWD_F32:
         if dropping:
             raise NotImplementedError("attention-weight dropout is implemented in the split-bf16 backward only")
@@ -323,8 +417,9 @@ class AttnBlockFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad) or in_w.requires_grad
         if FUSED_PROJ and E % 4 == 0 and E <= 128:
             # ---- projections fused with RoPE + operand formatting: the projected rows never reach HBM
-            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands_fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B,
-                                                                          Lq, S, E, H, dev, need_bwd)
+            fused = attn_operands_fused16 if _use16(drop) else attn_operands_fused
+            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, E, H, dev,
+                                                            need_bwd)
         else:
             # ---- projections, then RoPE + operand formatting
             if mode == "qk":
@@ -347,8 +442,9 @@ class AttnBlockFn(torch.autograd.Function):
                     v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
                     k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
                     keep = (q_pre, k_pre, v_pre)
-            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = attn_operands(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
-                                                                    S, E, H, dev, need_bwd=need_bwd)
+            unfused = attn_operands16 if _use16(drop) else attn_operands
+            Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = unfused(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
+                                                              S, E, H, dev, need_bwd=need_bwd)
             del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
         O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site)

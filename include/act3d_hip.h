@@ -116,6 +116,30 @@ int a3d_dropout(const float* x, float* y, size_t n, const unsigned long long* dr
  * a3d_dropout (c1 ignored); otherwise (c2 = b * H + h, c1 = query) the attention-weight indexing, i = key.  Test hook. */
 int a3d_dropout_mask(unsigned char* out, size_t n, const unsigned long long* drop_state, unsigned int c2, unsigned int c1,
                      unsigned int site, float p, void* stream);
+/* ---- split-fp16 attention (csrc/attention16.hip): the default attention core --------------------------------------------
+ * Replaces the same reference lines as a3d_attn_fwd / a3d_attn_bwd_bf16 (multihead_custom_attention.py:386-447 and its
+ * autograd) with half the MFMA work: q, k two-part fp16 (x = hi + lo, fp32-grade logits), P / dS / V / dO single fp16.
+ * Operand formats "16": rows16 [B][H][Npad][32] fp16 = hi(16) | lo(16); planes16 [B][H][parts][16][Npad] fp16, transposed
+ * (parts = 2: hi and lo planes -- v, and q / k for the backward; parts = 1: hi only).
+ * q must carry log2(e) (pass scale * log2 e to the *_split16 writers; a3d_rope_merge_bwd takes the same scale): scores and
+ * LSE2 are in log2 units.  drop_state NULL or drop_p == 0: no dropout (a3d_attn16_bwd rejects dropout for now). */
+int a3d_rope_split16(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
+                     void* planes_out, int plane_parts, int B, int N, int Npad, int E, int H, void* stream);
+int a3d_proj_rope_split16(const float* X, int ldx, const float* W, int ldw, const float* bias, int K, const float* xyz0,
+                          float scale0, void* rows0, void* planes0, int parts0, const float* xyz1, float scale1, void* rows1,
+                          void* planes1, int parts1, const float* freq, int B, int N, int Npad, int E, int H, void* stream);
+/* O [B][Lq][E] fp32, LSE2 [B][H][Lqp] fp32 (log2 units).  Qr, Kr rows16; Vp planes16 with BOTH parts.  ws as a3d_attn_fwd. */
+int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, const unsigned char* kmask, float* O, float* LSE2,
+                   float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
+                   const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
+/* Needs rows16 of q, k, v and planes16 of q, k with `plane_parts` parts.  Scratch: dOr [B][H][Lqp][16] fp16, dOp [B][H][16][Lqp] fp16,
+ * D [B][H][Lqp] fp32, rexp [B][H][Lqp] int32.  Outputs: dQp [nsplit][B][H][Lqp][16] (gradient w.r.t. the log2e-scaled,
+ * rotated q), dK, dV [B][H][Sp][16] fp32 -- the a3d_rope_merge_bwd layouts.  Lqp % 64 == 0. */
+int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* Kp, int plane_parts, const void* Vr,
+                   const unsigned char* kmask, const float* O, const float* dO, const float* LSE2, void* dOr, void* dOp,
+                   float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S, int Sp,
+                   int nsplit, const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
+
 /* a3d_attn_fwd / a3d_attn_bwd_bf16 with dropout on the attention weights: O = (keep o softmax(..) / (1 - p)) V. */
 int a3d_attn_fwd_dropout(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, float* O, float* LSE,
                          float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,

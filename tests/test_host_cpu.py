@@ -304,6 +304,57 @@ def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
         opt3.load_state_dict(bad)
 
 
+def test_reference_state_with_unused_parameters_loads_into_full_buffer_and_lr_resets(tmp_path):
+    """A real reference checkpoint has NO optimizer state for parameters whose .grad stayed None (FPN blocks of maps that
+    are never read; DDP find_unused_parameters=True, engine.py:121-124), while BaseTrainTester.get_optimizer puts every
+    requires_grad parameter into the flat buffer.  Loading must accept the state-less parameters (zero moments) and the
+    resume path must reset the step lr to args.lr as the reference does (engine.py:200-201)."""
+    a3d = load_pkg()
+    bounds = np.array([[-1, -1, -1], [1, 1, 1.0]])
+    torch.manual_seed(0)
+    m2 = a3d.Act3D(gripper_loc_bounds=bounds, num_sampling_level=2)
+    ref_opt = _reference_adamw(m2)
+    named2 = dict(m2.named_parameters())
+    trainable = [n for n, p in named2.items() if p.requires_grad]
+    unused = [n for n in trainable if "feature_pyramid" in n and ("layer_blocks.0" in n or "inner_blocks.0" in n)]
+    assert unused
+    g = torch.Generator().manual_seed(3)
+    for _ in range(2):
+        for n in trainable:
+            named2[n].grad = None if n in unused else torch.randn(named2[n].shape, generator=g)
+        ref_opt.step()
+    assert len(ref_opt.state_dict()["state"]) == len(trainable) - len(unused)
+    path = str(tmp_path / "ref.pth")
+    torch.save({"weight": {"module." + k: v for k, v in m2.state_dict().items()}, "optimizer": ref_opt.state_dict(),
+                "iter": 2, "best_loss": None}, path)
+    torch.manual_seed(9)
+    m3 = a3d.Act3D(gripper_loc_bounds=bounds, num_sampling_level=2)
+    flat3, opt3 = a3d.engine.get_optimizer(m3, lr=5e-5)            # active_names=None: every trainable parameter
+    assert set(flat3.slices) == set(trainable)
+    opt3.exp_avg.fill_(3.0)                                        # stale values must not survive in state-less slots
+    it, _ = a3d.engine.load_checkpoint(path, m3, opt3)
+    assert it == 2 and float(opt3.step_count) == 2
+    for n in unused:
+        a, b = flat3.slices[n]
+        assert float(opt3.exp_avg[a:b].abs().max()) == 0 and float(opt3.exp_avg_sq[a:b].abs().max()) == 0
+    n0 = next(n for n in trainable if n not in unused)
+    a, b = flat3.slices[n0]
+    assert torch.equal(opt3.exp_avg[a:b], ref_opt.state[named2[n0]]["exp_avg"].reshape(-1))
+    # the checkpoint's lr (1e-4 in the reference optimizer) is what load_state_dict leaves; the resume path overrides it
+    assert opt3.lr == pytest.approx(1e-4)
+    opt3.lr = 5e-5
+    assert [g_["lr"] for g_ in opt3.param_groups] == [5e-5, 5e-5] and opt3.state_dict()["param_groups"][1]["lr"] == 5e-5
+    # writing it back: the never-touched parameters carry no state, exactly like torch
+    sd = opt3.state_dict()
+    assert len(sd["state"]) == len(trainable) - len(unused)
+    ref_opt.load_state_dict(sd)
+    # unknown indices / wrong sizes still raise
+    bad = ref_opt.state_dict()
+    bad["state"][10 ** 6] = bad["state"][next(iter(bad["state"]))]
+    with pytest.raises(ValueError, match="not a parameter"):
+        opt3.load_state_dict(bad)
+
+
 # ------------------------------------------------------------------------------------------------ 2-process gloo
 def _dp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
