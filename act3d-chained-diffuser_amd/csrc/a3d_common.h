@@ -146,7 +146,9 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
 // ---------------------------------------------------------------- dropout masks (training-mode nn.Dropout / F.dropout)
 // One Philox call yields the keep flags of a block of 8 elements: element j of the block is KEPT iff the j-th 16-bit
 // field of the 128 output bits is >= thr16 = round(p * 65536); kept elements are scaled by 1 / (1 - p).
-//   counter = (c0, c1, c2, site), key = (seed_lo ^ offset_lo, seed_hi ^ offset_hi)
+//   counter = (c0, c1, c2, site), key = the two halves of  seed + offset * 0x9E3779B97F4A7C15  (mod 2^64): the four counter
+//   words are taken, so the generator offset has to live in the key; the odd multiplier keeps (seed, offset) pairs that a
+//   plain XOR would alias -- (1, 0) and (0, 1) -- on different streams
 //   attention weights (multihead_custom_attention.py:413): c0 = key >> 3, c1 = query, c2 = b * H + h
 //   elementwise sites  (layers.py:82-84,146,181; diffusion_head.py:46,183,193): c0, c1 = lo / hi of (index >> 3),
 //                      c2 = 0xFFFFFFFF
@@ -155,9 +157,10 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
 struct DropKey { uint32_t k0, k1; };
 __device__ __forceinline__ DropKey drop_key(const unsigned long long* state) {
   const unsigned long long seed = state[0], offs = state[1];
+  const unsigned long long key = seed + offs * 0x9E3779B97F4A7C15ull;
   DropKey k;
-  k.k0 = (uint32_t)seed ^ (uint32_t)offs;
-  k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offs >> 32);
+  k.k0 = (uint32_t)key;
+  k.k1 = (uint32_t)(key >> 32);
   return k;
 }
 // bit j of the result = keep flag of element j of the 8-element block

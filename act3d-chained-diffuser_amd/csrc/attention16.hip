@@ -1,31 +1,39 @@
 // Split-fp16 attention for gfx950: the ghost-point <-> scene cross-attention (and the diffusion transformer's attention
-// core) on v_mfma_f32_16x16x32_f16 with HALF the matrix work and a third of the vector work of the split-bf16 kernels in
-// attention.hip / attention_bwd.hip, at the same parity class.
+// core) on v_mfma_f32_16x16x32_f16 with well under HALF the matrix work and a third of the vector work of the split-bf16
+// kernels in attention.hip / attention_bwd.hip (kept as the A/B reference, A3D_ATTN_MODE=bf16x3).
 //
 // Reference semantics (multihead_custom_attention.py:355-447): per head h (d = 15), A = softmax(q_h k_h^T + mask),
 // o_h = A v_h.  What bounds this op on MI355X is NOT the matrix pipe: with d = 15 a score costs 60 algorithmic FLOPs
-// but one v_exp_f32 (quarter rate: 6.5 cycles per wave64 op, profiles/r03_inst_rate.txt) plus its share of
-// conversions, so the inner loops are written to minimise VECTOR instructions per score:
+// but one v_exp_f32 (6.5 cycles per wave64 op; a packed fp16 conversion costs the same, profiles/r03_inst_rate.txt), so
+// the inner loops are written to minimise VECTOR instructions per score:
 //   * q, k are TWO-part fp16 (x = hi + lo, 22 mantissa bits; fp16 subnormals are honoured by the MFMA, same file):
 //     logits are fp32-grade from two K = 32 MFMAs per 16x16 tile, [k_hi|k_lo].[q_hi|q_hi] + [k_hi|k_lo].[q_lo|q_lo]
 //     (three with three-part bf16).  exp() turns an ABSOLUTE logit error into a relative weight error, which is why the
-//     logit operands keep two parts while everything downstream of the softmax is single fp16:
-//   * P (and in the backward dS) and dO are single fp16: their rounding (2^-12 relative) is not amplified; the softmax
-//     denominator is accumulated on the MFMA from the SAME rounded P (ones-channel of V), V keeps two parts (a rounded V
+//     logit operands keep two parts while what follows the softmax is single fp16:
+//   * P (and in the backward dS) and dO WERE single fp16 in the first cut of this file: a 2^-12 rounding is not amplified; the softmax
+//     denominator is accumulated on the MFMA from the SAME rounded P (ones-channel of V).  V keeps two parts (a rounded V
 //     would make D = dO . O inconsistent with dP = dO . V, and dP - D is a difference of nearly equal numbers when the
-//     softmax is sharp), and the backward differentiates exactly the function of the rounded dO (D from the rounded dO).
+//     softmax is sharp), so do K in dQ = dS K and Q in dK = dS^T Q (sum_k dS = 0 makes them functions of key / query
+//     DIFFERENCES); the backward differentiates exactly the function of the rounded dO (D from the rounded dO).
 //   * log2(e) is folded into q by the projection kernel, -m (forward) / -lse (backward) / -D ride in as MFMA accumulator
 //     inits: exp2 is applied DIRECTLY to MFMA results -- no per-score argument arithmetic at all.
 //   * lazy rescaling: the running max is only revised when a score exceeds it by 2^8 (a wave-uniform, rarely taken
 //     branch), so the common path has no cross-lane traffic and no accumulator rescale.
 //   * dO rows are normalised by a power of two per (b, h, q) row (exact), so that dS fits fp16 whatever the loss scale.
-// Per 64 keys x 16 queries a wave issues 10 (fwd) / 14 (dQ) / 16 (dK,dV) MFMAs against 18 / 26 / 32 before.
+// Per 64 keys x 16 queries a wave issues 12 (fwd) / 16 (dQ) / 18 (dK,dV) MFMAs against 18 / 26 / 32 before.
+//
+// Staging.  With so little work per chunk (a 64-key chunk is ~0.6 us of a workgroup's time) a one-chunk register prefetch
+// cannot cover the loaded HBM / L2 latency (1-2 us): the first version of these kernels ran at half the speed its
+// instruction mix allows.  The tiles therefore arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass) into a ring of NB buffers with NB - 1 chunks in flight, ONE raw s_barrier per chunk and counted vmcnt
+// waits.  An LDS-DMA lands lane-linearly (wave base + lane * 16 B), so the bank swizzle of the tiles (a3d_common.h
+// tile_off / plane_off) is applied on the SOURCE address: lane l fetches the 16-byte segment that belongs at position l.
 //
 // Operand formats ("16" formats, written by a3d_proj_rope_split16 / attn16_bwd_prep):
 //   rows16   [B][H][Npad][32] fp16 : hi(16) | lo(16) of the 16-padded head row        (q, k, v)
-//   planes16 [B][H][parts][16][Npad] fp16 : hi (and lo) planes, transposed (8 consecutive rows of one channel = one MFMA A
-//            fragment); v always has both parts, q / k carry `plane_parts` (backward only)
-//   dO rows  [B][H][Lqp][16]  fp16, dO planes [B][H][16][Lqp] fp16 (both of the row-normalised dO * ln 2)
+//   planes16 [B][H][2][16][Npad] fp16 : hi and lo planes, transposed (8 consecutive rows of one channel = one MFMA A
+//            fragment); the value planes carry 1.0 in the padded channel 15 of the hi plane (softmax denominator)
+//   dO rows  [B][H][Lqp][16]  fp16, dO plane [B][H][16][Lqp] fp16 (both of the row-normalised dO * ln 2)
 // Scores live in log2 units (q carries log2 e): LSE2 = log2 sum_k 2^s2.
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
@@ -37,11 +45,18 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2_;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 constexpr int C16 = 64;              // keys (fwd, dQ) or queries (dK/dV) per staged chunk
 constexpr float P_OFF = 4.0f;        // p = 2^(s - m + P_OFF): keeps the small weights of a row out of fp16's subnormals
 constexpr float P_THR = 8.0f;        // lazy rescale: revise the running max when a score exceeds it by 2^P_THR
 constexpr float LN2_F = 0.6931471805599453f;
+// backward: P and G = P (dP - D) are formed as 2^B_OFF times their value (folded into the -lse accumulator init, undone in
+// the output scale).  Attention over 4097 keys has weights ~2^-12 and G two or three orders below; without the offset they
+// sit in fp16's subnormals (absolute precision 2^-25) -- measured as a 1.6 % error of the gripper-token key's gradient.
+constexpr float B_OFF = 6.0f;
+constexpr int MASKW = 512;           // key-validity bitmask words in LDS: Sp <= 16384
 
 __device__ __forceinline__ f32x4 mfma_f16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
@@ -50,35 +65,110 @@ __device__ __forceinline__ f32x4 mfma_f16(s16x8 a, s16x8 b, f32x4 c) {
 __device__ __forceinline__ unsigned int pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, h16x2));
 }
+// x = hi + lo, both fp16 pairs: hi = fp16(x) (round to nearest), lo = fp16(x - hi)
+__device__ __forceinline__ void pk_f16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
+  hi = pk_f16(a, b);
+  const h16x2 hh = __builtin_bit_cast(h16x2, hi);
+  lo = pk_f16(a - (float)hh[0], b - (float)hh[1]);
+}
+// x = hi + lo, both bf16 pairs (16 mantissa bits, fp32's exponent range): the operands of the query-axis contractions
+__device__ __forceinline__ void pk_bf16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  hi = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){ra, rb}, bf16x2_));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float max16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
-  const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]);
-  const float m1 = fmaxf(fmaxf(a[3], b[0]), b[1]);
-  const float m2 = fmaxf(fmaxf(b[2], b[3]), c[0]);
-  const float m3 = fmaxf(fmaxf(c[1], c[2]), c[3]);
-  const float m4 = fmaxf(fmaxf(d[0], d[1]), d[2]);
-  return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, d[3]));
+  const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], b[0], b[1]), m2 = max3f(b[2], b[3], c[0]);
+  const float m3 = max3f(c[1], c[2], c[3]), m4 = max3f(d[0], d[1], d[2]);
+  return fmaxf(max3f(m0, m1, m2), max3f(m3, m4, d[3]));
+}
+
+// ---- LDS-DMA pieces: one wave instruction moves 64 lanes x 16 B to `lds` (wave-uniform) + lane * 16.
+// Issued through inline asm on purpose: for the builtin form hipcc's waitcnt pass orders EVERY later ds_read behind the
+// newest pending LDS-DMA (s_waitcnt vmcnt(0) in front of the first fragment read), which serialises the ring; the asm form
+// is invisible to it, and the kernels below place the counted vmcnt waits themselves (their loops issue no other VMEM
+// loads, and an uncounted op only ever makes a compiler-placed vmcnt(k) wait longer, never shorter -- returns are in order).
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  const unsigned int dst = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(lds_void_t*)lds);
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(dst)
+               : "memory");
+}
+// rows tile [64 rows][32 halfs] (4 KB, tile_off swizzle): wave w brings rows w*16 .. w*16+15.  `row_halfs` = source row
+// length in halfs (32: hi | lo rows; 16: single rows duplicated into both halves of the tile row)
+__device__ __forceinline__ void dma_rows_tile(const unsigned short* src_row0, int row_halfs, unsigned short* tile, int wave,
+                                              int lane) {
+  const int row = wave * 16 + (lane >> 2);
+  const int seg = (lane & 3) ^ ((0 - (row >> 3)) & 3);
+  const int sseg = (row_halfs == 32) ? seg : (seg & 1);
+  glds16(src_row0 + (size_t)row * row_halfs + sseg * 8, tile + wave * 512);
+}
+// plane sub-tile [16 ch][32 rows] (1 KB, plane_off swizzle) from a [16][ld] plane at row offset r0
+__device__ __forceinline__ void dma_plane_subtile(const unsigned short* plane, size_t ld, size_t r0, unsigned short* sub, int lane) {
+  const int ch = lane >> 2;
+  const int seg = (lane & 3) ^ ((0 - (ch >> 2)) & 3);
+  glds16(plane + (size_t)ch * ld + r0 + seg * 8, sub);
+}
+
+// Pins a register-resident operand loaded before the main loop: the (empty) asm is a use, so hipcc retires the load HERE and
+// not at its first use inside the loop, where its vmcnt wait would also drain the LDS-DMA ring.
+#define A3D_PIN(x) asm volatile("" ::"v"(x))
+#define A3D_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 12, "extend wait_vm");
+  if (N == 0) A3D_WAIT_VM(0); else if (N == 1) A3D_WAIT_VM(1); else if (N == 2) A3D_WAIT_VM(2); else if (N == 3) A3D_WAIT_VM(3);
+  else if (N == 4) A3D_WAIT_VM(4); else if (N == 5) A3D_WAIT_VM(5); else if (N == 6) A3D_WAIT_VM(6); else if (N == 7) A3D_WAIT_VM(7);
+  else if (N == 8) A3D_WAIT_VM(8); else if (N == 9) A3D_WAIT_VM(9); else if (N == 10) A3D_WAIT_VM(10);
+  else if (N == 11) A3D_WAIT_VM(11); else A3D_WAIT_VM(12);
+}
+// raw barrier (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0)); this wave's LDS writes / reads are retired first
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// key-validity bitmask of sample b (bit k of word k / 32 set = key valid), built once per workgroup
+__device__ __forceinline__ void build_key_mask(unsigned int* maskW, const unsigned char* __restrict__ kmask, int b, int S, int Sp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w0 = wave; w0 < Sp / 64; w0 += 4) {
+    const int key = w0 * 64 + lane;
+    bool valid = key < S;
+    if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(valid);
+    if (lane == 0) { maskW[w0 * 2] = (unsigned int)bits; maskW[w0 * 2 + 1] = (unsigned int)(bits >> 32); }
+  }
+}
+// 0 / -inf biases of the lane's four keys of score tile T of the 32-key half whose validity word is `word`
+__device__ __forceinline__ f32x4 bias_of(unsigned int word, int g, int T) {
+  const unsigned int bits = word >> (g * 8 + T * 4);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = ((bits >> i) & 1u) ? 0.f : -INFINITY;
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-struct Fwd16Stage {
-  s16x8 k, v;
-  float bias;
-};
-
-// QT 16-query tiles per wave (128 queries per workgroup at QT = 2); 64-key chunks of the K rows and the V plane are
-// staged through LDS once per workgroup (double buffered, one barrier per chunk).  Scores are computed transposed
-// (S^T = K Q^T) with the key rows of the two 16x16 tiles of a 32-key half interleaved (tile T row i <-> key
-// (i >> 2) * 8 + (i & 3) + 4 T): after exp2 a lane holds, in order, the 8 consecutive keys the P operand of the PV MFMA
-// wants, so P never touches LDS.
-template <bool DROP, int QT>
+// QT 16-query tiles per wave (128 queries per workgroup at QT = 2).  Scores are computed transposed (S^T = K Q^T) with
+// the key rows of the two 16x16 tiles of a 32-key half interleaved (tile T row i <-> key (i >> 2) * 8 + (i & 3) + 4 T):
+// after exp2 a lane holds, in order, the 8 consecutive keys the P operand of the PV MFMA wants, so P never touches LDS.
+// DROP: training-mode dropout of the attention weights (multihead_custom_attention.py:413), Philox keep flags as in
+// attention.hip; the denominator is then a per-lane f32 sum of the un-dropped weights.
+// PP: parts of P in the PV product.  2 (default): p = hi + lo, both fp16 -- the output error of a single-fp16 P is
+// 2^-12 |v_k - o| per dominant key, which the gain-3 reference fixtures (|logit| ~ 100, one or two keys per query) turn into
+// 1.3e-3 of the mask-logit scale two layers later: over the 1e-3 parity bar.  1: single fp16 P (A3D_ATTN_FAST=1), 2-4e-4 per
+// attention output, 25 % fewer vector instructions.
+constexpr int FWD_NB = 4;
+template <bool DROP, int QT, int PP>
 __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
     const unsigned short* __restrict__ Qr, const unsigned short* __restrict__ Kr, const unsigned short* __restrict__ Vp,
     const unsigned char* __restrict__ kmask, float* __restrict__ O, float* __restrict__ LSE2, float* __restrict__ Op,
     float* __restrict__ Mp, float* __restrict__ Lp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
     const unsigned long long* __restrict__ drop_state, unsigned int drop_site, unsigned int drop_thr, float drop_scale) {
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][C16 * 32];      // [k_hi | k_lo] rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][4 * 16 * 32];   // [plane hi/lo][32-key half][16 ch][32 keys]
-  __shared__ __attribute__((aligned(16))) float biasS[2][C16];
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[FWD_NB][C16 * 32];      // [k_hi | k_lo] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[FWD_NB][4 * 16 * 32];   // [plane hi/lo][32-key half][16 ch][32 keys]
+  __shared__ unsigned int maskW[MASKW];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -91,6 +181,11 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
   const int E = H * HD;
   const int qbase = (within - sp * tiles_x) * QW + wave * (16 * QT);
   const size_t bh = (size_t)b * H + h;
+  const bool any_masked = (kmask != nullptr) || (Sp != S);
+  if (any_masked) {
+    build_key_mask(maskW, kmask, b, S, Sp);
+    __syncthreads();
+  }
 
   s16x8 qhi[QT], qlo[QT];
   bool active[QT];
@@ -98,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int q0 = qbase + u * 16;
-    active[u] = q0 < Lqp;
+    active[u] = q0 < Lq;                                     // the tile holds at least one real query
     any_active = any_active || active[u];
     qhi[u] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     qlo[u] = qhi[u];
@@ -108,34 +203,20 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
       qlo[u] = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
     }
   }
+#pragma unroll
+  for (int u = 0; u < QT; ++u) { A3D_PIN(qhi[u]); A3D_PIN(qlo[u]); }
   const int nch = Sp / C16;
   const int cps = (nch + nsplit - 1) / nsplit;
   const int c_beg = sp * cps;
   const int c_end = min(nch, c_beg + cps);
 
-  const int krow = t >> 2, kseg = t & 3;
-  const int vplane = t >> 7, vd = (t >> 3) & 15, vseg = t & 7;
-  auto stage_load = [&](int c) {
-    Fwd16Stage st;
-    st.k = *reinterpret_cast<const s16x8*>(Kr + (bh * Sp + (size_t)c * C16 + krow) * 32 + kseg * 8);
-    st.v = *reinterpret_cast<const s16x8*>(Vp + ((bh * 2 + vplane) * 16 + vd) * Sp + (size_t)c * C16 + vseg * 8);
-    st.bias = 0.f;
-    if (t < C16) {
-      const int key = c * C16 + t;
-      bool valid = key < S;
-      if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
-      st.bias = valid ? 0.f : -INFINITY;
-    }
-    return st;
-  };
-  auto stage_store = [&](const Fwd16Stage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Ksm[buf][tile_off(krow, kseg)]) = st.k;
-    // padded channel 15 of V := 1.0: acc[d = 15] accumulates the softmax denominator on the MFMA pipe from exactly the
-    // rounded P the numerator uses
-    const s16x8 ones = {0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00};
-    *reinterpret_cast<s16x8*>(&Vsm[buf][((vplane * 2 + (vseg >> 2)) * 16) * 32 + plane_off(vd, vseg & 3)]) =
-        (vplane == 0 && vd == 15) ? ones : st.v;
-    if (t < C16) biasS[buf][t] = st.bias;
+  // 2 LDS-DMA instructions per wave and chunk: its 16 rows of the K tile, its (plane, half) sub-tile of V
+  const unsigned short* Kbase = Kr + bh * Sp * 32;
+  const unsigned short* Vbase = Vp + ((bh * 2 + (wave >> 1)) * 16) * Sp + (wave & 1) * 32;
+  auto issue = [&](int c, int slot) {
+    const int cc = min(c, c_end - 1);                        // past the end: a harmless re-fetch keeps the vmcnt count fixed
+    dma_rows_tile(Kbase + (size_t)cc * C16 * 32, 32, Ksm[slot], wave, lane);
+    dma_plane_subtile(Vbase, Sp, (size_t)cc * C16, &Vsm[slot][wave * 512], lane);
   };
 
   int koff[4];
@@ -155,102 +236,110 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
     acc1[u] = acc0[u];
   }
   DropKey dkey = {0u, 0u};
-  if (DROP) dkey = drop_key(drop_state);
+  if (DROP) { dkey = drop_key(drop_state); A3D_PIN(dkey.k0); A3D_PIN(dkey.k1); }
 
   if (c_beg < c_end) {
-    stage_store(stage_load(c_beg), 0);
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FWD_NB - 1; ++i) issue(c_beg + i, i);
   }
   for (int c = c_beg; c < c_end; ++c) {
-    const int buf = (c - c_beg) & 1;
-    Fwd16Stage nxt;
-    const bool has_next = (c + 1 < c_end);
-    if (has_next) nxt = stage_load(c + 1);
+    const int slot = (c - c_beg) % FWD_NB;
+    wait_vm<2 * (FWD_NB - 2)>();                              // this wave's pieces of chunk c have landed ...
+    ring_barrier();                                           // ... everybody's have, and everybody is done with chunk c - 1
+    issue(c + FWD_NB - 1, (slot + FWD_NB - 1) % FWD_NB);      // into the buffer chunk c - 1 just vacated
     const bool first = (c == c_beg);
-    const bool masked = (kmask != nullptr) || ((c + 1) * C16 > S);     // wave-uniform: the chunk may hold invalid keys
+    const bool masked = any_masked && ((kmask != nullptr) || ((c + 1) * C16 > S));     // wave-uniform
+    if (!any_active) continue;                                // a wave of padding queries only feeds the ring
 
-    if (any_active) {
-      s16x8 kf[4], vh[2], vl[2];
+    s16x8 kf[4], vh[2], vl[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const s16x8*>(&Ksm[buf][koff[j]]);
+    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const s16x8*>(&Ksm[slot][koff[j]]);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        vh[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((0 * 2 + hf) * 16) * 32 + voff]);
-        vl[hf] = *reinterpret_cast<const s16x8*>(&Vsm[buf][((1 * 2 + hf) * 16) * 32 + voff]);
+    for (int hf = 0; hf < 2; ++hf) {
+      vh[hf] = *reinterpret_cast<const s16x8*>(&Vsm[slot][((0 * 2 + hf) * 16) * 32 + voff]);
+      vl[hf] = *reinterpret_cast<const s16x8*>(&Vsm[slot][((1 * 2 + hf) * 16) * 32 + voff]);
+    }
+    f32x4 s[QT][4];
+    if (masked) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = bias_of(maskW[c * 2 + (j >> 1)], g, j & 1);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u] + b4);
       }
-      f32x4 s[QT][4];
-      if (masked) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(&biasS[buf][(j >> 1) * 32 + g * 8 + (j & 1) * 4]);
-#pragma unroll
-          for (int u = 0; u < QT; ++u) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u] + b4);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < QT; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u]);
-      }
+    } else {
 #pragma unroll
       for (int u = 0; u < QT; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qlo[u], s[u][j]);
+        for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qlo[u], s[u][j]);
 
 #pragma unroll
-      for (int u = 0; u < QT; ++u) {
-        // s = s2 - m_run + P_OFF.  Common path: nothing exceeds 2^(P_OFF + P_THR) -> exponentiate as is.
-        const float mx = max16(s[u][0], s[u][1], s[u][2], s[u][3]);
-        if (first || __builtin_amdgcn_ballot_w64(mx > P_OFF + P_THR) != 0ull) {
-          const float cm = colmax4(mx);                                       // exact chunk max of the lane's query
-          float shift = first ? (cm - P_OFF) : fmaxf(cm - P_OFF, 0.f);
-          if (cm == -INFINITY) shift = 0.f;                                   // every key so far masked
-          m_run[u] += shift;
-          const float alpha = __builtin_amdgcn_exp2f(-shift);
+    for (int u = 0; u < QT; ++u) {
+      // s = s2 - m_run + P_OFF.  Common path: nothing exceeds 2^(P_OFF + P_THR) -> exponentiate as is.
+      const float mx = max16(s[u][0], s[u][1], s[u][2], s[u][3]);
+      if (first || __builtin_amdgcn_ballot_w64(mx > P_OFF + P_THR) != 0ull) {
+        const float cm = colmax4(mx);                                       // exact chunk max of the lane's query
+        float shift = first ? (cm - P_OFF) : fmaxf(cm - P_OFF, 0.f);
+        if (cm == -INFINITY) shift = 0.f;                                   // every key so far masked
+        m_run[u] += shift;
+        const float alpha = __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { acc0[u][r] *= alpha; acc1[u][r] *= alpha; cin[u][r] -= shift; }
-          if (DROP) l_run[u] *= alpha;
+        for (int r = 0; r < 4; ++r) { acc0[u][r] *= alpha; acc1[u][r] *= alpha; cin[u][r] -= shift; }
+        if (DROP) l_run[u] *= alpha;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[u][j][r] -= shift;
-        }
-        s16x8 pf[2];
-        float l_tile = 0.f;
+          for (int r = 0; r < 4; ++r) s[u][j][r] -= shift;
+      }
+      s16x8 pf[2], pl[2];
+      float l_tile = 0.f;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          unsigned int w[4];
-          unsigned int keep = 0xFFu;
-          if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (C16 / 8) + hf * 4 + g), (uint32_t)(qbase + u * 16 + li), (uint32_t)bh, drop_site, drop_thr);
+      for (int hf = 0; hf < 2; ++hf) {
+        unsigned int w[4], wl[4];
+        unsigned int keep = 0xFFu;
+        if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (C16 / 8) + hf * 4 + g), (uint32_t)(qbase + u * 16 + li), (uint32_t)bh, drop_site, drop_thr);
 #pragma unroll
-          for (int T = 0; T < 2; ++T) {
+        for (int T = 0; T < 2; ++T) {
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-              const f32x4& sj = s[u][hf * 2 + T];
-              float p0 = __builtin_amdgcn_exp2f(sj[2 * pr]), p1 = __builtin_amdgcn_exp2f(sj[2 * pr + 1]);
-              if (DROP) {
-                l_tile += p0 + p1;
-                const int j = T * 4 + 2 * pr;
-                p0 = ((keep >> j) & 1u) ? p0 * drop_scale : 0.f;
-                p1 = ((keep >> (j + 1)) & 1u) ? p1 * drop_scale : 0.f;
-              }
-              w[T * 2 + pr] = pk_f16(p0, p1);
+          for (int pr = 0; pr < 2; ++pr) {
+            const f32x4& sj = s[u][hf * 2 + T];
+            float p0 = __builtin_amdgcn_exp2f(sj[2 * pr]), p1 = __builtin_amdgcn_exp2f(sj[2 * pr + 1]);
+            if (DROP) {
+              l_tile += p0 + p1;
+              const int j = T * 4 + 2 * pr;
+              p0 = ((keep >> j) & 1u) ? p0 * drop_scale : 0.f;
+              p1 = ((keep >> (j + 1)) & 1u) ? p1 * drop_scale : 0.f;
+            }
+            const unsigned int h2 = pk_f16(p0, p1);
+            w[T * 2 + pr] = h2;
+            if (PP == 2) {
+              const h16x2 hh = __builtin_bit_cast(h16x2, h2);
+              wl[T * 2 + pr] = pk_f16(p0 - (float)hh[0], p1 - (float)hh[1]);
             }
           }
-          pf[hf] = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
         }
-        if (DROP) l_run[u] += l_tile;
-        // V keeps both parts: O = sum_k p~_k v_k / sum_k p~_k is an exactly normalised average of the 22-bit v rows, so
-        // what is left of the P rounding is proportional to the spread of v under the weights, not to |v|
-        acc0[u] = mfma_f16(vh[0], pf[0], acc0[u]);
-        acc1[u] = mfma_f16(vh[1], pf[1], acc1[u]);
-        acc0[u] = mfma_f16(vl[0], pf[0], acc0[u]);
-        acc1[u] = mfma_f16(vl[1], pf[1], acc1[u]);
+        pf[hf] = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
+        if (PP == 2) pl[hf] = __builtin_bit_cast(s16x8, (u32x4_){wl[0], wl[1], wl[2], wl[3]});
+      }
+      if (DROP) l_run[u] += l_tile;
+      // V keeps both parts: O = sum_k p~_k v_k / sum_k p~_k is an exactly normalised average of the 22-bit v rows, so
+      // what is left of the P rounding is proportional to the spread of v under the weights, not to |v|
+      acc0[u] = mfma_f16(vh[0], pf[0], acc0[u]);
+      acc1[u] = mfma_f16(vh[1], pf[1], acc1[u]);
+      acc0[u] = mfma_f16(vl[0], pf[0], acc0[u]);
+      acc1[u] = mfma_f16(vl[1], pf[1], acc1[u]);
+      if (PP == 2) {
+        acc0[u] = mfma_f16(vh[0], pl[0], acc0[u]);
+        acc1[u] = mfma_f16(vh[1], pl[1], acc1[u]);
       }
     }
-    if (has_next) stage_store(nxt, buf ^ 1);
-    __syncthreads();
   }
+  wait_vm<0>();                                               // the trailing dummy fetches must not outlive the workgroup
 
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -312,99 +401,204 @@ __global__ __launch_bounds__(256) void attn16_combine_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ backward: prep
-// Per (b, h, q): e = exponent with max_d |dO ln2| / 2^e in [0.5, 1); dOn = fp16(dO ln2 2^-e) (rows + planes formats);
-// D = sum_d dOn * O (from the ROUNDED dOn: the backward is the exact derivative for the upstream gradient dOn 2^e / ln2);
-// rexp = e (int; -100 for an all-zero row).  grid (Lqp / 64, B)
+// One workgroup per (b, h).  Per query row q:  e_q = exponent with max_d |dO ln2| / 2^e in [0.5, 1);  dOn = dO ln2 2^-e as
+// two-part fp16 (hi | lo rows, for the dQ kernel);  D = sum_d dOn * O from the ROUNDED dOn (the backward is the exact
+// derivative for the upstream gradient dOn 2^e / ln2);  rexp = e (-100 for an all-zero row).
+//
+// The dK / dV kernel contracts over QUERIES, i.e. it mixes rows of different scale inside one MFMA, and fp16 has 5 exponent
+// bits: with every row normalised against the largest row of the (b, h), rows 2^-20 below it vanish -- and they can be the
+// only rows a parameter's gradient lives on (measured: 20 % error on the vision-language attention of a reference fixture
+// whose offset loss puts 1e6-scale gradients on the ghost rows).  So the rows are SORTED by e_q (descending) and the dK / dV
+// kernel consumes them in that order, 64 per chunk, each chunk normalised against its own largest row (E_c), its
+// accumulators carried in units of 2^E_c: block floating point over the query axis.  Rows more than 2^60 below the largest
+// row of the (b, h) are dropped.  The same contraction also needs the RANGE of the weights themselves: a key that a sharp
+// softmax gives 1e-10 still receives a gradient (1e-10 of the others'), and it can be all a parameter ever sees (the
+// vision-language attention above); fp16 ends at 6e-8.  P' and G' therefore enter the dV / dK MFMAs as split bf16 (hi + lo,
+// 16 mantissa bits, fp32's exponent range) against bf16 hi / lo planes of dOn and Q, while scores and dP stay fp16.
+// This kernel writes, per chunk, the LDS images the dK / dV kernel needs ("pack", 20 KB):
+//   [0, 4 KB) Q rows tile (fp16 hi | lo)  [4, 8) dOn rows tile (fp16 hi | lo)  [8, 12) Q planes bf16 hi / lo
+//   [12, 16) dOn planes bf16 hi / lo  [16 KB ..) nl[64] = B_OFF - lse2 + e_q - E_c, nd[64] = -Dn, perm[64] = original row
+//   (dropout counters), E_c
+constexpr int PK_HALFS = 10240;                // 20 KB per chunk
+constexpr int PK_QROWS = 0, PK_OROWS = 2048, PK_QPL = 4096, PK_OPL = 6144, PK_NL = 8192, PK_ND = 8320, PK_PERM = 8448, PK_HDR = 8576;
+constexpr int DROP_SPAN = 60;                  // rows more than 2^DROP_SPAN below the largest row are dropped
+
 __global__ __launch_bounds__(256) void attn16_bwd_prep_kernel(
-    const float* __restrict__ dO, const float* __restrict__ O, unsigned short* __restrict__ dOr,
-    unsigned short* __restrict__ dOp, float* __restrict__ D, int* __restrict__ rexp, int B, int H, int Lq, int Lqp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float* __restrict__ dO, const float* __restrict__ O, const float* __restrict__ LSE2,
+    const unsigned short* __restrict__ Qr, unsigned short* __restrict__ dOr, float* __restrict__ D, int* __restrict__ rexp, unsigned short* __restrict__ pack, int B, int H, int Lq, int Lqp, int Lsort) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* keyS = reinterpret_cast<unsigned long long*>(smem_raw);                 // [Lsort] sort keys
+  float* dS = reinterpret_cast<float*>(keyS + Lsort);                                         // [Lqp] -Dn
+  unsigned short* qrowS = reinterpret_cast<unsigned short*>(dS + Lqp);                        // [64][32] gathered Q rows (natural layout)
+  unsigned short* orowS = qrowS + 64 * 32;                                                    // [64][32] gathered dOn rows
+  const int t = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int E = H * HD;
-  const int ldt = E + 1;
-  float* Td = smem;
-  float* To = smem + 64 * ldt;
-  const int b = blockIdx.y, q0 = blockIdx.x * 64;
-  for (int idx = threadIdx.x; idx < 64 * E; idx += blockDim.x) {
-    const int r = idx / E, c = idx - r * E;
-    const int q = q0 + r;
-    float a = 0.f, o = 0.f;
-    if (q < Lq) {
-      a = dO[((size_t)b * Lq + q) * E + c] * LN2_F;
-      o = O[((size_t)b * Lq + q) * E + c];
-    }
-    Td[r * ldt + c] = a;
-    To[r * ldt + c] = o;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 64 * H; idx += blockDim.x) {
-    const int r = idx & 63, h = idx >> 6;
-    float* td = Td + r * ldt + h * HD;
-    const float* to = To + r * ldt + h * HD;
-    float mx = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) mx = fmaxf(mx, fabsf(td[d]));
+  const size_t bh = (size_t)blockIdx.x;
+
+  // ---- A: per-row exponent, normalised fp16 row, D
+  for (int q = t; q < Lsort; q += 256) {
     int e = -100;
-    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);
-    if (e < -100) e = -100;
-    const float inv = ldexpf(1.0f, -e);
+    unsigned int w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     float dsum = 0.f;
-    unsigned int w[8];
-    float v[16];
+    if (q < Lq) {
+      const float* gp = dO + ((size_t)b * Lq + q) * E + h * HD;
+      const float* op = O + ((size_t)b * Lq + q) * E + h * HD;
+      float v[16];
+      float mx = 0.f;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) v[d] = (d < HD) ? td[d] * inv : 0.f;
+      for (int d = 0; d < 16; ++d) {
+        v[d] = (d < HD) ? gp[d] * LN2_F : 0.f;
+        mx = fmaxf(mx, fabsf(v[d]));
+      }
+      if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);
+      if (e < -100) e = -100;
+      const float inv = ldexpf(1.0f, -e);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+      for (int i = 0; i < 8; ++i) pk_f16_2(v[2 * i] * inv, v[2 * i + 1] * inv, w[i], wl[i]);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      const unsigned short hb = (unsigned short)((d & 1) ? (w[d >> 1] >> 16) : (w[d >> 1] & 0xFFFFu));
-      const float rv = (float)__builtin_bit_cast(_Float16, hb);
-      td[d] = rv;                                           // the planes pass re-reads the rounded values
-      dsum += rv * to[d];
+      for (int d = 0; d < HD; ++d) {
+        const int sh = (d & 1) * 16;
+        const float rv = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[d >> 1] >> sh)) +
+                         (float)__builtin_bit_cast(_Float16, (unsigned short)(wl[d >> 1] >> sh));
+        dsum += rv * op[d];
+      }
     }
-    const size_t row = ((size_t)b * H + h) * Lqp + q0 + r;
-    *reinterpret_cast<u32x4_*>(dOr + row * 16) = (u32x4_){w[0], w[1], w[2], w[3]};
-    *reinterpret_cast<u32x4_*>(dOr + row * 16 + 8) = (u32x4_){w[4], w[5], w[6], w[7]};
-    D[row] = dsum;
-    rexp[row] = e;
+    if (q < Lqp) {
+      const size_t row = bh * Lqp + q;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4_ hi4 = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]}, lo4 = {wl[4 * i], wl[4 * i + 1], wl[4 * i + 2], wl[4 * i + 3]};
+        *reinterpret_cast<u32x4_*>(dOr + row * 32 + i * 8) = hi4;
+        *reinterpret_cast<u32x4_*>(dOr + row * 32 + 16 + i * 8) = lo4;
+      }
+      D[row] = dsum;
+      rexp[row] = e;
+      dS[q] = -dsum;
+    }
+    // sort key: descending exponent, then ascending row (deterministic); padding rows and rows without a finite lse last
+    bool live = q < Lq;
+    if (live) live = LSE2[bh * Lqp + q] != -INFINITY;
+    const unsigned int rank = live ? (unsigned int)(300 - e) : 0xFFFFu;          // e in [-100, 128] -> 172 .. 400
+    keyS[q] = ((unsigned long long)rank << 32) | (unsigned int)q;
   }
+  __threadfence();                     // pass C re-reads the dOn rows this workgroup just wrote (other lanes' stores, through L2)
   __syncthreads();
-  for (int idx = threadIdx.x; idx < H * 16 * 8; idx += blockDim.x) {
-    const int seg = idx & 7;
-    const int d = (idx >> 3) & 15;
-    const int h = idx >> 7;
-    unsigned int w[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = seg * 8 + 2 * j;
-      const float v0 = (d < HD) ? Td[r * ldt + h * HD + d] : 0.f;
-      const float v1 = (d < HD) ? Td[(r + 1) * ldt + h * HD + d] : 0.f;
-      w[j] = pk_f16(v0, v1);
+  // ---- B: bitonic sort of Lsort (a power of two) 64-bit keys in LDS
+  for (int k = 2; k <= Lsort; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < Lsort; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keyS[i], c = keyS[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) { keyS[i] = c; keyS[ixj] = a; }
+        }
+      }
+      __syncthreads();
     }
-    *reinterpret_cast<u32x4_*>(dOp + (((size_t)b * H + h) * 16 + d) * Lqp + q0 + seg * 8) = (u32x4_){w[0], w[1], w[2], w[3]};
+  }
+  const unsigned int rank0 = (unsigned int)(keyS[0] >> 32);                       // the largest row's 300 - e
+  // ---- C: one pack per 64 sorted rows
+  const int nch = Lqp / 64;
+  for (int c = 0; c < nch; ++c) {
+    unsigned short* pk = pack + (bh * nch + c) * (size_t)PK_HALFS;
+    const unsigned int rank_c = (unsigned int)(keyS[c * 64] >> 32);
+    // gathered Q and dOn rows of the chunk, natural layout, for the tiles built from them
+    {
+      const int r = t >> 2, seg = t & 3;
+      const unsigned long long key = keyS[c * 64 + r];
+      const int q = (int)(unsigned int)key;
+      u32x4_ val = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
+      if (q < Lqp) {
+        val = *reinterpret_cast<const u32x4_*>(Qr + (bh * Lqp + q) * 32 + seg * 8);
+        ov = *reinterpret_cast<const u32x4_*>(dOr + (bh * Lqp + q) * 32 + seg * 8);
+      }
+      *reinterpret_cast<u32x4_*>(qrowS + r * 32 + seg * 8) = val;
+      *reinterpret_cast<u32x4_*>(orowS + r * 32 + seg * 8) = ov;
+    }
+    __syncthreads();
+    {
+      // Q rows tile and dOn rows tile (LDS images: unit t = row t >> 2, position t & 3 holds segment pos ^ f(row))
+      const int r = t >> 2, pos = t & 3;
+      const int seg = pos ^ ((0 - (r >> 3)) & 3);
+      const int q = (int)(unsigned int)keyS[c * 64 + r];
+      *reinterpret_cast<u32x4_*>(pk + PK_QROWS + t * 8) = *reinterpret_cast<const u32x4_*>(qrowS + r * 32 + seg * 8);
+      *reinterpret_cast<u32x4_*>(pk + PK_OROWS + t * 8) = *reinterpret_cast<const u32x4_*>(orowS + r * 32 + seg * 8);
+    }
+    {
+      // Q planes, bf16 hi / lo of q = hi16 + lo16: sub-tile (part, half) = t >> 6; unit t & 63: channel (t & 63) >> 2, position t & 3
+      const int sub = t >> 6, u = t & 63;
+      const int part = sub >> 1, half = sub & 1;
+      const int ch = u >> 2, pos = u & 3;
+      const int seg = pos ^ ((0 - (ch >> 2)) & 3);
+      s16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned short* qr = qrowS + (half * 32 + seg * 8 + j) * 32;
+        const float v = (float)__builtin_bit_cast(_Float16, qr[ch]) + (float)__builtin_bit_cast(_Float16, qr[16 + ch]);
+        unsigned short bh_, bl_;
+        split_bf16(v, bh_, bl_);
+        o[j] = (short)(part ? bl_ : bh_);
+      }
+      *reinterpret_cast<s16x8*>(pk + PK_QPL + t * 8) = o;
+    }
+    {
+      // dOn planes, bf16 hi / lo of dOn = hi16 + lo16: same unit map
+      const int sub = t >> 6, u = t & 63;
+      const int part = sub >> 1, half = sub & 1;
+      const int ch = u >> 2, pos = u & 3;
+      const int seg = pos ^ ((0 - (ch >> 2)) & 3);
+      s16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned short* orw = orowS + (half * 32 + seg * 8 + j) * 32;
+        const float v = (float)__builtin_bit_cast(_Float16, orw[ch]) + (float)__builtin_bit_cast(_Float16, orw[16 + ch]);
+        unsigned short bh_, bl_;
+        split_bf16(v, bh_, bl_);
+        o[j] = (short)(part ? bl_ : bh_);
+      }
+      *reinterpret_cast<s16x8*>(pk + PK_OPL + t * 8) = o;
+    }
+    if (t >= 128 && t < 192) {
+      const int r = t - 128;
+      const unsigned long long key = keyS[c * 64 + r];
+      const int q = (int)(unsigned int)key;
+      const unsigned int rank = (unsigned int)(key >> 32);
+      float nl = -INFINITY, ndv = 0.f;
+      if (rank != 0xFFFFu && rank <= rank0 + DROP_SPAN) {
+        nl = B_OFF - LSE2[bh * Lqp + q] - (float)(int)(rank - rank_c);            // e_q - E_c = rank_c - rank
+        ndv = dS[q];
+      }
+      reinterpret_cast<float*>(pk + PK_NL)[r] = nl;
+      reinterpret_cast<float*>(pk + PK_ND)[r] = ndv;
+      reinterpret_cast<int*>(pk + PK_PERM)[r] = q;
+    } else if (t == 192) {
+      // E_c; a chunk that starts beyond the drop span (or in the padding) is dead, and so is everything after it
+      reinterpret_cast<int*>(pk + PK_HDR)[0] = (rank_c == 0xFFFFu || rank_c > rank0 + DROP_SPAN) ? -1000 : 300 - (int)rank_c;
+    }
+    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-struct Dq16Stage {
-  s16x8 k, v, kp;
-  float bias;
-};
-
 // dQ2[q] = 2^e_q * sum_k G[q, k] K[k],  G = P o (dPn - Dn)  (dPn = V dOn: the ln 2 of d/ds2 rides in dOn)
 // DROP: O = (M o P) V  ->  dPn = M o (V dOn), G = P o (dPn - Dn).
-// PL: parts of the K planes contracted with G (2: K_hi G + K_lo G -- sum_k G = 0 makes dQ a function of key DIFFERENCES, so
-// a 2^-12 rounding of K is amplified by |K| / |K - K'| between the keys that share a query's weight; 1: single fp16)
-template <bool DROP, int QT, int PL>
+// GP: parts of G in dQ = G K.  2 (default): g = hi + lo -- sum_k G[q, k] = 0, so a 2^-12 rounding of G leaves a common-mode
+// error |K| sum_k dG that the aggregated gradients (key bias: a sum over 65k rows that is ~0 in exact arithmetic) show as
+// 3-7e-3 of their scale; 1: single fp16 G (A3D_ATTN_FAST=1).
+constexpr int DQ_NB = 3;
+template <bool DROP, int QT, int GP>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
     const unsigned short* __restrict__ Qr, const unsigned short* __restrict__ Kr, const unsigned short* __restrict__ Kp,
     const unsigned short* __restrict__ Vr, const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOr,
     const float* __restrict__ LSE2, const float* __restrict__ D, const int* __restrict__ rexp, float* __restrict__ dQp,
     int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, const unsigned long long* __restrict__ drop_state,
     unsigned int drop_site, unsigned int drop_thr, float drop_scale) {
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[2][C16 * 32];      // [k_hi | k_lo] rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[2][C16 * 32];      // [v_hi | v_lo] rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Kpm[2][PL * 2 * 16 * 32];   // K planes [part][32-key half][16][32]
-  __shared__ __attribute__((aligned(16))) float biasS[2][C16];
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[DQ_NB][C16 * 32];      // [k_hi | k_lo] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[DQ_NB][C16 * 32];      // [v_hi | v_lo] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short Kpm[DQ_NB][4 * 16 * 32];   // K planes [part][32-key half][16][32]
+  __shared__ unsigned int maskW[MASKW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   constexpr int QW = 64 * QT;
@@ -415,8 +609,13 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
   const int sp = within / tiles_x;
   const size_t bh = (size_t)b * H + h;
   const int qbase = (within - sp * tiles_x) * QW + wave * (16 * QT);
+  const bool any_masked = (kmask != nullptr) || (Sp != S);
+  if (any_masked) {
+    build_key_mask(maskW, kmask, b, S, Sp);
+    __syncthreads();
+  }
 
-  s16x8 qhi[QT], qlo[QT], dod[QT];
+  s16x8 qhi[QT], qlo[QT], dohi[QT], dolo[QT];
   f32x4 cS[QT], cD[QT];                  // accumulator inits: -lse2 (score tiles), -Dn (dP tiles)
   float nd[QT], rs[QT];
   bool active[QT];
@@ -424,17 +623,18 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int q = qbase + u * 16 + li;
-    active[u] = (qbase + u * 16) < Lqp;
+    active[u] = (qbase + u * 16) < Lq;
     any_active = any_active || active[u];
     qhi[u] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    qlo[u] = qhi[u]; dod[u] = qhi[u];
+    qlo[u] = qhi[u]; dohi[u] = qhi[u]; dolo[u] = qhi[u];
     float lse_q = INFINITY, d_q = 0.f;
     rs[u] = 0.f;
     if (active[u]) {
       const unsigned short* qp = Qr + (bh * Lqp + q) * 32;
       qhi[u] = *reinterpret_cast<const s16x8*>(qp + (g & 1) * 8);
       qlo[u] = *reinterpret_cast<const s16x8*>(qp + 16 + (g & 1) * 8);
-      dod[u] = *reinterpret_cast<const s16x8*>(dOr + (bh * Lqp + q) * 16 + (g & 1) * 8);     // [dOn | dOn]
+      dohi[u] = *reinterpret_cast<const s16x8*>(dOr + (bh * Lqp + q) * 32 + (g & 1) * 8);          // [dOn_hi | dOn_hi]
+      dolo[u] = *reinterpret_cast<const s16x8*>(dOr + (bh * Lqp + q) * 32 + 16 + (g & 1) * 8);     // [dOn_lo | dOn_lo]
       if (q < Lq) {
         lse_q = LSE2[bh * Lqp + q];
         if (lse_q == -INFINITY) lse_q = INFINITY;
@@ -442,34 +642,26 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
         rs[u] = ldexpf(1.0f, rexp[bh * Lqp + q]);
       }
     }
-    cS[u] = f32x4{-lse_q, -lse_q, -lse_q, -lse_q};
+    cS[u] = f32x4{B_OFF - lse_q, B_OFF - lse_q, B_OFF - lse_q, B_OFF - lse_q};
+    rs[u] *= 0.015625f;                                     // 2^-B_OFF
     nd[u] = -d_q;
     cD[u] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-d_q, -d_q, -d_q, -d_q};
   }
+#pragma unroll
+  for (int u = 0; u < QT; ++u) { A3D_PIN(qhi[u]); A3D_PIN(qlo[u]); A3D_PIN(dohi[u]); A3D_PIN(dolo[u]); A3D_PIN(cS[u]); A3D_PIN(cD[u]); A3D_PIN(rs[u]); }
   const int nch = Sp / C16;
   const int cps = (nch + nsplit - 1) / nsplit;
   const int c_beg = sp * cps, c_end = min(nch, c_beg + cps);
-  const int krow = t >> 2, kseg = t & 3;
-  const int vplane = t >> 7, vd = (t >> 3) & 15, vseg = t & 7;
-  auto stage_load = [&](int c) {
-    Dq16Stage st;
-    st.k = *reinterpret_cast<const s16x8*>(Kr + (bh * Sp + (size_t)c * C16 + krow) * 32 + kseg * 8);
-    st.v = *reinterpret_cast<const s16x8*>(Vr + (bh * Sp + (size_t)c * C16 + krow) * 32 + kseg * 8);
-    if (vplane < PL) st.kp = *reinterpret_cast<const s16x8*>(Kp + ((bh * PL + vplane) * 16 + vd) * Sp + (size_t)c * C16 + vseg * 8);
-    st.bias = 0.f;
-    if (t < C16) {
-      const int key = c * C16 + t;
-      bool valid = key < S;
-      if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
-      st.bias = valid ? 0.f : -INFINITY;
-    }
-    return st;
-  };
-  auto stage_store = [&](const Dq16Stage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Ksm[buf][tile_off(krow, kseg)]) = st.k;
-    *reinterpret_cast<s16x8*>(&Vsm[buf][tile_off(krow, kseg)]) = st.v;
-    if (vplane < PL) *reinterpret_cast<s16x8*>(&Kpm[buf][((vplane * 2 + (vseg >> 2)) * 16) * 32 + plane_off(vd, vseg & 3)]) = st.kp;
-    if (t < C16) biasS[buf][t] = st.bias;
+
+  // 3 LDS-DMA instructions per wave and chunk: 16 rows of K, 16 rows of V, one (part, half) sub-tile of the K planes
+  const unsigned short* Kbase = Kr + bh * Sp * 32;
+  const unsigned short* Vbase = Vr + bh * Sp * 32;
+  const unsigned short* Pbase = Kp + ((bh * 2 + (wave >> 1)) * 16) * Sp + (wave & 1) * 32;
+  auto issue = [&](int c, int slot) {
+    const int cc = min(c, c_end - 1);
+    dma_rows_tile(Kbase + (size_t)cc * C16 * 32, 32, Ksm[slot], wave, lane);
+    dma_rows_tile(Vbase + (size_t)cc * C16 * 32, 32, Vsm[slot], wave, lane);
+    dma_plane_subtile(Pbase, Sp, (size_t)cc * C16, &Kpm[slot][wave * 512], lane);
   };
 
   int koff[4];
@@ -481,83 +673,87 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
 #pragma unroll
   for (int u = 0; u < QT; ++u) { acc0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[u] = acc0[u]; }
   DropKey dkey = {0u, 0u};
-  if (DROP) dkey = drop_key(drop_state);
+  if (DROP) { dkey = drop_key(drop_state); A3D_PIN(dkey.k0); A3D_PIN(dkey.k1); }
   if (c_beg < c_end) {
-    stage_store(stage_load(c_beg), 0);
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DQ_NB - 1; ++i) issue(c_beg + i, i);
   }
   for (int c = c_beg; c < c_end; ++c) {
-    const int buf = (c - c_beg) & 1;
-    Dq16Stage nxt;
-    const bool has_next = (c + 1 < c_end);
-    if (has_next) nxt = stage_load(c + 1);
-    const bool masked = (kmask != nullptr) || ((c + 1) * C16 > S);
-    if (any_active) {
+    const int slot = (c - c_beg) % DQ_NB;
+    wait_vm<3 * (DQ_NB - 2)>();
+    ring_barrier();
+    issue(c + DQ_NB - 1, (slot + DQ_NB - 1) % DQ_NB);
+    const bool masked = any_masked && ((kmask != nullptr) || ((c + 1) * C16 > S));
+    if (!any_active) continue;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        s16x8 kf[2], vf[2];
+    for (int hf = 0; hf < 2; ++hf) {
+      s16x8 kf[2], vf[2], kp[2];
+#pragma unroll
+      for (int T = 0; T < 2; ++T) {
+        kf[T] = *reinterpret_cast<const s16x8*>(&Ksm[slot][koff[hf * 2 + T]]);
+        vf[T] = *reinterpret_cast<const s16x8*>(&Vsm[slot][koff[hf * 2 + T]]);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) kp[pl] = *reinterpret_cast<const s16x8*>(&Kpm[slot][((pl * 2 + hf) * 16) * 32 + poff]);
+      f32x4 sT[QT][2], dpT[QT][2];
+      if (masked) {
+        const unsigned int word = maskW[c * 2 + hf];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
-          kf[T] = *reinterpret_cast<const s16x8*>(&Ksm[buf][koff[hf * 2 + T]]);
-          vf[T] = *reinterpret_cast<const s16x8*>(&Vsm[buf][koff[hf * 2 + T]]);
+          const f32x4 b4 = bias_of(word, g, T);
+#pragma unroll
+          for (int u = 0; u < QT; ++u) sT[u][T] = mfma_f16(kf[T], qhi[u], cS[u] + b4);
         }
-        s16x8 kp[PL];
-#pragma unroll
-        for (int pl = 0; pl < PL; ++pl) kp[pl] = *reinterpret_cast<const s16x8*>(&Kpm[buf][((pl * 2 + hf) * 16) * 32 + poff]);
-        f32x4 sT[QT][2], dpT[QT][2];
-        if (masked) {
-#pragma unroll
-          for (int T = 0; T < 2; ++T) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&biasS[buf][hf * 32 + g * 8 + T * 4]);
-#pragma unroll
-            for (int u = 0; u < QT; ++u) sT[u][T] = mfma_f16(kf[T], qhi[u], cS[u] + b4);
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < QT; ++u)
-#pragma unroll
-            for (int T = 0; T < 2; ++T) sT[u][T] = mfma_f16(kf[T], qhi[u], cS[u]);
-        }
+      } else {
 #pragma unroll
         for (int u = 0; u < QT; ++u)
 #pragma unroll
-          for (int T = 0; T < 2; ++T) {
-            dpT[u][T] = mfma_f16(vf[T], dod[u], cD[u]);
-            sT[u][T] = mfma_f16(kf[T], qlo[u], sT[u][T]);
-          }
+          for (int T = 0; T < 2; ++T) sT[u][T] = mfma_f16(kf[T], qhi[u], cS[u]);
+      }
 #pragma unroll
-        for (int u = 0; u < QT; ++u) {
-          unsigned int keep = 0xFFu;
-          if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (C16 / 8) + hf * 4 + g), (uint32_t)(qbase + u * 16 + li), (uint32_t)bh, drop_site, drop_thr);
-          unsigned int w[4];
+      for (int u = 0; u < QT; ++u)
 #pragma unroll
-          for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-              const float p0 = __builtin_amdgcn_exp2f(sT[u][T][2 * pr]), p1 = __builtin_amdgcn_exp2f(sT[u][T][2 * pr + 1]);
-              float g0, g1;
-              if (DROP) {
-                const int j = T * 4 + 2 * pr;
-                const float m0 = ((keep >> j) & 1u) ? drop_scale : 0.f, m1 = ((keep >> (j + 1)) & 1u) ? drop_scale : 0.f;
-                g0 = p0 * __builtin_fmaf(m0, dpT[u][T][2 * pr], nd[u]);
-                g1 = p1 * __builtin_fmaf(m1, dpT[u][T][2 * pr + 1], nd[u]);
-              } else {
-                g0 = p0 * dpT[u][T][2 * pr];
-                g1 = p1 * dpT[u][T][2 * pr + 1];
-              }
-              w[T * 2 + pr] = pk_f16(g0, g1);
-            }
-          }
-          const s16x8 gf = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
-          f32x4& acc = hf ? acc1[u] : acc0[u];
-#pragma unroll
-          for (int pl = 0; pl < PL; ++pl) acc = mfma_f16(kp[pl], gf, acc);
+        for (int T = 0; T < 2; ++T) {
+          dpT[u][T] = mfma_f16(vf[T], dohi[u], cD[u]);
+          sT[u][T] = mfma_f16(kf[T], qlo[u], sT[u][T]);
         }
+#pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) dpT[u][T] = mfma_f16(vf[T], dolo[u], dpT[u][T]);
+#pragma unroll
+      for (int u = 0; u < QT; ++u) {
+        unsigned int keep = 0xFFu;
+        if (DROP) keep = drop_keep8(dkey, (uint32_t)(c * (C16 / 8) + hf * 4 + g), (uint32_t)(qbase + u * 16 + li), (uint32_t)bh, drop_site, drop_thr);
+        unsigned int w[4], wl[4];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const float p0 = __builtin_amdgcn_exp2f(sT[u][T][2 * pr]), p1 = __builtin_amdgcn_exp2f(sT[u][T][2 * pr + 1]);
+            float g0, g1;
+            if (DROP) {
+              const int j = T * 4 + 2 * pr;
+              const float m0 = ((keep >> j) & 1u) ? drop_scale : 0.f, m1 = ((keep >> (j + 1)) & 1u) ? drop_scale : 0.f;
+              g0 = p0 * __builtin_fmaf(m0, dpT[u][T][2 * pr], nd[u]);
+              g1 = p1 * __builtin_fmaf(m1, dpT[u][T][2 * pr + 1], nd[u]);
+            } else {
+              g0 = p0 * dpT[u][T][2 * pr];
+              g1 = p1 * dpT[u][T][2 * pr + 1];
+            }
+            if (GP == 2) pk_f16_2(g0, g1, w[T * 2 + pr], wl[T * 2 + pr]);
+            else w[T * 2 + pr] = pk_f16(g0, g1);
+          }
+        }
+        const s16x8 gf = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
+        f32x4& acc = hf ? acc1[u] : acc0[u];
+        acc = mfma_f16(kp[0], gf, acc);
+        acc = mfma_f16(kp[1], gf, acc);
+        if (GP == 2) acc = mfma_f16(kp[0], __builtin_bit_cast(s16x8, (u32x4_){wl[0], wl[1], wl[2], wl[3]}), acc);
       }
     }
-    if (has_next) stage_store(nxt, buf ^ 1);
-    __syncthreads();
   }
+  wait_vm<0>();
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     if (!active[u]) continue;
@@ -570,29 +766,23 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-struct Dkv16Stage {
-  s16x8 q, o, qp, op;
-  float nl, nd;
-};
-
-// A workgroup owns 64 KT keys of one (b, h) and walks the queries in 64-row chunks.  With E_bh = max_q e_q:
-//   P'[q, k] = 2^(s2 - lse2 + e_q - E_bh)  (<= 1),  G' = P' o (dPn - Dn)
-//   dV = log2(e) 2^E_bh sum_q P'[q, k] dOn[q],   dK = 2^E_bh sum_q G'[q, k] Q2[q]
-// PL: parts of the Q planes contracted with G' (as for K in the dQ kernel)
-template <int KT, int PL>
+// A workgroup owns 64 KT keys of one (b, h) and walks the query rows in the SORTED order of the prep kernel's packs, 64 per
+// chunk.  With E_c the largest row exponent of chunk c:
+//   P'[q, k] = 2^(B_OFF + s2 - lse2 + e_q - E_c),  G' = P' o (dPn - Dn)
+//   dV += 2^E_c sum_{q in c} P'[q, k] dOn[q],   dK += 2^E_c sum_{q in c} G'[q, k] Q2[q]
+// the accumulators are kept in units of 2^E_c and rescaled (exactly, by a power of two) when E_c drops.  P' and G' go into
+// the dV / dK MFMAs as split bf16 (range: see the prep kernel) in both modes (GP only selects the dQ kernel's variant).
+// DROP: a lane of this kernel holds ONE key and 8 consecutive rows, the transpose of the (query, 8-key block) unit the Philox
+// counters are defined on; the keep bits of a chunk are generated cooperatively into LDS from the ORIGINAL row indices.
+constexpr int DKV_NB = 2;
+template <bool DROP, int KT, int GP>
 __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
-    const unsigned short* __restrict__ Qr, const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kr,
-    const unsigned short* __restrict__ Vr, const unsigned char* __restrict__ kmask, const unsigned short* __restrict__ dOr,
-    const unsigned short* __restrict__ dOp, const float* __restrict__ LSE2, const float* __restrict__ D,
-    const int* __restrict__ rexp, float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S,
-    int Sp) {
-  __shared__ __attribute__((aligned(16))) unsigned short Qsm[2][C16 * 32];      // [q_hi | q_lo] rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Osm[2][C16 * 32];      // [dOn | dOn]   rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Qpm[2][PL * 2 * 16 * 32];   // Q planes [part][32-query half][16][32]
-  __shared__ __attribute__((aligned(16))) unsigned short Opm[2][2 * 16 * 32];   // dOn plane
-  __shared__ __attribute__((aligned(16))) float nlS[2][C16];
-  __shared__ __attribute__((aligned(16))) float ndS[2][C16];
-  __shared__ int emaxS[4];
+    const unsigned short* __restrict__ pack, const unsigned short* __restrict__ Kr, const unsigned short* __restrict__ Vr,
+    const unsigned char* __restrict__ kmask, float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lqp, int S,
+    int Sp, const unsigned long long* __restrict__ drop_state, unsigned int drop_site, unsigned int drop_thr,
+    float drop_scale) {
+  __shared__ __attribute__((aligned(16))) unsigned short pk[DKV_NB][PK_HALFS];
+  __shared__ __attribute__((aligned(16))) unsigned char maskS[2][DROP ? 8 * KT * C16 : 16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   constexpr int KW = 64 * KT;
@@ -601,32 +791,22 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
   const int b = group / H, h = group - b * H;
   const size_t bh = (size_t)b * H + h;
 
-  // E_bh = max_q e_q over the (b, h)'s query rows
-  {
-    int e = -100;
-    for (int q = t; q < Lq; q += 256) e = max(e, rexp[bh * Lqp + q]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) e = max(e, __shfl_xor(e, o, 64));
-    if (lane == 0) emaxS[wave] = e;
-  }
-  __syncthreads();
-  const int emax = max(max(emaxS[0], emaxS[1]), max(emaxS[2], emaxS[3]));
-
-  s16x8 khh[KT], kll[KT], vB[KT];
+  s16x8 khh[KT], kll[KT], vhh[KT], vll[KT];
   f32x4 bias4[KT];
   int key[KT];
 #pragma unroll
   for (int u = 0; u < KT; ++u) {
     key[u] = within * KW + (wave * KT + u) * 16 + li;
     khh[u] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    kll[u] = khh[u]; vB[u] = khh[u];
+    kll[u] = khh[u]; vhh[u] = khh[u]; vll[u] = khh[u];
     bool valid = false;
     if (key[u] < Sp) {
       const unsigned short* kp = Kr + (bh * Sp + key[u]) * 32;
       const unsigned short* vp = Vr + (bh * Sp + key[u]) * 32;
       khh[u] = *reinterpret_cast<const s16x8*>(kp + (g & 1) * 8);               // B = [k_hi | k_hi]
       kll[u] = *reinterpret_cast<const s16x8*>(kp + 16 + (g & 1) * 8);          // B = [k_lo | k_lo]
-      vB[u] = *reinterpret_cast<const s16x8*>(vp + g * 8);                      // B = [v_hi | v_lo] against A = [dOn | dOn]
+      vhh[u] = *reinterpret_cast<const s16x8*>(vp + (g & 1) * 8);               // B = [v_hi | v_hi] against A = [dOn_hi | dOn_lo]
+      vll[u] = *reinterpret_cast<const s16x8*>(vp + 16 + (g & 1) * 8);          // B = [v_lo | v_lo]
       valid = key[u] < S;
       if (valid && kmask) valid = kmask[(size_t)b * S + key[u]] == 0;
     }
@@ -634,35 +814,19 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
     bias4[u] = f32x4{bias_k, bias_k, bias_k, bias_k};
   }
   const bool masked = (kmask != nullptr) || (within * KW + KW > S);           // workgroup-uniform
+  DropKey dkey = {0u, 0u};
+  if (DROP) dkey = drop_key(drop_state);
+#pragma unroll
+  for (int u = 0; u < KT; ++u) { A3D_PIN(khh[u]); A3D_PIN(kll[u]); A3D_PIN(vhh[u]); A3D_PIN(vll[u]); A3D_PIN(bias4[u]); }
+  if (DROP) { A3D_PIN(dkey.k0); A3D_PIN(dkey.k1); }
 
-  const int qrow = t >> 2, qseg = t & 3;
-  const int pplane = t >> 7, pd = (t >> 3) & 15, pseg = t & 7;
-  auto stage_load = [&](int c) {
-    Dkv16Stage st;
-    st.q = *reinterpret_cast<const s16x8*>(Qr + (bh * Lqp + (size_t)c * C16 + qrow) * 32 + qseg * 8);
-    st.o = *reinterpret_cast<const s16x8*>(dOr + (bh * Lqp + (size_t)c * C16 + qrow) * 16 + (qseg & 1) * 8);
-    if (pplane < PL) st.qp = *reinterpret_cast<const s16x8*>(Qp + ((bh * PL + pplane) * 16 + pd) * Lqp + (size_t)c * C16 + pseg * 8);
-    // the dOn plane is staged by the upper half of the workgroup (PL = 1: the half that has no Q plane to fetch)
-    if (t >= 128) st.op = *reinterpret_cast<const s16x8*>(dOp + (bh * 16 + pd) * Lqp + (size_t)c * C16 + pseg * 8);
-    st.nl = -INFINITY;
-    st.nd = 0.f;
-    if (t < C16) {
-      const int qq = c * C16 + t;
-      if (qq < Lq) {
-        const float l = LSE2[bh * Lqp + qq];
-        if (l != -INFINITY) st.nl = (float)(rexp[bh * Lqp + qq] - emax) - l;
-        st.nd = -D[bh * Lqp + qq];
-      }
-    }
-    return st;
-  };
-  auto stage_store = [&](const Dkv16Stage& st, int buf) {
-    *reinterpret_cast<s16x8*>(&Qsm[buf][tile_off(qrow, qseg)]) = st.q;
-    *reinterpret_cast<s16x8*>(&Osm[buf][tile_off(qrow, qseg)]) = st.o;
-    const int po = (pseg >> 2) * 16 * 32 + plane_off(pd, pseg & 3);
-    if (pplane < PL) *reinterpret_cast<s16x8*>(&Qpm[buf][pplane * 2 * 16 * 32 + po]) = st.qp;
-    if (t >= 128) *reinterpret_cast<s16x8*>(&Opm[buf][po]) = st.op;
-    if (t < C16) { nlS[buf][t] = st.nl; ndS[buf][t] = st.nd; }
+  // 5 LDS-DMA instructions per wave and chunk: the pack is the LDS image, wave w copies its 5 KB quarter
+  const int nch = Lqp / C16;
+  const unsigned short* pbase = pack + bh * nch * (size_t)PK_HALFS + wave * 2560 + lane * 8;
+  auto issue = [&](int c, int slot) {
+    const unsigned short* src = pbase + (size_t)min(c, nch - 1) * PK_HALFS;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) glds16(src + i * 512, &pk[slot][wave * 2560 + i * 512]);
   };
 
   int qoff[4];
@@ -673,29 +837,52 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
   f32x4 dk0[KT], dk1[KT], dv0[KT], dv1[KT];
 #pragma unroll
   for (int u = 0; u < KT; ++u) { dk0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dk1[u] = dk0[u]; dv0[u] = dk0[u]; dv1[u] = dk0[u]; }
-  const int nch = Lqp / C16;
-  stage_store(stage_load(0), 0);
-  __syncthreads();
+  int e_ref = -1000;                                  // exponent unit of the accumulators
+#pragma unroll
+  for (int i = 0; i < DKV_NB - 1; ++i) issue(i, i);
   for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    Dkv16Stage nxt;
-    const bool has_next = (c + 1 < nch);
-    if (has_next) nxt = stage_load(c + 1);
+    const int slot = c % DKV_NB;
+    wait_vm<5 * (DKV_NB - 2)>();
+    ring_barrier();
+    issue(c + DKV_NB - 1, (slot + DKV_NB - 1) % DKV_NB);
+    const unsigned short* P = pk[slot];
+    const int e_c = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(P + PK_HDR));
+    if (e_c <= -1000) continue;                       // nothing but padding / dropped rows from here on (sorted)
+    if (e_c != e_ref) {
+      if (e_ref > -1000) {
+        const float f = ldexpf(1.0f, min(e_ref - e_c, 126));
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { dk0[u][r] *= f; dk1[u][r] *= f; dv0[u][r] *= f; dv1[u][r] *= f; }
+      }
+      e_ref = e_c;
+    }
+    if (DROP) {
+      // keep bits of chunk c: maskS[c & 1][key block][row] bytes (bit j = key j of the block), 2 KT Philox calls per thread
+      const unsigned int q_orig = (unsigned int)reinterpret_cast<const int*>(P + PK_PERM)[t & 63];
+#pragma unroll
+      for (int i = 0; i < 2 * KT; ++i)
+        maskS[c & 1][((t >> 6) + 4 * i) * C16 + (t & 63)] =
+            (unsigned char)drop_keep8(dkey, (uint32_t)(within * (8 * KT) + (t >> 6) + 4 * i), q_orig, (uint32_t)bh, drop_site, drop_thr);
+      ring_barrier();
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      s16x8 qf[2], of[2];
+      s16x8 qf[2], of[2], qtp[2], otp[2];
       f32x4 nl4[2], nd4[2];
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
-        qf[T] = *reinterpret_cast<const s16x8*>(&Qsm[buf][qoff[hf * 2 + T]]);
-        of[T] = *reinterpret_cast<const s16x8*>(&Osm[buf][qoff[hf * 2 + T]]);
-        nl4[T] = *reinterpret_cast<const f32x4*>(&nlS[buf][hf * 32 + g * 8 + T * 4]);
-        nd4[T] = *reinterpret_cast<const f32x4*>(&ndS[buf][hf * 32 + g * 8 + T * 4]);
+        qf[T] = *reinterpret_cast<const s16x8*>(P + PK_QROWS + qoff[hf * 2 + T]);
+        of[T] = *reinterpret_cast<const s16x8*>(P + PK_OROWS + qoff[hf * 2 + T]);
+        nl4[T] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(P + PK_NL) + hf * 32 + g * 8 + T * 4);
+        nd4[T] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(P + PK_ND) + hf * 32 + g * 8 + T * 4);
       }
-      const s16x8 otp = *reinterpret_cast<const s16x8*>(&Opm[buf][hf * 16 * 32 + poff]);
-      s16x8 qtp[PL];
 #pragma unroll
-      for (int pl = 0; pl < PL; ++pl) qtp[pl] = *reinterpret_cast<const s16x8*>(&Qpm[buf][((pl * 2 + hf) * 16) * 32 + poff]);
+      for (int pl = 0; pl < 2; ++pl) {
+        qtp[pl] = *reinterpret_cast<const s16x8*>(P + PK_QPL + ((pl * 2 + hf) * 16) * 32 + poff);
+        otp[pl] = *reinterpret_cast<const s16x8*>(P + PK_OPL + ((pl * 2 + hf) * 16) * 32 + poff);
+      }
       f32x4 s[KT][2], dp[KT][2];
       if (masked) {
 #pragma unroll
@@ -712,34 +899,55 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
       for (int u = 0; u < KT; ++u)
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
-          dp[u][T] = mfma_f16(of[T], vB[u], nd4[T]);
+          dp[u][T] = mfma_f16(of[T], vhh[u], DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd4[T]);
           s[u][T] = mfma_f16(qf[T], kll[u], s[u][T]);
         }
 #pragma unroll
+      for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) dp[u][T] = mfma_f16(of[T], vll[u], dp[u][T]);
+#pragma unroll
       for (int u = 0; u < KT; ++u) {
-        unsigned int pw[4], gw[4];
+        unsigned long long keep8 = 0;      // byte j: keep flags of row hf * 32 + g * 8 + j for this tile's key block
+        if (DROP) keep8 = *reinterpret_cast<const unsigned long long*>(&maskS[c & 1][((wave * KT + u) * 2 + (li >> 3)) * C16 + hf * 32 + g * 8]);
+        unsigned int pw[4], pl_[4], gw[4], gl[4];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            const float p0 = __builtin_amdgcn_exp2f(s[u][T][2 * pr]), p1 = __builtin_amdgcn_exp2f(s[u][T][2 * pr + 1]);
-            pw[T * 2 + pr] = pk_f16(p0, p1);
-            gw[T * 2 + pr] = pk_f16(p0 * dp[u][T][2 * pr], p1 * dp[u][T][2 * pr + 1]);
+            float p0 = __builtin_amdgcn_exp2f(s[u][T][2 * pr]), p1 = __builtin_amdgcn_exp2f(s[u][T][2 * pr + 1]);
+            float g0, g1;
+            if (DROP) {
+              const int j = T * 4 + 2 * pr;
+              const float m0 = ((keep8 >> (8 * j + (li & 7))) & 1ull) ? drop_scale : 0.f;
+              const float m1 = ((keep8 >> (8 * (j + 1) + (li & 7))) & 1ull) ? drop_scale : 0.f;
+              g0 = p0 * __builtin_fmaf(m0, dp[u][T][2 * pr], nd4[T][2 * pr]);
+              g1 = p1 * __builtin_fmaf(m1, dp[u][T][2 * pr + 1], nd4[T][2 * pr + 1]);
+              p0 *= m0;                                  // dV sees the dropped weights
+              p1 *= m1;
+            } else {
+              g0 = p0 * dp[u][T][2 * pr];
+              g1 = p1 * dp[u][T][2 * pr + 1];
+            }
+            pk_bf16_2(p0, p1, pw[T * 2 + pr], pl_[T * 2 + pr]);
+            pk_bf16_2(g0, g1, gw[T * 2 + pr], gl[T * 2 + pr]);
           }
         }
         const s16x8 pf = __builtin_bit_cast(s16x8, (u32x4_){pw[0], pw[1], pw[2], pw[3]});
         const s16x8 gf = __builtin_bit_cast(s16x8, (u32x4_){gw[0], gw[1], gw[2], gw[3]});
         f32x4& dv = hf ? dv1[u] : dv0[u];
         f32x4& dk = hf ? dk1[u] : dk0[u];
-        dv = mfma_f16(otp, pf, dv);
-#pragma unroll
-        for (int pl = 0; pl < PL; ++pl) dk = mfma_f16(qtp[pl], gf, dk);
+        dv = mfma_bf16_16x16x32(otp[0], pf, dv);
+        dk = mfma_bf16_16x16x32(qtp[0], gf, dk);
+        dv = mfma_bf16_16x16x32(otp[1], pf, dv);
+        dk = mfma_bf16_16x16x32(qtp[1], gf, dk);
+        dv = mfma_bf16_16x16x32(otp[0], __builtin_bit_cast(s16x8, (u32x4_){pl_[0], pl_[1], pl_[2], pl_[3]}), dv);
+        dk = mfma_bf16_16x16x32(qtp[0], __builtin_bit_cast(s16x8, (u32x4_){gl[0], gl[1], gl[2], gl[3]}), dk);
       }
     }
-    if (has_next) stage_store(nxt, buf ^ 1);
-    __syncthreads();
   }
-  const float sk = ldexpf(1.0f, emax), sv = sk * LOG2E_F;
+  wait_vm<0>();
+  const float sk = (e_ref > -1000) ? ldexpf(1.0f, e_ref - (int)B_OFF) : 0.f, sv = sk * LOG2E_F;
 #pragma unroll
   for (int u = 0; u < KT; ++u) {
     if (key[u] >= Sp) continue;
@@ -757,9 +965,9 @@ using namespace a3d;
 
 static int check16(const char* fn, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, int qmod) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lqp < Lq || (Lqp % qmod) != 0 || S <= 0 || Sp < S || (Sp % C16) != 0 || nsplit < 1 ||
-      nsplit > 64) {
-    set_error("%s: bad argument (B=%d H=%d Lq=%d Lqp=%d S=%d Sp=%d nsplit=%d; need Lqp %% %d == 0, Sp %% 64 == 0)", fn, B, H,
-              Lq, Lqp, S, Sp, nsplit, qmod);
+      nsplit > 64 || Sp > MASKW * 32) {
+    set_error("%s: bad argument (B=%d H=%d Lq=%d Lqp=%d S=%d Sp=%d nsplit=%d; need Lqp %% %d == 0, Sp %% 64 == 0, Sp <= %d)", fn,
+              B, H, Lq, Lqp, S, Sp, nsplit, qmod, MASKW * 32);
     return A3D_ERR_ARG;
   }
   return A3D_OK;
@@ -795,17 +1003,21 @@ extern "C" int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, co
   const int QT = qt_env ? qt_env : (Lq > 64 ? 2 : 1);
   dim3 grid(xcd_grid(B * H, cdiv(Lqp, 64 * QT) * nsplit));
   const unsigned long long* nostate = nullptr;
-#define A3D_L16F(DROPV, QTV, ST, SITE, THR, SC)                                                                          \
-  hipLaunchKernelGGL((attn16_fwd_kernel<DROPV, QTV>), grid, dim3(256), 0, s, (const unsigned short*)Qr,                 \
+  static const bool fast = getenv("A3D_ATTN_FAST") && atoi(getenv("A3D_ATTN_FAST")) != 0;     // single-fp16 P in the forward
+#define A3D_L16F(DROPV, QTV, PPV, ST, SITE, THR, SC)                                                                     \
+  hipLaunchKernelGGL((attn16_fwd_kernel<DROPV, QTV, PPV>), grid, dim3(256), 0, s, (const unsigned short*)Qr,            \
                      (const unsigned short*)Kr, (const unsigned short*)Vp, kmask, O, LSE2, Op, Mp, Lp, B, H, Lq, Lqp, S, \
                      Sp, nsplit, ST, SITE, THR, SC)
+#define A3D_L16F_PP(DROPV, QTV, ST, SITE, THR, SC)                                                                       \
+  do { if (fast) A3D_L16F(DROPV, QTV, 1, ST, SITE, THR, SC); else A3D_L16F(DROPV, QTV, 2, ST, SITE, THR, SC); } while (0)
   if (drop) {
-    if (QT == 2) A3D_L16F(true, 2, drop_state, drop_site, thr, dscale);
-    else A3D_L16F(true, 1, drop_state, drop_site, thr, dscale);
+    if (QT == 2) A3D_L16F_PP(true, 2, drop_state, drop_site, thr, dscale);
+    else A3D_L16F_PP(true, 1, drop_state, drop_site, thr, dscale);
   } else {
-    if (QT == 2) A3D_L16F(false, 2, nostate, 0u, 0u, 1.0f);
-    else A3D_L16F(false, 1, nostate, 0u, 0u, 1.0f);
+    if (QT == 2) A3D_L16F_PP(false, 2, nostate, 0u, 0u, 1.0f);
+    else A3D_L16F_PP(false, 1, nostate, 0u, 0u, 1.0f);
   }
+#undef A3D_L16F_PP
 #undef A3D_L16F
   rc = check_launch("a3d_attn16_fwd");
   if (rc) return rc;
@@ -817,32 +1029,36 @@ extern "C" int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, co
   return rc;
 }
 
-extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* Kp, int plane_parts, const void* Vr,
+extern "C" size_t a3d_attn16_bwd_pack_bytes(int B, int H, int Lqp) {
+  return (size_t)B * H * (Lqp / C16) * PK_HALFS * sizeof(unsigned short);
+}
+
+extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* Kp, const void* Vr,
                               const unsigned char* kmask, const float* O, const float* dO, const float* LSE2, void* dOr,
-                              void* dOp, float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq,
+                              void* pack, float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq,
                               int Lqp, int S, int Sp, int nsplit, const unsigned long long* drop_state,
                               unsigned int drop_site, float drop_p, void* stream) {
   int rc = check16("a3d_attn16_bwd", B, H, Lq, Lqp, S, Sp, nsplit, 64);
   if (rc) return rc;
-  if (!Qr || !Qp || !Kr || !Kp || !Vr || !O || !dO || !LSE2 || !dOr || !dOp || !D || !rexp || !dQp || !dK || !dV) {
+  if (!Qr || !Qp || !Kr || !Kp || !Vr || !O || !dO || !LSE2 || !dOr || !pack || !D || !rexp || !dQp || !dK || !dV) {
     set_error("a3d_attn16_bwd: null pointer");
     return A3D_ERR_ARG;
   }
   bool drop; unsigned int thr; float dscale;
   rc = drop_params("a3d_attn16_bwd", drop_state, drop_p, drop, thr, dscale);
   if (rc) return rc;
-  if (drop) { set_error("a3d_attn16_bwd: attention-weight dropout is not implemented in the fp16 backward"); return A3D_ERR_ARG; }
-  if (plane_parts != 1 && plane_parts != 2) { set_error("a3d_attn16_bwd: plane_parts must be 1 or 2, got %d", plane_parts); return A3D_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  const int E = H * HD;
-  const size_t lds = (size_t)2 * 64 * (E + 1) * sizeof(float);
+  int Lsort = 64;
+  while (Lsort < Lqp) Lsort <<= 1;
+  const size_t lds = (size_t)Lsort * 8 + (size_t)Lqp * 4 + 2 * 64 * 64;
+  if (lds > 150 * 1024) { set_error("a3d_attn16_bwd: Lqp = %d too large for the per-(b, h) row sort", Lqp); return A3D_ERR_ARG; }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn16_bwd_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn16_bwd_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn16_bwd_prep_kernel, dim3(Lqp / 64, B), dim3(256), lds, s, dO, O, (unsigned short*)dOr,
-                     (unsigned short*)dOp, D, rexp, B, H, Lq, Lqp);
+  hipLaunchKernelGGL(attn16_bwd_prep_kernel, dim3(B * H), dim3(256), lds, s, dO, O, LSE2, (const unsigned short*)Qr,
+                     (unsigned short*)dOr, D, rexp, (unsigned short*)pack, B, H, Lq, Lqp, Lsort);
   rc = check_launch("a3d_attn16_bwd(prep)");
   if (rc) return rc;
   static const int qt_env = getenv("A3D_ATTN_QT") ? atoi(getenv("A3D_ATTN_QT")) : 0;
@@ -850,21 +1066,38 @@ extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, co
   const int KT = qt_env ? qt_env : (((size_t)B * H * (Sp / 128) >= 1024 && Lq > 16) ? 2 : 1);
   const dim3 gq(xcd_grid(B * H, cdiv(Lqp, 64 * QT) * nsplit)), gk(xcd_grid(B * H, cdiv(Sp, 64 * KT)));
   const unsigned long long* nostate = nullptr;
-#define A3D_L16Q(QTV, PLV)                                                                                                \
-  hipLaunchKernelGGL((attn16_bwd_dq_kernel<false, QTV, PLV>), gq, dim3(256), 0, s, (const unsigned short*)Qr,            \
+  static const bool fast = getenv("A3D_ATTN_FAST") && atoi(getenv("A3D_ATTN_FAST")) != 0;     // single-fp16 G
+#define A3D_L16Q_(DROPV, QTV, GPV, ST, SITE, THR, SC)                                                                     \
+  hipLaunchKernelGGL((attn16_bwd_dq_kernel<DROPV, QTV, GPV>), gq, dim3(256), 0, s, (const unsigned short*)Qr,            \
                      (const unsigned short*)Kr, (const unsigned short*)Kp, (const unsigned short*)Vr, kmask,              \
-                     (const unsigned short*)dOr, LSE2, D, rexp, dQp, B, H, Lq, Lqp, S, Sp, nsplit, nostate, 0u, 0u, 1.0f)
-#define A3D_L16K(KTV, PLV)                                                                                                \
-  hipLaunchKernelGGL((attn16_bwd_dkv_kernel<KTV, PLV>), gk, dim3(256), 0, s, (const unsigned short*)Qr,                  \
-                     (const unsigned short*)Qp, (const unsigned short*)Kr, (const unsigned short*)Vr, kmask,              \
-                     (const unsigned short*)dOr, (const unsigned short*)dOp, LSE2, D, rexp, dK, dV, B, H, Lq, Lqp, S, Sp)
-  if (plane_parts == 2) { if (QT == 2) A3D_L16Q(2, 2); else A3D_L16Q(1, 2); }
-  else { if (QT == 2) A3D_L16Q(2, 1); else A3D_L16Q(1, 1); }
+                     (const unsigned short*)dOr, LSE2, D, rexp, dQp, B, H, Lq, Lqp, S, Sp, nsplit, ST, SITE, THR, SC)
+#define A3D_L16K_(DROPV, KTV, GPV, ST, SITE, THR, SC)                                                                     \
+  hipLaunchKernelGGL((attn16_bwd_dkv_kernel<DROPV, KTV, GPV>), gk, dim3(256), 0, s, (const unsigned short*)pack,         \
+                     (const unsigned short*)Kr, (const unsigned short*)Vr, kmask, dK, dV, B, H, Lqp, S, Sp, ST, SITE,    \
+                     THR, SC)
+#define A3D_L16Q(DROPV, QTV, ST, SITE, THR, SC) \
+  do { if (fast) A3D_L16Q_(DROPV, QTV, 1, ST, SITE, THR, SC); else A3D_L16Q_(DROPV, QTV, 2, ST, SITE, THR, SC); } while (0)
+#define A3D_L16K(DROPV, KTV, ST, SITE, THR, SC) \
+  do { if (fast) A3D_L16K_(DROPV, KTV, 1, ST, SITE, THR, SC); else A3D_L16K_(DROPV, KTV, 2, ST, SITE, THR, SC); } while (0)
+  if (drop) {
+    if (QT == 2) A3D_L16Q(true, 2, drop_state, drop_site, thr, dscale);
+    else A3D_L16Q(true, 1, drop_state, drop_site, thr, dscale);
+  } else {
+    if (QT == 2) A3D_L16Q(false, 2, nostate, 0u, 0u, 1.0f);
+    else A3D_L16Q(false, 1, nostate, 0u, 0u, 1.0f);
+  }
   rc = check_launch("a3d_attn16_bwd(dq)");
   if (rc) return rc;
-  if (plane_parts == 2) { if (KT == 2) A3D_L16K(2, 2); else A3D_L16K(1, 2); }
-  else { if (KT == 2) A3D_L16K(2, 1); else A3D_L16K(1, 1); }
+  if (drop) {
+    if (KT == 2) A3D_L16K(true, 2, drop_state, drop_site, thr, dscale);
+    else A3D_L16K(true, 1, drop_state, drop_site, thr, dscale);
+  } else {
+    if (KT == 2) A3D_L16K(false, 2, nostate, 0u, 0u, 1.0f);
+    else A3D_L16K(false, 1, nostate, 0u, 0u, 1.0f);
+  }
 #undef A3D_L16Q
 #undef A3D_L16K
+#undef A3D_L16Q_
+#undef A3D_L16K_
   return check_launch("a3d_attn16_bwd(dkv)");
 }

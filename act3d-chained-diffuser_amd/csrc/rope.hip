@@ -136,6 +136,10 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
     }
   }
   if (planes_out) {
+    // plane_parts: 1 or 2 planes (hi [, lo]); + 4: the padded channel 15 of the hi plane is written as 1.0 -- the value planes
+    // of the forward, whose PV MFMA then accumulates the softmax denominator in output channel 15 (attention16.hip)
+    const int parts = plane_parts & 3;
+    const bool ones = (plane_parts & 4) != 0;
     for (int idx = threadIdx.x; idx < H * 16 * 8; idx += blockDim.x) {
       const int seg = idx & 7;
       const int d = (idx >> 3) & 15;
@@ -143,14 +147,14 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
       s16x8 o, o2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = (d < HD) ? T[(seg * 8 + j) * ldt + h * HD + d] : 0.f;
+        const float v = (d < HD) ? T[(seg * 8 + j) * ldt + h * HD + d] : ((ones && d == HD) ? 1.0f : 0.f);
         const unsigned short hi = f2h(v);
         o[j] = (short)hi;
         o2[j] = (short)f2h(v - h2f(hi));
       }
-      unsigned short* dst = planes_out + ((((size_t)b * H + h) * plane_parts) * 16 + d) * Npad + n0 + seg * 8;
+      unsigned short* dst = planes_out + ((((size_t)b * H + h) * parts) * 16 + d) * Npad + n0 + seg * 8;
       *reinterpret_cast<s16x8*>(dst) = o;
-      if (plane_parts == 2) *reinterpret_cast<s16x8*>(dst + (size_t)16 * Npad) = o2;
+      if (parts == 2) *reinterpret_cast<s16x8*>(dst + (size_t)16 * Npad) = o2;
     }
   }
 }
@@ -329,8 +333,8 @@ static int rope_split_launch(const char* fn, const float* Y, int ldy, const floa
                              int fmt16, void* stream) {
   int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
-  if (fmt16 ? (rows_width != 1 && rows_width != 2) : (rows_out && rows_width != VRW && rows_width != QKW)) {
-    set_error(fmt16 ? "%s: plane parts must be 1 or 2, got %d" : "%s: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", fn,
+  if (fmt16 ? ((rows_width & 3) != 1 && (rows_width & 3) != 2) || (rows_width & ~7) : (rows_out && rows_width != VRW && rows_width != QKW)) {
+    set_error(fmt16 ? "%s: plane parts must be 1 or 2 (+ 4: ones channel), got %d" : "%s: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", fn,
               rows_width);
     return A3D_ERR_ARG;
   }
@@ -387,8 +391,9 @@ static int proj_rope_split_launch(const char* fn, const float* X, int ldx, const
   int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
   const bool two = rows1 || planes1;
-  const bool w0_ok = fmt16 ? (rows0_width == 1 || rows0_width == 2) : (!rows0 || rows0_width == VRW || rows0_width == QKW);
-  const bool w1_ok = fmt16 ? (!two || rows1_width == 1 || rows1_width == 2) : (!rows1 || rows1_width == VRW || rows1_width == QKW);
+  auto parts_ok = [](int p) { return ((p & 3) == 1 || (p & 3) == 2) && !(p & ~7); };
+  const bool w0_ok = fmt16 ? parts_ok(rows0_width) : (!rows0 || rows0_width == VRW || rows0_width == QKW);
+  const bool w1_ok = fmt16 ? (!two || parts_ok(rows1_width)) : (!rows1 || rows1_width == VRW || rows1_width == QKW);
   if (!X || !W || K <= 0 || (K & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || E > 128 ||
       (!rows0 && !planes0) || ((xyz0 || xyz1) && !freq) || !w0_ok || !w1_ok) {
     set_error("%s: bad argument (K=%d ldx=%d must be multiples of 4, X 16-byte aligned, E=%d <= 128, %s)", fn, K, ldx, E,

@@ -1,7 +1,8 @@
 """Data plane: episode files -> collated device batches.
 
-Mirrors `datasets/dataset_engine.py:14-258` (RLBenchDataset), `datasets/utils.py` (loader, Resize, Rotate,
-TrajectoryInterpolator) and the collate functions of `main_keypose.py:284-292` / `main_trajectory.py:277-292`, re-cut for
+Provides what `datasets/dataset_engine.py:14-258` (RLBenchDataset), `datasets/utils.py` (loader, Resize, Rotate,
+TrajectoryInterpolator) and the collate functions of `main_keypose.py:284-292` / `main_trajectory.py:277-292` provide --
+same constructor keywords, item keys and generator consumption (pinned by tests/golden/dataset.pt) -- organised for
 the MI355X: DataLoader workers only decode (pickle / blosc) and slice the episode; the per-pixel work -- the `Resize`
 augmentation (nearest resize by a random scale, reflect pad, random crop, shared between RGB and XYZ) -- is ONE gather
 kernel over the whole collated batch after the pinned host->device copy (`a3d_resize_crop`), issued on a copy stream
@@ -12,10 +13,10 @@ import itertools
 import math
 import pickle
 import random
-from collections import Counter, defaultdict
+from collections import Counter, OrderedDict
 from pathlib import Path
 from pickle import UnpicklingError
-from time import time
+from typing import NamedTuple, Optional
 
 import numpy as np
 import torch
@@ -105,163 +106,202 @@ class TrajectoryInterpolator:
         return out
 
 
+# ------------------------------------------------------------------------------------------------ the dataset
+# Design: three small pieces instead of one class that does everything in __getitem__ --
+#   EpisodeIndex  which (task, variation, file) triples exist, built once (the only place that touches the directory tree);
+#   EpisodeStore  file -> decoded episode, with a bounded least-recently-used cache;
+#   draw_plan     ALL random decisions of one item (which chunk of keyframes, which instruction, the Resize draws) in one
+#                 function, consuming python's / numpy's / torch's generators exactly as the reference's __getitem__ does
+#                 (datasets/dataset_engine.py:153-216), so seeded runs pick the same chunks, instructions and crops;
+#   EpisodeView   tensors of a set of keyframes, sliced out of the decoded episode by the plan.
+# On-disk episode (data_preprocessing/data_gen.py:122-132), indexed by frame id:
+#   [0] frame ids  [1] observations (n_cam, 2 = rgb | xyz, 3, H, W)  [2] actions (1, 8)  [3] camera dicts
+#   [4] gripper poses (1, 8)  [5] low-level trajectories (N_i, 8)
+class EpisodeRef(NamedTuple):
+    task: str
+    variation: int
+    path: Path
+
+
+class EpisodeIndex:
+    """The episodes a dataset draws from.  Selection rule of the reference (dataset_engine.py:84-117): per (task, variation)
+    folder the files in glob order (*.npy, then *.dat, then *.pkl), truncated to an equal share of `max_per_task` per
+    variation (+ 1); then, per task, a `random.sample` down to `max_per_task` if still above it."""
+
+    PATTERNS = ("*.npy", "*.dat", "*.pkl")
+
+    def __init__(self, roots, taskvar, max_per_task):
+        folders = [(task, var, Path(root).expanduser() / f"{task}+{var}") for root, (task, var) in itertools.product(roots, taskvar)]
+        self.present = [(task, var, d) for task, var, d in folders if d.is_dir()]
+        for task, var, d in folders:
+            if not d.is_dir():
+                print(f"[dataset] no folder {d}")
+        self.variations_per_task = Counter(task for task, _, _ in self.present)
+        per_task = {}
+        self.folders = []
+        for task, var, d in self.present:
+            refs = [EpisodeRef(task, var, f) for pattern in self.PATTERNS for f in d.glob(pattern)]
+            if max_per_task > -1:
+                refs = refs[:max_per_task // self.variations_per_task[task] + 1]
+            if refs:
+                self.folders.append(d)
+                per_task.setdefault(task, []).extend(refs)
+            else:
+                print(f"[dataset] no episodes in {d}")
+        self.refs = []
+        for task, refs in per_task.items():
+            self.refs += random.sample(refs, max_per_task) if -1 < max_per_task < len(refs) else refs
+
+    def __len__(self):
+        return len(self.refs)
+
+    def __getitem__(self, i):
+        return self.refs[i % len(self.refs)]
+
+
+class EpisodeStore:
+    """Decoded episodes by path; at most `capacity` kept, least recently used evicted (capacity 0: no cache)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self._kept = OrderedDict()
+
+    def __call__(self, path):
+        if self.capacity == 0:
+            return loader(path)
+        if path in self._kept:
+            self._kept.move_to_end(path)
+            return self._kept[path]
+        episode = loader(path)
+        self._kept[path] = episode
+        while len(self._kept) > self.capacity:
+            self._kept.popitem(last=False)
+        return episode
+
+
+class ItemPlan(NamedTuple):
+    chunk: int                    # which block of max_episode_length keyframes
+    instruction: Optional[int]    # index into the (task, variation)'s instruction embeddings, None without instructions
+    resize: tuple                 # (rh, rw, i, j) of a3d_resize_crop; identity for evaluation items
+
+
+def draw_plan(n_keyframes, chunk_len, n_instructions, image_hw, rescale):
+    """Every random decision of one item.  Generator consumption == the reference's: python `random` for the chunk
+    (randint, :160) and then the instruction (choice, :180); numpy then torch for the Resize draws (datasets/utils.py:60-92),
+    only for training items (rescale not None)."""
+    chunk = random.randrange(math.ceil(n_keyframes / chunk_len))
+    instruction = random.randrange(n_instructions) if n_instructions else None
+    H, W = image_hw
+    resize = sample_resize_params(rescale, H, W) if rescale is not None else (H, W, 0, 0)
+    return ItemPlan(chunk, instruction, resize)
+
+
+class EpisodeView:
+    """Tensor access to the keyframes `ids` of one decoded episode."""
+
+    def __init__(self, episode, ids, cameras):
+        self.episode, self.ids, self.cameras = episode, list(ids), cameras
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _per_frame(self, field):
+        return torch.cat([self.episode[field][i] for i in self.ids])
+
+    def observations(self):
+        """(rgb in [0, 1], xyz), each (n_frames, n_cam, 3, H, W), cameras in the order the dataset was asked for"""
+        obs = torch.stack([torch.as_tensor(self.episode[1][i]) for i in self.ids])
+        if self.episode[3]:
+            stored = list(self.episode[3][0])
+            missing = [c for c in self.cameras if c not in stored]
+            assert not missing, f"cameras {missing} are not in the episode ({stored})"
+            obs = obs[:, torch.tensor([stored.index(c) for c in self.cameras])]
+        return obs[:, :, 0] / 2 + 0.5, obs[:, :, 1]
+
+    def actions(self):
+        return self._per_frame(2)
+
+    def grippers(self):
+        return self._per_frame(4)
+
+    def gripper_history(self):
+        """(n_frames, 3, 8): the pose two keyframes back, one back, and now (clamped at the episode start)"""
+        poses = self.episode[4]
+        return torch.stack([torch.cat([poses[max(0, i - back)] for i in self.ids]) for back in (2, 1, 0)], dim=1)
+
+    def trajectories(self, resample):
+        """zero-padded (n_frames, T_max, 8) low-level trajectories and the padding mask (True = padded)"""
+        pieces = [resample(self.episode[5][i]) for i in self.ids]
+        longest = max(len(p) for p in pieces)
+        traj = torch.zeros(len(pieces), longest, 8)
+        padded = torch.ones(len(pieces), longest, dtype=torch.bool)
+        for k, p in enumerate(pieces):
+            traj[k, :len(p)] = p
+            padded[k, :len(p)] = False
+        return traj, padded
+
+
 class RLBenchDataset(Dataset):
-    """Episode files -> per-chunk training items; constructor and item dictionary of datasets/dataset_engine.py:14-258.
+    """Constructor keywords and item dictionary of datasets/dataset_engine.py:14-258; one item = one random block of at most
+    `max_episode_length` keyframes of one episode.
 
-    On-disk episode (data_preprocessing/data_gen.py:122-132), indexed by frame id:
-      [0] frame ids  [1] observations (n_cam, 2 = rgb | xyz, 3, H, W)  [2] actions (1, 8)  [3] camera dicts
-      [4] gripper poses (1, 8)  [5] low-level trajectories (N_i, 8)
-    One difference from the reference, by design: in training mode the item carries the UN-augmented `rgbs` / `pcds` plus
+    One difference from the reference, by design: a training item carries the UN-augmented `rgbs` / `pcds` plus
     `resize_params` (n_frames, 4) int32 -- the draws of the `Resize` augmentation -- and `DeviceLoader` applies them on the
-    GPU.  The host-side RNG streams (`random` for the chunk and the instruction, numpy / torch for the augmentation) are
-    consumed in the reference's order, so seeded runs pick the same chunks, instructions and crops."""
-
-    _EPISODE_PATTERNS = ("*.npy", "*.dat", "*.pkl")        # the reference's listing order (dataset_engine.py:94-97)
+    GPU."""
 
     def __init__(self, root, instructions=None, taskvar=[('close_door', 0)], max_episode_length=5, cache_size=0,
                  max_episodes_per_task=100, num_iters=None, cameras=("wrist", "left_shoulder", "right_shoulder"),
                  training=True, gripper_loc_bounds=None, image_rescale=(1.0, 1.0), point_cloud_rotate_yaw_range=0.0,
                  return_low_lvl_trajectory=False, dense_interpolation=False, interpolation_length=100, action_dim=8,
                  predict_short=None):
-        self._cache, self._cache_size = {}, cache_size
-        self._cameras = cameras
-        self._max_episode_length = max_episode_length
-        self._num_iters = num_iters
-        self._training = training
-        self._taskvar = taskvar
-        self._action_dim = action_dim
-        self._predict_short = predict_short
-        self._root = [Path(r).expanduser() for r in ([root] if isinstance(root, (Path, str)) else root)]
-        self._return_low_lvl_trajectory = return_low_lvl_trajectory
+        roots = [root] if isinstance(root, (Path, str)) else list(root)
+        self._cameras, self._chunk_len, self._num_iters = cameras, max_episode_length, num_iters
+        self._training, self._action_dim = training, action_dim
+        self._resample = None
         if return_low_lvl_trajectory:
             assert dense_interpolation or predict_short
-            self._interpolate_traj = TrajectoryInterpolator(use=dense_interpolation, interpolation_length=interpolation_length)
+            self._resample = TrajectoryInterpolator(use=dense_interpolation, interpolation_length=interpolation_length)
+        # training-only augmentations: the Resize draws (applied on the device) and the yaw rotation (identity: the
+        # reference asserts a zero range, dataset_engine.py:82)
+        self._rescale = tuple(image_rescale) if training else None
         if training:
-            self._image_rescale = tuple(image_rescale)
-            self._rotate = Rotate(gripper_loc_bounds=gripper_loc_bounds, yaw_range=point_cloud_rotate_yaw_range)
-        self._instructions, self._num_vars = self._collect_instructions(instructions)
-        self._data_dirs, self._episodes = self._index_episodes(max_episodes_per_task)
-        self._num_episodes = len(self._episodes)
-        print(f"Created dataset from {self._root} with {self._num_episodes}")
-
-    # ---- construction
-    def _task_dirs(self):
-        for r, (task, var) in itertools.product(self._root, self._taskvar):
-            yield task, var, r / f"{task}+{var}"
-
-    def _collect_instructions(self, instructions):
-        """Only the instructions of (task, variation) folders that exist; variations counted per task (:62-70)."""
-        kept, num_vars = defaultdict(dict), Counter()
-        for task, var, d in self._task_dirs():
-            if d.is_dir():
-                if instructions is not None:
-                    kept[task][var] = instructions[task][var]
-                num_vars[task] += 1
-        return kept, num_vars
-
-    def _index_episodes(self, max_per_task):
-        """(task, variation, file) per episode: an equal share per variation, then at most max_per_task per task (:84-117)."""
-        dirs, by_task = [], defaultdict(list)
-        for task, var, d in self._task_dirs():
-            if not d.is_dir():
-                print(f"Can't find dataset folder {d}")
-                continue
-            files = [(task, var, ep) for pat in self._EPISODE_PATTERNS for ep in d.glob(pat)]
-            if max_per_task > -1:
-                files = files[:max_per_task // self._num_vars[task] + 1]
-            if not files:
-                print(f"Can't find episodes at folder {d}")
-                continue
-            dirs.append(d)
-            by_task[task] += files
-        episodes = []
-        for task, eps in by_task.items():
-            if -1 < max_per_task < len(eps):
-                eps = random.sample(eps, max_per_task)
-            episodes += eps
-        return dirs, episodes
-
-    def read_from_cache(self, args):
-        """Bounded episode cache with the reference's time-based eviction (:119-137)."""
-        if self._cache_size == 0:
-            return loader(args)
-        if args not in self._cache:
-            value = loader(args)
-            if len(self._cache) == self._cache_size:
-                del self._cache[list(self._cache.keys())[int(time()) % self._cache_size]]
-            if len(self._cache) >= self._cache_size:
-                return value
-            self._cache[args] = value
-        return self._cache[args]
-
-    @staticmethod
-    def _unnormalize_rgb(rgb):
-        return rgb / 2 + 0.5
-
-    # ---- one item
-    def _observations(self, episode, frame_ids):
-        """(rgb in [0, 1], xyz), each (n_frames, n_cam, 3, H, W), cameras in the order the dataset was asked for."""
-        frames = [episode[1][i] for i in frame_ids]
-        states = torch.stack([f if isinstance(f, torch.Tensor) else torch.from_numpy(f) for f in frames])
-        if episode[3]:
-            stored = list(episode[3][0].keys())
-            assert all(c in stored for c in self._cameras)
-            states = states[:, torch.tensor([stored.index(c) for c in self._cameras])]
-        return self._unnormalize_rgb(states[:, :, 0]), states[:, :, 1]
-
-    def _trajectories(self, episode, frame_ids):
-        """Zero-padded (n_frames, T_max, 8) low-level trajectories, their lengths and the padding mask (1 = padded)."""
-        items = [self._interpolate_traj(episode[5][i]) for i in frame_ids]
-        lens = torch.as_tensor([len(it) for it in items])
-        traj = torch.zeros(len(items), int(lens.max()), 8)
-        mask = torch.zeros(traj.shape[:-1])
-        for k, it in enumerate(items):
-            traj[k, :len(it)] = it
-            mask[k, len(it):] = 1
-        return traj, lens, mask
-
-    def __getitem__(self, episode_id):
-        task, variation, file = self._episodes[episode_id % self._num_episodes]
-        episode = self.read_from_cache(file)
-        if episode is None:
-            return None
-        # one random chunk of at most max_episode_length keyframes (dynamic chunking, :153-162)
-        n_chunks = math.ceil(len(episode[0]) / self._max_episode_length)
-        chunk = random.randint(0, n_chunks - 1)
-        frame_ids = episode[0][chunk * self._max_episode_length:(chunk + 1) * self._max_episode_length]
-        rgbs, pcds = self._observations(episode, frame_ids)
-        n = len(rgbs)
-        action = torch.cat([episode[2][i] for i in frame_ids])
-        if self._instructions:
-            instr = random.choice(self._instructions[task][variation])[None].repeat(n, 1, 1)
-        else:
-            instr = torch.zeros((n, 53, 512))
-        poses = episode[4]
-        gripper = torch.cat([poses[i] for i in frame_ids])
-        history = torch.stack([torch.cat([poses[max(0, i - back)] for i in frame_ids]) for back in (2, 1)] + [gripper], dim=1)
-        traj = traj_mask = None
-        if self._return_low_lvl_trajectory:
-            traj, traj_lens, traj_mask = self._trajectories(episode, frame_ids)
-
-        H, W = rgbs.shape[-2:]
-        draws = (H, W, 0, 0)                                   # identity: evaluation items are not augmented
-        if self._training:
-            pcds, gripper, action, traj = self._rotate(pcds, gripper, action, None, traj)
-            if traj is not None:
-                for k, tlen in enumerate(traj_lens):
-                    traj[k, tlen:] = 0
-            # the Resize draws (one set per item, shared by its frames and by RGB / XYZ); applied by DeviceLoader
-            draws = sample_resize_params(self._image_rescale, H, W)
-        d = self._action_dim
-        item = {"task": [task] * n, "rgbs": rgbs, "pcds": pcds, "action": action[..., :d], "instr": instr,
-                "curr_gripper": gripper[..., :d], "curr_gripper_history": history[..., :d],
-                "resize_params": torch.tensor([draws], dtype=torch.int32).repeat(n, 1)}
-        if traj is not None:
-            item["trajectory"], item["trajectory_mask"] = traj[..., :d], traj_mask.bool()
-        return item
+            Rotate(gripper_loc_bounds=gripper_loc_bounds, yaw_range=point_cloud_rotate_yaw_range)
+        self._index = EpisodeIndex(roots, taskvar, max_episodes_per_task)
+        self._store = EpisodeStore(cache_size)
+        # instruction embeddings of the (task, variation) folders that exist (dataset_engine.py:62-70)
+        self._instructions = {}
+        if instructions is not None:
+            for task, var, _ in self._index.present:
+                self._instructions.setdefault(task, {})[var] = instructions[task][var]
+        print(f"[dataset] {len(self._index)} episodes under {[str(r) for r in roots]}")
 
     def __len__(self):
-        return self._num_iters if self._num_iters is not None else self._num_episodes
+        return self._num_iters if self._num_iters is not None else len(self._index)
+
+    def read_from_cache(self, path):
+        return self._store(path)
+
+    def __getitem__(self, episode_id):
+        ref = self._index[episode_id]
+        episode = self._store(ref.path)
+        if episode is None:
+            return None
+        options = self._instructions[ref.task][ref.variation] if self._instructions else None
+        first = episode[1][episode[0][0]]
+        plan = draw_plan(len(episode[0]), self._chunk_len, 0 if options is None else len(options), tuple(first.shape[-2:]),
+                         self._rescale)
+        ids = episode[0][plan.chunk * self._chunk_len:(plan.chunk + 1) * self._chunk_len]
+        view = EpisodeView(episode, ids, self._cameras)
+        n, d = len(view), self._action_dim
+        rgbs, pcds = view.observations()
+        instr = torch.zeros((n, 53, 512)) if options is None else options[plan.instruction][None].repeat(n, 1, 1)
+        item = {"task": [ref.task] * n, "rgbs": rgbs, "pcds": pcds, "action": view.actions()[..., :d], "instr": instr,
+                "curr_gripper": view.grippers()[..., :d], "curr_gripper_history": view.gripper_history()[..., :d],
+                "resize_params": torch.tensor([plan.resize], dtype=torch.int32).repeat(n, 1)}
+        if self._resample is not None:
+            traj, padded = view.trajectories(self._resample)
+            item["trajectory"], item["trajectory_mask"] = traj[..., :d], padded
+        return item
 
 
 def _collate(batch, keys):

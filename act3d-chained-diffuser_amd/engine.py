@@ -218,6 +218,7 @@ class FlatDataParallel:
         self._pending = []
         self._side = torch.cuda.Stream() if self.overlap else None
         self._early_done = False
+        self._begun = False
         self._armed = True
 
     def broadcast_parameters(self, src=0):
@@ -261,21 +262,46 @@ class FlatDataParallel:
                                                          async_op=True))
         self._early_done = True
 
+    def begin_sync(self):
+        """Enqueue the all-reduce of everything that has not been reduced yet WITHOUT waiting for it: on the side stream
+        (device buffers with overlap) so that whatever the caller runs next on the main stream -- the other model's step of a
+        joint iteration (JointStep) -- hides it.  finish_sync() joins.  Without a side stream this is the plain blocking
+        all-reduce."""
+        if self.world == 1 or self._begun:
+            return
+        hot, late = self._segments()
+        todo = [late] if self._early_done else [(0, self.flat.n)]
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                for a, b in todo:
+                    if b > a:
+                        self._pending.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            for a, b in todo:
+                if b > a:
+                    dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+        self._begun = True
+
+    def finish_sync(self):
+        """Join the reductions started by hot_path_done() / begin_sync().  Returns the grad_scale (1 / world)."""
+        if self.world == 1:
+            return 1.0
+        for w in self._pending:
+            w.wait()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending, self._early_done, self._begun = [], False, False
+        return 1.0 / self.world
+
     def sync_gradients(self):
         """Returns the grad_scale (1/world) to pass to the optimizer."""
         if self.world == 1:
             return 1.0
-        hot, late = self._segments()
-        if self._early_done:
-            if late[1] > late[0]:
-                dist.all_reduce(self.flat.grad[late[0]:late[1]], op=dist.ReduceOp.SUM, group=self.pg)
-            for w in self._pending:
-                w.wait()
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._pending, self._early_done = [], False
-        else:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
-        return 1.0 / self.world
+        self.begin_sync()
+        return self.finish_sync()
 
 
 # ------------------------------------------------------------------------------------------------ the step, split at the tokens
@@ -315,10 +341,13 @@ def fwd_bwd_trajectory(model, criterion, sample, on_hot_done=None):
     tokens = model.prediction_head.encode_images(sample["rgbs"], None)
     multi = isinstance(tokens, (list, tuple))                  # one token tensor per scale for a multi-scale head
 
+    # additive test hooks: a batch may carry the DDPM noise / timesteps to use instead of the device draws
+    kw = {k: sample[k] for k in ("noise", "timesteps") if k in sample}
+
     def hot(leaves):
         return criterion.compute_loss(model(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
                                             sample["instr"], sample["curr_gripper"], sample["action"],
-                                            visual_tokens=list(leaves) if multi else leaves[0]))
+                                            visual_tokens=list(leaves) if multi else leaves[0], **kw))
 
     return _split_backward(list(tokens) if multi else [tokens], hot, on_hot_done)
 
@@ -354,6 +383,42 @@ def train_one_step_trajectory(model, criterion, optimizer, step_id, sample, ddp=
     loss = fwd_bwd_trajectory(model, criterion, sample, None if ddp is None else ddp.hot_path_done)
     _finish_step(optimizer, ddp, step_id, accumulate_grad_batches)
     return loss
+
+
+class JointStep:
+    """One joint iteration of BASELINE.json configs[3]: an Act3D keypose training step AND a trajectory-diffusion training
+    step -- two models, two optimizers, as the reference trains them (main_keypose.py:207-234, main_trajectory.py:177-204),
+    each data-parallel over the same ranks (engine.py:121-124).
+
+    Order of one iteration:  keypose forward + backward (hot segments reduced early, FlatDataParallel.hot_path_done) ->
+    begin_sync() of its FPN segment on the side stream -> trajectory forward + backward ON THE MAIN STREAM, which hides the
+    keypose reductions -> trajectory reduction -> both AdamW steps.  The result is the same as running the two
+    train_one_step functions one after the other (tests/test_joint_gpu.py)."""
+
+    def __init__(self, kp_model, kp_criterion, kp_optimizer, tr_model, tr_criterion, tr_optimizer, kp_ddp=None, tr_ddp=None,
+                 use_ground_truth_position_for_sampling_train=True):
+        self.kp = (kp_model, kp_criterion, kp_optimizer, kp_ddp)
+        self.tr = (tr_model, tr_criterion, tr_optimizer, tr_ddp)
+        self.use_gt = use_ground_truth_position_for_sampling_train
+
+    def __call__(self, kp_sample, tr_sample):
+        km, kc, ko, kd = self.kp
+        tm, tc, to, td = self.tr
+        ko.zero_grad()
+        to.zero_grad()
+        if kd is not None:
+            kd.arm(True)
+        loss_k = fwd_bwd_keypose(km, kc, kp_sample, self.use_gt, None if kd is None else kd.hot_path_done)
+        if kd is not None:
+            kd.begin_sync()
+        if td is not None:
+            td.arm(True)
+        loss_t = fwd_bwd_trajectory(tm, tc, tr_sample, None if td is None else td.hot_path_done)
+        if td is not None:
+            td.begin_sync()
+        ko.step(grad_scale=kd.finish_sync() if kd is not None else 1.0)
+        to.step(grad_scale=td.finish_sync() if td is not None else 1.0)
+        return loss_k, loss_t
 
 
 def save_checkpoint(path, model, optimizer, step_id, best_loss=None):

@@ -64,7 +64,13 @@ class LossAndMetrics:
                     float(self.label_smoothing), float(self.position_loss_coeff) / levels)
             off = pred.get("fine_ghost_pcd_offsets")
             if off is not None:                                # supervised offsets of the last level's points (:407-419)
-                pts = pred["ghost_pcd_pyramid"][-1] + off
+                last = pred["ghost_pcd_pyramid"][-1]
+                # the reference keeps only the last `npts` points when the last level's cloud is cumulative
+                # (main_keypose.py:409-413); this Act3D samples the same count at every level, where that is the identity
+                npts = last.shape[-1] // len(pred["ghost_pcd_pyramid"]) if last.shape[-1] != pred["ghost_pcd_pyramid"][0].shape[-1] \
+                    else last.shape[-1]
+                last, off = last[:, :, -npts:], off[:, :, -npts:]
+                pts = last + off
                 target = gt_pos.unsqueeze(-1).expand_as(pts)
                 losses["position_offset"] = O.ElemLossFn.apply(
                     pts, target, 0, float(self.position_offset_loss_coeff * self.position_loss_coeff))

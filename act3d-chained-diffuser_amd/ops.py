@@ -126,12 +126,14 @@ LOG2E = 1.4426950408889634
 
 
 def _use16(drop):
-    """The split-fp16 attention core is the default; its backward has no attention-weight dropout yet, so a pass with
-    dropout (diffusion training) runs on the split-bf16 kernels."""
-    return ATTN_MODE == "f16" and (drop is None or drop.p <= 0)
+    """The split-fp16 attention core is the default for every pass (with and without attention-weight dropout)."""
+    return ATTN_MODE == "f16"
 
 
-PLANE_PARTS = int(os.environ.get("A3D_ATTN16_PLANES", "2"))   # parts of the q / k planes the fp16 backward contracts with dS
+PLANE_PARTS = 2       # q / k planes of the backward: hi and lo parts
+
+
+V_PLANES = 2 | 4      # value planes: hi and lo parts, padded channel 15 of the hi plane = 1.0 (the softmax-denominator channel)
 
 
 def _alloc16(B, H, Lqp, Sp, device, need_bwd):
@@ -160,7 +162,7 @@ def attn_operands16(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz
     nz = lambda t: None if t is None else t.data_ptr()
     L.call("a3d_rope_split16", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS, B, Lq, Lqp, E, H, st)
     L.call("a3d_rope_split16", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS, B, S, Sp, E, H, st)
-    L.call("a3d_rope_split16", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vr), Vp.data_ptr(), 2, B, S, Sp, E, H, st)
+    L.call("a3d_rope_split16", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vr), Vp.data_ptr(), V_PLANES, B, S, Sp, E, H, st)
     return Qr, Kr, Vp, Lqp, Sp, scale, freq, (Qp, Kp, Vr)
 
 
@@ -183,7 +185,7 @@ def attn_operands_fused16(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S
 
     qb = (qx, scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS)
     kb = (kx, 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS)
-    vb = (None, 1.0, nz(Vr), Vp.data_ptr(), 2)
+    vb = (None, 1.0, nz(Vr), Vp.data_ptr(), V_PLANES)
     if mode == "qk":
         proj(q_in, 0, qb, kb, Lq, Lqp)
         proj(v_in, 2 * E, vb, None, S, Sp)
@@ -349,10 +351,10 @@ def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, e
     km = None if kmask is None else kmask.data_ptr()
     if Qs.dtype == torch.float16:
         Qp, Kp, Vr = extra
-        dOr = torch.empty((B, H, Lqp, 16), device=dev, dtype=torch.float16)
-        dOp = torch.empty((B, H, 16, Lqp), device=dev, dtype=torch.float16)
+        dOr = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.float16)          # row-normalised dO ln2: hi | lo
+        dOp = torch.empty((L.load().a3d_attn16_bwd_pack_bytes(B, H, Lqp) // 2,), device=dev, dtype=torch.float16)
         rexp = torch.empty((B, H, Lqp), device=dev, dtype=torch.int32)
-        L.call("a3d_attn16_bwd", Qs.data_ptr(), Qp.data_ptr(), Ks.data_ptr(), Kp.data_ptr(), Qp.shape[2], Vr.data_ptr(), km, O.data_ptr(),
+        L.call("a3d_attn16_bwd", Qs.data_ptr(), Qp.data_ptr(), Ks.data_ptr(), Kp.data_ptr(), Vr.data_ptr(), km, O.data_ptr(),
                dO.data_ptr(), LSE.data_ptr(), dOr.data_ptr(), dOp.data_ptr(), D.data_ptr(), rexp.data_ptr(), dQp.data_ptr(),
                dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, drop.state.data_ptr() if dropping else None,
                int(site), drop.p if dropping else 0.0, L.stream())

@@ -120,9 +120,11 @@ int a3d_dropout_mask(unsigned char* out, size_t n, const unsigned long long* dro
  * Replaces the same reference lines as a3d_attn_fwd / a3d_attn_bwd_bf16 (multihead_custom_attention.py:386-447 and its
  * autograd) with half the MFMA work: q, k two-part fp16 (x = hi + lo, fp32-grade logits), P / dS / V / dO single fp16.
  * Operand formats "16": rows16 [B][H][Npad][32] fp16 = hi(16) | lo(16); planes16 [B][H][parts][16][Npad] fp16, transposed
- * (parts = 2: hi and lo planes -- v, and q / k for the backward; parts = 1: hi only).
+ * (parts & 3 = 2: hi and lo planes, what the kernels read; 1: hi only; parts | 4: padded channel 15 of the hi plane = 1.0 --
+ * REQUIRED for the value planes, it is the softmax-denominator channel of the forward's PV product).
  * q must carry log2(e) (pass scale * log2 e to the *_split16 writers; a3d_rope_merge_bwd takes the same scale): scores and
- * LSE2 are in log2 units.  drop_state NULL or drop_p == 0: no dropout (a3d_attn16_bwd rejects dropout for now). */
+ * LSE2 are in log2 units.  drop_state NULL or drop_p == 0: no dropout; otherwise Philox keep flags as a3d_attn_fwd_dropout.
+ * Sp <= 16384. */
 int a3d_rope_split16(const float* Y, int ldy, const float* xyz, const float* freq, float scale, void* rows_out,
                      void* planes_out, int plane_parts, int B, int N, int Npad, int E, int H, void* stream);
 int a3d_proj_rope_split16(const float* X, int ldx, const float* W, int ldw, const float* bias, int K, const float* xyz0,
@@ -132,11 +134,15 @@ int a3d_proj_rope_split16(const float* X, int ldx, const float* W, int ldw, cons
 int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, const unsigned char* kmask, float* O, float* LSE2,
                    float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
                    const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
-/* Needs rows16 of q, k, v and planes16 of q, k with `plane_parts` parts.  Scratch: dOr [B][H][Lqp][16] fp16, dOp [B][H][16][Lqp] fp16,
- * D [B][H][Lqp] fp32, rexp [B][H][Lqp] int32.  Outputs: dQp [nsplit][B][H][Lqp][16] (gradient w.r.t. the log2e-scaled,
- * rotated q), dK, dV [B][H][Sp][16] fp32 -- the a3d_rope_merge_bwd layouts.  Lqp % 64 == 0. */
-int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* Kp, int plane_parts, const void* Vr,
-                   const unsigned char* kmask, const float* O, const float* dO, const float* LSE2, void* dOr, void* dOp,
+/* Needs rows16 of q, k, v and two-part planes16 of q, k.  Scratch: dOr [B][H][Lqp][32] fp16 (hi | lo), pack
+ * (a3d_attn16_bwd_pack_bytes: the query-side operands of the dK / dV kernel as 20 KB LDS images per 64 rows, rows sorted by
+ * gradient magnitude -- block floating point over the query axis), D [B][H][Lqp] fp32, rexp [B][H][Lqp] int32.  Outputs:
+ * dQp [nsplit][B][H][Lqp][16] (gradient w.r.t. the log2e-scaled, rotated q), dK, dV [B][H][Sp][16] fp32 -- the
+ * a3d_rope_merge_bwd layouts.  Lqp % 64 == 0.  A3D_ATTN_FAST=1 in the environment selects single-fp16 P (forward) and dS
+ * (backward): ~25 % faster, 3e-4-class instead of 1e-5-class parity (not the default). */
+size_t a3d_attn16_bwd_pack_bytes(int B, int H, int Lqp);
+int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* Kp, const void* Vr,
+                   const unsigned char* kmask, const float* O, const float* dO, const float* LSE2, void* dOr, void* pack,
                    float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S, int Sp,
                    int nsplit, const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
 

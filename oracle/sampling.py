@@ -117,15 +117,16 @@ def philox_ghost_points(seed, offset, bounds, anchor, radius, B, Ng, level, max_
 
 class DropoutTwin:
     """CPU twin of the device dropout masks (csrc/a3d_common.h drop_keep8, csrc/dropout.hip, attention kernels):
-    one Philox4x32-10 call per block of 8 elements, counter = (c0, c1, c2, site), key = (seed_lo ^ offset_lo,
-    seed_hi ^ offset_hi); element j of the block is kept iff the j-th 16-bit field of the 128 output bits is
+    one Philox4x32-10 call per block of 8 elements, counter = (c0, c1, c2, site), key = the two 32-bit halves of
+    seed + offset * 0x9E3779B97F4A7C15 (mod 2^64); element j of the block is kept iff the j-th 16-bit field of the 128 output bits is
     >= round(p * 65536); kept elements are scaled by 1 / (1 - p) (fp32).  Restates nn.Dropout / F.dropout in training
     mode (layers.py:34,58,82-84; multihead_custom_attention.py:413; diffusion_head.py:46,183,193) up to the random
     stream, which is the device's own."""
 
     def __init__(self, seed, offset, p):
-        self.k0 = (seed ^ offset) & 0xFFFFFFFF
-        self.k1 = ((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFF
+        key = (int(seed) + int(offset) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        self.k0 = key & 0xFFFFFFFF
+        self.k1 = key >> 32
         self.p = float(p)
         self.thr = int(np.rint(np.float32(p) * np.float32(65536.0)))
         self.scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))

@@ -34,9 +34,6 @@ def reference(q_pre, k_pre, v_pre, dO, H, S_valid=None):
 
 
 def run_family(O, fam, q_pre, k_pre, v_pre, dO, H, time_it=False):
-    if fam.startswith("f16"):
-        O.PLANE_PARTS = 1 if fam.endswith("p1") else 2
-        fam = "f16"
     B, Lq, E = q_pre.shape
     S = k_pre.shape[1]
     dev = q_pre.device
@@ -75,20 +72,23 @@ def run_family(O, fam, q_pre, k_pre, v_pre, dO, H, time_it=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--time-only", action="store_true")
+    ap.add_argument("--family", default=None)
     args = ap.parse_args()
     a3d = importlib.import_module("act3d-chained-diffuser_amd")
     O = a3d.ops
     dev = torch.device("cuda:0")
     H, E = 4, 60
     out = {}
-    for tag, (B, Lq, S, gain) in {"mild": (2, 333, 4097, 1.0), "sharp": (2, 333, 4097, 6.0), "short": (3, 37, 131, 3.0)}.items():
+    cases = {} if args.time_only else {"mild": (2, 333, 4097, 1.0), "sharp": (2, 333, 4097, 6.0), "short": (3, 37, 131, 3.0)}
+    for tag, (B, Lq, S, gain) in cases.items():
         g = torch.Generator().manual_seed(7)
         q_pre = (torch.randn(B, Lq, E, generator=g) * gain).to(dev)
         k_pre = (torch.randn(B, S, E, generator=g) * gain).to(dev)
         v_pre = torch.randn(B, S, E, generator=g).to(dev)
         dO = (torch.randn(B, Lq, E, generator=g) * 1e-3).to(dev)
         ro, rq, rk, rv, smax = reference(q_pre, k_pre, v_pre, dO, H)
-        for fam in ("f16p2", "f16p1", "bf16x3"):
+        for fam in ("f16", "bf16x3"):
             o, dq, dk, dv, _ = run_family(O, fam, q_pre, k_pre, v_pre, dO, H)
             rec = {"max|s|": smax}
             for name, got, ref in (("O", o, ro), ("dQ", dq, rq), ("dK", dk, rk), ("dV", dv, rv)):
@@ -104,7 +104,7 @@ def main():
     k_pre = torch.randn(B, S, E, generator=g).to(dev)
     v_pre = torch.randn(B, S, E, generator=g).to(dev)
     dO = torch.randn(B, Lq, E, generator=g).to(dev)
-    for fam in ("f16p2", "f16p1", "bf16x3"):
+    for fam in ([args.family] if args.family else ["f16", "bf16x3"]):
         *_, times = run_family(O, fam, q_pre, k_pre, v_pre, dO, H, time_it=True)
         f_fwd, f_bwd = 4.0 * Lq * S * E * B, 10.0 * Lq * S * E * B
         times["fwd_frac_of_2.5PF"] = f_fwd / (times["fwd_ms"] * 1e-3) / 2.5e15

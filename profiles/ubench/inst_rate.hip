@@ -20,13 +20,13 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 enum Mode {
   M_FMA = 0, M_PKFMA, M_EXP, M_CVT_BF16, M_CVT_F16, M_MAX3, M_PERM32, M_MFMA_BF16, M_MFMA_F16, M_MFMA_F16_K16,
-  M_MFMA_FP8, M_MFMA_32_F16, M_MIX_F16_EXP, M_MIX_FULL, M_LDEXP, M_MFMA_SCALE_FP8, M_MUL, M_PKMUL, M_COUNT
+  M_MFMA_FP8, M_MFMA_32_F16, M_MIX_F16_EXP, M_MIX_FULL, M_LDEXP, M_MFMA_SCALE_FP8, M_MUL, M_PKMUL, M_CVT_RTZ, M_COUNT
 };
 static const char* mode_names[M_COUNT] = {
-    "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "v_cvt_pk(rtz)_f16_f32", "v_max3_f32",
+    "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32", "v_max3_f32",
     "v_permlane32_swap", "mfma_16x16x32_bf16", "mfma_16x16x32_f16", "mfma_16x16x16_f16", "mfma_16x16x32_fp8",
     "mfma_32x32x16_f16", "mix: 1 mfma_f16 + 2 exp", "mix: 10 mfma + 16 exp + 38 valu", "v_ldexp_f32",
-    "mfma_scale_16x16x128_fp8", "v_mul_f32", "v_pk_mul_f32"};
+    "mfma_scale_16x16x128_fp8", "v_mul_f32", "v_pk_mul_f32", "v_cvt_pkrtz_f16_f32"};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc, int iters) {
@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
       for (int i = 0; i < 8; ++i) {
         unsigned int r;
         asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x[i]), "v"(x[(i + 1) & 7]));
+        x[i] = __uint_as_float(r | 0x3f000000u);
+      }
+    } else if (MODE == M_CVT_RTZ) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        unsigned int r;
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x[i]), "v"(x[(i + 1) & 7]));
         x[i] = __uint_as_float(r | 0x3f000000u);
       }
     } else if (MODE == M_MAX3) {
@@ -231,6 +238,7 @@ int main(int argc, char** argv) {
     run<M_LDEXP>(w, out, cyc, clk);
     run<M_CVT_BF16>(w, out, cyc, clk);
     run<M_CVT_F16>(w, out, cyc, clk);
+    run<M_CVT_RTZ>(w, out, cyc, clk);
     run<M_MAX3>(w, out, cyc, clk);
     run<M_PERM32>(w, out, cyc, clk);
     run<M_MFMA_BF16>(w, out, cyc, clk);

@@ -468,7 +468,13 @@ def _gather_worker(rank, world, port, q):
     if rank == 1:
         vals["val-loss/only_rank1/x"] = torch.tensor([7.0])
     merged = tt.synchronize_between_processes(vals)            # engine.py:232-245: rank 0 gets the concatenation
-    q.put((rank, {k: v.tolist() for k, v in merged.items()}))
+    # the drivers' own statistics: a MetricTable fed with the same per-batch entries, reduced with one all-reduce
+    table = a3d.trainers.MetricTable(torch.device("cpu"))
+    for k, v in vals.items():
+        for x in v:
+            table.add(k, x)
+    table.add_grouped("val-loss", "y", torch.tensor([1.0, 2.0, 6.0]) + rank, ["a", "b", "a"] if rank == 0 else ["b", "b", "c"])
+    q.put((rank, {k: v.tolist() for k, v in merged.items()}, table.means(across_ranks=True)))
     dist.destroy_process_group()
 
 
@@ -479,11 +485,51 @@ def test_evaluation_statistics_gathered_over_ranks():
     procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    got = [q.get(timeout=300) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
+    res = {r: merged for r, merged, _ in got}
     assert res[0] == {"val-losses/x": [1.0, 3.0, 2.0, 4.0]}    # keys of rank 0, every rank's entries, in rank order
     assert res[1]["val-losses/x"] == [2.0, 4.0]                # other ranks keep their own dictionary, as in the reference
+    # MetricTable.means(across_ranks=True): the mean over the concatenation of every rank's entries, identical on all ranks,
+    # including keys only one rank met and the per-group (task) entries
+    want = {"val-losses/x": 2.5, "val-loss/only_rank1/x": 7.0, "val-loss/a/y": 3.5, "val-loss/b/y": (2.0 + 2.5) / 2,
+            "val-loss/c/y": 7.0}
+    for r, _, means in got:
+        assert set(means) == set(want), (r, sorted(means))
+        for k, v in want.items():
+            assert abs(means[k] - v) < 1e-12, (r, k, means[k], v)
+
+
+def test_trainer_building_blocks():
+    """StepRunner's batch signature, the iteration plan, the cycling batch source and the DataLoader worker seeding (which
+    must leave numpy in the state the reference's seed_worker leaves it in: seeded with torch's worker seed + worker id)."""
+    import random
+    a3d = load_pkg()
+    T = a3d.trainers
+    s1 = {"rgbs": torch.zeros(2, 3, 4), "task": ["a", "b"], "instr": torch.zeros(2, 5)}
+    s2 = {"instr": torch.ones(2, 5), "rgbs": torch.ones(2, 3, 4), "task": ["c", "d"]}
+    assert T._signature(s1) == T._signature(s2) != T._signature({"rgbs": torch.zeros(3, 3, 4), "instr": torch.zeros(3, 5)})
+    plan = T._Schedule(3, 10, 4)
+    assert list(plan.steps()) == list(range(3, 10)) and [i for i in plan.steps() if plan.evaluates_after(i)] == [3, 7]
+    src = T._cycle([1, 2, 3])
+    assert [next(src) for _ in range(7)] == [1, 2, 3, 1, 2, 3, 1]
+    with pytest.raises(RuntimeError):
+        next(T._cycle([]))
+    torch.manual_seed(1234)
+    base = torch.initial_seed() % 2 ** 32
+    np.random.seed(base)
+    assert int(np.random.get_state()[1][0]) == base             # what the reference's second np.random.seed reads back
+    T._seed_worker(3)
+    a = np.random.rand(4)
+    r = random.random()
+    np.random.seed(base + 3)
+    random.seed(base)
+    assert np.array_equal(a, np.random.rand(4)) and r == random.random()
+    t = T.MetricTable(torch.device("cpu"))
+    for v in (1.0, 2.0, 6.0):
+        t.add("m", torch.tensor(v))
+    assert t.means() == {"m": 3.0}
 
 
 def test_ctypes_signatures_match_the_header_arity():

@@ -35,6 +35,18 @@ def report(name, got, ref, atol, rtol=0.0):
                              f"got {[got[tuple(i)].item() for i in idx]} ref {[ref[tuple(i)].item() for i in idx]}")
 
 
+def report_grad(a3d, name, got, ref, atol, rtol=0.0):
+    """Gradient parity of the attention blocks.  Split-bf16 family (A3D_ATTN_MODE=bf16x3): the element-wise bound it has always
+    met (errors ~1e-5).  Split-fp16 family (the default): dO and the weights entering dV are single fp16 by design (2^-12
+    per element, DESIGN.md "attention numerics"), so the bound is north_star's 1e-3 of the tensor's scale; observed
+    2-4e-4."""
+    if a3d.ops.ATTN_MODE == "f16":
+        scale = max(1.0, ref.detach().abs().max().item())
+        report(name, got, ref, max(atol, 1e-3 * scale), rtol)
+    else:
+        report(name, got, ref, atol, rtol)
+
+
 def bf16_bits(x):
     return x.to(torch.bfloat16).view(torch.int16)
 
@@ -202,19 +214,32 @@ def test_attn_block_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
     report(f"attn_block[{mode}] fwd", y, ref, 1e-4)      # observed ~1e-5: fp32-grade logits (three-part q, k operands)
     y.backward(dy.to(dev))
     gtol = 5e-4
-    report("attn_block d q_in", dq.grad, cq.grad, gtol, 1e-3)
+    report_grad(a3d, "attn_block d q_in", dq.grad, cq.grad, gtol, 1e-3)
     if mode == "none" or mode == "kv":
-        report("attn_block d k_in", dk.grad, ck.grad, gtol, 1e-3)
+        report_grad(a3d, "attn_block d k_in", dk.grad, ck.grad, gtol, 1e-3)
     if mode != "kv":
-        report("attn_block d v_in", dv.grad, cv.grad, gtol, 1e-3)
-    report("attn_block d resid", dr.grad, cr.grad, gtol, 1e-3)
+        report_grad(a3d, "attn_block d v_in", dv.grad, cv.grad, gtol, 1e-3)
+    report_grad(a3d, "attn_block d resid", dr.grad, cr.grad, gtol, 1e-3)
     sc = max(1.0, math.sqrt(B * max(Lq, S)) / 8)
-    report("attn_block d in_w", mha.in_proj_weight.grad, ciw.grad, gtol * sc, 2e-3)
-    report("attn_block d in_b", mha.in_proj_bias.grad, cib.grad, gtol * sc, 2e-3)
-    report("attn_block d out_w", mha.out_proj.weight.grad, cow.grad, gtol * sc, 2e-3)
-    report("attn_block d out_b", mha.out_proj.bias.grad, cob.grad, gtol * sc, 2e-3)
-    report("attn_block d ln_g", norm.weight.grad, cg.grad, gtol * sc, 2e-3)
-    report("attn_block d ln_b", norm.bias.grad, cb.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d in_w", mha.in_proj_weight.grad, ciw.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d in_b", mha.in_proj_bias.grad, cib.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d out_w", mha.out_proj.weight.grad, cow.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d out_b", mha.out_proj.bias.grad, cob.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d ln_g", norm.weight.grad, cg.grad, gtol * sc, 2e-3)
+    report_grad(a3d, "attn_block d ln_b", norm.bias.grad, cb.grad, gtol * sc, 2e-3)
+
+
+@pytest.mark.parametrize("B,Lq,S,E,H,rope,masked,mode", [(2, 37, 131, 60, 4, True, False, "kv"), (2, 16, 70, 120, 8, True, True, "qk"),
+                                                          (1, 130, 4097, 60, 4, True, False, "kv")])
+def test_attn_block_fwd_bwd_split_bf16_family(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
+    """The split-bf16 kernels (attention.hip / attention_bwd.hip, A3D_ATTN_MODE=bf16x3) stay covered: same check, the tight
+    element-wise gradient bounds."""
+    old = a3d.ops.ATTN_MODE
+    a3d.ops.ATTN_MODE = "bf16x3"
+    try:
+        test_attn_block_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode)
+    finally:
+        a3d.ops.ATTN_MODE = old
 
 
 def test_attn_softmax_rescale_spike(a3d, dev):
