@@ -503,7 +503,9 @@ class GraphedStep:
         with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
             optimizer.step(grad_scale=1.0 / self.world)
 
-    def __call__(self, inputs=None):
+    def launch(self, inputs=None):
+        """Enqueue the step up to (not including) the point where the gradient reductions must have finished: input copies,
+        forward + backward replay(s) and, under DP, the all-reduces (started, not awaited).  finish() completes the step."""
         if inputs is not None:
             for k, v in inputs.items():
                 if torch.is_tensor(v) and k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
@@ -513,6 +515,28 @@ class GraphedStep:
             self.ddp.arm(True)
             self.ddp.hot_path_done()           # hot segments on the side stream (whole buffer later if overlap is off) ...
             self.g_late.replay()               # ... while the FPN backward runs
-            self.ddp.sync_gradients()
+            self.ddp.begin_sync()
+
+    def finish(self):
+        if self.world > 1:
+            self.ddp.finish_sync()
             self.g_opt.replay()
         return self.loss
+
+    def __call__(self, inputs=None):
+        self.launch(inputs)
+        return self.finish()
+
+
+class GraphedJointStep:
+    """JointStep on captured graphs: one GraphedStep per model; the keypose reductions are started before the trajectory
+    graphs are replayed and awaited after them, so the trajectory forward / backward hides them (same order of operations as
+    JointStep.__call__)."""
+
+    def __init__(self, keypose_step, trajectory_step):
+        self.kp, self.tr = keypose_step, trajectory_step
+
+    def __call__(self, kp_sample=None, tr_sample=None):
+        self.kp.launch(kp_sample)
+        self.tr.launch(tr_sample)
+        return self.kp.finish(), self.tr.finish()

@@ -122,17 +122,18 @@ def kernel_rooflines(a3d, device, B):
     """Live timing of the dominant hand-written kernels at the workload's shapes (ghost attention: Lq=333, S=4097,
     E=60, H=4) against their rooflines.  Algorithmic FLOPs per launch: forward 4*Lq*S*E*B (QK^T + PV), backward
     10*Lq*S*E*B (five contractions); the fused k,v in-projection + RoPE + operand-format kernel is HBM-bound:
-    algorithmic bytes = the fp32 input rows + the bf16 operand tensors it writes.  See DESIGN.md, kernels."""
+    algorithmic bytes = the fp32 input rows + the 16-bit operand tensors it writes.  See DESIGN.md, kernels."""
     O = a3d.ops
     H, E, Lq, S = 4, 60, 333, 4097
+    f16 = O.ATTN_MODE == "f16"
     g = torch.Generator().manual_seed(1)
     q_pre = torch.randn(B * Lq, E, generator=g).to(device)
     kv_pre = torch.randn(B * S, 2 * E, generator=g).to(device)
     q_xyz = torch.rand(B, Lq, 3, generator=g).to(device)
     k_xyz = torch.rand(B, S, 3, generator=g).to(device)
-    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O.attn_operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E,
-                                                               kv_pre.data_ptr() + E * 4, 2 * E, q_xyz, k_xyz, B, Lq, S, E, H,
-                                                               device, need_bwd=True)
+    operands = O.attn_operands16 if f16 else O.attn_operands
+    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E, kv_pre.data_ptr() + E * 4, 2 * E,
+                                                       q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=True)
     ns = O.pick_nsplit(B, H, Lqp, Sp)
     Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns)
     dO = torch.randn_like(Oo)
@@ -144,30 +145,42 @@ def kernel_rooflines(a3d, device, B):
     w = torch.randn(3 * E, E, generator=g).to(device)
     bb = torch.zeros(3 * E, device=device)
     Spad = (S + 63) // 64 * 64
-    bf = torch.bfloat16
-    Kr = torch.empty((B, H, Spad, O.QKW), device=device, dtype=bf)
-    Kp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
-    Vr = torch.empty((B, H, Spad, 32), device=device, dtype=bf)
-    Vp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
-    t_proj = time_kernel(lambda: O.L.call(
-        "a3d_proj_rope_split", x.data_ptr(), E, w.data_ptr() + E * E * 4, E, bb.data_ptr() + E * 4, E,
-        k_xyz.data_ptr(), 1.0, Kr.data_ptr(), O.QKW, Kp.data_ptr(), None, 1.0, Vr.data_ptr(), 32, Vp.data_ptr(),
-        freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
-    bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (O.QKW + 32 + 32 + 32))      # x rows + K rows/planes + V rows/planes
-    # MFMA FLOPs actually executed (SURVEY 8d's "MFMA utilisation"): v_mfma_f32_16x16x32_bf16 = 16384 FLOP each; per
-    # (64 keys x 16 queries) tile the forward issues 12 score + 6 PV, dQ 20 + 6, dK/dV 20 + 12 (split operands, d 15 -> 16)
+    if f16:
+        hf = torch.float16
+        Kr = torch.empty((B, H, Spad, 32), device=device, dtype=hf)
+        Kp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
+        Vr = torch.empty((B, H, Spad, 32), device=device, dtype=hf)
+        Vp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
+        t_proj = time_kernel(lambda: O.L.call(
+            "a3d_proj_rope_split16", x.data_ptr(), E, w.data_ptr() + E * E * 4, E, bb.data_ptr() + E * 4, E,
+            k_xyz.data_ptr(), 1.0, Kr.data_ptr(), Kp.data_ptr(), 2, None, 1.0, Vr.data_ptr(), Vp.data_ptr(), O.V_PLANES,
+            freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
+        bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (32 + 32 + 32 + 32))      # x rows + K rows/planes + V rows/planes
+        # v_mfma_f32_16x16x32_{f16,bf16} = 16384 FLOP each; per (64 keys x 16 queries) the forward issues 8 score + 6 PV,
+        # dQ 8 score + 8 dP + 6 dQ, dK/dV 8 score + 8 dP + 6 dV + 6 dK (two-part operands, d 15 -> 16)
+        per_fwd, per_bwd, dt = 14, 22 + 28, "fp16 / bf16 MFMA on two-part operands (x = hi + lo; fp32 accumulate)"
+    else:
+        bf = torch.bfloat16
+        Kr = torch.empty((B, H, Spad, O.QKW), device=device, dtype=bf)
+        Kp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
+        Vr = torch.empty((B, H, Spad, 32), device=device, dtype=bf)
+        Vp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=bf)
+        t_proj = time_kernel(lambda: O.L.call(
+            "a3d_proj_rope_split", x.data_ptr(), E, w.data_ptr() + E * E * 4, E, bb.data_ptr() + E * 4, E,
+            k_xyz.data_ptr(), 1.0, Kr.data_ptr(), O.QKW, Kp.data_ptr(), None, 1.0, Vr.data_ptr(), 32, Vp.data_ptr(),
+            freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
+        bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (O.QKW + 32 + 32 + 32))
+        per_fwd, per_bwd, dt = 18, 26 + 32, "bf16 MFMA on split operands (q,k = hi+lo+lo2, p,v = hi+lo)"
     tiles = B * H * (Lqp // 16) * (Sp // 64)
-    x_fwd = tiles * 18 * 16384.0
-    x_bwd = tiles * (26 + 32) * 16384.0
+    x_fwd = tiles * per_fwd * 16384.0
+    x_bwd = tiles * per_bwd * 16384.0
     return {
         "attn_fwd": {"bound": "mfma", "achieved": f_fwd / (t_fwd * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": "bf16 (split operands)",
+                     "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": dt, "family": O.ATTN_MODE,
                      "executed_tflops": x_fwd / (t_fwd * 1e-3) / 1e12, "mfma_util_executed": x_fwd / (t_fwd * 1e-3) / 2.5e15},
-        "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 157.3 if O.BWD_F32 else 2500.0,
-                     "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6,
-                     "dtype": "f32 MFMA" if O.BWD_F32 else "bf16 (split operands)",
-                     **({} if O.BWD_F32 else {"executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12,
-                                              "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15})},
+        "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 2500.0,
+                     "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6, "dtype": dt, "family": O.ATTN_MODE,
+                     "executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12, "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15},
         "kv_proj_rope": {"bound": "hbm", "achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "ms": t_proj, "launches_per_step": 6},
     }
@@ -176,7 +189,7 @@ def kernel_rooflines(a3d, device, B):
 def pmc_record(B):
     """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
     counters cannot be read from inside this process).  None when no record exists for this batch size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_B{B}.json")   # B = 64 (round 2 kernels)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_pmc_B{B}.json")   # B = 64 (round 3 kernels)
     try:
         with open(path) as fh:
             return json.load(fh)["kernels"]
@@ -184,49 +197,67 @@ def pmc_record(B):
         return None
 
 
-def joint_step_bench(a3d, device, B=16, steps=10, warmup=3):
-    """BASELINE configs[3] at its per-GPU shape (DP batch 128 over 8 GPUs = 16 per GPU): one joint iteration = one Act3D
-    keypose training step AND one trajectory-diffusion training step on B samples each (two models, two optimizers, as the
-    reference trains them: main_keypose.py / main_trajectory.py), each a hipGraph replay."""
+def joint_step_bench(a3d, device, B=16, steps=10, warmup=3, world=1, rank=0):
+    """BASELINE configs[3] (joint Act3D + trajectory-diffusion training, DP batch 128 over 8 GPUs = 16 per GPU): one joint
+    iteration = one Act3D keypose training step AND one trajectory-diffusion training step on B samples each per rank (two
+    models, two optimizers, as the reference trains them: main_keypose.py / main_trajectory.py), both data-parallel over the
+    same ranks, hipGraph replays (engine.GraphedJointStep: the keypose all-reduces are hidden behind the trajectory step).
+    Timed like the main line: barrier + synchronize on both sides, max over ranks."""
+    import torch.distributed as dist
     import bench_denoise as BD
     E = a3d.engine
     model = build_model(a3d, device, torch.bfloat16)
     crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
-    kb = synthetic_batch(B, 4, device, seed=77)
+    kb = synthetic_batch(B, 4, device, seed=77 + rank)
 
     def kp_fwd_bwd(sample, on_hot_done=None):
         return E.fwd_bwd_keypose(model, crit, sample, True, on_hot_done)
 
-    _, kopt = E.get_optimizer(model, lr=1e-4, active_names=E.discover_active_parameters(model, lambda: kp_fwd_bwd(kb)))
-    kstep = E.GraphedStep(kp_fwd_bwd, kopt, kb, warmup=2)
-
+    kflat, kopt = E.get_optimizer(model, lr=1e-4, active_names=E.discover_active_parameters(model, lambda: kp_fwd_bwd(kb)))
     planner = BD.build_planner(a3d, device, train=True)
-    tb = BD.synthetic_inputs(B, 50, 3, device)
+    tb = BD.synthetic_inputs(B, 50, 3, device, seed=1 + rank)
     tcrit = a3d.TrajectoryCriterion()
 
-    def tr_fwd_bwd(sample):
-        loss = tcrit.compute_loss(planner(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
-                                          sample["instr"], sample["curr_gripper"], sample["action"]))
-        loss.backward()
-        return loss.detach()
+    def tr_fwd_bwd(sample, on_hot_done=None):
+        return E.fwd_bwd_trajectory(planner, tcrit, sample, on_hot_done)
 
-    _, topt = E.get_optimizer(planner, lr=1e-4, active_names=E.discover_active_parameters(planner, lambda: tr_fwd_bwd(tb)))
-    tstep = E.GraphedStep(tr_fwd_bwd, topt, tb, warmup=2)
-
+    tflat, topt = E.get_optimizer(planner, lr=1e-4, active_names=E.discover_active_parameters(planner, lambda: tr_fwd_bwd(tb)))
+    kddp = tddp = None
+    if world > 1:
+        overlap = os.environ.get("A3D_DP_OVERLAP", "1") == "1"
+        kddp = E.FlatDataParallel(kflat, overlap=overlap, model=model)
+        tddp = E.FlatDataParallel(tflat, overlap=overlap, model=planner)
+        kddp.broadcast_parameters()
+        tddp.broadcast_parameters()
+    step = E.GraphedJointStep(E.GraphedStep(kp_fwd_bwd, kopt, kb, ddp=kddp, warmup=2),
+                              E.GraphedStep(tr_fwd_bwd, topt, tb, ddp=tddp, warmup=2))
     for _ in range(warmup):
-        lk, lt = kstep(), tstep()
+        lk, lt = step()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        lk, lt = kstep(), tstep()
+        lk, lt = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    dt /= steps
     assert torch.isfinite(lk).all() and torch.isfinite(lt).all()
-    return {"metric": "train samples/sec (keypose+diffusion fwd+bwd, joint iteration)", "value": B / dt, "unit": "samples/s",
-            "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "higher_is_better": True, "data": "synthetic",
-            "config": {"workload": f"per-GPU shape of BASELINE configs[3]: Act3D keypose step (B={B} keyframes, 4 cameras, 3 levels) "
-                                   f"+ DiffusionPlanner step (B={B} trajectories, horizon 50, 3 cameras, dropout 0.1), both with "
-                                   "backbone + FPN + AdamW, two hipGraph replays per iteration", "hipgraph": True,
+    return {"metric": "train samples/sec (keypose+diffusion fwd+bwd, joint iteration)", "value": world * B / dt, "unit": "samples/s",
+            "n_gpus": world, "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "higher_is_better": True, "scaling": "weak",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: Act3D keypose step (B={B} keyframes per GPU, 4 cameras, 3 levels) + "
+                                   f"DiffusionPlanner step (B={B} trajectories per GPU, horizon 50, 3 cameras, dropout 0.1), both with "
+                                   "backbone + FPN + AdamW; hipGraph replays, joint iteration = engine.GraphedJointStep",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "hipgraph": True,
+                       "allreduce": None if world == 1 else "RCCL all-reduce of both models' flat gradient buffers per iteration; hot-path "
+                                    "segments start during the FPN backward, the keypose reductions complete behind the trajectory step",
                        "final_losses": [float(lk.item()), float(lt.item())]}}
 
 
@@ -322,21 +353,35 @@ def main():
         elapsed = t.item()
     loss_val = float(loss.item())
 
+    was_graphed = graphed is not None
+    joint_dp = None
+    if world > 1 and not args.skip_secondary:
+        # BASELINE configs[3] under data parallelism: every rank takes part (collectives), rank 0 reports it in `secondary`
+        del graphed
+        torch.cuda.empty_cache()
+        try:
+            joint_dp = joint_step_bench(a3d, device, 16, steps=max(3, args.steps // 2), warmup=2, world=world, rank=rank)
+        except Exception as e:
+            joint_dp = {"error": repr(e)[:300]}
+        joint_dp["name"] = "joint_keypose_diffusion_cfg4"
+        graphed = None
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         res = {
             "metric": "train samples/sec (Act3D keypose fwd+bwd+AdamW step)", "value": world * B * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA on split operands (q,k = hi+lo+lo2, p,v = hi+lo; fp32 accumulate) in attention; fp32 MFMA "
-                     "linears; " + ("bf16 frozen backbone + FPN" if args.backbone_dtype == "bf16" else "fp32 backbone + FPN"),
+            "dtype": ("fp16 / bf16 MFMA on two-part operands (x = hi + lo; fp32 accumulate) in attention; " if a3d.ops.ATTN_MODE == "f16"
+                      else "bf16 MFMA on split operands (q,k = hi+lo+lo2, p,v = hi+lo; fp32 accumulate) in attention; ") +
+                     "fp32 MFMA linears; " + ("bf16 frozen backbone + FPN" if args.backbone_dtype == "bf16" else "fp32 backbone + FPN"),
             "data": "synthetic",
             "config": {"workload": "Act3D keypose training step, 18-PerAct-task shapes: 4 cameras 256x256, 3 ghost-point "
                                    "levels, 1000 ghost points (333/level), E=60, frozen synthetic CLIP-RN50-shaped backbone "
                                    "+ trainable FPN included in the step",
                        "per_gpu_batch_keyframes": B, "global_batch": world * B, "parallelism": f"dp{world}",
                        "batch_note": "keyframe rows; reference default = 16 episodes x <=5 keyframes per step",
-                       "hipgraph": graphed is not None, "final_loss": loss_val,
+                       "hipgraph": was_graphed, "final_loss": loss_val,
                        "allreduce": None if ddp is None else ("hot-path segments overlapped with the FPN backward" if ddp.overlap
                                                               else "one all-reduce after backward")},
         }
@@ -372,7 +417,7 @@ def main():
             pmc = pmc_record(B) or {}
             r["traffic"] = pmc.get(dom, {}).get("hbm_bytes")
             if dom in pmc:
-                r["traffic_source"] = f"profiles/r02_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
+                r["traffic_source"] = f"profiles/r03_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
                 r["pmc"] = pmc[dom].get("pmc")
             res["roofline"] = r
             res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
@@ -390,7 +435,7 @@ def main():
             for name, fn in (("diffusion_train_script_shape", lambda: BD.training_bench(a3d, device, 22, 50, 3, steps=10, warmup=3)),
                              ("diffusion_train_cfg3_shape", lambda: BD.training_bench(a3d, device, 64, 16, 3, steps=10, warmup=3)),
                              ("diffusion_sampling_cfg3", lambda: BD.sampling_bench(a3d, device, 64, 16, 3, reps=3)),
-                             ("joint_keypose_diffusion_cfg4_per_gpu_shape", lambda: joint_step_bench(a3d, device, 16))):
+                             ("joint_keypose_diffusion_cfg4", lambda: joint_step_bench(a3d, device, 16))):
                 try:
                     r = fn()
                 except Exception as e:
@@ -398,6 +443,8 @@ def main():
                 r["name"] = name
                 res["secondary"].append(r)
                 torch.cuda.empty_cache()
+        if joint_dp is not None:
+            res["secondary"] = [joint_dp]
         if world == 1 and not args.skip_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a3d, args.cpu_batch, args.cpu_steps)
