@@ -423,25 +423,30 @@ constexpr int PK_HALFS = 10240;                // 20 KB per chunk
 constexpr int PK_QROWS = 0, PK_OROWS = 2048, PK_QPL = 4096, PK_OPL = 6144, PK_NL = 8192, PK_ND = 8320, PK_PERM = 8448, PK_HDR = 8576;
 constexpr int DROP_SPAN = 60;                  // rows more than 2^DROP_SPAN below the largest row are dropped
 
+constexpr int PREP_GROUP = 8;                 // chunks (of 64 sorted rows) staged per barrier round
+
 __global__ __launch_bounds__(256) void attn16_bwd_prep_kernel(
     const float* __restrict__ dO, const float* __restrict__ O, const float* __restrict__ LSE2,
-    const unsigned short* __restrict__ Qr, unsigned short* __restrict__ dOr, float* __restrict__ D, int* __restrict__ rexp, unsigned short* __restrict__ pack, int B, int H, int Lq, int Lqp, int Lsort) {
+    const unsigned short* __restrict__ Qr, unsigned short* __restrict__ dOr, float* __restrict__ D,
+    int* __restrict__ rexp, unsigned short* __restrict__ pack, int B, int H, int Lq, int Lqp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned long long* keyS = reinterpret_cast<unsigned long long*>(smem_raw);                 // [Lsort] sort keys
-  float* dS = reinterpret_cast<float*>(keyS + Lsort);                                         // [Lqp] -Dn
-  unsigned short* qrowS = reinterpret_cast<unsigned short*>(dS + Lqp);                        // [64][32] gathered Q rows (natural layout)
-  unsigned short* orowS = qrowS + 64 * 32;                                                    // [64][32] gathered dOn rows
+  unsigned int* keyS = reinterpret_cast<unsigned int*>(smem_raw);                             // [Lqp] (300 - e) << 16 | row
+  unsigned int* sortS = keyS + Lqp;                                                           // [Lqp] the same, ascending
+  float* dS = reinterpret_cast<float*>(sortS + Lqp);                                          // [Lqp] -Dn
+  unsigned short* qrowS = reinterpret_cast<unsigned short*>(dS + Lqp);                        // [<= 512][32] gathered Q rows
+  unsigned short* orowS = qrowS + PREP_GROUP * 64 * 32;                                       // [<= 512][32] gathered dOn rows
   const int t = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int E = H * HD;
   const size_t bh = (size_t)blockIdx.x;
 
-  // ---- A: per-row exponent, normalised fp16 row, D
-  for (int q = t; q < Lsort; q += 256) {
+  // ---- A: per-row exponent, normalised two-part fp16 row, D
+  for (int q = t; q < Lqp; q += 256) {
     int e = -100;
     unsigned int w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     float dsum = 0.f;
-    if (q < Lq) {
+    bool live = q < Lq;
+    if (live) {
       const float* gp = dO + ((size_t)b * Lq + q) * E + h * HD;
       const float* op = O + ((size_t)b * Lq + q) * E + h * HD;
       float v[16];
@@ -463,119 +468,116 @@ __global__ __launch_bounds__(256) void attn16_bwd_prep_kernel(
                          (float)__builtin_bit_cast(_Float16, (unsigned short)(wl[d >> 1] >> sh));
         dsum += rv * op[d];
       }
+      live = LSE2[bh * Lqp + q] != -INFINITY;
     }
-    if (q < Lqp) {
-      const size_t row = bh * Lqp + q;
+    const size_t row = bh * Lqp + q;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4_*>(dOr + row * 32 + i * 8) = (u32x4_){w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+      *reinterpret_cast<u32x4_*>(dOr + row * 32 + 16 + i * 8) = (u32x4_){wl[4 * i], wl[4 * i + 1], wl[4 * i + 2], wl[4 * i + 3]};
+    }
+    D[row] = dsum;
+    rexp[row] = e;
+    dS[q] = -dsum;
+    // sort key: descending exponent, then ascending row (deterministic); padding rows and rows without a finite lse last
+    keyS[q] = ((live ? (unsigned int)(300 - e) : 0xFFFFu) << 16) | (unsigned int)q;          // e in [-100, 128] -> 172 .. 400
+  }
+  __syncthreads();
+  // ---- B: rank of every (distinct) key by counting the smaller ones: one barrier, deterministic
+  for (int q = t; q < Lqp; q += 256) {
+    const unsigned int k = keyS[q];
+    int pos = 0;
+    for (int j = 0; j < Lqp; j += 4) {
+      const u32x4_ o = *reinterpret_cast<const u32x4_*>(keyS + j);
+      pos += (o[0] < k) + (o[1] < k) + (o[2] < k) + (o[3] < k);
+    }
+    sortS[pos] = k;
+  }
+  __syncthreads();
+  const unsigned int rank0 = sortS[0] >> 16;                                                   // the largest row's 300 - e
+  // ---- C: one pack per 64 sorted rows, PREP_GROUP chunks per staging round
+  const int nch = Lqp / 64;
+  for (int c0 = 0; c0 < nch; c0 += PREP_GROUP) {
+    const int ng = min(PREP_GROUP, nch - c0);
+    // gathered Q rows of the group, natural layout; the dOn rows are recomputed from dO with the stored exponent (the same
+    // operations as pass A, so the same bits) rather than re-read from dOr: reading back another lane's global stores would
+    // need a device-scope fence, and a release fence writes back every dirty line of the XCD's L2 (measured: 50 us here)
+    for (int idx = t; idx < ng * 256; idx += 256) {
+      const int r = idx >> 2, seg = idx & 3;
+      const int q = (int)(sortS[c0 * 64 + r] & 0xFFFFu);
+      *reinterpret_cast<u32x4_*>(qrowS + r * 32 + seg * 8) = *reinterpret_cast<const u32x4_*>(Qr + (bh * Lqp + q) * 32 + seg * 8);
+    }
+    for (int r = t; r < ng * 64; r += 256) {
+      const unsigned int key = sortS[c0 * 64 + r];
+      const int q = (int)(key & 0xFFFFu);
+      unsigned int w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wl[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      if ((key >> 16) != 0xFFFFu) {                          // a live row: its exponent is in the sort key (rows without one are dead)
+        const float* gp = dO + ((size_t)b * Lq + q) * E + h * HD;
+        const float inv = ldexpf(1.0f, (int)(key >> 16) - 300);
+        float v[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) v[d] = (d < HD) ? gp[d] * LN2_F : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk_f16_2(v[2 * i] * inv, v[2 * i + 1] * inv, w[i], wl[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const u32x4_ hi4 = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]}, lo4 = {wl[4 * i], wl[4 * i + 1], wl[4 * i + 2], wl[4 * i + 3]};
-        *reinterpret_cast<u32x4_*>(dOr + row * 32 + i * 8) = hi4;
-        *reinterpret_cast<u32x4_*>(dOr + row * 32 + 16 + i * 8) = lo4;
+        *reinterpret_cast<u32x4_*>(orowS + r * 32 + i * 8) = (u32x4_){w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+        *reinterpret_cast<u32x4_*>(orowS + r * 32 + 16 + i * 8) = (u32x4_){wl[4 * i], wl[4 * i + 1], wl[4 * i + 2], wl[4 * i + 3]};
       }
-      D[row] = dsum;
-      rexp[row] = e;
-      dS[q] = -dsum;
-    }
-    // sort key: descending exponent, then ascending row (deterministic); padding rows and rows without a finite lse last
-    bool live = q < Lq;
-    if (live) live = LSE2[bh * Lqp + q] != -INFINITY;
-    const unsigned int rank = live ? (unsigned int)(300 - e) : 0xFFFFu;          // e in [-100, 128] -> 172 .. 400
-    keyS[q] = ((unsigned long long)rank << 32) | (unsigned int)q;
-  }
-  __threadfence();                     // pass C re-reads the dOn rows this workgroup just wrote (other lanes' stores, through L2)
-  __syncthreads();
-  // ---- B: bitonic sort of Lsort (a power of two) 64-bit keys in LDS
-  for (int k = 2; k <= Lsort; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < Lsort; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keyS[i], c = keyS[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > c) == up) { keyS[i] = c; keyS[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  const unsigned int rank0 = (unsigned int)(keyS[0] >> 32);                       // the largest row's 300 - e
-  // ---- C: one pack per 64 sorted rows
-  const int nch = Lqp / 64;
-  for (int c = 0; c < nch; ++c) {
-    unsigned short* pk = pack + (bh * nch + c) * (size_t)PK_HALFS;
-    const unsigned int rank_c = (unsigned int)(keyS[c * 64] >> 32);
-    // gathered Q and dOn rows of the chunk, natural layout, for the tiles built from them
-    {
-      const int r = t >> 2, seg = t & 3;
-      const unsigned long long key = keyS[c * 64 + r];
-      const int q = (int)(unsigned int)key;
-      u32x4_ val = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
-      if (q < Lqp) {
-        val = *reinterpret_cast<const u32x4_*>(Qr + (bh * Lqp + q) * 32 + seg * 8);
-        ov = *reinterpret_cast<const u32x4_*>(dOr + (bh * Lqp + q) * 32 + seg * 8);
-      }
-      *reinterpret_cast<u32x4_*>(qrowS + r * 32 + seg * 8) = val;
-      *reinterpret_cast<u32x4_*>(orowS + r * 32 + seg * 8) = ov;
     }
     __syncthreads();
-    {
-      // Q rows tile and dOn rows tile (LDS images: unit t = row t >> 2, position t & 3 holds segment pos ^ f(row))
-      const int r = t >> 2, pos = t & 3;
-      const int seg = pos ^ ((0 - (r >> 3)) & 3);
-      const int q = (int)(unsigned int)keyS[c * 64 + r];
-      *reinterpret_cast<u32x4_*>(pk + PK_QROWS + t * 8) = *reinterpret_cast<const u32x4_*>(qrowS + r * 32 + seg * 8);
-      *reinterpret_cast<u32x4_*>(pk + PK_OROWS + t * 8) = *reinterpret_cast<const u32x4_*>(orowS + r * 32 + seg * 8);
-    }
-    {
-      // Q planes, bf16 hi / lo of q = hi16 + lo16: sub-tile (part, half) = t >> 6; unit t & 63: channel (t & 63) >> 2, position t & 3
-      const int sub = t >> 6, u = t & 63;
-      const int part = sub >> 1, half = sub & 1;
-      const int ch = u >> 2, pos = u & 3;
-      const int seg = pos ^ ((0 - (ch >> 2)) & 3);
-      s16x8 o;
+    for (int cg = 0; cg < ng; ++cg) {
+      const int c = c0 + cg;
+      unsigned short* pk = pack + (bh * nch + c) * (size_t)PK_HALFS;
+      const unsigned short* qg = qrowS + cg * 64 * 32;
+      const unsigned short* og = orowS + cg * 64 * 32;
+      const unsigned int rank_c = sortS[c * 64] >> 16;
+      {
+        // Q rows tile and dOn rows tile (LDS images: unit t = row t >> 2, position t & 3 holds segment pos ^ f(row))
+        const int r = t >> 2, pos = t & 3;
+        const int seg = pos ^ ((0 - (r >> 3)) & 3);
+        *reinterpret_cast<u32x4_*>(pk + PK_QROWS + t * 8) = *reinterpret_cast<const u32x4_*>(qg + r * 32 + seg * 8);
+        *reinterpret_cast<u32x4_*>(pk + PK_OROWS + t * 8) = *reinterpret_cast<const u32x4_*>(og + r * 32 + seg * 8);
+      }
+      {
+        // Q and dOn planes, bf16 hi / lo of x = hi16 + lo16: sub-tile (part, half) = t >> 6; unit t & 63: channel (t & 63) >> 2,
+        // position t & 3
+        const int sub = t >> 6, u = t & 63;
+        const int part = sub >> 1, half = sub & 1;
+        const int ch = u >> 2, pos = u & 3;
+        const int seg = pos ^ ((0 - (ch >> 2)) & 3);
+        s16x8 oq, oo;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned short* qr = qrowS + (half * 32 + seg * 8 + j) * 32;
-        const float v = (float)__builtin_bit_cast(_Float16, qr[ch]) + (float)__builtin_bit_cast(_Float16, qr[16 + ch]);
-        unsigned short bh_, bl_;
-        split_bf16(v, bh_, bl_);
-        o[j] = (short)(part ? bl_ : bh_);
+        for (int j = 0; j < 8; ++j) {
+          const int rr = (half * 32 + seg * 8 + j) * 32;
+          const float vq = (float)__builtin_bit_cast(_Float16, qg[rr + ch]) + (float)__builtin_bit_cast(_Float16, qg[rr + 16 + ch]);
+          const float vo = (float)__builtin_bit_cast(_Float16, og[rr + ch]) + (float)__builtin_bit_cast(_Float16, og[rr + 16 + ch]);
+          unsigned short qh, ql, oh, ol;
+          split_bf16(vq, qh, ql);
+          split_bf16(vo, oh, ol);
+          oq[j] = (short)(part ? ql : qh);
+          oo[j] = (short)(part ? ol : oh);
+        }
+        *reinterpret_cast<s16x8*>(pk + PK_QPL + t * 8) = oq;
+        *reinterpret_cast<s16x8*>(pk + PK_OPL + t * 8) = oo;
       }
-      *reinterpret_cast<s16x8*>(pk + PK_QPL + t * 8) = o;
-    }
-    {
-      // dOn planes, bf16 hi / lo of dOn = hi16 + lo16: same unit map
-      const int sub = t >> 6, u = t & 63;
-      const int part = sub >> 1, half = sub & 1;
-      const int ch = u >> 2, pos = u & 3;
-      const int seg = pos ^ ((0 - (ch >> 2)) & 3);
-      s16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned short* orw = orowS + (half * 32 + seg * 8 + j) * 32;
-        const float v = (float)__builtin_bit_cast(_Float16, orw[ch]) + (float)__builtin_bit_cast(_Float16, orw[16 + ch]);
-        unsigned short bh_, bl_;
-        split_bf16(v, bh_, bl_);
-        o[j] = (short)(part ? bl_ : bh_);
+      if (t < 64) {
+        const unsigned int key = sortS[c * 64 + t];
+        const int q = (int)(key & 0xFFFFu);
+        const unsigned int rank = key >> 16;
+        float nl = -INFINITY, ndv = 0.f;
+        if (rank != 0xFFFFu && rank <= rank0 + DROP_SPAN) {
+          nl = B_OFF - LSE2[bh * Lqp + q] - (float)(int)(rank - rank_c);            // e_q - E_c = rank_c - rank
+          ndv = dS[q];
+        }
+        reinterpret_cast<float*>(pk + PK_NL)[t] = nl;
+        reinterpret_cast<float*>(pk + PK_ND)[t] = ndv;
+        reinterpret_cast<int*>(pk + PK_PERM)[t] = q;
+      } else if (t == 64) {
+        // E_c; a chunk that starts beyond the drop span (or in the padding) is dead, and so is everything after it
+        reinterpret_cast<int*>(pk + PK_HDR)[0] = (rank_c == 0xFFFFu || rank_c > rank0 + DROP_SPAN) ? -1000 : 300 - (int)rank_c;
       }
-      *reinterpret_cast<s16x8*>(pk + PK_OPL + t * 8) = o;
-    }
-    if (t >= 128 && t < 192) {
-      const int r = t - 128;
-      const unsigned long long key = keyS[c * 64 + r];
-      const int q = (int)(unsigned int)key;
-      const unsigned int rank = (unsigned int)(key >> 32);
-      float nl = -INFINITY, ndv = 0.f;
-      if (rank != 0xFFFFu && rank <= rank0 + DROP_SPAN) {
-        nl = B_OFF - LSE2[bh * Lqp + q] - (float)(int)(rank - rank_c);            // e_q - E_c = rank_c - rank
-        ndv = dS[q];
-      }
-      reinterpret_cast<float*>(pk + PK_NL)[r] = nl;
-      reinterpret_cast<float*>(pk + PK_ND)[r] = ndv;
-      reinterpret_cast<int*>(pk + PK_PERM)[r] = q;
-    } else if (t == 192) {
-      // E_c; a chunk that starts beyond the drop span (or in the padding) is dead, and so is everything after it
-      reinterpret_cast<int*>(pk + PK_HDR)[0] = (rank_c == 0xFFFFu || rank_c > rank0 + DROP_SPAN) ? -1000 : 300 - (int)rank_c;
     }
     __syncthreads();
   }
@@ -1048,17 +1050,15 @@ extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, co
   rc = drop_params("a3d_attn16_bwd", drop_state, drop_p, drop, thr, dscale);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  int Lsort = 64;
-  while (Lsort < Lqp) Lsort <<= 1;
-  const size_t lds = (size_t)Lsort * 8 + (size_t)Lqp * 4 + 2 * 64 * 64;
-  if (lds > 150 * 1024) { set_error("a3d_attn16_bwd: Lqp = %d too large for the per-(b, h) row sort", Lqp); return A3D_ERR_ARG; }
+  const size_t lds = (size_t)Lqp * 12 + (size_t)2 * PREP_GROUP * 64 * 64;
+  if (Lqp > 32768) { set_error("a3d_attn16_bwd: Lqp = %d too large for the per-(b, h) row sort", Lqp); return A3D_ERR_ARG; }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn16_bwd_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(attn16_bwd_prep_kernel, dim3(B * H), dim3(256), lds, s, dO, O, LSE2, (const unsigned short*)Qr,
-                     (unsigned short*)dOr, D, rexp, (unsigned short*)pack, B, H, Lq, Lqp, Lsort);
+                     (unsigned short*)dOr, D, rexp, (unsigned short*)pack, B, H, Lq, Lqp);
   rc = check_launch("a3d_attn16_bwd(prep)");
   if (rc) return rc;
   static const int qt_env = getenv("A3D_ATTN_QT") ? atoi(getenv("A3D_ATTN_QT")) : 0;

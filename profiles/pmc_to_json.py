@@ -12,8 +12,9 @@ import os
 import sys
 
 GROUPS = {
-    "attn_fwd": ["attn_fwd_kernel", "attn_combine_kernel"],
-    "attn_bwd": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel"],
+    "attn_fwd": ["attn_fwd_kernel", "attn_combine_kernel", "attn16_fwd_kernel", "attn16_combine_kernel"],
+    "attn_bwd": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel", "attn16_bwd_prep_kernel",
+                 "attn16_bwd_dq_kernel", "attn16_bwd_dkv_kernel"],
     "kv_proj_rope": ["proj_rope_split_kernel"],
 }
 

@@ -380,6 +380,17 @@ def _dp_worker(rank, world, port, q):
     ddp2.hot_path_done()
     scale2 = ddp2.sync_gradients()
     ok2 = torch.allclose(flat.grad * scale2, g * 1.5, atol=1e-6)
+    # begin_sync / finish_sync (what JointStep uses to hide one model's reduction behind the other model's step): starting
+    # twice is harmless, the result is the plain all-reduce, and the object is reusable afterwards
+    ddp3 = a3d.engine.FlatDataParallel(flat, overlap=True)
+    flat.grad.copy_(g * (rank + 1))
+    ddp3.hot_path_done()
+    ddp3.begin_sync()
+    ddp3.begin_sync()
+    scale3 = ddp3.finish_sync()
+    ok2 = ok2 and torch.allclose(flat.grad * scale3, g * 1.5, atol=1e-6) and not ddp3._begun and not ddp3._pending
+    flat.grad.copy_(g * (rank + 1))
+    ok2 = ok2 and torch.allclose(flat.grad * ddp3.sync_gradients(), g * 1.5, atol=1e-6)
     gathered = [torch.zeros_like(ref) for _ in range(world)]
     dist.all_gather(gathered, ref)
     same = all(torch.equal(gathered[0], t) for t in gathered)
