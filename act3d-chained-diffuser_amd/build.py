@@ -10,13 +10,14 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "obj")
 LIB_PATH = os.path.join(PKG_DIR, "libact3d_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
-SOURCES = ["api.hip", "linear.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "attention16.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip", "denoise.hip", "single_query.hip", "data.hip", "conv1x1.hip"]
+SOURCES = ["api.hip", "linear.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "attention16.hip", "attention8.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip", "denoise.hip", "single_query.hip", "data.hip", "conv1x1.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # The attention kernels never produce NaNs on their own (masked rows are handled explicitly, -inf only enters exp2):
 # without IEEE-mode sNaN quieting hipcc drops the canonicalising v_max_f32 x, x it otherwise puts in front of every fmaxf
 # on an MFMA result (12 of 108 VALU instructions per 64-key chunk of the VALU-bound forward loop).
 _ATTN_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
-EXTRA_FLAGS = {"attention.hip": _ATTN_FLAGS, "attention_bwd.hip": _ATTN_FLAGS, "attention16.hip": _ATTN_FLAGS}
+EXTRA_FLAGS = {"attention.hip": _ATTN_FLAGS, "attention_bwd.hip": _ATTN_FLAGS, "attention16.hip": _ATTN_FLAGS,
+               "attention8.hip": _ATTN_FLAGS}
 
 
 def _hipcc():
@@ -34,7 +35,8 @@ def build(force=False, verbose=False):
     """Compile every csrc/*.hip for gfx950 and link libact3d_hip.so.  Returns the library path."""
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, "a3d_common.h"), os.path.join(INCLUDE, "act3d_hip.h"), os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, "a3d_common.h"), os.path.join(CSRC, "attn_ring.h"), os.path.join(INCLUDE, "act3d_hip.h"),
+            os.path.abspath(__file__)]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     for s in srcs:

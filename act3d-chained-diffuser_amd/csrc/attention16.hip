@@ -1,153 +1,57 @@
 // Split-fp16 attention for gfx950: the ghost-point <-> scene cross-attention (and the diffusion transformer's attention
-// core) on v_mfma_f32_16x16x32_f16 with well under HALF the matrix work and a third of the vector work of the split-bf16
-// kernels in attention.hip / attention_bwd.hip (kept as the A/B reference, A3D_ATTN_MODE=bf16x3).
+// core) on v_mfma_f32_16x16x32_f16 / _bf16.  Default family of the package (ops.ATTN_MODE = "f16"); the three-part bf16
+// kernels in attention.hip / attention_bwd.hip stay as the A/B reference (A3D_ATTN_MODE=bf16x3).
 //
 // Reference semantics (multihead_custom_attention.py:355-447): per head h (d = 15), A = softmax(q_h k_h^T + mask),
 // o_h = A v_h.  What bounds this op on MI355X is NOT the matrix pipe: with d = 15 a score costs 60 algorithmic FLOPs
-// but one v_exp_f32 (6.5 cycles per wave64 op; a packed fp16 conversion costs the same, profiles/r03_inst_rate.txt), so
+// but one v_exp_f32 (6.5 cycles per wave64 op; a packed 16-bit conversion costs the same, profiles/r03_inst_rate.txt), so
 // the inner loops are written to minimise VECTOR instructions per score:
 //   * q, k are TWO-part fp16 (x = hi + lo, 22 mantissa bits; fp16 subnormals are honoured by the MFMA, same file):
 //     logits are fp32-grade from two K = 32 MFMAs per 16x16 tile, [k_hi|k_lo].[q_hi|q_hi] + [k_hi|k_lo].[q_lo|q_lo]
-//     (three with three-part bf16).  exp() turns an ABSOLUTE logit error into a relative weight error, which is why the
-//     logit operands keep two parts while what follows the softmax is single fp16:
-//   * P (and in the backward dS) and dO WERE single fp16 in the first cut of this file: a 2^-12 rounding is not amplified; the softmax
-//     denominator is accumulated on the MFMA from the SAME rounded P (ones-channel of V).  V keeps two parts (a rounded V
-//     would make D = dO . O inconsistent with dP = dO . V, and dP - D is a difference of nearly equal numbers when the
-//     softmax is sharp), so do K in dQ = dS K and Q in dK = dS^T Q (sum_k dS = 0 makes them functions of key / query
-//     DIFFERENCES); the backward differentiates exactly the function of the rounded dO (D from the rounded dO).
+//     (three with three-part bf16).  exp() turns an ABSOLUTE logit error into a relative weight error.
 //   * log2(e) is folded into q by the projection kernel, -m (forward) / -lse (backward) / -D ride in as MFMA accumulator
 //     inits: exp2 is applied DIRECTLY to MFMA results -- no per-score argument arithmetic at all.
 //   * lazy rescaling: the running max is only revised when a score exceeds it by 2^8 (a wave-uniform, rarely taken
 //     branch), so the common path has no cross-lane traffic and no accumulator rescale.
-//   * dO rows are normalised by a power of two per (b, h, q) row (exact), so that dS fits fp16 whatever the loss scale.
-// Per 64 keys x 16 queries a wave issues 12 (fwd) / 16 (dQ) / 18 (dK,dV) MFMAs against 18 / 26 / 32 before.
+//   * the softmax denominator is accumulated on the MFMA from the SAME rounded P (ones-channel of V, written by the
+//     projection kernel).
+//   * dO rows are normalised by a power of two per (b, h, q) row (exact), so that G = P (dP - D) fits the 16-bit formats
+//     whatever the loss scale.
+// What is NOT single 16-bit, and why (every item was first built single-part, measured, and widened; DESIGN.md section 4
+// holds the numbers): P in the forward is two-part fp16 (single: 1.27e-3 of scale on the gain-3 Act3D fixture, bar 1e-3);
+// G in dQ is two-part (single breaks sum_k G = 0: key-bias gradients off by 3-7e-3); V is two-part (a rounded V makes
+// D = dO . O inconsistent with dP = dO . V, a difference of nearly equal numbers when the softmax is sharp); dO is two-part;
+// and the contractions over the QUERY axis (dK = G^T Q, dV = P^T dO) run in split bf16, not fp16: keys with tiny weights
+// (2^-30 and below, but thousands of them feed one context row's gradient) fall out of fp16's range whatever the offset.
+// A3D_ATTN_FAST=1 selects the single-part P / G variants (fwd 0.104 vs 0.127 ms) for users who accept 2.5e-4-class errors.
+// Per 64 keys x 16 queries a wave issues 14 (fwd) / 22 (dQ) / 28 (dK,dV) MFMAs against 18 / 26 / 32 in the bf16 family,
+// and roughly half its vector instructions.
 //
-// Staging.  With so little work per chunk (a 64-key chunk is ~0.6 us of a workgroup's time) a one-chunk register prefetch
-// cannot cover the loaded HBM / L2 latency (1-2 us): the first version of these kernels ran at half the speed its
-// instruction mix allows.  The tiles therefore arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
-// ds_write pass) into a ring of NB buffers with NB - 1 chunks in flight, ONE raw s_barrier per chunk and counted vmcnt
-// waits.  An LDS-DMA lands lane-linearly (wave base + lane * 16 B), so the bank swizzle of the tiles (a3d_common.h
-// tile_off / plane_off) is applied on the SOURCE address: lane l fetches the 16-byte segment that belongs at position l.
+// Staging.  Tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NB
+// buffers with NB - 1 chunks in flight, ONE raw s_barrier per chunk and counted vmcnt waits.  An LDS-DMA lands
+// lane-linearly (wave base + lane * 16 B), so the bank swizzle of the tiles (a3d_common.h tile_off / plane_off) is applied
+// on the SOURCE address: lane l fetches the 16-byte segment that belongs at position l.  (Measured: the ring removed the
+// staging VGPRs and ds_writes but did not change the kernel time -- the kernels are issue-bound on VALU + MFMA, not
+// latency-bound; it is kept because the staging registers and the ds_write pass are gone.)
 //
-// Operand formats ("16" formats, written by a3d_proj_rope_split16 / attn16_bwd_prep):
+// Backward of the query axis ("packs").  attn16_bwd_prep sorts the queries of one (b, h) by the exponent of their dO row
+// (descending), and writes per 64 sorted queries one 20 KB LDS image: fp16 two-part Q rows and dOn rows for the score /
+// dP MFMAs, bf16 hi/lo Q^T and dOn^T planes for the dK / dV MFMAs, -LSE, -D, the permutation and the chunk exponent.
+// attn16_bwd_dkv carries its accumulators in units of 2^E_chunk (a power-of-two rescale per chunk, monotone because of the
+// sort; rows 2^60 below the largest are dropped) -- block floating point over the query axis, so that dO of any dynamic
+// range (padded queries, masked losses) keeps 16 significant bits per row.
+//
+// Operand formats ("16" formats, written by a3d_proj_rope_split16 / a3d_rope_split16 / attn16_bwd_prep):
 //   rows16   [B][H][Npad][32] fp16 : hi(16) | lo(16) of the 16-padded head row        (q, k, v)
 //   planes16 [B][H][2][16][Npad] fp16 : hi and lo planes, transposed (8 consecutive rows of one channel = one MFMA A
 //            fragment); the value planes carry 1.0 in the padded channel 15 of the hi plane (softmax denominator)
-//   dO rows  [B][H][Lqp][16]  fp16, dO plane [B][H][16][Lqp] fp16 (both of the row-normalised dO * ln 2)
+//   dOr      [B][H][Lqp][32] fp16 : hi | lo of the row-normalised dO * ln 2;  pack: see PK_* below
 // Scores live in log2 units (q carries log2 e): LSE2 = log2 sum_k 2^s2.
-#include "a3d_common.h"
+#include "attn_ring.h"
 #include "../../include/act3d_hip.h"
 #include <stdlib.h>
 
 namespace a3d {
-
-typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2_;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
-constexpr int C16 = 64;              // keys (fwd, dQ) or queries (dK/dV) per staged chunk
-constexpr float P_OFF = 4.0f;        // p = 2^(s - m + P_OFF): keeps the small weights of a row out of fp16's subnormals
-constexpr float P_THR = 8.0f;        // lazy rescale: revise the running max when a score exceeds it by 2^P_THR
-constexpr float LN2_F = 0.6931471805599453f;
-// backward: P and G = P (dP - D) are formed as 2^B_OFF times their value (folded into the -lse accumulator init, undone in
-// the output scale).  Attention over 4097 keys has weights ~2^-12 and G two or three orders below; without the offset they
-// sit in fp16's subnormals (absolute precision 2^-25) -- measured as a 1.6 % error of the gripper-token key's gradient.
-constexpr float B_OFF = 6.0f;
-constexpr int MASKW = 512;           // key-validity bitmask words in LDS: Sp <= 16384
-
-__device__ __forceinline__ f32x4 mfma_f16(s16x8 a, s16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-}
-// two floats -> packed fp16 (round to nearest even; v_cvt_pk_f16_f32)
-__device__ __forceinline__ unsigned int pk_f16(float a, float b) {
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, h16x2));
-}
-// x = hi + lo, both fp16 pairs: hi = fp16(x) (round to nearest), lo = fp16(x - hi)
-__device__ __forceinline__ void pk_f16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
-  hi = pk_f16(a, b);
-  const h16x2 hh = __builtin_bit_cast(h16x2, hi);
-  lo = pk_f16(a - (float)hh[0], b - (float)hh[1]);
-}
-// x = hi + lo, both bf16 pairs (16 mantissa bits, fp32's exponent range): the operands of the query-axis contractions
-__device__ __forceinline__ void pk_bf16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-  hi = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
-  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){ra, rb}, bf16x2_));
-}
-__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-__device__ __forceinline__ float max16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
-  const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], b[0], b[1]), m2 = max3f(b[2], b[3], c[0]);
-  const float m3 = max3f(c[1], c[2], c[3]), m4 = max3f(d[0], d[1], d[2]);
-  return fmaxf(max3f(m0, m1, m2), max3f(m3, m4, d[3]));
-}
-
-// ---- LDS-DMA pieces: one wave instruction moves 64 lanes x 16 B to `lds` (wave-uniform) + lane * 16.
-// Issued through inline asm on purpose: for the builtin form hipcc's waitcnt pass orders EVERY later ds_read behind the
-// newest pending LDS-DMA (s_waitcnt vmcnt(0) in front of the first fragment read), which serialises the ring; the asm form
-// is invisible to it, and the kernels below place the counted vmcnt waits themselves (their loops issue no other VMEM
-// loads, and an uncounted op only ever makes a compiler-placed vmcnt(k) wait longer, never shorter -- returns are in order).
-__device__ __forceinline__ void glds16(const void* g, void* lds) {
-  const unsigned int dst = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(lds_void_t*)lds);
-  unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(g), "s"(dst)
-               : "memory");
-}
-// rows tile [64 rows][32 halfs] (4 KB, tile_off swizzle): wave w brings rows w*16 .. w*16+15.  `row_halfs` = source row
-// length in halfs (32: hi | lo rows; 16: single rows duplicated into both halves of the tile row)
-__device__ __forceinline__ void dma_rows_tile(const unsigned short* src_row0, int row_halfs, unsigned short* tile, int wave,
-                                              int lane) {
-  const int row = wave * 16 + (lane >> 2);
-  const int seg = (lane & 3) ^ ((0 - (row >> 3)) & 3);
-  const int sseg = (row_halfs == 32) ? seg : (seg & 1);
-  glds16(src_row0 + (size_t)row * row_halfs + sseg * 8, tile + wave * 512);
-}
-// plane sub-tile [16 ch][32 rows] (1 KB, plane_off swizzle) from a [16][ld] plane at row offset r0
-__device__ __forceinline__ void dma_plane_subtile(const unsigned short* plane, size_t ld, size_t r0, unsigned short* sub, int lane) {
-  const int ch = lane >> 2;
-  const int seg = (lane & 3) ^ ((0 - (ch >> 2)) & 3);
-  glds16(plane + (size_t)ch * ld + r0 + seg * 8, sub);
-}
-
-// Pins a register-resident operand loaded before the main loop: the (empty) asm is a use, so hipcc retires the load HERE and
-// not at its first use inside the loop, where its vmcnt wait would also drain the LDS-DMA ring.
-#define A3D_PIN(x) asm volatile("" ::"v"(x))
-#define A3D_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  static_assert(N >= 0 && N <= 12, "extend wait_vm");
-  if (N == 0) A3D_WAIT_VM(0); else if (N == 1) A3D_WAIT_VM(1); else if (N == 2) A3D_WAIT_VM(2); else if (N == 3) A3D_WAIT_VM(3);
-  else if (N == 4) A3D_WAIT_VM(4); else if (N == 5) A3D_WAIT_VM(5); else if (N == 6) A3D_WAIT_VM(6); else if (N == 7) A3D_WAIT_VM(7);
-  else if (N == 8) A3D_WAIT_VM(8); else if (N == 9) A3D_WAIT_VM(9); else if (N == 10) A3D_WAIT_VM(10);
-  else if (N == 11) A3D_WAIT_VM(11); else A3D_WAIT_VM(12);
-}
-// raw barrier (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0)); this wave's LDS writes / reads are retired first
-__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// key-validity bitmask of sample b (bit k of word k / 32 set = key valid), built once per workgroup
-__device__ __forceinline__ void build_key_mask(unsigned int* maskW, const unsigned char* __restrict__ kmask, int b, int S, int Sp) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int w0 = wave; w0 < Sp / 64; w0 += 4) {
-    const int key = w0 * 64 + lane;
-    bool valid = key < S;
-    if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
-    const unsigned long long bits = __builtin_amdgcn_ballot_w64(valid);
-    if (lane == 0) { maskW[w0 * 2] = (unsigned int)bits; maskW[w0 * 2 + 1] = (unsigned int)(bits >> 32); }
-  }
-}
-// 0 / -inf biases of the lane's four keys of score tile T of the 32-key half whose validity word is `word`
-__device__ __forceinline__ f32x4 bias_of(unsigned int word, int g, int T) {
-  const unsigned int bits = word >> (g * 8 + T * 4);
-  f32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = ((bits >> i) & 1u) ? 0.f : -INFINITY;
-  return r;
-}
 
 // ------------------------------------------------------------------------------------------------ forward
 // QT 16-query tiles per wave (128 queries per workgroup at QT = 2).  Scores are computed transposed (S^T = K Q^T) with
@@ -965,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
 
 using namespace a3d;
 
-static int check16(const char* fn, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, int qmod) {
+int a3d::attn16_check_shapes(const char* fn, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, int qmod) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lqp < Lq || (Lqp % qmod) != 0 || S <= 0 || Sp < S || (Sp % C16) != 0 || nsplit < 1 ||
       nsplit > 64 || Sp > MASKW * 32) {
     set_error("%s: bad argument (B=%d H=%d Lq=%d Lqp=%d S=%d Sp=%d nsplit=%d; need Lqp %% %d == 0, Sp %% 64 == 0, Sp <= %d)", fn,
@@ -990,7 +894,7 @@ static int drop_params(const char* fn, const unsigned long long* drop_state, flo
 extern "C" int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, const unsigned char* kmask, float* O,
                               float* LSE2, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
                               const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream) {
-  int rc = check16("a3d_attn16_fwd", B, H, Lq, Lqp, S, Sp, nsplit, 16);
+  int rc = attn16_check_shapes("a3d_attn16_fwd", B, H, Lq, Lqp, S, Sp, nsplit, 16);
   if (rc) return rc;
   if (!Qr || !Kr || !Vp || !O || !LSE2 || (nsplit > 1 && !ws)) { set_error("a3d_attn16_fwd: null pointer"); return A3D_ERR_ARG; }
   bool drop; unsigned int thr; float dscale;
@@ -1023,12 +927,16 @@ extern "C" int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, co
 #undef A3D_L16F
   rc = check_launch("a3d_attn16_fwd");
   if (rc) return rc;
-  if (nsplit > 1) {
-    const int cg = (int)std::min<size_t>((rows * HDP + 255) / 256, 4096);
-    hipLaunchKernelGGL(attn16_combine_kernel, dim3(cg), dim3(256), 0, s, Op, Mp, Lp, O, LSE2, B, H, Lq, Lqp, nsplit);
-    rc = check_launch("a3d_attn16_fwd(combine)");
-  }
+  if (nsplit > 1) rc = attn16_launch_combine(Op, Mp, Lp, O, LSE2, B, H, Lq, Lqp, nsplit, s);
   return rc;
+}
+
+int a3d::attn16_launch_combine(const float* Op, const float* Mp, const float* Lp, float* O, float* LSE2, int B, int H, int Lq,
+                               int Lqp, int nsplit, hipStream_t s) {
+  const size_t rows = (size_t)B * H * Lqp;
+  const int cg = (int)std::min<size_t>((rows * HDP + 255) / 256, 4096);
+  hipLaunchKernelGGL(attn16_combine_kernel, dim3(cg), dim3(256), 0, s, Op, Mp, Lp, O, LSE2, B, H, Lq, Lqp, nsplit);
+  return check_launch("a3d_attn16_fwd(combine)");
 }
 
 extern "C" size_t a3d_attn16_bwd_pack_bytes(int B, int H, int Lqp) {
@@ -1040,7 +948,7 @@ extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, co
                               void* pack, float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq,
                               int Lqp, int S, int Sp, int nsplit, const unsigned long long* drop_state,
                               unsigned int drop_site, float drop_p, void* stream) {
-  int rc = check16("a3d_attn16_bwd", B, H, Lq, Lqp, S, Sp, nsplit, 64);
+  int rc = attn16_check_shapes("a3d_attn16_bwd", B, H, Lq, Lqp, S, Sp, nsplit, 64);
   if (rc) return rc;
   if (!Qr || !Qp || !Kr || !Kp || !Vr || !O || !dO || !LSE2 || !dOr || !pack || !D || !rexp || !dQp || !dK || !dV) {
     set_error("a3d_attn16_bwd: null pointer");

@@ -1,0 +1,121 @@
+// Pieces shared by the split-fp16 attention kernels (attention16.hip) and the fp8 forward (attention8.hip): vector types,
+// 16-bit packing helpers, the LDS-DMA ring primitives, the key-validity bitmask.  See attention16.hip for the design notes.
+#pragma once
+#include "a3d_common.h"
+
+namespace a3d {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+constexpr int C16 = 64;              // keys (fwd, dQ) or queries (dK/dV) per staged chunk
+constexpr float P_OFF = 4.0f;        // p = 2^(s - m + P_OFF): keeps the small weights of a row out of fp16's subnormals
+constexpr float P_THR = 8.0f;        // lazy rescale: revise the running max when a score exceeds it by 2^P_THR
+constexpr float LN2_F = 0.6931471805599453f;
+// backward: P and G = P (dP - D) are formed as 2^B_OFF times their value (folded into the -lse accumulator init, undone in
+// the output scale).  Attention over 4097 keys has weights ~2^-12 and G two or three orders below; without the offset they
+// sit in fp16's subnormals (absolute precision 2^-25) -- measured as a 1.6 % error of the gripper-token key's gradient.
+constexpr float B_OFF = 6.0f;
+constexpr int MASKW = 512;           // key-validity bitmask words in LDS: Sp <= 16384
+
+__device__ __forceinline__ f32x4 mfma_f16(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+// two floats -> packed fp16 (round to nearest even; v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned int pk_f16(float a, float b) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, h16x2));
+}
+// x = hi + lo, both fp16 pairs: hi = fp16(x) (round to nearest), lo = fp16(x - hi)
+__device__ __forceinline__ void pk_f16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
+  hi = pk_f16(a, b);
+  const h16x2 hh = __builtin_bit_cast(h16x2, hi);
+  lo = pk_f16(a - (float)hh[0], b - (float)hh[1]);
+}
+// x = hi + lo, both bf16 pairs (16 mantissa bits, fp32's exponent range): the operands of the query-axis contractions
+__device__ __forceinline__ void pk_bf16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  hi = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){ra, rb}, bf16x2_));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float max16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
+  const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], b[0], b[1]), m2 = max3f(b[2], b[3], c[0]);
+  const float m3 = max3f(c[1], c[2], c[3]), m4 = max3f(d[0], d[1], d[2]);
+  return fmaxf(max3f(m0, m1, m2), max3f(m3, m4, d[3]));
+}
+
+// ---- LDS-DMA pieces: one wave instruction moves 64 lanes x 16 B to `lds` (wave-uniform) + lane * 16.
+// Issued through inline asm on purpose: for the builtin form hipcc's waitcnt pass orders EVERY later ds_read behind the
+// newest pending LDS-DMA (s_waitcnt vmcnt(0) in front of the first fragment read), which serialises the ring; the asm form
+// is invisible to it, and the kernels below place the counted vmcnt waits themselves (their loops issue no other VMEM
+// loads, and an uncounted op only ever makes a compiler-placed vmcnt(k) wait longer, never shorter -- returns are in order).
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  const unsigned int dst = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(lds_void_t*)lds);
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(dst)
+               : "memory");
+}
+// rows tile [64 rows][32 halfs] (4 KB, tile_off swizzle): wave w brings rows w*16 .. w*16+15.  `row_halfs` = source row
+// length in halfs (32: hi | lo rows; 16: single rows duplicated into both halves of the tile row)
+__device__ __forceinline__ void dma_rows_tile(const unsigned short* src_row0, int row_halfs, unsigned short* tile, int wave,
+                                              int lane) {
+  const int row = wave * 16 + (lane >> 2);
+  const int seg = (lane & 3) ^ ((0 - (row >> 3)) & 3);
+  const int sseg = (row_halfs == 32) ? seg : (seg & 1);
+  glds16(src_row0 + (size_t)row * row_halfs + sseg * 8, tile + wave * 512);
+}
+// plane sub-tile [16 ch][32 rows] (1 KB, plane_off swizzle) from a [16][ld] plane at row offset r0
+__device__ __forceinline__ void dma_plane_subtile(const unsigned short* plane, size_t ld, size_t r0, unsigned short* sub, int lane) {
+  const int ch = lane >> 2;
+  const int seg = (lane & 3) ^ ((0 - (ch >> 2)) & 3);
+  glds16(plane + (size_t)ch * ld + r0 + seg * 8, sub);
+}
+
+// Pins a register-resident operand loaded before the main loop: the (empty) asm is a use, so hipcc retires the load HERE and
+// not at its first use inside the loop, where its vmcnt wait would also drain the LDS-DMA ring.
+#define A3D_PIN(x) asm volatile("" ::"v"(x))
+#define A3D_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 12, "extend wait_vm");
+  if (N == 0) A3D_WAIT_VM(0); else if (N == 1) A3D_WAIT_VM(1); else if (N == 2) A3D_WAIT_VM(2); else if (N == 3) A3D_WAIT_VM(3);
+  else if (N == 4) A3D_WAIT_VM(4); else if (N == 5) A3D_WAIT_VM(5); else if (N == 6) A3D_WAIT_VM(6); else if (N == 7) A3D_WAIT_VM(7);
+  else if (N == 8) A3D_WAIT_VM(8); else if (N == 9) A3D_WAIT_VM(9); else if (N == 10) A3D_WAIT_VM(10);
+  else if (N == 11) A3D_WAIT_VM(11); else A3D_WAIT_VM(12);
+}
+// raw barrier (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0)); this wave's LDS writes / reads are retired first
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// key-validity bitmask of sample b (bit k of word k / 32 set = key valid), built once per workgroup
+__device__ __forceinline__ void build_key_mask(unsigned int* maskW, const unsigned char* __restrict__ kmask, int b, int S, int Sp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w0 = wave; w0 < Sp / 64; w0 += 4) {
+    const int key = w0 * 64 + lane;
+    bool valid = key < S;
+    if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(valid);
+    if (lane == 0) { maskW[w0 * 2] = (unsigned int)bits; maskW[w0 * 2 + 1] = (unsigned int)(bits >> 32); }
+  }
+}
+// 0 / -inf biases of the lane's four keys of score tile T of the 32-key half whose validity word is `word`
+__device__ __forceinline__ f32x4 bias_of(unsigned int word, int g, int T) {
+  const unsigned int bits = word >> (g * 8 + T * 4);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = ((bits >> i) & 1u) ? 0.f : -INFINITY;
+  return r;
+}
+
+// launches attn16_combine_kernel (attention16.hip): flash-decoding combine of `nsplit` partial results
+int attn16_launch_combine(const float* Op, const float* Mp, const float* Lp, float* O, float* LSE2, int B, int H, int Lq,
+                          int Lqp, int nsplit, hipStream_t s);
+int attn16_check_shapes(const char* fn, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, int qmod);
+
+}  // namespace a3d

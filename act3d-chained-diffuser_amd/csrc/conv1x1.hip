@@ -160,201 +160,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const unsigned short* __re
   }
 }
 
-// WM x WN waves (64 x 64 outputs each), KSUB 32-channel sub-steps staged per barrier.  Verified configuration (round 2):
-// 4 waves, KSUB = 1 (WN = 1 / 2 / 4 for N = 64 / 128 / >= 256).  The other instantiations are tuning candidates selected with
-// A3D_C1_TILE="wm,wn,ksub" (DESIGN.md §8-6): more rows per weight fetch (8 waves, 128 x 256 tile) and fewer barriers (KSUB = 2).
-template <int WM, int WN, int KSUB>
-__global__ __launch_bounds__(64 * WM * WN) void conv1x1_tile_kernel(const unsigned short* __restrict__ x,
-                                                                const unsigned short* __restrict__ w,
-                                                                const float* __restrict__ in_scale,
-                                                                const float* __restrict__ in_shift, int in_relu,
-                                                                unsigned short* __restrict__ y, float* __restrict__ partial,
-                                                                long long M, int K, int N) {
-  constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
-  constexpr int XL = BM * 4 * KSUB / NT, WL = BN * 4 * KSUB / NT;   // 16-byte segments each thread stages per barrier
-  static_assert(XL * NT == BM * 4 * KSUB && WL * NT == BN * 4 * KSUB, "tile does not divide over the threads");
-  extern __shared__ __attribute__((aligned(16))) unsigned short c1_smem[];
-  unsigned short* Xs = c1_smem;                                     // [2][KSUB][BM * 32]
-  unsigned short* Ws = Xs + 2 * KSUB * BM * 32;                     // [2][KSUB][BN * 32]
-  float* redS = reinterpret_cast<float*>(Ws + 2 * KSUB * BN * 32);  // [WM * WN][64]
-  float* redQ = redS + WM * WN * 64;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.y * BN;
-  const long long mtiles = (M + BM - 1) / BM;
-  const int ksteps = K / (C1_BK * KSUB);
-  float ssum[4][4], ssq[4][4];                                    // [tn][r]: channel n0 + wn * 64 + tn * 16 + g * 4 + r
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
-
-  for (long long mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
-    const long long m0 = mt * BM;
-    uint4 xr[XL], wr[WL];
-    // segment idx of a stage: row = idx / (4 KSUB), sub = (idx / 4) % KSUB, seg = idx % 4  (KSUB * 64 contiguous bytes per row)
-    auto load = [&](int ks) {
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const int idx = t + i * NT, row = idx / (4 * KSUB), cs = idx % (4 * KSUB);
-        const long long m = m0 + row < M ? m0 + row : M - 1;                   // clamped: tail rows are masked at the store
-        xr[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks * C1_BK * KSUB + cs * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int idx = t + i * NT, row = idx / (4 * KSUB), cs = idx % (4 * KSUB);
-        wr[i] = *reinterpret_cast<const uint4*>(w + (size_t)(n0 + row) * K + ks * C1_BK * KSUB + cs * 8);
-      }
-    };
-    auto stage = [&](int buf, int ks) {
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const int idx = t + i * NT, row = idx / (4 * KSUB), cs = idx % (4 * KSUB), sub = cs >> 2, seg = cs & 3;
-        uint4 v = xr[i];
-        if (in_scale) {
-          // producer's BatchNorm-apply (+ ReLU) on the 8 channels of this segment, rounded back to bf16 like the
-          // activation the unfused path materialises
-          const int k0 = ks * C1_BK * KSUB + cs * 8;
-          const float4 s0 = *reinterpret_cast<const float4*>(in_scale + k0), s1 = *reinterpret_cast<const float4*>(in_scale + k0 + 4);
-          const float4 h0 = *reinterpret_cast<const float4*>(in_shift + k0), h1 = *reinterpret_cast<const float4*>(in_shift + k0 + 4);
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-          unsigned int u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
-            float b = __uint_as_float(u[j] & 0xFFFF0000u) * sc[2 * j + 1] + sh[2 * j + 1];
-            if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-            u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
-          }
-          v = make_uint4(u[0], u[1], u[2], u[3]);
-        }
-        *reinterpret_cast<uint4*>(&Xs[(buf * KSUB + sub) * BM * 32 + plane_off(row, seg)]) = v;
-      }
-#pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int idx = t + i * NT, row = idx / (4 * KSUB), cs = idx % (4 * KSUB), sub = cs >> 2, seg = cs & 3;
-        *reinterpret_cast<uint4*>(&Ws[(buf * KSUB + sub) * BN * 32 + plane_off(row, seg)]) = wr[i];
-      }
-    };
-
-    f32x4 acc[4][4];                                              // [tn][tm]: D[n = g * 4 + r][m = li]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load(0);
-    __syncthreads();                                              // previous tile's LDS reads are done
-    stage(0, 0);
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int buf = ks & 1;
-      if (ks + 1 < ksteps) load(ks + 1);
-      __syncthreads();                                            // stage(buf) visible; reads of buf ^ 1 (step ks - 1) done
-#pragma unroll
-      for (int sub = 0; sub < KSUB; ++sub) {
-        const unsigned short* Xb = Xs + (buf * KSUB + sub) * BM * 32;
-        const unsigned short* Wb = Ws + (buf * KSUB + sub) * BN * 32;
-        s16x8 xa[4], wb[4];
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) xa[tm] = *reinterpret_cast<const s16x8*>(&Xb[plane_off(wm * 64 + tm * 16 + li, g)]);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) wb[tn] = *reinterpret_cast<const s16x8*>(&Wb[plane_off(wn * 64 + tn * 16 + li, g)]);
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
-      }
-      if (ks + 1 < ksteps) stage(buf ^ 1, ks + 1);
-    }
-    // ---- epilogue: round once, 8-byte stores (4 consecutive channels of one row), statistics of the rounded values
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      const long long m = m0 + wm * 64 + tm * 16 + li;
-      const bool ok = m < M;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = f2bf(acc[tn][tm][r]);
-          if (ok) {
-            const float v = bf2f(h[r]);
-            ssum[tn][r] += v;
-            ssq[tn][r] += v * v;
-          }
-        }
-        if (ok) {
-          const uint2 pk = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
-          *reinterpret_cast<uint2*>(y + (size_t)m * N + n0 + wn * 64 + tn * 16 + g * 4) = pk;
-        }
-      }
-    }
-  }
-  if (!partial) return;
-  // ---- per-workgroup partial statistics: sum over the 16 rows a lane group holds, then over the WM waves along M
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = ssum[tn][r], q = ssq[tn][r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (li == 0) { redS[wave * 64 + tn * 16 + g * 4 + r] = s; redQ[wave * 64 + tn * 16 + g * 4 + r] = q; }
-    }
-  __syncthreads();
-  for (int i = t; i < BN; i += NT) {
-    const int wn_i = i >> 6, c = i & 63;
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int j = 0; j < WM; ++j) { s += redS[(j * WN + wn_i) * 64 + c]; q += redQ[(j * WN + wn_i) * 64 + c]; }
-    float* p = partial + (size_t)blockIdx.x * 2 * N;
-    p[n0 + i] = s;
-    p[N + n0 + i] = q;
-  }
-}
-
 }  // namespace a3d
 
 using namespace a3d;
-
-struct C1Tile { int wm, wn, ksub; };
-
-// A3D_C1_TILE="wm,wn,ksub" (read at every call) selects a tuning candidate of conv1x1_tile_kernel; unset / not applicable to
-// this N: {0, 0, 0} = the verified conv1x1_kernel above.  The tile's row count (64 wm) does not depend on K, so
-// a3d_conv1x1_nslab and the launch agree; ksub = 2 silently drops to 1 when K is not a multiple of 64.
-static C1Tile c1_tile(int K, int N) {
-  const char* e = getenv("A3D_C1_TILE");
-  int wm = 0, wn = 0, ks = 0;
-  if (e && sscanf(e, "%d,%d,%d", &wm, &wn, &ks) == 3) {
-    const bool known = (wm == 1 && wn == 4) || (wm == 2 && wn == 4) || (wm == 2 && wn == 2) || (wm == 4 && wn == 1) || (wm == 4 && wn == 2);
-    if (known && (ks == 1 || ks == 2) && N % (64 * wn) == 0) return C1Tile{wm, wn, (ks == 2 && K % 64 == 0) ? 2 : 1};
-  }
-  return C1Tile{0, 0, 0};
-}
-
-static int c1_tile_slabs(size_t M, int K, int N) {
-  const C1Tile tl = c1_tile(K, N);
-  const size_t mtiles = (M + 64 * tl.wm - 1) / (64 * tl.wm);
-  const int ntiles = N / (64 * tl.wn);
-  const size_t cap = (size_t)std::max(1, 2048 / ntiles);            // ~8 workgroups per CU over the whole grid
-  return (int)std::min(mtiles, cap);
-}
-
-
-template <int WM, int WN, int KSUB>
-static void c1_launch(int slabs, hipStream_t s, const unsigned short* x, const unsigned short* w, const float* in_scale,
-                      const float* in_shift, int in_relu, unsigned short* y, float* partial, long long M, int K, int N) {
-  const size_t lds = (size_t)2 * KSUB * 64 * (WM + WN) * 32 * sizeof(unsigned short) + (size_t)2 * WM * WN * 64 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_tile_kernel<WM, WN, KSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL((conv1x1_tile_kernel<WM, WN, KSUB>), dim3(slabs, N / (64 * WN)), dim3(64 * WM * WN), lds, s, x, w, in_scale,
-                     in_shift, in_relu, y, partial, M, K, N);
-}
-
 
 static int c1_slabs(size_t M, int N) {
   const int wn = N >= 256 ? 4 : (N >= 128 ? 2 : 1);
@@ -367,7 +175,7 @@ static int c1_slabs(size_t M, int N) {
 
 extern "C" int a3d_conv1x1_nslab(size_t M, int N) {
   if (M == 0 || N <= 0) return 0;
-  return c1_tile(64, N).wm ? c1_tile_slabs(M, 64, N) : c1_slabs(M, N);
+  return c1_slabs(M, N);
 }
 
 extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu,
@@ -382,17 +190,6 @@ extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_
   const unsigned short* xs = (const unsigned short*)x;
   const unsigned short* ws = (const unsigned short*)w;
   unsigned short* ys = (unsigned short*)y;
-  const C1Tile tl = c1_tile(K, N);
-  if (tl.wm) {                                  // tuning candidates (A3D_C1_TILE), not part of the verified default path
-    const int tslabs = c1_tile_slabs(M, K, N);
-    const long long m = (long long)M;
-#define C1_CASE(a, b, c) if (tl.wm == a && tl.wn == b && tl.ksub == c) c1_launch<a, b, c>(tslabs, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, m, K, N)
-    C1_CASE(1, 4, 1); else C1_CASE(2, 2, 1); else C1_CASE(4, 1, 1);
-    else C1_CASE(1, 4, 2); else C1_CASE(2, 2, 2); else C1_CASE(4, 1, 2);
-    else C1_CASE(2, 4, 1); else C1_CASE(2, 4, 2); else C1_CASE(4, 2, 1); else C1_CASE(4, 2, 2);
-#undef C1_CASE
-    return check_launch("a3d_conv1x1_bn_fwd(tile)");
-  }
   const int slabs = c1_slabs(M, N);
   if (N >= 256)
     hipLaunchKernelGGL(conv1x1_kernel<4>, dim3(slabs, N / 256), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);

@@ -250,13 +250,45 @@ __device__ __forceinline__ void wg_load_rows(const float* __restrict__ src, int 
   __syncthreads();
 }
 
+// L2 warm-up of the weights a per-sample kernel is about to stream.  Between two layers' per-sample kernels the cross
+// attention streams ~200 MB of K / V cache through the 4 MiB L2 of every XCD, so each dn_rest launch finds its 0.75 MB of
+// weights evicted and would fetch them miss by miss on its dependent path (25 phases, one exposed HBM round trip per weight
+// chunk: PMC showed 8.6 MB of HBM fetch per launch = 8 XCDs x the layer's weights, MfmaUtil 2.5 %).  Here every workgroup
+// touches, up front and all at once, one dword of each 128-byte line of its share of the matrices (the workgroups of one
+// XCD -- blockIdx % 8 -- split the lines among themselves), so that the misses overlap each other instead of the compute.
+struct WarmList { const float* p[6]; int n[6]; };
+__device__ __forceinline__ void wg_warm_l2(const WarmList& wl, int nblocks) {
+  const int per_xcd = max(1, min(8, nblocks >> 3));
+  const int part = (blockIdx.x >> 3) % per_xcd;
+  float keep[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) keep[i] = 0.f;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    if (wl.p[m] == nullptr) continue;
+    const int nline = (wl.n[m] + 31) >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                               // <= 8 x blockDim lines per matrix and workgroup share
+      const int line = (i * (int)blockDim.x + (int)threadIdx.x) * per_xcd + part;
+      if (line < nline) keep[i] += wl.p[m][min(line * 32, wl.n[m] - 1)];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(keep[i]));
+}
+
 // ------------------------------------------------------------------------------------------------ head
 __global__ __launch_bounds__(512) void dn_head_kernel(const float* __restrict__ traj, int D, a3d_dn_head_params p,
-                                                      float* __restrict__ x_out, int L, int E, int H) {
+                                                      float* __restrict__ x_out, int L, int E, int H, int warm) {
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], As[DR * LDX], Ts[DR * LDX], Qs[DR * LDX];
   extern __shared__ __attribute__((aligned(16))) float kvS[];          // [S_lang][2E]: the instruction tokens' k | v rows
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
+  if (warm) {
+    const WarmList wl = {{p.enc_w1, p.lang_kv ? p.q_w : nullptr, p.lang_kv ? p.out_w : nullptr, nullptr, nullptr, nullptr},
+                         {E * E, E * E, E * E, 0, 0, 0}};
+    wg_warm_l2(wl, gridDim.x);
+  }
   // trajectory rows (D = 9 channels) padded to one 16-channel block
   for (int i = threadIdx.x; i < DR * 16; i += blockDim.x) {
     const int r = i >> 4, c = i & 15;
@@ -439,7 +471,7 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
 __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
                                                       const float* __restrict__ Op, const float* __restrict__ Mp,
                                                       a3d_dn_rest_params p, float* __restrict__ x_out, int B, int L,
-                                                      int E, int H, int nsplit) {
+                                                      int E, int H, int nsplit, int warm) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                       // [16][LDX]  residual stream
   float* As = Xs + DR * LDX;              // [16][LDX]
@@ -449,6 +481,11 @@ __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ 
   float* Hs = QK + DR * LDQK;             // [16][LDH]
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
+  if (warm) {
+    const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
+                         {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
+    wg_warm_l2(wl, gridDim.x);
+  }
   wg_load_rows(x_in + (size_t)b * L * E, E, L, Xs, LDX, Epad);
   wg_zero_pad(As, LDX, E, Epad);
   wg_zero_pad(Bs, LDX, E, Epad);
@@ -501,10 +538,14 @@ __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------ tail
 __global__ __launch_bounds__(512) void dn_tail_kernel(const float* __restrict__ pos_feats, const float* __restrict__ rot_feats,
                                                       const float* __restrict__ traj, int D, a3d_dn_tail_params p,
-                                                      float* __restrict__ traj_out, int L, int E, int t_step) {
+                                                      float* __restrict__ traj_out, int L, int E, int t_step, int warm) {
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], Ts[DR * LDX], Us[DR * 16];
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
+  if (warm) {
+    const WarmList wl = {{p.pos_w0, p.rot_w0, nullptr, nullptr, nullptr, nullptr}, {E * E, E * E, 0, 0, 0, 0}};
+    wg_warm_l2(wl, gridDim.x);
+  }
   wg_zero_pad(Ts, LDX, E, Epad);
   wg_load_rows(pos_feats + (size_t)b * L * E, E, L, Xs, LDX, Epad);
   wg_linear<1>(Xs, LDX, E, p.pos_w0, E, p.pos_b0, E, Ts, LDX);
@@ -573,6 +614,12 @@ static int dn_threads() {
   return n;
 }
 
+// L2 warm-up of the weights at the head of the per-sample kernels (wg_warm_l2); A3D_DN_WARM=0 for the A/B run
+static int dn_warm() {
+  static const int w = (getenv("A3D_DN_WARM") && atoi(getenv("A3D_DN_WARM")) == 0) ? 0 : 1;
+  return w;
+}
+
 static int dn_check(const char* fn, int B, int L, int E, int H) {
   if (B <= 0 || L <= 0 || L > DR || E <= 0 || E > 128 || (E % 6) != 0 || H * HD != E) {
     set_error("%s: bad shape (B=%d L=%d E=%d H=%d; L <= 16, E = 15 H <= 128)", fn, B, L, E, H);
@@ -600,7 +647,7 @@ extern "C" int a3d_dn_head(const float* traj, int D, const a3d_dn_head_params* p
     (void)hipFuncSetAttribute((const void*)dn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, traj, D, *p, x_out, L, E, H);
+  hipLaunchKernelGGL(dn_head_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, traj, D, *p, x_out, L, E, H, dn_warm());
   return check_launch("a3d_dn_head");
 }
 
@@ -640,7 +687,7 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
   const float* Op = ws;
   const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
   hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E, H,
-                     nsplit);
+                     nsplit, dn_warm());
   return check_launch("a3d_dn_rest");
 }
 
@@ -652,7 +699,7 @@ extern "C" int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const
     return A3D_ERR_ARG;
   }
   hipLaunchKernelGGL(dn_tail_kernel, dim3(B), dim3(dn_threads()), 0, (hipStream_t)stream, pos_feats, rot_feats, traj, D, *p, traj_out, L,
-                     E, t_step);
+                     E, t_step, dn_warm());
   return check_launch("a3d_dn_tail");
 }
 

@@ -121,13 +121,21 @@ def pick_nsplit(B, H, Lqp, Sp):
     return ns
 
 
-ATTN_MODE = os.environ.get("A3D_ATTN_MODE", "f16")      # "f16": split-fp16 kernels (attention16.hip); "bf16x3": attention.hip
+# "f16": split-fp16 kernels (attention16.hip, default, the parity path); "bf16x3": attention.hip (A/B reference);
+# "fp8": OPT-IN e4m3 forward (attention8.hip, BASELINE configs[4]) on the fp16 operands -- e4m3 tolerance, not the 1e-3 bar.
+# It serves forwards that keep NO gradient (evaluation, inference, sampling); a forward whose backward will run stays on
+# the split-fp16 kernels: the backward recomputes the weights from 16-bit logits and needs the forward's O and LSE to be
+# consistent with them (sum_k G = 0), and with an fp8 O / LSE the ghost-attention gradients were measured 40-100 % off
+#  -- the gradient of a near-uniform attention is a small covariance on a large common mode.
+ATTN_MODE = os.environ.get("A3D_ATTN_MODE", "f16")
+if ATTN_MODE not in ("f16", "bf16x3", "fp8"):
+    raise ValueError("A3D_ATTN_MODE must be f16, bf16x3 or fp8, got %r" % ATTN_MODE)
 LOG2E = 1.4426950408889634
 
 
 def _use16(drop):
-    """The split-fp16 attention core is the default for every pass (with and without attention-weight dropout)."""
-    return ATTN_MODE == "f16"
+    """The split-fp16 operand formats feed every pass of the default and the fp8 mode (with and without dropout)."""
+    return ATTN_MODE in ("f16", "fp8")
 
 
 PLANE_PARTS = 2       # q / k planes of the backward: hi and lo parts
@@ -313,7 +321,7 @@ def dropout_mask(drop, site, n, bh=None, q=None):
     return out
 
 
-def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0):
+def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0, need_bwd=False):
     """Attention core on pre-formatted operands; the operand dtype selects the kernel family (fp16: attention16.hip, whose
     LSE is in log2 units; bf16: attention.hip)."""
     dev = Qs.device
@@ -325,6 +333,12 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, si
         ws = torch.empty((nsplit * B * H * Lqp * 18,), device=dev, dtype=F32)
     if Qs.dtype == torch.float16:
         dropping = drop is not None and drop.p > 0
+        if ATTN_MODE == "fp8" and not dropping and not need_bwd:
+            ops8 = torch.empty((L.load().a3d_attn8_operand_bytes(B, H, Sp),), device=dev, dtype=torch.uint8)
+            L.call("a3d_attn8_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), ops8.data_ptr(),
+                   None if kmask is None else kmask.data_ptr(), O.data_ptr(), LSE.data_ptr(),
+                   None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
+            return O, LSE
         L.call("a3d_attn16_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
                O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
                drop.state.data_ptr() if dropping else None, int(site), drop.p if dropping else 0.0, L.stream())
@@ -395,6 +409,7 @@ class AttnBlockFn(torch.autograd.Function):
               "qk" (query is key, value differs -- :277-303), "none" (three inputs).
     Returns (y, attn_out) where attn_out is the pre-residual attention output (rarely needed).
     """
+    grad_mode = True        # torch.is_grad_enabled() of the caller, recorded by attn_block just before apply()
 
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode,
@@ -415,8 +430,9 @@ class AttnBlockFn(torch.autograd.Function):
         wp, bp = in_w.data_ptr(), in_b.data_ptr()
         f4 = 4
         # grad mode is always off inside Function.forward: ask the ctx whether a backward can follow (the in-projection
-        # parameters count -- they get .grad through wgrad even when no input needs a gradient)
-        need_bwd = any(ctx.needs_input_grad) or in_w.requires_grad
+        # parameters count -- they get .grad through wgrad even when no input needs a gradient), and the caller's grad mode
+        # (attn_block records it): under torch.no_grad() no backward follows whatever the parameters say
+        need_bwd = AttnBlockFn.grad_mode and (any(ctx.needs_input_grad) or in_w.requires_grad)
         if FUSED_PROJ and E % 4 == 0 and E <= 128:
             # ---- projections fused with RoPE + operand formatting: the projected rows never reach HBM
             fused = attn_operands_fused16 if _use16(drop) else attn_operands_fused
@@ -449,7 +465,7 @@ class AttnBlockFn(torch.autograd.Function):
                                                               S, E, H, dev, need_bwd=need_bwd)
             del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
-        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site)
+        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site, need_bwd=need_bwd)
         Y = linear2d(O.view(B * Lq, E), out_w, out_b)
         if drop is not None:
             dropout_raw(Y, drop, site + 1, out=Y)          # seq1 + dropout(attn_out): Y now holds the dropped branch
@@ -626,6 +642,7 @@ def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=
         mode = "qk"
     else:
         mode = "none"
+    AttnBlockFn.grad_mode = torch.is_grad_enabled()
     return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
                              mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site)
 

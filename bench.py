@@ -48,11 +48,11 @@ def synthetic_batch(B, ncam, device, seed):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in s.items()}
 
 
-def build_model(a3d, device, backbone_dtype):
+def build_model(a3d, device, backbone_dtype, levels=3, ghost_points=1000):
     torch.manual_seed(0)
     m = a3d.Act3D(backbone="clip", image_size=(256, 256), embedding_dim=60, num_attn_heads=4,
-                  gripper_loc_bounds=PERACT_BOUNDS, num_ghost_points=1000, num_ghost_points_val=10000,
-                  num_sampling_level=3, weight_tying=True, gp_emb_tying=True, use_instruction=False)
+                  gripper_loc_bounds=PERACT_BOUNDS, num_ghost_points=ghost_points, num_ghost_points_val=10000,
+                  num_sampling_level=levels, weight_tying=True, gp_emb_tying=True, use_instruction=False)
     m.to(device)
     m.backbone_dtype = backbone_dtype
     m.fpn_dtype = backbone_dtype
@@ -197,6 +197,107 @@ def pmc_record(B):
         return None
 
 
+def cfg5_fp8_bench(a3d, device, B=16, steps=10, warmup=3):
+    """BASELINE configs[4] (74 HiveFormer tasks, fp8 MFMA attention, 4 ghost-point levels at 10 000 points): the Act3D keypose
+    EVALUATION forward at those token counts (3 cameras, 4 levels x 2500 ghost points, B keyframes per GPU; backbone + FPN +
+    hot path), hipGraph-replayed, with the OPT-IN fp8 attention forward (A3D_ATTN_MODE=fp8, csrc/attention8.hip; e4m3
+    tolerance, tests/test_attn8_gpu.py) and with the default split-fp16 attention.  The fp8 mode serves gradient-free
+    forwards only (ops.ATTN_MODE), so the training step at these shapes -- the third number -- runs the default kernels."""
+    E, O = a3d.engine, a3d.ops
+    crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    batch = synthetic_batch(B, 3, device, seed=55)
+    res = {}
+    old = O.ATTN_MODE
+    try:
+        model = build_model(a3d, device, torch.bfloat16, levels=4, ghost_points=10000)
+        model.eval()
+
+        def forward():
+            with torch.no_grad():
+                return model(batch["rgbs"], batch["pcds"], batch["instr"], batch["curr_gripper"], gt_action=None)
+
+        for mode in ("f16", "fp8"):
+            O.ATTN_MODE = mode
+            for _ in range(2):
+                out = forward()
+            torch.cuda.synchronize()
+            graph = None
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    forward()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = forward()
+                graph = g
+            except Exception as e:                       # capture can fail (library versions): time the eager forward
+                res[mode + "_graph_error"] = repr(e)[:200]
+                torch.cuda.synchronize()
+            run = graph.replay if graph is not None else forward
+            for _ in range(warmup):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            assert torch.isfinite(out["position"]).all()
+            res[mode] = {"samples_per_s": B / dt, "ms_per_forward": dt * 1e3, "hipgraph": graph is not None}
+            del graph
+        O.ATTN_MODE = "f16"
+        model.train()
+
+        def fwd_bwd(sample, on_hot_done=None):
+            return E.fwd_bwd_keypose(model, crit, sample, True, on_hot_done)
+
+        flat, opt = E.get_optimizer(model, lr=1e-4, active_names=E.discover_active_parameters(model, lambda: fwd_bwd(batch)))
+        step = E.GraphedStep(fwd_bwd, opt, batch, warmup=2)
+        for _ in range(warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res["train_default_mode"] = {"samples_per_s": B / dt, "ms_per_step": dt * 1e3, "final_loss": float(loss.item())}
+        del step, model, flat, opt
+        torch.cuda.empty_cache()
+        # the ghost attention of one level at these shapes, forward only, both families (events on the launch stream)
+        Lq, S, H, Ed = 2500, 3 * 32 * 32 + 1, 4, 60
+        g = torch.Generator().manual_seed(3)
+        qc = torch.randn(B * Lq, Ed, generator=g).to(device)
+        kc = torch.randn(B * S, Ed, generator=g).to(device)
+        vc = torch.randn(B * S, Ed, generator=g).to(device)
+        Qs, Ks, Vt, Lqp, Sp = O.attn_operands16(qc.data_ptr(), Ed, kc.data_ptr(), Ed, vc.data_ptr(), Ed, None, None, B, Lq, S, Ed, H,
+                                                device, need_bwd=False)[:5]
+        ns = O.pick_nsplit(B, H, Lqp, Sp)
+        t = {}
+        for mode in ("f16", "fp8"):
+            O.ATTN_MODE = mode
+            t[mode] = time_kernel(lambda: O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns))
+        flops = 4.0 * Lq * S * Ed * B
+    finally:
+        O.ATTN_MODE = old
+    return {"metric": "keyposes/sec (Act3D evaluation forward, configs[4] token counts, fp8 attention)",
+            "value": res["fp8"]["samples_per_s"], "unit": "samples/s", "n_gpus": 1, "ms_per_step": res["fp8"]["ms_per_forward"],
+            "steps": steps, "warmup": warmup, "higher_is_better": True, "data": "synthetic",
+            "dtype": "fp8 e4m3 attention forward (opt-in, e4m3 tolerance); bf16 backbone / FPN; fp32 elsewhere",
+            "fp8_mode": res["fp8"], "default_mode_split_fp16": res["f16"], "train_step_default_mode": res["train_default_mode"],
+            **{k: v for k, v in res.items() if k.endswith("_graph_error")},
+            "config": {"workload": f"BASELINE configs[4] token counts: B={B} keyframes per GPU, 3 cameras 256x256, 4 levels x 2500 ghost "
+                                   "points (num_ghost_points_val=10000), E=60, H=4; backbone + FPN + hot path, no gradient",
+                       "attention_mode": "A3D_ATTN_MODE=fp8"},
+            "roofline": {"bound": "mfma", "kernel": "attn8_fwd (+ amax + pack), ghost attention of one level: Lq=2500, S=3073",
+                         "achieved": flops / (t["fp8"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": flops / (t["fp8"] * 1e-3) / 2.5e15, "ms": t["fp8"], "split_fp16_ms": t["f16"],
+                         "split_fp16_frac": flops / (t["f16"] * 1e-3) / 2.5e15, "traffic": None,
+                         "dtype": "e4m3 MFMA 16x16x32 (fp32 accumulate); peak priced at the bf16 dense rate"}}
+
+
 def joint_step_bench(a3d, device, B=16, steps=10, warmup=3, world=1, rank=0):
     """BASELINE configs[3] (joint Act3D + trajectory-diffusion training, DP batch 128 over 8 GPUs = 16 per GPU): one joint
     iteration = one Act3D keypose training step AND one trajectory-diffusion training step on B samples each per rank (two
@@ -276,6 +377,7 @@ def main():
                     help="only the dominant-kernel micro-benchmarks (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--skip-secondary", action="store_true",
                     help="skip the ChainedDiffuser entries (diffusion training step, 100-step sampling) of `secondary`")
+    ap.add_argument("--only-cfg5", action="store_true", help="run only the configs[4] / fp8-attention secondary entry and print it")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -298,6 +400,9 @@ def main():
     B = args.batch
     if args.kernels_only:
         print(json.dumps({"kernels": kernel_rooflines(a3d, device, B), "per_gpu_batch_keyframes": B}))
+        return
+    if args.only_cfg5:
+        print(json.dumps(cfg5_fp8_bench(a3d, device, 16)))
         return
     model = build_model(a3d, device, torch.bfloat16 if args.backbone_dtype == "bf16" else torch.float32)
     crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
@@ -435,7 +540,8 @@ def main():
             for name, fn in (("diffusion_train_script_shape", lambda: BD.training_bench(a3d, device, 22, 50, 3, steps=10, warmup=3)),
                              ("diffusion_train_cfg3_shape", lambda: BD.training_bench(a3d, device, 64, 16, 3, steps=10, warmup=3)),
                              ("diffusion_sampling_cfg3", lambda: BD.sampling_bench(a3d, device, 64, 16, 3, reps=3)),
-                             ("joint_keypose_diffusion_cfg4", lambda: joint_step_bench(a3d, device, 16))):
+                             ("joint_keypose_diffusion_cfg4", lambda: joint_step_bench(a3d, device, 16)),
+                             ("keypose_cfg5_fp8_attention", lambda: cfg5_fp8_bench(a3d, device, 16))):
                 try:
                     r = fn()
                 except Exception as e:

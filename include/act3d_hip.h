@@ -146,6 +146,17 @@ int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, const void* K
                    float* D, int* rexp, float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S, int Sp,
                    int nsplit, const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
 
+/* OPT-IN fp8 forward (BASELINE.json configs[4], "fp8 MFMA attention"; ops.ATTN_MODE = "fp8"): e4m3fn operands on
+ * v_mfma_f32_16x16x32_fp8_fp8 with power-of-two amax scales per (sample, head) (csrc/attention8.hip).  Replaces the same
+ * reference code as a3d_attn16_fwd (multihead_custom_attention.py:386-447) at e4m3's tolerance, NOT at the 1e-3 parity bar.
+ * Takes the "16" operands of a3d_attn16_fwd (Qr, Kr rows16; Vp two-part planes16 with the ones channel) and derives its own:
+ * ops8 = a3d_attn8_operand_bytes(B, H, Sp) bytes of scratch, 256-byte aligned (K8 rows, V8 planes, amax words), rewritten
+ * by every call (amax reduction + pack kernel + forward: three launches).  No dropout variant.  O, LSE2, ws as
+ * a3d_attn16_fwd, so a3d_attn16_bwd can consume them. */
+size_t a3d_attn8_operand_bytes(int B, int H, int Sp);
+int a3d_attn8_fwd(const void* Qr, const void* Kr, const void* Vp, void* ops8, const unsigned char* kmask, float* O,
+                  float* LSE2, float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
+
 /* a3d_attn_fwd / a3d_attn_bwd_bf16 with dropout on the attention weights: O = (keep o softmax(..) / (1 - p)) V. */
 int a3d_attn_fwd_dropout(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, float* O, float* LSE,
                          float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""The opt-in fp8 attention forward (csrc/attention8.hip) beside the split-fp16 default on one MI355X: error against a
+float64 softmax at several logit ranges, and timings (whole call = amax + pack + forward, and the forward kernel's share from
+a rocprofv3 trace of this script) at the configs[1] and configs[4] ghost-attention shapes.
+    python profiles/attn8_check.py > gpurun_out/r03/attn8_check.txt"""
+import importlib
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+a3d = importlib.import_module("act3d-chained-diffuser_amd")
+O = a3d.ops
+dev = torch.device("cuda:0")
+H, E = 4, 60
+
+
+def operands(B, Lq, S, gain, seed):
+    g = torch.Generator().manual_seed(seed)
+    q_pre = (torch.randn(B, Lq, E, generator=g) * gain).to(dev)
+    k_pre = (torch.randn(B, S, E, generator=g) * gain).to(dev)
+    v_pre = torch.randn(B, S, E, generator=g).to(dev)
+    qc, kc, vc = q_pre.reshape(B * Lq, E).contiguous(), k_pre.reshape(B * S, E).contiguous(), v_pre.reshape(B * S, E).contiguous()
+    ops = O.attn_operands16(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None, B, Lq, S, E, H, dev, need_bwd=False)
+    return q_pre, k_pre, v_pre, ops, (qc, kc, vc)
+
+
+def fwd(mode, ops, B, Lq, S):
+    Qs, Ks, Vt, Lqp, Sp = ops[:5]
+    O.ATTN_MODE = mode
+    try:
+        return O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, O.pick_nsplit(B, H, Lqp, Sp))
+    finally:
+        O.ATTN_MODE = "f16"
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+for gain in (0.5, 1.0, 2.0, 3.0, 4.0):
+    B, Lq, S = 2, 2500, 3073
+    q_pre, k_pre, v_pre, ops, keep = operands(B, Lq, S, gain, 3)
+    qh = (q_pre.double() * 15 ** -0.5).view(B, Lq, H, 15).transpose(1, 2)
+    kh = k_pre.double().view(B, S, H, 15).transpose(1, 2)
+    vh = v_pre.double().view(B, S, H, 15).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    p = torch.softmax(s, -1)
+    ref = (p @ vh).transpose(1, 2).reshape(B, Lq, E)
+    neff = (1.0 / (p * p).sum(-1)).median().item()
+    rec = {"gain": gain, "max|log2-logit|": s.abs().max().item() * math.log2(math.e), "median n_eff": neff}
+    for mode in ("fp8", "f16"):
+        o, lse = fwd(mode, ops, B, Lq, S)
+        d = o.double() - ref
+        rec[mode] = {"max_abs_err": d.abs().max().item(), "ref_absmax": ref.abs().max().item(),
+                     "rel_l2": (d.norm() / ref.norm()).item()}
+    print("accuracy", json.dumps(rec), flush=True)
+
+for tag, (B, Lq, S) in {"configs[1] ghost attention (B=64, Lq=333, S=4097)": (64, 333, 4097),
+                        "configs[4] ghost attention (B=16, Lq=2500, S=3073)": (16, 2500, 3073)}.items():
+    _, _, _, ops, keep = operands(B, Lq, S, 1.0, 1)
+    rec = {"shape": tag}
+    for mode in ("f16", "fp8"):
+        ms = timeit(lambda: fwd(mode, ops, B, Lq, S))
+        rec[mode + "_ms"] = ms
+        rec[mode + "_frac_of_2.5PF"] = 4.0 * Lq * S * E * B / (ms * 1e-3) / 2.5e15
+    print("time", json.dumps(rec), flush=True)

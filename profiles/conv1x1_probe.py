@@ -1,6 +1,8 @@
 """A/B of the opt-in fused 1x1-convolution path of the frozen backbone (A3D_FUSED_CONV1X1): backbone forward time at the
 bench shape (256 images 256x256, bf16) with MIOpen convolutions + separate BatchNorm kernels vs the fused GEMM.
-usage (GPU box): python profiles/conv1x1_probe.py [tile ...]     (tile = "wm,wn,ksub", see csrc/conv1x1.hip)"""
+usage (GPU box): python profiles/conv1x1_probe.py
+Round 3 ran this with ten wider-tile candidates as well (profiles/r03_conv1x1_probe.json: best 12.6 ms against MIOpen's 11.9 ms,
+and none of the ten reproduced the reference output); they were deleted, the verified 4-wave kernel stays opt-in."""
 import importlib
 import json
 import os
@@ -17,15 +19,8 @@ bb = a3d.nn.SyntheticCLIPResNet50().to(dev).train()
 x = torch.rand(256, 3, 256, 256, device=dev)
 norm = a3d.nn.ClipNormalize().to(dev)
 res = {}
-# (label, fused flag, A3D_C1_TILE): the MIOpen path, the verified default tile, then the tuning candidates
-runs = [("miopen", False, None), ("fused_default", True, None)] + \
-       [(f"fused_tile_{t}", True, t) for t in (sys.argv[1:] or ["1,4,2", "2,4,1", "2,4,2"])]
-for label, flag, tile in runs:
+for label, flag in [("miopen", False), ("fused_default", True)]:
     a3d.nn.FUSED_CONV1X1 = flag
-    if tile is None:
-        os.environ.pop("A3D_C1_TILE", None)
-    else:
-        os.environ["A3D_C1_TILE"] = tile
     with torch.no_grad():
         for _ in range(3):
             a3d.nn.run_frozen_backbone(bb, x, torch.bfloat16, keep_dtype=True, normalize=norm)
@@ -38,5 +33,4 @@ for label, flag, tile in runs:
         torch.cuda.synchronize()
     res[label] = e0.elapsed_time(e1) / 5
 a3d.nn.FUSED_CONV1X1 = False
-os.environ.pop("A3D_C1_TILE", None)
 print(json.dumps({"backbone_forward_ms": res, "images": 256}))

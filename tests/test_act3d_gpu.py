@@ -193,10 +193,41 @@ def test_act3d_free_running_numpy_sampler(a3d, dev, tag):
 ])
 def test_act3d_full_shapes_vs_oracle_teacher_forced(a3d, dev, name, B, ncam, levels, Ng, bounds, seed):
     """Full token counts of the training configurations -- HIP vs CPU oracle, per-level teacher forcing."""
+    _full_shapes_case(a3d, dev, name, B, ncam, levels, Ng, bounds, seed)
+
+
+# The opt-in fp8 attention forward (csrc/attention8.hip), which serves gradient-free forwards only (ops.ATTN_MODE).  Its stated
+# tolerance grows with the logit range (tests/test_attn8_gpu.py:fp8_tolerance: relative L2 of one attention output =
+# 2^-5 (1.5 + L / 8) at |log2-logit| <= L), so this fixture uses gain-1 parameters (the mild logits of a freshly initialised
+# model, L ~ 10) where the default-mode test above uses gain 2 (L ~ 50, where e4m3 logits are meaningless: 25 % of the
+# mask-logit scale, measured).  The mask logits average the attention outputs' independent errors once more (a ghost
+# point's feature is LayerNorm(residual + attention)): bound 2^-6 of each tensor's scale, observed <= 5.1e-3.
+FP8_FWD_TOL = 2.0 ** -6
+
+
+def test_act3d_cfg5_shapes_fp8_attention_mode(a3d, dev):
+    """BASELINE.json configs[4]: 4 levels at 10 000 ghost points, fp8 MFMA attention -- the opt-in A3D_ATTN_MODE=fp8, forward
+    without gradient, against the fp32 oracle at e4m3's tolerance (the default mode's test above holds the same shapes, with
+    gradients, to 1e-3).  The general attention cores must really have run on a3d_attn8_fwd."""
+    old, seen, call = a3d.ops.ATTN_MODE, [], a3d.lib.call
+    a3d.ops.ATTN_MODE = "fp8"
+    a3d.ops.L.call = lambda name, *args: (seen.append(name), call(name, *args))[1]
+    try:
+        _full_shapes_case(a3d, dev, "cfg5-fp8", 2, 3, 4, 2500, C.HIVEFORMER_BOUNDS, 6, fwd_tol=FP8_FWD_TOL, gain=1.0,
+                          forward_only=True)
+    finally:
+        a3d.ops.ATTN_MODE = old
+        a3d.ops.L.call = call
+    # 4 levels x 2 ghost-point attention layers (the query stream runs the single-query kernels)
+    assert seen.count("a3d_attn8_fwd") == 8 and "a3d_attn16_fwd" not in seen and "a3d_attn_fwd" not in seen, \
+        sorted(set(n for n in seen if "attn" in n))
+
+
+def _full_shapes_case(a3d, dev, name, B, ncam, levels, Ng, bounds, seed, fwd_tol=1e-3, gain=2.0, forward_only=False):
     E = 60
     man = torch.load(os.path.join(HERE, "golden", "act3d_manifest.pt"), weights_only=False)
     cfg = dict(E=E, levels=levels, ncam=ncam, use_instruction=False)
-    P = act3d_params(cfg, seed, 2.0, man["named_parameters"])
+    P = act3d_params(cfg, seed, gain, man["named_parameters"])
     leaf, Po = {}, {}
     for n, t in P.items():
         if id(t) not in leaf:
@@ -228,24 +259,28 @@ def test_act3d_full_shapes_vs_oracle_teacher_forced(a3d, dev, name, B, ncam, lev
     d1 = inp["feats"][1].to(dev).requires_grad_()
     t1 = C.tokens_from_maps(d1)
     dfeats = [C.tokens_from_maps(d0)] + [t1] * (levels - 1)
-    out = m(None, inp["pcd"].to(dev), None, inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
-            ghost_points=[g.to(dev) for g in ghost], teacher_positions=[t.to(dev) for t in teacher], visual_features=dfeats)
+    with torch.set_grad_enabled(not forward_only):
+        out = m(None, inp["pcd"].to(dev), None, inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
+                ghost_points=[g.to(dev) for g in ghost], teacher_positions=[t.to(dev) for t in teacher], visual_features=dfeats)
     for i in range(levels):
         if i > 0:
             assert torch.equal(out["topk_indices_pyramid"][i].cpu(), oout["topk_indices"][i]), f"top-k indices level {i}"
         for l in range(2):
-            scale_close(f"{name} mask L{i} layer{l}", out["ghost_pcd_masks_pyramid"][i][l], oout["ghost_pcd_masks_pyramid"][i][l])
+            scale_close(f"{name} mask L{i} layer{l}", out["ghost_pcd_masks_pyramid"][i][l], oout["ghost_pcd_masks_pyramid"][i][l],
+                        tol=fwd_tol)
         o_top = oout["ghost_pcd_masks_pyramid"][i][-1].max(-1).indices
         gap = oout["ghost_pcd_masks_pyramid"][i][-1].topk(2, -1).values
-        safe = (gap[:, 0] - gap[:, 1]) > 2e-3
+        safe = (gap[:, 0] - gap[:, 1]) > 2 * fwd_tol * max(1.0, oout["ghost_pcd_masks_pyramid"][i][-1].abs().max().item())
         d_top = out["ghost_pcd_masks_pyramid"][i][-1].max(-1).indices.cpu()
         assert torch.equal(d_top[safe], o_top[safe]), f"argmax level {i}"
-    rel_close(f"{name} rotation", out["rotation"], oout["rotation"], 1e-3, 0)
+    rel_close(f"{name} rotation", out["rotation"], oout["rotation"], fwd_tol, 0)
     crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
                                      ground_truth_gaussian_spread=0.01)
     losses = crit.compute_loss(out, {"action": inp["action"].to(dev), "task": ["t"] * B})
     for k, v in olosses.items():
-        rel_close(f"{name} loss " + k, losses[k], v, 1e-3, 1e-3)
+        rel_close(f"{name} loss " + k, losses[k], v, fwd_tol, fwd_tol)
+    if forward_only:
+        return
     sum(losses.values()).backward()
     named = dict(m.named_parameters())
     bad = []

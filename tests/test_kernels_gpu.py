@@ -799,20 +799,6 @@ def test_conv1x1_gemm_with_folded_batchnorm(a3d, dev, M, K, N, pro):
     _check_conv1x1(a3d, dev, M, K, N, pro)
 
 
-@pytest.mark.skipif(os.environ.get("A3D_TEST_EXPERIMENTAL") != "1",
-                    reason="tuning candidates of the 1x1-convolution GEMM (A3D_C1_TILE): written at the end of round 2 without "
-                           "GPU time left to run them; set A3D_TEST_EXPERIMENTAL=1 to test them before selecting one")
-@pytest.mark.parametrize("tile", ["1,4,1", "1,4,2", "2,4,1", "2,4,2", "2,2,1", "2,2,2", "4,1,1", "4,1,2", "4,2,1", "4,2,2"])
-def test_conv1x1_tile_candidates(a3d, dev, tile):
-    os.environ["A3D_C1_TILE"] = tile
-    try:
-        for M, K, N, pro in [(1000, 256, 256, True), (4096, 64, 256, False), (777, 512, 512, True), (64, 2048, 1024, False),
-                             (16, 128, 256, True), (3000, 256, 128, True), (500, 64, 64, False)]:
-            _check_conv1x1(a3d, dev, M, K, N, pro)
-    finally:
-        del os.environ["A3D_C1_TILE"]
-
-
 def _check_conv1x1(a3d, dev, M, K, N, pro):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)
