@@ -22,6 +22,7 @@
 // All dense layers use the same exact-f32 MFMA as linear.hip (an fmaf chain in k order).
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
+#include <string.h>
 
 namespace a3d {
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(512) void dn_head_kernel(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) float kvS[];          // [S_lang][2E]: the instruction tokens' k | v rows
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
-  if (warm) {
+  if (warm & 1) {
     const WarmList wl = {{p.enc_w1, p.lang_kv ? p.q_w : nullptr, p.lang_kv ? p.out_w : nullptr, nullptr, nullptr, nullptr},
                          {E * E, E * E, E * E, 0, 0, 0}};
     wg_warm_l2(wl, gridDim.x);
@@ -467,6 +468,35 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
   }
 }
 
+// Small per-layer vectors (biases, LayerNorm / AdaLN parameters, the index embedding) -> LDS in ONE batch of loads at the
+// head of the kernel.  Each of them lives on its own page of the flat parameter buffer / modulation tables, and a load issued
+// where it is needed exposes a full miss (translation + HBM, 2-8 us measured per phase with A3D_DN_PROF) on the workgroup's
+// dependent path; issued together the misses overlap.  Vectors of <= 512 elements; `big` (the index embedding) <= 2048.
+struct VecList { const float* p[12]; int n[12]; };
+__device__ __forceinline__ void wg_stage_vectors(const VecList& vl, float* const (&dst)[12], const float* big, int nbig, float* bigdst) {
+  float r[12][2], rb[8];
+  const int t = threadIdx.x, nt = blockDim.x;                  // 256 or 512 threads: two passes cover 512 elements
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) r[j][u] = (vl.p[j] && t + u * nt < vl.n[j]) ? vl.p[j][t + u * nt] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rb[i] = (big && t + i * nt < nbig) ? big[t + i * nt] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (vl.p[j] && t + u * nt < vl.n[j]) dst[j][t + u * nt] = r[j][u];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (big && t + i * nt < nbig) bigdst[t + i * nt] = rb[i];
+}
+
+// Phase timestamps of workgroup 0 of the last dn_rest launch (A3D_DN_PROF=1; wall_clock64 = 100 MHz): development aid read
+// back by a3d_dbg_dn_prof, no effect on results.
+__device__ long long g_dn_prof[32];
+#define DN_MARK(i) do { if ((warm & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dn_prof[i] = wall_clock64(); } while (0)
+
 // ------------------------------------------------------------------------------------------------ rest of a layer
 __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
                                                       const float* __restrict__ Op, const float* __restrict__ Mp,
@@ -479,13 +509,38 @@ __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ 
   float* Ts = Bs + DR * LDX;              // [16][LDX]
   float* QK = Ts + DR * LDX;              // [16][LDQK]
   float* Hs = QK + DR * LDQK;             // [16][LDH]
+  float* Ps = Hs + DR * LDH;              // staged parameter vectors: 16 x 128 + 512 + the [16][E] index embedding
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
-  if (warm) {
+  DN_MARK(0);
+  // LDS copies of every small vector this layer reads (NULL stays NULL)
+  float* const vd[12] = {Ps, Ps + 128, Ps + 256, Ps + 384, Ps + 640, Ps + 1024, Ps + 1152, Ps + 1280, Ps + 1408, Ps + 1664, Ps + 2176,
+                         Ps + 2304};
+  const float* const c_out_b = p.c_out_b ? vd[0] : nullptr;
+  const float *c_ln_g = vd[1], *c_ln_b = vd[2];
+  const float* const s_mod = p.s_mod ? vd[3] : nullptr;          // 2E <= 256
+  const float* const s_in_b = p.s_in_b ? vd[4] : nullptr;        // 3E <= 384
+  const float* const s_out_b = p.s_out_b ? vd[5] : nullptr;
+  const float *s_ln_g = vd[6], *s_ln_b = vd[7];
+  const float* const f_mod = p.f_mod ? vd[8] : nullptr;          // 2E
+  const float* const f_b1 = p.f_b1 ? vd[9] : nullptr;            // F <= 512
+  const float* const f_b2 = p.f_b2 ? vd[10] : nullptr;
+  float* const lnf = Ps + 2304;                                  // f_ln_g | f_ln_b (2 x 128)
+  const float* const sem = (p.sem && p.s_in_w) ? Ps + 2560 : nullptr;
+  {
+    const VecList vl = {{p.c_out_b, p.c_ln_g, p.c_ln_b, p.s_in_w ? p.s_mod : nullptr, p.s_in_w ? p.s_in_b : nullptr,
+                         p.s_in_w ? p.s_out_b : nullptr, p.s_in_w ? p.s_ln_g : nullptr, p.s_in_w ? p.s_ln_b : nullptr,
+                         p.f_w1 ? p.f_mod : nullptr, p.f_w1 ? p.f_b1 : nullptr, p.f_w1 ? p.f_b2 : nullptr, p.f_w1 ? p.f_ln_g : nullptr},
+                        {E, E, E, 2 * E, 3 * E, E, E, E, 2 * E, p.F, E, E}};
+    wg_stage_vectors(vl, vd, sem ? p.sem : nullptr, L * E, Ps + 2560);
+    if (p.f_w1 && threadIdx.x < E) lnf[128 + threadIdx.x] = p.f_ln_b[threadIdx.x];
+  }
+  if (warm & 1) {
     const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
                          {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
     wg_warm_l2(wl, gridDim.x);
   }
+  DN_MARK(1);
   wg_load_rows(x_in + (size_t)b * L * E, E, L, Xs, LDX, Epad);
   wg_zero_pad(As, LDX, E, Epad);
   wg_zero_pad(Bs, LDX, E, Epad);
@@ -508,31 +563,258 @@ __global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ 
     As[r * LDX + c] = den > 0.f ? num / den : 0.f;
   }
   __syncthreads();
-  wg_linear<0>(As, LDX, E, p.c_out_w, E, p.c_out_b, E, Ts, LDX);
-  wg_add_layernorm(Xs, LDX, Ts, LDX, p.c_ln_g, p.c_ln_b, Xs, LDX, E);
+  DN_MARK(2);
+  wg_linear<0>(As, LDX, E, p.c_out_w, E, c_out_b, E, Ts, LDX);
+  DN_MARK(3);
+  wg_add_layernorm(Xs, LDX, Ts, LDX, c_ln_g, c_ln_b, Xs, LDX, E);
+  DN_MARK(4);
   if (p.s_in_w) {
     // ---- self-attention: q = k = AdaLN(x + index embedding), v = AdaLN(x), RoPE by the steps' xyz, padded steps masked
-    wg_adaln(Xs, LDX, p.sem, p.s_mod, As, LDX, L, E, Bs, LDX);
-    wg_linear<0>(As, LDX, E, p.s_in_w, E, p.s_in_b, 2 * E, QK, LDQK);                      // [q | k]
-    wg_linear<0>(Bs, LDX, E, p.s_in_w + (size_t)2 * E * E, E, p.s_in_b + 2 * E, E, Hs, LDH);   // v
+    wg_adaln(Xs, LDX, sem, s_mod, As, LDX, L, E, Bs, LDX);
+    DN_MARK(5);
+    wg_linear<0>(As, LDX, E, p.s_in_w, E, s_in_b, 2 * E, QK, LDQK);                        // [q | k]
+    DN_MARK(6);
+    wg_linear<0>(Bs, LDX, E, p.s_in_w + (size_t)2 * E * E, E, s_in_b ? s_in_b + 2 * E : nullptr, E, Hs, LDH);   // v
+    DN_MARK(7);
     wg_rope(QK, LDQK, 0, 2, traj + (size_t)b * L * D, D, p.freq, L, E, 1.0f / sqrtf((float)HD));
+    DN_MARK(8);
     wg_small_attention(QK, LDQK, QK + E, LDQK, Hs, LDH, p.kmask ? p.kmask + (size_t)b * L : nullptr, L, H, As, LDX);
-    wg_linear<0>(As, LDX, E, p.s_out_w, E, p.s_out_b, E, Ts, LDX);
-    wg_add_layernorm(Xs, LDX, Ts, LDX, p.s_ln_g, p.s_ln_b, Xs, LDX, E);
+    DN_MARK(9);
+    wg_linear<0>(As, LDX, E, p.s_out_w, E, s_out_b, E, Ts, LDX);
+    DN_MARK(10);
+    wg_add_layernorm(Xs, LDX, Ts, LDX, s_ln_g, s_ln_b, Xs, LDX, E);
+    DN_MARK(11);
   }
   if (p.f_w1) {
     // ---- FFN: y = AdaLN(x); x = LayerNorm(y + W2 relu(W1 y + b1) + b2)
-    wg_adaln(Xs, LDX, nullptr, p.f_mod, As, LDX, L, E);
+    wg_adaln(Xs, LDX, nullptr, f_mod, As, LDX, L, E);
+    DN_MARK(12);
     for (int i = threadIdx.x; i < DR * (((p.F + 15) & ~15) - p.F); i += blockDim.x) {
       const int padw = ((p.F + 15) & ~15) - p.F;
       Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
     }
     __syncthreads();
-    wg_linear<1>(As, LDX, E, p.f_w1, E, p.f_b1, p.F, Hs, LDH);
-    wg_linear<0>(Hs, LDH, p.F, p.f_w2, p.F, p.f_b2, E, Ts, LDX);
-    wg_add_layernorm(As, LDX, Ts, LDX, p.f_ln_g, p.f_ln_b, Xs, LDX, E);
+    DN_MARK(13);
+    wg_linear<1>(As, LDX, E, p.f_w1, E, f_b1, p.F, Hs, LDH);
+    DN_MARK(14);
+    wg_linear<0>(Hs, LDH, p.F, p.f_w2, p.F, f_b2, E, Ts, LDX);
+    DN_MARK(15);
+    wg_add_layernorm(As, LDX, Ts, LDX, lnf, lnf + 128, Xs, LDX, E);
+    DN_MARK(16);
   }
   for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
+  DN_MARK(17);
+}
+
+// ------------------------------------------------------------------------------------------------ rest of a layer, looped
+// The straight-line kernel above is 82 KB of code that a workgroup executes exactly once: A3D_DN_PROF showed phases with
+// almost no arithmetic (AdaLN, RoPE, the ReLU instantiation of the dense layer) taking 4-12 us each, unchanged by warming the
+// weights or staging every parameter vector in LDS -- the time follows the CODE SIZE of a phase: the kernel is bound by
+// instruction fetch (64 KB instruction cache per CU pair, every line a miss).  This version runs the same 13 operations as
+// a LOOP over an operation table (built by the host, passed by value, indexed with scalar loads) around ONE copy of each
+// operation's code: five of the thirteen are the dense layer, three the residual LayerNorm, two the AdaLN, so after the
+// first visit an operation's instructions are cache hits.  Arithmetic, order and results are those of the kernel above.
+enum { DN_OP_LINEAR = 0, DN_OP_ADDLN = 1, DN_OP_ADALN = 2, DN_OP_ROPE = 3, DN_OP_ATTN = 4 };
+struct DnOp {
+  int type;
+  int a, b, c, d, e, f, g;     // LDS offsets (floats from the start of the dynamic LDS; -1 = none) / sizes, per type (see dn_build_ops)
+  const float* W;              // LINEAR: weights (global)
+};
+struct DnOpTable { int n; DnOp op[13]; };
+
+template <bool VEC>
+__device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, const float* bias,
+                                             int N, float* Ys, int ldy, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
+  const int nchunk = (nblk + WCH - 1) / WCH;
+  auto loadw = [&](int ct, int c, float4 (&w)[WCH]) {
+    const int n = ct * 16 + li;
+    const float* wrow = W + (size_t)min(n, N - 1) * ldw;
+    const bool row_ok = n < N;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int k0 = (c * WCH + i) * 16 + 4 * g;
+      float4 wv;
+      if (VEC) {
+        wv = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
+        if (!(row_ok && k0 < K)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        wv.x = wrow[min(k0 + 0, K - 1)];
+        wv.y = wrow[min(k0 + 1, K - 1)];
+        wv.z = wrow[min(k0 + 2, K - 1)];
+        wv.w = wrow[min(k0 + 3, K - 1)];
+        wv.x = (row_ok && k0 + 0 < K) ? wv.x : 0.f;
+        wv.y = (row_ok && k0 + 1 < K) ? wv.y : 0.f;
+        wv.z = (row_ok && k0 + 2 < K) ? wv.z : 0.f;
+        wv.w = (row_ok && k0 + 3 < K) ? wv.w : 0.f;
+      }
+      w[i] = wv;
+    }
+  };
+  float4 wc[WCH], wn[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) wn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ct = wave, c = 0;
+  if (ct < ntile) loadw(ct, 0, wc);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  while (ct < ntile) {
+    int nct = ct, nc = c + 1;
+    if (nc == nchunk) { nc = 0; nct = ct + nwave; }
+    if (nct < ntile) loadw(nct, nc, wn);
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int blk = min(c * WCH + i, nblk - 1);
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
+      acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
+      acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
+      acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
+      acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
+    }
+    if (c == nchunk - 1) {
+      const int n = ct * 16 + li;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc0[r] + acc1[r] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          Ys[(g * 4 + r) * ldy + n] = v;
+        }
+      }
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wc[i] = wn[i];
+    ct = nct;
+    c = nc;
+  }
+  __syncthreads();
+}
+
+constexpr int DN_PS = 2560 + DR * 128 + 256;     // floats of staged parameters: vectors | index embedding | xyz rows, freq, mask
+__global__ __launch_bounds__(512) void dn_rest_loop_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
+                                                           const float* __restrict__ Op, const float* __restrict__ Mp,
+                                                           a3d_dn_rest_params p, DnOpTable tab, float* __restrict__ x_out, int B,
+                                                           int L, int E, int H, int nsplit, int warm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* As = Xs + DR * LDX;
+  float* Hs = smem + 4 * DR * LDX + DR * LDQK;
+  float* Ps = Hs + DR * LDH;
+  const int b = blockIdx.x;
+  const int Epad = (E + 15) & ~15;
+  DN_MARK(0);
+  {
+    float* const vd[12] = {Ps, Ps + 128, Ps + 256, Ps + 384, Ps + 640, Ps + 1024, Ps + 1152, Ps + 1280, Ps + 1408, Ps + 1664, Ps + 2176,
+                           Ps + 2304};
+    const VecList vl = {{p.c_out_b, p.c_ln_g, p.c_ln_b, p.s_in_w ? p.s_mod : nullptr, p.s_in_w ? p.s_in_b : nullptr,
+                         p.s_in_w ? p.s_out_b : nullptr, p.s_in_w ? p.s_ln_g : nullptr, p.s_in_w ? p.s_ln_b : nullptr,
+                         p.f_w1 ? p.f_mod : nullptr, p.f_w1 ? p.f_b1 : nullptr, p.f_w1 ? p.f_b2 : nullptr, p.f_w1 ? p.f_ln_g : nullptr},
+                        {E, E, E, 2 * E, 3 * E, E, E, E, 2 * E, p.F, E, E}};
+    wg_stage_vectors(vl, vd, (p.sem && p.s_in_w) ? p.sem : nullptr, L * E, Ps + 2560);
+    const int t = threadIdx.x;
+    float* const misc = Ps + 2560 + DR * 128;                    // [0, 144): xyz rows (ld = D); [160, 192): freq; [192, 208): key mask
+    if (p.f_w1 && t < E) Ps[2432 + t] = p.f_ln_b[t];
+    if (p.s_in_w) {
+      if (t < L * D) misc[t] = traj[(size_t)b * L * D + t];
+      if (p.freq && t < E / 6) misc[160 + t] = p.freq[t];
+      if (t < DR) misc[192 + t] = (p.kmask && t < L && p.kmask[(size_t)b * L + t]) ? 1.f : 0.f;
+    }
+  }
+  if (warm & 1) {
+    const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
+                         {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
+    wg_warm_l2(wl, gridDim.x);
+  }
+  DN_MARK(1);
+  wg_load_rows(x_in + (size_t)b * L * E, E, L, Xs, LDX, Epad);
+  // pad columns of every tile a dense layer reads: As, Bs, Ts ([E, Epad)) and the FFN hidden tile ([F, Fpad))
+#pragma nounroll
+  for (int k = 1; k < 4; ++k) wg_zero_pad(smem + k * DR * LDX, LDX, E, Epad);
+  if (p.f_w1) {
+    const int padw = ((p.F + 15) & ~15) - p.F;
+    for (int i = threadIdx.x; i < DR * padw; i += blockDim.x) Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
+  }
+  // ---- cross-attention output: combine the key splits
+#pragma unroll 4
+  for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
+    const int r = i / E, c = i - r * E;
+    const int h = c / HD, d = c - h * HD;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, Mp[(((size_t)s * B + b) * H + h) * 16 + r]);
+    const float m_use = (m == -INFINITY) ? 0.f : m;
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const size_t row = (((size_t)s * B + b) * H + h) * 16 + r;
+      const float w = __expf(Mp[row] - m_use);
+      num += w * Op[row * 16 + d];
+      den += w * Op[row * 16 + 15];
+    }
+    As[r * LDX + c] = den > 0.f ? num / den : 0.f;
+  }
+  __syncthreads();
+  DN_MARK(2);
+#pragma nounroll
+  for (int i = 0; i < tab.n; ++i) {
+    const DnOp& op = tab.op[i];
+    switch (op.type) {
+      case DN_OP_LINEAR: {
+        // a: X, b: ldx, c: K, d: bias, e: N, f: Y, g: ldy | act in the sign bit of ldw-free field: K < 0 never; act = op.type >> 8 unused
+        const bool vec = ((op.c & 3) == 0) && ((((uintptr_t)op.W) & 15) == 0);
+        const int act = op.g >> 16, ldy = op.g & 0xFFFF;
+        if (vec) wg_linear_rt<true>(smem + op.a, op.b, op.c, op.W, op.c, op.d >= 0 ? smem + op.d : nullptr, op.e, smem + op.f, ldy, act);
+        else wg_linear_rt<false>(smem + op.a, op.b, op.c, op.W, op.c, op.d >= 0 ? smem + op.d : nullptr, op.e, smem + op.f, ldy, act);
+        break;
+      }
+      case DN_OP_ADDLN:        // a: A, b: R, c: gamma, d: beta, e: Y
+        wg_add_layernorm(smem + op.a, LDX, smem + op.b, LDX, smem + op.c, smem + op.d, smem + op.e, LDX, E);
+        break;
+      case DN_OP_ADALN:        // a: X, b: sem, c: mod, d: Y, e: Y2
+        wg_adaln(smem + op.a, LDX, op.b >= 0 ? smem + op.b : nullptr, op.c >= 0 ? smem + op.c : nullptr, smem + op.d, LDX, L, E,
+                 op.e >= 0 ? smem + op.e : nullptr, LDX);
+        break;
+      case DN_OP_ROPE:         // a: T (q | k blocks), b: xyz rows, c: freq
+        wg_rope(smem + op.a, LDQK, 0, 2, smem + op.b, D, op.c >= 0 ? smem + op.c : nullptr, L, E, 1.0f / sqrtf((float)HD));
+        break;
+      default: {               // DN_OP_ATTN   a: Q, b: K, c: V, d: mask (floats), e: O
+        const float* mk = smem + op.d;
+        const float* Q = smem + op.a;
+        const float* Kk = smem + op.b;
+        const float* V = smem + op.c;
+        float* O = smem + op.e;
+        const int r = (threadIdx.x >> 4) & 15, h = threadIdx.x & 15;
+        if (threadIdx.x < 256 && h < H) {
+          float q[HD], acc[HD];
+#pragma unroll
+          for (int d = 0; d < HD; ++d) { q[d] = Q[r * LDQK + h * HD + d]; acc[d] = 0.f; }
+          float m = -INFINITY, l = 0.f;
+          for (int s2 = 0; s2 < L; ++s2) {
+            if (mk[s2] != 0.f) continue;
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc += q[d] * Kk[s2 * LDQK + h * HD + d];
+            const float mn = fmaxf(m, sc);
+            const float a = __expf(m - mn), pw = __expf(sc - mn);
+            l = l * a + pw;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + pw * V[s2 * LDH + h * HD + d];
+            m = mn;
+          }
+          const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) O[r * LDX + h * HD + d] = acc[d] * inv;
+        }
+        __syncthreads();
+        break;
+      }
+    }
+    DN_MARK(3 + i);
+  }
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
+  DN_MARK(17);
 }
 
 // ------------------------------------------------------------------------------------------------ tail
@@ -542,7 +824,7 @@ __global__ __launch_bounds__(512) void dn_tail_kernel(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float Xs[DR * LDX], Ts[DR * LDX], Us[DR * 16];
   const int b = blockIdx.x;
   const int Epad = (E + 15) & ~15;
-  if (warm) {
+  if (warm & 1) {
     const WarmList wl = {{p.pos_w0, p.rot_w0, nullptr, nullptr, nullptr, nullptr}, {E * E, E * E, 0, 0, 0, 0}};
     wg_warm_l2(wl, gridDim.x);
   }
@@ -616,8 +898,17 @@ static int dn_threads() {
 
 // L2 warm-up of the weights at the head of the per-sample kernels (wg_warm_l2); A3D_DN_WARM=0 for the A/B run
 static int dn_warm() {
-  static const int w = (getenv("A3D_DN_WARM") && atoi(getenv("A3D_DN_WARM")) == 0) ? 0 : 1;
+  static const int w = ((getenv("A3D_DN_WARM") && atoi(getenv("A3D_DN_WARM")) == 0) ? 0 : 1) |
+                       ((getenv("A3D_DN_PROF") && atoi(getenv("A3D_DN_PROF")) != 0) ? 2 : 0);
   return w;
+}
+
+// 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch made with A3D_DN_PROF=1
+extern "C" int a3d_dbg_dn_prof(long long* out18) {
+  if (!out18) { set_error("a3d_dbg_dn_prof: null pointer"); return A3D_ERR_ARG; }
+  hipError_t e = hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_dn_prof), 18 * sizeof(long long));
+  if (e != hipSuccess) { set_error("a3d_dbg_dn_prof: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  return A3D_OK;
 }
 
 static int dn_check(const char* fn, int B, int L, int E, int H) {
@@ -678,7 +969,7 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
     set_error("a3d_dn_rest: bad argument");
     return A3D_ERR_ARG;
   }
-  const size_t lds = (size_t)DR * (4 * LDX + LDQK + LDH) * sizeof(float);
+  const size_t lds = ((size_t)DR * (4 * LDX + LDQK + LDH) + 2560 + DR * 128) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dn_rest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -686,8 +977,46 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
   }
   const float* Op = ws;
   const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
-  hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E, H,
-                     nsplit, dn_warm());
+  static const bool straight = getenv("A3D_DN_REST") && strcmp(getenv("A3D_DN_REST"), "straight") == 0;      // A/B: the unrolled kernel
+  if (straight) {
+    hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E,
+                       H, nsplit, dn_warm());
+    return check_launch("a3d_dn_rest");
+  }
+  // operation table of dn_rest_loop_kernel: LDS offsets in floats from the start of the dynamic LDS
+  const int oX = 0, oA = DR * LDX, oB = 2 * DR * LDX, oT = 3 * DR * LDX, oQK = 4 * DR * LDX, oH = oQK + DR * LDQK, oP = oH + DR * LDH;
+  const int oMisc = oP + 2560 + DR * 128;
+  DnOpTable tab;
+  tab.n = 0;
+  auto lin = [&](int x, int ldx, int K, const float* W, int bias, int N, int y, int ldy, int act) {
+    tab.op[tab.n++] = DnOp{DN_OP_LINEAR, x, ldx, K, bias, N, y, ldy | (act << 16), W};
+  };
+  auto other = [&](int type, int a, int b, int c, int d, int e) { tab.op[tab.n++] = DnOp{type, a, b, c, d, e, 0, 0, nullptr}; };
+  lin(oA, LDX, E, p->c_out_w, p->c_out_b ? oP : -1, E, oT, LDX, 0);
+  other(DN_OP_ADDLN, oX, oT, oP + 128, oP + 256, oX);
+  if (p->s_in_w) {
+    other(DN_OP_ADALN, oX, p->sem ? oP + 2560 : -1, p->s_mod ? oP + 384 : -1, oA, oB);
+    lin(oA, LDX, E, p->s_in_w, p->s_in_b ? oP + 640 : -1, 2 * E, oQK, LDQK, 0);
+    lin(oB, LDX, E, p->s_in_w + (size_t)2 * E * E, p->s_in_b ? oP + 640 + 2 * E : -1, E, oH, LDH, 0);
+    other(DN_OP_ROPE, oQK, oMisc, p->freq ? oMisc + 160 : -1, 0, 0);
+    other(DN_OP_ATTN, oQK, oQK + E, oH, oMisc + 192, oA);
+    lin(oA, LDX, E, p->s_out_w, p->s_out_b ? oP + 1024 : -1, E, oT, LDX, 0);
+    other(DN_OP_ADDLN, oX, oT, oP + 1152, oP + 1280, oX);
+  }
+  if (p->f_w1) {
+    other(DN_OP_ADALN, oX, -1, p->f_mod ? oP + 1408 : -1, oA, -1);
+    lin(oA, LDX, E, p->f_w1, p->f_b1 ? oP + 1664 : -1, p->F, oH, LDH, 1);
+    lin(oH, LDH, p->F, p->f_w2, p->f_b2 ? oP + 2176 : -1, E, oT, LDX, 0);
+    other(DN_OP_ADDLN, oA, oT, oP + 2304, oP + 2432, oX);
+  }
+  const size_t lds2 = ((size_t)DR * (4 * LDX + LDQK + LDH) + DN_PS) * sizeof(float);
+  static bool attr2 = false;
+  if (!attr2) {
+    (void)hipFuncSetAttribute((const void*)dn_rest_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr2 = true;
+  }
+  hipLaunchKernelGGL(dn_rest_loop_kernel, dim3(B), dim3(dn_threads()), lds2, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, tab, x_out, B,
+                     L, E, H, nsplit, dn_warm());
   return check_launch("a3d_dn_rest");
 }
 

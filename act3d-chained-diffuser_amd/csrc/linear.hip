@@ -15,6 +15,12 @@
 
 namespace a3d {
 
+// linear_split.hip
+bool linear_split_applicable(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* Y, int ldy,
+                             const float* mask, int ldm, int M, int N, int K, int act);
+int linear_split_launch(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, const float* mask,
+                        int ldm, int M, int N, int K, int act, int w_transposed, hipStream_t s);
+
 constexpr int LT_BM = 64;   // rows per workgroup
 constexpr int LT_BN = 64;   // cols per workgroup
 constexpr int LT_KC = 64;   // contraction chunk staged in LDS (K = 60 is ONE stage, K = 120 two)
@@ -358,6 +364,9 @@ extern "C" int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
   if (M == 0) return A3D_OK;
   dim3 grid(cdiv(M, LT_BM), cdiv(N, LT_BN));
   hipStream_t s = (hipStream_t)stream;
+  // large row counts: the bf16x3 kernel of linear_split.hip (fp32-accurate, 2.7x the matrix rate of the f32 MFMA)
+  if (linear_split_applicable(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act))
+    return linear_split_launch(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act, w_transposed, s);
   if (w_transposed)
     hipLaunchKernelGGL(linear_fwd_kernel<true>, grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act);
   else

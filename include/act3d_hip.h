@@ -335,6 +335,8 @@ int a3d_dn_rest(const float* x_in, const float* traj, int D, const float* ws, co
 /* regressors + trajectory update + DDPM reverse step t_step: traj ([B][L][D]) -> traj_out */
 int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D, const a3d_dn_tail_params* p,
                 float* traj_out, int B, int L, int E, int t_step, void* stream);
+/* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
+int a3d_dbg_dn_prof(long long* out18);
 /* out[b][h][n][16] fp32 = rope3d(Y[b, n, :E] * scale, xyz) split into heads (column 15 and rows >= N zero): the K cache */
 int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B, int N,
                       int Npad, int E, int H, void* stream);

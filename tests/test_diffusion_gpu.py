@@ -201,14 +201,16 @@ def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
     named = dict(m.named_parameters())
     for n, gref in r["grads"].items():
         scale_close("grad " + n, named[n].grad, gref, 1.5e-3, floor=1e-3)
-    worst = 0.0
-    for n, nr in r["grad_norms"].items():
-        # norms of all 900+ gradient tensors (only six are stored in full): 5e-3 -- the sum of four L1 losses back-propagates
-        # through four chained predictions, and sign(pred - gt) is discontinuous where a prediction error crosses zero
-        rel = abs(named[n].grad.norm().item() - nr) / (nr + 1e-4)
-        worst = max(worst, rel)
-        assert rel <= 5e-3, f"grad norm {n}: {named[n].grad.norm().item()} vs {nr}"
-    print(f"[parity] worst relative gradient-norm deviation over {len(r['grad_norms'])} tensors: {worst:.2e}")
+    # norms of all 900+ gradient tensors (only six are stored in full).  The loss is a sum of four L1 terms back-propagated
+    # through four chained predictions, and sign(pred - gt) is discontinuous where a prediction error crosses zero: a tensor
+    # whose gradient sees such a flipped element deviates by that element's share.  So: 1.5e-3 for every tensor but an explicit,
+    # printed and bounded set of kink-affected ones (at most 1 % of the tensors, none beyond 5e-3).
+    dev_rel = {n: abs(named[n].grad.norm().item() - nr) / (nr + 1e-4) for n, nr in r["grad_norms"].items()}
+    kinked = {n: v for n, v in dev_rel.items() if v > 1.5e-3}
+    print(f"[parity] relative gradient-norm deviation over {len(dev_rel)} tensors: worst {max(dev_rel.values()):.2e}, "
+          f"{len(kinked)} above 1.5e-3: {sorted(kinked.items(), key=lambda kv: -kv[1])[:8]}")
+    assert len(kinked) <= max(1, len(dev_rel) // 100), kinked
+    assert all(v <= 5e-3 for v in kinked.values()), kinked
     # ---- 5 steps of the sampling loop (no K/V cache: the fine-scale context follows the prediction)
     m.eval()
     _, trace = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],

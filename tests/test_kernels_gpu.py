@@ -36,15 +36,16 @@ def report(name, got, ref, atol, rtol=0.0):
 
 
 def report_grad(a3d, name, got, ref, atol, rtol=0.0):
-    """Gradient parity of the attention blocks.  Split-bf16 family (A3D_ATTN_MODE=bf16x3): the element-wise bound it has always
-    met (errors ~1e-5).  Split-fp16 family (the default): dO and the weights entering dV are single fp16 by design (2^-12
-    per element, DESIGN.md "attention numerics"), so the bound is north_star's 1e-3 of the tensor's scale; observed
-    2-4e-4."""
-    if a3d.ops.ATTN_MODE == "f16":
-        scale = max(1.0, ref.detach().abs().max().item())
-        report(name, got, ref, max(atol, 1e-3 * scale), rtol)
-    else:
-        report(name, got, ref, atol, rtol)
+    """Gradient parity of the attention blocks: the same element-wise bound for both kernel families.  (The first cut of the
+    split-fp16 family carried single-fp16 dO and weights and needed 1e-3 of the tensor's scale here; with two-part operands
+    throughout its errors are at or below the split-bf16 family's on every output, profiles/r03_attn_family_check.txt.)"""
+    report(name, got, ref, atol, rtol)
+
+
+def report_scaled(name, got, ref, tol=1.5e-3):
+    """|got - ref| <= tol * max|ref| element-wise: the bound for parameter gradients (sums over all rows of a batch), stated
+    relative to the tensor's own scale as north_star does (1e-3 class; 1.5e-3 as for the model-level gradients)."""
+    report(name, got, ref, tol * ref.detach().abs().max().item())
 
 
 def bf16_bits(x):
@@ -71,6 +72,26 @@ def test_mfma_layout_probes(a3d, dev):
     A4d, B4d = A4.to(dev), B4.to(dev)
     L.call("a3d_dbg_mfma_f32", A4d.data_ptr(), B4d.data_ptr(), D2.data_ptr(), L.stream())
     report("mfma_f32_16x16x4", D2, A4 @ B4, 1e-6)
+
+
+def test_linear_large_m_reads_weights_at_4_byte_alignment(a3d, dev):
+    """The large-M (bf16x3, linear_split.hip) path with weights and bias that sit at odd float offsets of one buffer, as the
+    parameters do inside engine.FlatParams: forward, ReLU and the transposed-weight (dgrad) read."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 5000, 120, 60
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    flat = torch.zeros(N * K + N + 7, device=dev)
+    wd = flat[1:1 + N * K].view(N, K)
+    bd = flat[3 + N * K:3 + N * K + N]
+    wd.copy_(w)
+    bd.copy_(b)
+    assert wd.data_ptr() % 16 != 0 and bd.data_ptr() % 16 != 0
+    report("linear_fwd, unaligned W", O.linear2d(x.to(dev), wd, bd, act=1), F.relu(F.linear(x, w, b)), 2e-5, 1e-5)
+    dy = torch.randn(M, N, generator=g)
+    report("linear_dgrad, unaligned W", O.dgrad2d(dy.to(dev), wd), dy @ w, 2e-5, 1e-5)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 5, 60), (333, 60, 60), (1000, 120, 60), (70, 480, 120), (257, 120, 480),
