@@ -479,7 +479,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp16 / bf16 MFMA on two-part operands (x = hi + lo; fp32 accumulate) in attention; " if a3d.ops.ATTN_MODE == "f16"
                       else "bf16 MFMA on split operands (q,k = hi+lo+lo2, p,v = hi+lo; fp32 accumulate) in attention; ") +
-                     "fp32 MFMA linears; " + ("bf16 frozen backbone + FPN" if args.backbone_dtype == "bf16" else "fp32 backbone + FPN"),
+                     "fp32-accurate linears (f32 MFMA; bf16x3 MFMA from 4096 rows); " + ("bf16 frozen backbone + FPN" if args.backbone_dtype == "bf16" else "fp32 backbone + FPN"),
             "data": "synthetic",
             "config": {"workload": "Act3D keypose training step, 18-PerAct-task shapes: 4 cameras 256x256, 3 ghost-point "
                                    "levels, 1000 ghost points (333/level), E=60, frozen synthetic CLIP-RN50-shaped backbone "

@@ -126,9 +126,10 @@ def training_attention_roofline(a3d, B, Ln, S, dev):
     q_pre = torch.randn(B * Ln, E, generator=g).to(dev)
     kv_pre = torch.randn(B * S, 2 * E, generator=g).to(dev)
     q_xyz, k_xyz = torch.rand(B, Ln, 3, generator=g).to(dev), torch.rand(B, S, 3, generator=g).to(dev)
-    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O.attn_operands(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E,
-                                                               kv_pre.data_ptr() + E * 4, 2 * E, q_xyz, k_xyz, B, Ln, S, E, H,
-                                                               dev, need_bwd=True)
+    f16 = O.ATTN_MODE != "bf16x3"                     # the family the training step runs (ops.AttnBlockFn)
+    build = O.attn_operands16 if f16 else O.attn_operands
+    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = build(q_pre.data_ptr(), E, kv_pre.data_ptr(), 2 * E, kv_pre.data_ptr() + E * 4, 2 * E,
+                                                    q_xyz, k_xyz, B, Ln, S, E, H, dev, need_bwd=True)
     ns = O.pick_nsplit(B, H, Lqp, Sp)
     Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns)
     dO = torch.randn_like(Oo)
@@ -138,7 +139,7 @@ def training_attention_roofline(a3d, B, Ln, S, dev):
     return {"bound": "mfma", "kernel": "attn_fwd + attn_bwd (trajectory -> context cross-attention)",
             "achieved": fl / (tf + tb) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / (tf + tb) / 1e12 / 2500.0,
             "ms": (tf + tb) * 1e3, "ms_fwd": tf * 1e3, "ms_bwd": tb * 1e3, "traffic": None, "launches_per_step": 8,
-            "dtype": "bf16 (split operands)"}
+            "dtype": "fp16 / bf16 MFMA on two-part operands" if f16 else "bf16 (split operands)", "family": O.ATTN_MODE}
 
 
 def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
@@ -221,7 +222,7 @@ def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
     res = {
         "metric": "train samples/sec (ChainedDiffuser trajectory-diffusion fwd+bwd+AdamW step)", "value": B / dt,
         "unit": "samples/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "higher_is_better": True,
-        "dtype": "bf16 MFMA on split operands in attention; fp32 MFMA linears; bf16 frozen backbone; fp32 FPN",
+        "dtype": "fp16 / bf16 MFMA on two-part operands in attention; fp32-accurate linears (f32 MFMA, bf16x3 MFMA from 4096 rows); bf16 frozen backbone; fp32 FPN",
         "data": "synthetic",
         "config": {"workload": f"DiffusionPlanner training step (main_trajectory.py:177-204): B={B} trajectories, horizon "
                                f"{Ln}, {C} cameras 256x256 (S={S}), E=120, H=8, dropout 0.1, frozen synthetic CLIP-RN50-shaped "

@@ -201,19 +201,16 @@ def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
     named = dict(m.named_parameters())
     for n, gref in r["grads"].items():
         scale_close("grad " + n, named[n].grad, gref, 1.5e-3, floor=1e-3)
-    # norms of all 900+ gradient tensors (only six are stored in full).  The loss is a sum of four L1 terms back-propagated
-    # through four chained predictions, and sign(pred - gt) is discontinuous where a prediction error crosses zero: a tensor
-    # whose gradient sees such a flipped element deviates by that element's share.  So: 1.5e-3 for every tensor but an explicit,
-    # printed and bounded set of kink-affected ones (at most 1 % of the tensors, none beyond 5e-3).
+    # norms of all 900+ gradient tensors (only six are stored in full): 1.5e-3 each, no exceptions (observed worst 1.6e-4 on
+    # MI355X, profiles/r03_parity_report.txt; the L1 sign kinks of the four chained predictions that made round 2 allow 5e-3
+    # do not show at this fixture's margins once the attention gradients are 1e-5-class)
     dev_rel = {n: abs(named[n].grad.norm().item() - nr) / (nr + 1e-4) for n, nr in r["grad_norms"].items()}
-    kinked = {n: v for n, v in dev_rel.items() if v > 1.5e-3}
-    print(f"[parity] relative gradient-norm deviation over {len(dev_rel)} tensors: worst {max(dev_rel.values()):.2e}, "
-          f"{len(kinked)} above 1.5e-3: {sorted(kinked.items(), key=lambda kv: -kv[1])[:8]}")
-    assert len(kinked) <= max(1, len(dev_rel) // 100), kinked
-    assert all(v <= 5e-3 for v in kinked.values()), kinked
+    worst = max(dev_rel, key=dev_rel.get)
+    print(f"[parity] relative gradient-norm deviation over {len(dev_rel)} tensors: worst {dev_rel[worst]:.2e} ({worst})")
+    assert dev_rel[worst] <= 1.5e-3, (worst, dev_rel[worst])
     # ---- 5 steps of the sampling loop (no K/V cache: the fine-scale context follows the prediction)
     m.eval()
     _, trace = m.compute_trajectory(inp["mask"], None, inp["pcd"], inp["instr"], inp["curr_gripper"], inp["goal_gripper"],
                                     init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=toks, n_steps=5,
                                     return_trace=True)
-    scale_close("state after 5 steps", trace[-1], r["sample_state_after_5_steps"], 2e-3)
+    scale_close("state after 5 steps", trace[-1], r["sample_state_after_5_steps"], 1e-3)      # observed 2.4e-7 of scale
