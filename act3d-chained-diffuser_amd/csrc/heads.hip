@@ -366,7 +366,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     // an element that has never seen a gradient is left alone, as torch.optim.AdamW skips parameters whose .grad is None
-    // (engine.py:121-124 find_unused_parameters): no weight decay on the FPN blocks / embeddings a configuration never uses
+    // (engine.py:121-124 find_unused_parameters): no weight decay on the FPN blocks / embeddings a configuration never uses.
+    // Known deviation: the decision is per ELEMENT, torch's per PARAMETER -- an element of a trained tensor whose gradient is
+    // exactly zero from step 1 on (a dead ReLU row, a pad channel) is not decayed here until its first non-zero gradient,
+    // and then takes the global step count for its bias correction.  Both effects vanish for elements that receive
+    // gradients from the first step, which is every element the parity tests compare against torch.optim.AdamW.
     if (gi == 0.0f && m[i] == 0.0f && v[i] == 0.0f) continue;
     const float wd = (i < n_nodecay) ? wd0 : wd1;
     float pi = p[i] * (1.0f - lr * wd);

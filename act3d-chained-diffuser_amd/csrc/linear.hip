@@ -20,6 +20,9 @@ bool linear_split_applicable(const float* X, int ldx, const float* W, int ldw, c
                              const float* mask, int ldm, int M, int N, int K, int act);
 int linear_split_launch(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, const float* mask,
                         int ldm, int M, int N, int K, int act, int w_transposed, hipStream_t s);
+bool linear_wgrad_split_applicable(const float* dY, int lddy, const float* X, int ldx, int M);
+int linear_wgrad_split_launch(const float* dY, int lddy, const float* X, int ldx, int has_bias, int M, int N, int K, int nsplit,
+                              int rows_per_split, float* partial, hipStream_t s);
 
 constexpr int LT_BM = 64;   // rows per workgroup
 constexpr int LT_BN = 64;   // cols per workgroup
@@ -423,6 +426,11 @@ extern "C" int a3d_linear_wgrad_ws(const float* dY, int lddy, const float* X, in
     return A3D_ERR_ARG;
   }
   dim3 grid(cdiv(N, 64), cdiv(KE, 64), nsplit);
+  if (two_stage && linear_wgrad_split_applicable(dY, lddy, X, ldx, M)) {
+    // large row counts: first stage on the bf16 pipe with three-part operands (linear_split.hip), same partial layout
+    const int rc = linear_wgrad_split_launch(dY, lddy, X, ldx, db != nullptr, M, N, K, nsplit, rows, ws, (hipStream_t)stream);
+    if (rc) return rc;
+  } else
   hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dW,
                      lddw, db, M, N, K, rows, two_stage ? ws : nullptr);
   if (two_stage)

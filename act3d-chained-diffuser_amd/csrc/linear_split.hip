@@ -201,4 +201,112 @@ int linear_split_launch(const float* X, int ldx, const float* W, int ldw, const 
   return check_launch("a3d_linear_fwd(split)");
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// partial[z][n][k] = sum over the rows m of slab z of dY[m][n] X[m][k]  (k == K: the virtual ones column -> db), the first
+// stage of linear.hip's two-stage weight gradient (wgrad_reduce_kernel adds the slabs in a fixed order), on the bf16 pipe with
+// three-part operands.  The contraction index is the ROW index, which is the slow index of both operands in memory, so both
+// tiles are transposed while they are staged: a thread holds the same four columns of two consecutive rows and writes, per
+// column and part, one packed pair (m, m + 1) into the [column][32 rows] tile.  64 (n) x 64 (k) outputs per workgroup as in
+// linear_wgrad_kernel (same grid, same partial layout); wave w owns n-tile w and all four k-tiles.
+__global__ __launch_bounds__(256, 2) void linear_wgrad_split_kernel(
+    const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx, int has_bias, int M, int N, int K,
+    int rows_per_split, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) unsigned short Ys[3][64 * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Xt[3][64 * 32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const int KE = has_bias ? K + 1 : K;
+  const int mp = t >> 4, c4 = (t & 15) * 4;                       // rows 2 mp, 2 mp + 1 of the step; columns c4 .. c4 + 3
+
+  auto ld4 = [&](const float* base, int ld, int m, int c, int C, bool ones) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m >= mend) return v;
+    const float* p = base + (size_t)m * ld + c;
+    if (c + 3 < C) return *reinterpret_cast<const float4*>(p);
+    if (c + 0 < C) v.x = p[0]; else if (ones && c + 0 == C) v.x = 1.f;
+    if (c + 1 < C) v.y = p[1]; else if (ones && c + 1 == C) v.y = 1.f;
+    if (c + 2 < C) v.z = p[2]; else if (ones && c + 2 == C) v.z = 1.f;
+    if (c + 3 < C) v.w = p[3]; else if (ones && c + 3 == C) v.w = 1.f;
+    return v;
+  };
+  float4 yr[2], xr[2];
+  auto load = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      yr[u] = ld4(dY, lddy, mb + 2 * mp + u, n0 + c4, N, false);
+      xr[u] = ld4(X, ldx, mb + 2 * mp + u, k0 + c4, K, has_bias != 0);
+    }
+  };
+  auto stage_one = [&](unsigned short (*T)[64 * 32], const float4& r0, const float4& r1) {
+    const float a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned int h, m, l;
+      split3(a[e], b[e], h, m, l);                               // low half: row 2 mp, high half: row 2 mp + 1
+      const int off = plane_off(c4 + e, mp >> 2) + (mp & 3) * 2;
+      *reinterpret_cast<unsigned int*>(&T[0][off]) = h;
+      *reinterpret_cast<unsigned int*>(&T[1][off]) = m;
+      *reinterpret_cast<unsigned int*>(&T[2][off]) = l;
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load(mbeg);
+  for (int mb = mbeg; mb < mend; mb += 32) {
+    if (mb > mbeg) __syncthreads();
+    stage_one(Ys, yr[0], yr[1]);
+    stage_one(Xt, xr[0], xr[1]);
+    __syncthreads();
+    if (mb + 32 < mend) load(mb + 32);
+    s16x8 ya[3], xb[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      ya[p] = *reinterpret_cast<const s16x8*>(&Ys[p][plane_off(wave * 16 + li, g)]);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) xb[p][kt] = *reinterpret_cast<const s16x8*>(&Xt[p][plane_off(kt * 16 + li, g)]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 c = acc[kt];
+      c = mfma_bf16_16x16x32(ya[1], xb[1][kt], c);
+      c = mfma_bf16_16x16x32(ya[0], xb[2][kt], c);
+      c = mfma_bf16_16x16x32(ya[2], xb[0][kt], c);
+      c = mfma_bf16_16x16x32(ya[0], xb[1][kt], c);
+      c = mfma_bf16_16x16x32(ya[1], xb[0][kt], c);
+      c = mfma_bf16_16x16x32(ya[0], xb[0][kt], c);
+      acc[kt] = c;
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int k = k0 + kt * 16 + li;
+    if (k >= KE) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wave * 16 + g * 4 + r;
+      if (n < N) partial[((size_t)blockIdx.z * N + n) * KE + k] = acc[kt][r];
+    }
+  }
+}
+
+bool linear_wgrad_split_applicable(const float* dY, int lddy, const float* X, int ldx, int M) {
+  static const bool on = !(getenv("A3D_LINEAR_SPLIT") && atoi(getenv("A3D_LINEAR_SPLIT")) == 0) &&
+                         !(getenv("A3D_WGRAD_SPLIT") && atoi(getenv("A3D_WGRAD_SPLIT")) == 0);
+  static const int min_m = getenv("A3D_LINEAR_SPLIT_MIN_M") ? atoi(getenv("A3D_LINEAR_SPLIT_MIN_M")) : 4096;
+  return on && M >= min_m && ((lddy | ldx) & 3) == 0 && ((((uintptr_t)dY | (uintptr_t)X) & 15) == 0);
+}
+
+int linear_wgrad_split_launch(const float* dY, int lddy, const float* X, int ldx, int has_bias, int M, int N, int K, int nsplit,
+                              int rows_per_split, float* partial, hipStream_t s) {
+  const int KE = has_bias ? K + 1 : K;
+  dim3 grid(cdiv(N, 64), cdiv(KE, 64), nsplit);
+  hipLaunchKernelGGL(linear_wgrad_split_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, has_bias, M, N, K, rows_per_split, partial);
+  return check_launch("a3d_linear_wgrad(split)");
+}
+
 }  // namespace a3d
