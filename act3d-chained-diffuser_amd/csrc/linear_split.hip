@@ -16,6 +16,7 @@
 // into registers while the current one is multiplied.  Workgroups that share X rows (the column blocks of one row block) run
 // back to back on one XCD (xcd_decode), so X comes from HBM once.
 // w_transposed (dgrad: dX = dY W) reads W[k][n] rows and transposes them while staging (the W tile is small).
+// The weight gradient of the same layers (first stage of the two-stage reduction) is at the end of this file.
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
 #include <stdlib.h>

@@ -380,9 +380,8 @@ class DiffusionHead(nn.Module):
         # sample through ~25 dependent phases, whatever the batch) while the cross-attention is HBM-bound (time ~ samples), so
         # the batch is cut into groups that run the same launch sequence on their own streams: one group's cross-attention
         # streams the cache while the others sit in their per-sample kernels.
-        ng = max(1, min(DN_GROUPS, B // 8)) if B >= 16 else 1
-        cuts = [(B * i) // ng for i in range(ng + 1)]
-        st["groups"] = [(cuts[i], cuts[i + 1]) for i in range(ng)]
+        st["groups"] = dn_sample_groups(B, DN_GROUPS)
+        ng = len(st["groups"])
         bg = max(b1 - b0 for b0, b1 in st["groups"])
         st["nsplit"] = max(1, min(8, Sp // 128, -(-DN_TARGET_WGS // (bg * H))))
         nws = O.L.load().a3d_dn_cross_ws_floats(bg, H, st["nsplit"])
@@ -502,6 +501,13 @@ FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
 DN_GROUPS = int(os.environ.get("A3D_DN_GROUPS", "1"))
 _DN_SIDE = {}
 _DN_GROUP = {}
+
+
+def dn_sample_groups(B, wanted):
+    """[(b0, b1), ...]: the batch cut into at most `wanted` contiguous groups of at least 8 samples (one group below 16)."""
+    ng = max(1, min(int(wanted), B // 8)) if B >= 16 else 1
+    cuts = [(B * i) // ng for i in range(ng + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(ng)]
 
 
 def _dn_side_stream(dev, gi=0):

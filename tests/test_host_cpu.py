@@ -580,3 +580,17 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_nslab(1 << 20, 64) == 2048 and lib.a3d_conv1x1_nslab(1000, 64) == 4
     assert lib.a3d_conv1x1_nslab(1 << 20, 1024) == 512 and lib.a3d_conv1x1_nslab(100, 256) == 2
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
+
+
+def test_denoise_sample_groups_partition_the_batch():
+    """diffusion.dn_sample_groups: contiguous, covering, >= 8 samples per group, one group for small batches."""
+    a3d = load_pkg()
+    g = a3d.diffusion.dn_sample_groups
+    assert g(64, 1) == [(0, 64)]
+    assert g(64, 4) == [(0, 16), (16, 32), (32, 48), (48, 64)]
+    assert g(15, 4) == [(0, 15)] and g(16, 4) == [(0, 8), (8, 16)]
+    for B in (16, 22, 37, 64, 100):
+        for want in (1, 2, 3, 4, 8):
+            cuts = g(B, want)
+            assert cuts[0][0] == 0 and cuts[-1][1] == B and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert len(cuts) <= want and all(b1 - b0 >= 8 for b0, b1 in cuts)
