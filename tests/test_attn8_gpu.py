@@ -5,15 +5,20 @@ Two kinds of check, both through the C-ABI:
    in [-7, 7], weights that are powers of two, values on e4m3's grid) -- lane layouts, the LDS-DMA ring, key masks and
    tails, the power-of-two scales, the ones channel, key splits and both query-tile variants must then reproduce the
    float64 softmax to fp32 rounding;
- * accuracy at e4m3's tolerance: random projected operands at the logit range of the configs[4] fixture against float64.
+ * accuracy at e4m3's tolerance: random projected operands at the logit range of the configs[4] fixture against float64;
+ * the amax / pack kernels against the oracle quantiser (oracle/fp8.py), bit for bit.
 """
 import importlib
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import fp8 as OF  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -157,3 +162,46 @@ def test_attn8_accuracy_at_the_configs4_shapes(a3d, dev, gain):
     assert l8 <= tol, (l8, tol)
     assert e8 <= 2.5 * tol * omax, (e8, tol, omax)
     assert e16 <= 1e-4 * max(1.0, omax)
+
+
+def test_attn8_pack_kernels_equal_the_oracle_quantiser_bit_for_bit(a3d, dev):
+    """amax reduction + pack kernel against oracle/fp8.py (itself pinned to torch's float8_e4m3fn on CPU): the per-(sample, head)
+    maxima are the exact fp32 maxima of the fp16 hi parts, the scales follow from them, and every K8 / V8 byte is the
+    round-to-nearest-even e4m3 code of (hi + lo) * 2^scale.  (A value exactly midway between two codes may take either
+    neighbour -- counted and printed; everything else must match bit for bit.)"""
+    L = a3d.lib
+    B, H, Lq, S = 2, 4, 300, 1000
+    Qs, Ks, Vt, Lqp, Sp, _, _ = _projected_case(a3d, dev, B, Lq, S, 1.5, 11)
+    O = torch.empty((B, Lq, H * 15), device=dev)
+    LSE = torch.empty((B, H, Lqp), device=dev)
+    nbytes = L.load().a3d_attn8_operand_bytes(B, H, Sp)
+    ops8 = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+    L.call("a3d_attn8_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), ops8.data_ptr(), None, O.data_ptr(), LSE.data_ptr(), None,
+           B, H, Lq, Lqp, S, Sp, 1, L.stream())
+    torch.cuda.synchronize()
+    kv = (B * H * Sp * 16 + 255) // 256 * 256
+    raw = ops8.cpu().numpy()
+    K8 = raw[:B * H * Sp * 16].reshape(B, H, Sp, 16)
+    V8 = raw[kv:kv + B * H * Sp * 16].reshape(B, H, 16, Sp)
+    amax = raw[2 * kv:2 * kv + B * H * 16].view(np.float32).reshape(B, H, 4)
+    q16 = Qs.float().cpu().numpy().reshape(B, H, Lqp, 32)
+    k16 = Ks.float().cpu().numpy().reshape(B, H, Sp, 32)
+    v16 = Vt.float().cpu().numpy().reshape(B, H, 2, 16, Sp)
+    ref_amax = np.stack([np.abs(k16[:, :, :S, :16]).max((2, 3)), np.abs(q16[:, :, :Lq, :16]).max((2, 3)),
+                         np.abs(v16[:, :, 0, :15]).max((2, 3))], -1)
+    assert np.array_equal(amax[..., :3], ref_amax), (amax[..., :3], ref_amax)
+    ek, ev = OF.attention_scales(ref_amax[..., 0], ref_amax[..., 1], ref_amax[..., 2])
+    kx = (k16[..., :16] + k16[..., 16:]) * np.exp2(ek.astype(np.float32))[..., None, None]
+    vx = v16[:, :, 0] + v16[:, :, 1]
+    vx[:, :, :15] *= np.exp2(ev.astype(np.float32))[..., None, None]          # channel 15 (the ones column) is not scaled
+    ties = 0
+    for name, got, x in (("K8", K8, kx), ("V8", V8, vx)):
+        ref = OF.e4m3_bytes(x)
+        bad = np.nonzero(got != ref)
+        if bad[0].size:
+            g, r_, xv = OF.e4m3_values(got[bad]).astype(np.float64), OF.e4m3_values(ref[bad]).astype(np.float64), x[bad].astype(np.float64)
+            is_tie = np.abs(np.abs(xv - g) - np.abs(xv - r_)) == 0.0
+            assert is_tie.all(), f"{name}: {int((~is_tie).sum())} bytes differ from the oracle, e.g. x={xv[~is_tie][:4]} got={g[~is_tie][:4]} ref={r_[~is_tie][:4]}"
+            ties += int(is_tie.sum())
+    print(f"[parity] attn8 pack: amax words, {K8.size} K8 bytes and {V8.size} V8 bytes equal the oracle; {ties} exact ties resolved differently")
+    assert torch.isfinite(O).all()

@@ -456,3 +456,25 @@ def test_dataset_items_equal_reference(tag, tmp_path):
         assert np.array_equal(aug, r[k].numpy()), k
     if training:
         assert (p[:, 0] != C.DATASET_IMAGE).any()          # the augmentation actually did something
+
+
+def test_fp8_oracle_equals_torch_float8_e4m3fn():
+    """oracle/fp8.py (the quantiser the opt-in fp8 attention's pack kernel is held to, tests/test_attn8_gpu.py) against torch's
+    own float8_e4m3fn conversion: every finite fp16 value, random floats over 22 binades, every midpoint between neighbouring
+    codes (round to nearest even) and every code's round trip."""
+    from oracle import fp8
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    h = h[np.isfinite(h)]
+    r = np.random.RandomState(0).randn(200000).astype(np.float32) * np.exp2(np.random.RandomState(1).randint(-12, 10, 200000)).astype(np.float32)
+    codes = np.arange(0, 0x7E, dtype=np.uint8)
+    vals = fp8.e4m3_values(codes)
+    mid = ((vals[:-1].astype(np.float64) + vals[1:].astype(np.float64)) / 2).astype(np.float32)
+    x = np.concatenate([h, r, mid, -mid, vals, -vals])
+    x = x[np.abs(x) <= 448]
+    ref = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(fp8.e4m3_bytes(x), ref)
+    assert np.array_equal(torch.from_numpy(codes).view(torch.float8_e4m3fn).float().numpy(), vals)
+    assert np.array_equal(fp8.e4m3_bytes(vals), codes)
+    assert np.array_equal(fp8.e4m3_bytes(np.float32([1000.0, -1e9])), np.uint8([0x7E, 0xFE]))        # saturation
+    ek, ev = fp8.attention_scales(np.float32([8.0, 0.3]), np.float32([3.0, 40.0]), np.float32([1.75, 0.01]))
+    assert ek.tolist() == [-1, 3] and ev.tolist() == [7, 14]
