@@ -460,8 +460,9 @@ def main():
 
     was_graphed = graphed is not None
     joint_dp = None
-    if world > 1 and not args.skip_secondary:
+    if world > 1 and not args.skip_secondary and os.environ.get("A3D_BENCH_JOINT_DP", "1") == "1":
         # BASELINE configs[3] under data parallelism: every rank takes part (collectives), rank 0 reports it in `secondary`
+        # (A3D_BENCH_JOINT_DP=0 or --skip-secondary leave the run at the headline step only)
         del graphed
         torch.cuda.empty_cache()
         try:
