@@ -959,10 +959,16 @@ extern "C" int a3d_attn16_bwd(const void* Qr, const void* Qp, const void* Kr, co
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)Lqp * 12 + (size_t)2 * PREP_GROUP * 64 * 64;
-  if (Lqp > 32768) { set_error("a3d_attn16_bwd: Lqp = %d too large for the per-(b, h) row sort", Lqp); return A3D_ERR_ARG; }
+  constexpr size_t PREP_LDS_MAX = 150 * 1024;          // the dynamic-LDS attribute set below (160 KB per CU on gfx950)
+  if (lds > PREP_LDS_MAX) {
+    const size_t max_lqp = (PREP_LDS_MAX - (size_t)2 * PREP_GROUP * 64 * 64) / 12 / 64 * 64;
+    set_error("a3d_attn16_bwd: Lqp = %d exceeds the per-(b, h) row sort of the prep kernel (12 B of LDS per query: Lqp <= %zu); "
+              "use the bf16x3 backward (a3d_attn_bwd_bf16) for longer query sets", Lqp, max_lqp);
+    return A3D_ERR_ARG;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn16_bwd_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn16_bwd_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_MAX);
     attr_set = true;
   }
   hipLaunchKernelGGL(attn16_bwd_prep_kernel, dim3(B * H), dim3(256), lds, s, dO, O, LSE2, (const unsigned short*)Qr,

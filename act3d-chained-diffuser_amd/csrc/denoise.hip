@@ -497,123 +497,15 @@ __device__ __forceinline__ void wg_stage_vectors(const VecList& vl, float* const
 __device__ long long g_dn_prof[32];
 #define DN_MARK(i) do { if ((warm & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dn_prof[i] = wall_clock64(); } while (0)
 
-// ------------------------------------------------------------------------------------------------ rest of a layer
-__global__ __launch_bounds__(512) void dn_rest_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
-                                                      const float* __restrict__ Op, const float* __restrict__ Mp,
-                                                      a3d_dn_rest_params p, float* __restrict__ x_out, int B, int L,
-                                                      int E, int H, int nsplit, int warm) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                       // [16][LDX]  residual stream
-  float* As = Xs + DR * LDX;              // [16][LDX]
-  float* Bs = As + DR * LDX;              // [16][LDX]
-  float* Ts = Bs + DR * LDX;              // [16][LDX]
-  float* QK = Ts + DR * LDX;              // [16][LDQK]
-  float* Hs = QK + DR * LDQK;             // [16][LDH]
-  float* Ps = Hs + DR * LDH;              // staged parameter vectors: 16 x 128 + 512 + the [16][E] index embedding
-  const int b = blockIdx.x;
-  const int Epad = (E + 15) & ~15;
-  DN_MARK(0);
-  // LDS copies of every small vector this layer reads (NULL stays NULL)
-  float* const vd[12] = {Ps, Ps + 128, Ps + 256, Ps + 384, Ps + 640, Ps + 1024, Ps + 1152, Ps + 1280, Ps + 1408, Ps + 1664, Ps + 2176,
-                         Ps + 2304};
-  const float* const c_out_b = p.c_out_b ? vd[0] : nullptr;
-  const float *c_ln_g = vd[1], *c_ln_b = vd[2];
-  const float* const s_mod = p.s_mod ? vd[3] : nullptr;          // 2E <= 256
-  const float* const s_in_b = p.s_in_b ? vd[4] : nullptr;        // 3E <= 384
-  const float* const s_out_b = p.s_out_b ? vd[5] : nullptr;
-  const float *s_ln_g = vd[6], *s_ln_b = vd[7];
-  const float* const f_mod = p.f_mod ? vd[8] : nullptr;          // 2E
-  const float* const f_b1 = p.f_b1 ? vd[9] : nullptr;            // F <= 512
-  const float* const f_b2 = p.f_b2 ? vd[10] : nullptr;
-  float* const lnf = Ps + 2304;                                  // f_ln_g | f_ln_b (2 x 128)
-  const float* const sem = (p.sem && p.s_in_w) ? Ps + 2560 : nullptr;
-  {
-    const VecList vl = {{p.c_out_b, p.c_ln_g, p.c_ln_b, p.s_in_w ? p.s_mod : nullptr, p.s_in_w ? p.s_in_b : nullptr,
-                         p.s_in_w ? p.s_out_b : nullptr, p.s_in_w ? p.s_ln_g : nullptr, p.s_in_w ? p.s_ln_b : nullptr,
-                         p.f_w1 ? p.f_mod : nullptr, p.f_w1 ? p.f_b1 : nullptr, p.f_w1 ? p.f_b2 : nullptr, p.f_w1 ? p.f_ln_g : nullptr},
-                        {E, E, E, 2 * E, 3 * E, E, E, E, 2 * E, p.F, E, E}};
-    wg_stage_vectors(vl, vd, sem ? p.sem : nullptr, L * E, Ps + 2560);
-    if (p.f_w1 && threadIdx.x < E) lnf[128 + threadIdx.x] = p.f_ln_b[threadIdx.x];
-  }
-  if (warm & 1) {
-    const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
-                         {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
-    wg_warm_l2(wl, gridDim.x);
-  }
-  DN_MARK(1);
-  wg_load_rows(x_in + (size_t)b * L * E, E, L, Xs, LDX, Epad);
-  wg_zero_pad(As, LDX, E, Epad);
-  wg_zero_pad(Bs, LDX, E, Epad);
-  wg_zero_pad(Ts, LDX, E, Epad);
-  // ---- cross-attention output: combine the key splits
-#pragma unroll 4
-  for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
-    const int r = i / E, c = i - r * E;
-    const int h = c / HD, d = c - h * HD;
-    float m = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, Mp[(((size_t)s * B + b) * H + h) * 16 + r]);
-    const float m_use = (m == -INFINITY) ? 0.f : m;
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const size_t row = (((size_t)s * B + b) * H + h) * 16 + r;
-      const float w = __expf(Mp[row] - m_use);
-      num += w * Op[row * 16 + d];
-      den += w * Op[row * 16 + 15];
-    }
-    As[r * LDX + c] = den > 0.f ? num / den : 0.f;
-  }
-  __syncthreads();
-  DN_MARK(2);
-  wg_linear<0>(As, LDX, E, p.c_out_w, E, c_out_b, E, Ts, LDX);
-  DN_MARK(3);
-  wg_add_layernorm(Xs, LDX, Ts, LDX, c_ln_g, c_ln_b, Xs, LDX, E);
-  DN_MARK(4);
-  if (p.s_in_w) {
-    // ---- self-attention: q = k = AdaLN(x + index embedding), v = AdaLN(x), RoPE by the steps' xyz, padded steps masked
-    wg_adaln(Xs, LDX, sem, s_mod, As, LDX, L, E, Bs, LDX);
-    DN_MARK(5);
-    wg_linear<0>(As, LDX, E, p.s_in_w, E, s_in_b, 2 * E, QK, LDQK);                        // [q | k]
-    DN_MARK(6);
-    wg_linear<0>(Bs, LDX, E, p.s_in_w + (size_t)2 * E * E, E, s_in_b ? s_in_b + 2 * E : nullptr, E, Hs, LDH);   // v
-    DN_MARK(7);
-    wg_rope(QK, LDQK, 0, 2, traj + (size_t)b * L * D, D, p.freq, L, E, 1.0f / sqrtf((float)HD));
-    DN_MARK(8);
-    wg_small_attention(QK, LDQK, QK + E, LDQK, Hs, LDH, p.kmask ? p.kmask + (size_t)b * L : nullptr, L, H, As, LDX);
-    DN_MARK(9);
-    wg_linear<0>(As, LDX, E, p.s_out_w, E, s_out_b, E, Ts, LDX);
-    DN_MARK(10);
-    wg_add_layernorm(Xs, LDX, Ts, LDX, s_ln_g, s_ln_b, Xs, LDX, E);
-    DN_MARK(11);
-  }
-  if (p.f_w1) {
-    // ---- FFN: y = AdaLN(x); x = LayerNorm(y + W2 relu(W1 y + b1) + b2)
-    wg_adaln(Xs, LDX, nullptr, f_mod, As, LDX, L, E);
-    DN_MARK(12);
-    for (int i = threadIdx.x; i < DR * (((p.F + 15) & ~15) - p.F); i += blockDim.x) {
-      const int padw = ((p.F + 15) & ~15) - p.F;
-      Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
-    }
-    __syncthreads();
-    DN_MARK(13);
-    wg_linear<1>(As, LDX, E, p.f_w1, E, f_b1, p.F, Hs, LDH);
-    DN_MARK(14);
-    wg_linear<0>(Hs, LDH, p.F, p.f_w2, p.F, f_b2, E, Ts, LDX);
-    DN_MARK(15);
-    wg_add_layernorm(As, LDX, Ts, LDX, lnf, lnf + 128, Xs, LDX, E);
-    DN_MARK(16);
-  }
-  for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
-  DN_MARK(17);
-}
-
 // ------------------------------------------------------------------------------------------------ rest of a layer, looped
-// The straight-line kernel above is 82 KB of code that a workgroup executes exactly once: A3D_DN_PROF showed phases with
-// almost no arithmetic (AdaLN, RoPE, the ReLU instantiation of the dense layer) taking 4-12 us each, unchanged by warming the
-// weights or staging every parameter vector in LDS -- the time follows the CODE SIZE of a phase: the kernel is bound by
-// instruction fetch (64 KB instruction cache per CU pair, every line a miss).  This version runs the same 13 operations as
-// a LOOP over an operation table (built by the host, passed by value, indexed with scalar loads) around ONE copy of each
-// operation's code: five of the thirteen are the dense layer, three the residual LayerNorm, two the AdaLN, so after the
-// first visit an operation's instructions are cache hits.  Arithmetic, order and results are those of the kernel above.
+// One workgroup per sample runs everything between two cross-attentions.  Round 3 measured the first (straight-line) version
+// of this kernel, 82 KB of code that a workgroup executes exactly once, with A3D_DN_PROF: phases with almost no arithmetic
+// (AdaLN, RoPE, the ReLU instantiation of the dense layer) took 4-12 us each in proportion to their CODE SIZE (instruction
+// fetch: 64 KB instruction cache per CU pair, every line a miss).  This version runs the same 13 operations as a LOOP over an
+// operation table (built by the host, passed by value, indexed with scalar loads) around ONE copy of each operation's code:
+// five of the thirteen are the dense layer, three the residual LayerNorm, two the AdaLN, so after the first visit an
+// operation's instructions are cache hits (32 KB of code; AdaLN 4.4 -> 1.0 us, RoPE 5.8 -> 1.1 us; the straight-line kernel was
+// deleted in round 4).
 enum { DN_OP_LINEAR = 0, DN_OP_ADDLN = 1, DN_OP_ADALN = 2, DN_OP_ROPE = 3, DN_OP_ATTN = 4 };
 struct DnOp {
   int type;
@@ -694,6 +586,7 @@ __device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, co
   __syncthreads();
 }
 
+constexpr int DN_MISC_XYZ = 160;                 // floats of the misc area that hold the sample's trajectory rows (L * D)
 constexpr int DN_PS = 2560 + DR * 128 + 256;     // floats of staged parameters: vectors | index embedding | xyz rows, freq, mask
 __global__ __launch_bounds__(512) void dn_rest_loop_kernel(const float* __restrict__ x_in, const float* __restrict__ traj, int D,
                                                            const float* __restrict__ Op, const float* __restrict__ Mp,
@@ -969,20 +862,12 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
     set_error("a3d_dn_rest: bad argument");
     return A3D_ERR_ARG;
   }
-  const size_t lds = ((size_t)DR * (4 * LDX + LDQK + LDH) + 2560 + DR * 128) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dn_rest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
+  if (D < 3 || L * D > DN_MISC_XYZ) {      // the staged xyz rows share a 256-float LDS area with freq (at 160) and the key mask (at 192)
+    set_error("a3d_dn_rest: L * D = %d trajectory values do not fit the %d-float staging area (D >= 3)", L * D, DN_MISC_XYZ);
+    return A3D_ERR_ARG;
   }
   const float* Op = ws;
   const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
-  static const bool straight = getenv("A3D_DN_REST") && strcmp(getenv("A3D_DN_REST"), "straight") == 0;      // A/B: the unrolled kernel
-  if (straight) {
-    hipLaunchKernelGGL(dn_rest_kernel, dim3(B), dim3(dn_threads()), lds, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, x_out, B, L, E,
-                       H, nsplit, dn_warm());
-    return check_launch("a3d_dn_rest");
-  }
   // operation table of dn_rest_loop_kernel: LDS offsets in floats from the start of the dynamic LDS
   const int oX = 0, oA = DR * LDX, oB = 2 * DR * LDX, oT = 3 * DR * LDX, oQK = 4 * DR * LDX, oH = oQK + DR * LDQK, oP = oH + DR * LDH;
   const int oMisc = oP + 2560 + DR * 128;

@@ -352,26 +352,63 @@ __global__ __launch_bounds__(256) void sample_ghost_kernel(
 __global__ void rng_advance_kernel(unsigned long long* state, unsigned long long n) { state[1] += n; }
 
 // ---------------------------------------------------------------- AdamW on the flat buffer
-// elements [0, n_nodecay) use weight decay wd0, the rest wd1.  step[0] holds the number of completed steps.
+// torch.optim.AdamW decides PER PARAMETER: a parameter whose .grad is None is skipped (no decay, no moment update, its own
+// `step` does not advance -- engine.py:121-124 find_unused_parameters: the FPN blocks / embeddings a configuration never
+// reads), every other parameter is updated in full, zero-gradient elements (dead ReLU rows, pad channels) included, with the
+// bias correction of ITS OWN step count.  The flat buffer has no None: seg_off [nseg + 1] delimits the parameters, and
+// seg_state [nseg][4] = {step, active, lr / bc1, sqrt(bc2)} carries the per-parameter state.  A parameter is "in the graph"
+// from the first step in which any element of its gradient segment is non-zero, and stays in (which tensors a model's
+// forward reaches is structural); adamw_prepare_kernel (one workgroup per parameter; the scan only runs until the parameter
+// is in) advances the step counts and leaves the coefficients for adamw_kernel, whose threads find their element's parameter
+// by bisection of the LDS-staged offsets.  Elements [0, n_nodecay) use weight decay wd0, the rest wd1.
+constexpr int ADAMW_LDS_SEGS = 4096;
+__global__ __launch_bounds__(256) void adamw_prepare_kernel(const float* __restrict__ g, const long long* __restrict__ seg_off,
+                                                            float* __restrict__ seg_state, float* __restrict__ step, float lr,
+                                                            float beta1, float beta2) {
+  const int seg = blockIdx.x;
+  float* st = seg_state + (size_t)seg * 4;
+  const long long a = seg_off[seg], b = seg_off[seg + 1];
+  int in_graph = st[0] > 0.0f;
+  if (!in_graph) {
+    int nz = 0;
+    for (long long i = a + threadIdx.x; i < b; i += blockDim.x) nz |= (g[i] != 0.0f);
+    in_graph = __syncthreads_or(nz);
+  }
+  if (threadIdx.x == 0) {
+    if (in_graph) {
+      const float t = st[0] + 1.0f;
+      st[0] = t;
+      st[1] = 1.0f;
+      st[2] = lr / (1.0f - powf(beta1, t));
+      st[3] = sqrtf(1.0f - powf(beta2, t));
+    } else {
+      st[1] = 0.0f;
+    }
+    if (seg == 0) step[0] += 1.0f;            // completed optimizer steps (the value torch keeps for every updated parameter)
+  }
+}
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    const float* __restrict__ step, size_t n, size_t n_nodecay,
-                                                    float lr, float beta1, float beta2, float eps, float wd0,
-                                                    float wd1, float gscale) {
-  const float t = step[0] + 1.0f;
-  const float bc1 = 1.0f - powf(beta1, t);
-  const float bc2 = 1.0f - powf(beta2, t);
-  const float step_size = lr / bc1;
-  const float bc2s = sqrtf(bc2);
+                                                    const long long* __restrict__ seg_off, const float* __restrict__ seg_state,
+                                                    int nseg, size_t n, size_t n_nodecay, float lr, float beta1, float beta2,
+                                                    float eps, float wd0, float wd1, float gscale) {
+  __shared__ long long offS[ADAMW_LDS_SEGS + 1];
+  const bool staged = nseg <= ADAMW_LDS_SEGS;
+  if (staged) {
+    for (int i = threadIdx.x; i <= nseg; i += blockDim.x) offS[i] = seg_off[i];
+    __syncthreads();
+  }
+  const long long* off = staged ? offS : seg_off;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = nseg - 1;                 // largest seg with off[seg] <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((size_t)off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const float* st = seg_state + (size_t)lo * 4;
+    if (st[1] == 0.0f) continue;               // parameter not in the graph: left alone, as torch skips .grad is None
+    const float step_size = st[2], bc2s = st[3];
     const float gi = g[i] * gscale;
-    // an element that has never seen a gradient is left alone, as torch.optim.AdamW skips parameters whose .grad is None
-    // (engine.py:121-124 find_unused_parameters): no weight decay on the FPN blocks / embeddings a configuration never uses.
-    // Known deviation: the decision is per ELEMENT, torch's per PARAMETER -- an element of a trained tensor whose gradient is
-    // exactly zero from step 1 on (a dead ReLU row, a pad channel) is not decayed here until its first non-zero gradient,
-    // and then takes the global step count for its bias correction.  Both effects vanish for elements that receive
-    // gradients from the first step, which is every element the parity tests compare against torch.optim.AdamW.
-    if (gi == 0.0f && m[i] == 0.0f && v[i] == 0.0f) continue;
     const float wd = (i < n_nodecay) ? wd0 : wd1;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
@@ -381,7 +418,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
-__global__ void step_inc_kernel(float* step) { step[0] += 1.0f; }
 
 // ---------------------------------------------------------------- keypose evaluation metrics, per-sample columns
 // LossAndMetrics.compute_metrics (main_keypose.py:431-482) as a table: one thread per sample writes
@@ -531,17 +567,19 @@ extern "C" int a3d_rng_advance(unsigned long long* state, unsigned long long n, 
 extern "C" void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
-extern "C" int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, size_t n, size_t n_nodecay,
-                              float lr, float beta1, float beta2, float eps, float wd_nodecay, float wd_decay,
-                              float grad_scale, void* stream) {
-  if (!p || !g || !m || !v || !step) { set_error("a3d_adamw_step: null pointer"); return A3D_ERR_ARG; }
+extern "C" int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, const long long* seg_off,
+                              float* seg_state, int nseg, size_t n, size_t n_nodecay, float lr, float beta1, float beta2, float eps,
+                              float wd_nodecay, float wd_decay, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step || !seg_off || !seg_state) { set_error("a3d_adamw_step: null pointer"); return A3D_ERR_ARG; }
   if (n == 0) return A3D_OK;
+  if (nseg <= 0) { set_error("a3d_adamw_step: the flat buffer needs at least one parameter segment (nseg = %d)", nseg); return A3D_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, p, g, m, v, step, n, n_nodecay, lr, beta1, beta2, eps, wd_nodecay, wd_decay, grad_scale);
-  int rc = check_launch("a3d_adamw_step");
+  hipLaunchKernelGGL(adamw_prepare_kernel, dim3(nseg), dim3(256), 0, s, g, seg_off, seg_state, step, lr, beta1, beta2);
+  int rc = check_launch("a3d_adamw_step(prepare)");
   if (rc) return rc;
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
-  return check_launch("a3d_adamw_step(inc)");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, p, g, m, v, seg_off, seg_state, nseg, n, n_nodecay, lr,
+                     beta1, beta2, eps, wd_nodecay, wd_decay, grad_scale);
+  return check_launch("a3d_adamw_step");
 }
 
 extern "C" int a3d_keypose_errors(const float* pos, const float* rot, const float* grip, const float* gt, int ldgt, float* cols,

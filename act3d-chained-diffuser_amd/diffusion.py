@@ -376,46 +376,17 @@ class DiffusionHead(nn.Module):
             st["lang_kv"] = O.linear_raw(instr.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
                                          mha.in_proj_bias.data_ptr() + E * f4, B * instr.shape[1], 2 * E, E, dev)
             st["tensors"].append(st["lang_kv"])
-        # Sample groups (DN_GROUPS): the per-sample kernels between two cross-attentions are latency-bound (one workgroup per
-        # sample through ~25 dependent phases, whatever the batch) while the cross-attention is HBM-bound (time ~ samples), so
-        # the batch is cut into groups that run the same launch sequence on their own streams: one group's cross-attention
-        # streams the cache while the others sit in their per-sample kernels.
-        st["groups"] = dn_sample_groups(B, DN_GROUPS)
-        ng = len(st["groups"])
-        bg = max(b1 - b0 for b0, b1 in st["groups"])
-        st["nsplit"] = max(1, min(8, Sp // 128, -(-DN_TARGET_WGS // (bg * H))))
-        nws = O.L.load().a3d_dn_cross_ws_floats(bg, H, st["nsplit"])
-        st["ws"] = [torch.empty((nws,), device=dev, dtype=torch.float32) for _ in range(ng)]
-        st["ws_side"] = [torch.empty((nws,), device=dev, dtype=torch.float32) for _ in range(ng)]   # rotation branch, concurrent
+        st["nsplit"] = max(1, min(8, Sp // 128, -(-DN_TARGET_WGS // (B * H))))
+        nws = O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"])
+        st["ws"] = torch.empty((nws,), device=dev, dtype=torch.float32)
+        st["ws_side"] = torch.empty((nws,), device=dev, dtype=torch.float32)      # rotation branch, concurrent
         return st
 
     @torch.no_grad()
     def fused_step(self, st, traj, t, noise, cond_data, cond_mask_u8, tb):
-        """One denoise step: network evaluation at timestep t + DDPM reverse step -> the next trajectory (B, L, D).  The
-        sample groups of build_fused run concurrently (fork / join on events: capturable)."""
-        out = torch.empty_like(traj)
-        groups = st["groups"]
-        if len(groups) == 1:
-            self._fused_step_group(st, 0, traj, t, noise, cond_data, cond_mask_u8, tb, out)
-            return out
-        dev = traj.device
-        cur = torch.cuda.current_stream(dev)
-        streams = _dn_group_streams(dev, len(groups) - 1)
-        for gi in range(1, len(groups)):
-            streams[gi - 1].wait_stream(cur)
-            with torch.cuda.stream(streams[gi - 1]):
-                self._fused_step_group(st, gi, traj, t, noise, cond_data, cond_mask_u8, tb, out)
-        self._fused_step_group(st, 0, traj, t, noise, cond_data, cond_mask_u8, tb, out)
-        for gi in range(1, len(groups)):
-            cur.wait_stream(streams[gi - 1])
-        return out
-
-    def _fused_step_group(self, st, gi, traj_all, t, noise_all, cond_data_all, cond_mask_all, tb, out_all):
+        """One denoise step: network evaluation at timestep t + DDPM reverse step -> the next trajectory (B, L, D)."""
         Lb = O.L
-        b0, b1 = st["groups"][gi]
-        traj = traj_all[b0:b1]
-        noise = None if noise_all is None else noise_all[b0:b1]
-        cond_data, cond_mask_u8 = cond_data_all[b0:b1], cond_mask_all[b0:b1]
+        out = torch.empty_like(traj)
         B, Ln, D = traj.shape
         H = self.num_attn_heads
         E = self.curr_gripper_embed.weight.shape[1]
@@ -425,7 +396,7 @@ class DiffusionHead(nn.Module):
         new = lambda: torch.empty((B, Ln, E), device=dev, dtype=torch.float32)
         hp = Lb.DnHeadParams(enc_w0=self.traj_encoder[0].weight.data_ptr(), enc_b0=self.traj_encoder[0].bias.data_ptr(),
                              enc_w1=self.traj_encoder[3].weight.data_ptr(), enc_b1=self.traj_encoder[3].bias.data_ptr(),
-                             sem=st["sem"].data_ptr(), lang_kv=None if st["lang_kv"] is None else st["lang_kv"][b0:b1].data_ptr(),
+                             sem=st["sem"].data_ptr(), lang_kv=None if st["lang_kv"] is None else st["lang_kv"].data_ptr(),
                              S_lang=st.get("S_lang", 0))
         if st["lang_kv"] is not None:
             ll = self.traj_lang_attention[0].layers[0]
@@ -440,8 +411,8 @@ class DiffusionHead(nn.Module):
             stream = Lb.stream()
             mo = [m.data_ptr() + t * 2 * E * f4 for m in rec["mods"]]
             cp = Lb.DnCrossParams(sem=st["sem"].data_ptr(), mod=mo[0], q_w=lay.cross_12.in_proj_weight.data_ptr(),
-                                  q_b=lay.cross_12.in_proj_bias.data_ptr(), freq=st["freq"].data_ptr(), Kf=rec["Kf"][b0:b1].data_ptr(),
-                                  Vt=rec["Vt"][b0:b1].data_ptr())
+                                  q_b=lay.cross_12.in_proj_bias.data_ptr(), freq=st["freq"].data_ptr(), Kf=rec["Kf"].data_ptr(),
+                                  Vt=rec["Vt"].data_ptr())
             Lb.call("a3d_dn_cross", xin.data_ptr(), traj.data_ptr(), D, C_byref(cp), ws.data_ptr(), B, Ln, E, H, st["S"],
                     st["Sp"], st["nsplit"], stream)
             ff = lay.ffn_12
@@ -451,7 +422,7 @@ class DiffusionHead(nn.Module):
                 s_mod=mo[1], s_in_w=lay.sa1.in_proj_weight.data_ptr(), s_in_b=lay.sa1.in_proj_bias.data_ptr(),
                 s_out_w=lay.sa1.out_proj.weight.data_ptr(), s_out_b=lay.sa1.out_proj.bias.data_ptr(),
                 s_ln_g=lay.norm_1.weight.data_ptr(), s_ln_b=lay.norm_1.bias.data_ptr(), freq=st["freq"].data_ptr(),
-                kmask=None if st["kmask"] is None else st["kmask"][b0:b1].data_ptr(), f_mod=mo[2], f_w1=ff[0].weight.data_ptr(), f_b1=ff[0].bias.data_ptr(),
+                kmask=None if st["kmask"] is None else st["kmask"].data_ptr(), f_mod=mo[2], f_w1=ff[0].weight.data_ptr(), f_b1=ff[0].bias.data_ptr(),
                 f_w2=ff[3].weight.data_ptr(), f_b2=ff[3].bias.data_ptr(), f_ln_g=lay.norm_122.weight.data_ptr(),
                 f_ln_b=lay.norm_122.bias.data_ptr(), F=ff[0].weight.shape[0])
             xout = new()
@@ -463,20 +434,20 @@ class DiffusionHead(nn.Module):
         n_traj = len(self.traj_attention[0].layers)
         n_pos = len(self.pos_attention[0].layers)
         for rec in recs[:n_traj]:
-            x = run_layer(x, rec, st["ws"][gi])
+            x = run_layer(x, rec, st["ws"])
         # the position and rotation stacks (diffusion_head.py:343-357) both start from x and are independent: the rotation
         # stack runs on a side stream (fork / join on events: capturable), its 64-workgroup per-sample kernels filling CUs
         # the position stack leaves idle
         cur = torch.cuda.current_stream(dev)
-        side = _dn_side_stream(dev, gi)
+        side = _dn_side_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             rf = x
             for rec in recs[n_traj + n_pos:]:
-                rf = run_layer(rf, rec, st["ws_side"][gi])
+                rf = run_layer(rf, rec, st["ws_side"])
         pf = x
         for rec in recs[n_traj:n_traj + n_pos]:
-            pf = run_layer(pf, rec, st["ws"][gi])
+            pf = run_layer(pf, rec, st["ws"])
         cur.wait_stream(side)
         rf.record_stream(cur)
         stream = Lb.stream()
@@ -486,8 +457,9 @@ class DiffusionHead(nn.Module):
                              rot_w1=rr[3].weight.data_ptr(), rot_b1=rr[3].bias.data_ptr(), noise=nz(noise),
                              cond_data=cond_data.data_ptr(), cond_mask=cond_mask_u8.data_ptr(), coef_pos=tb.coef_pos.data_ptr(),
                              coef_rot=tb.coef_rot.data_ptr())
-        Lb.call("a3d_dn_tail", pf.data_ptr(), rf.data_ptr(), traj.data_ptr(), D, C_byref(tp), out_all[b0:b1].data_ptr(), B, Ln, E,
+        Lb.call("a3d_dn_tail", pf.data_ptr(), rf.data_ptr(), traj.data_ptr(), D, C_byref(tp), out.data_ptr(), B, Ln, E,
                 int(t), stream)
+        return out
 
 
 # workgroups the cached cross-attention kernel aims for (key splits x samples x heads).  Every split repeats the query
@@ -495,35 +467,14 @@ class DiffusionHead(nn.Module):
 # (B x H = 512) 1 split 0.924 ms per denoise step, 2 splits 0.955, 4 splits 1.04, 8 splits 1.20
 DN_TARGET_WGS = int(os.environ.get("A3D_DN_TARGET_WGS", "512"))
 FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
-# sample groups of the fused denoise step (build_fused).  Default 1: with 2 or 4 groups the eager loop runs, but ending the
-# capture of the 100-step graph (group streams, each forking its own rotation side stream) segfaults inside
-# hipStreamEndCapture on ROCm 7.2 (measured, round 3), so the grouped schedule cannot be replayed as a graph yet.
-DN_GROUPS = int(os.environ.get("A3D_DN_GROUPS", "1"))
 _DN_SIDE = {}
-_DN_GROUP = {}
 
 
-def dn_sample_groups(B, wanted):
-    """[(b0, b1), ...]: the batch cut into at most `wanted` contiguous groups of at least 8 samples (one group below 16)."""
-    ng = max(1, min(int(wanted), B // 8)) if B >= 16 else 1
-    cuts = [(B * i) // ng for i in range(ng + 1)]
-    return [(cuts[i], cuts[i + 1]) for i in range(ng)]
-
-
-def _dn_side_stream(dev, gi=0):
-    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), gi)
+def _dn_side_stream(dev):
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     if key not in _DN_SIDE:
         _DN_SIDE[key] = torch.cuda.Stream(device=dev)
     return _DN_SIDE[key]
-
-
-def _dn_group_streams(dev, n):
-    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
-    pool = _DN_GROUP.setdefault(key, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
-
 
 
 def C_byref(struct):
@@ -667,7 +618,7 @@ class DiffusionPlanner(nn.Module):
         trace = []
         # fused per-step kernels (csrc/denoise.hip) whenever the trajectory fits one 16-row tile; else the op-by-op path
         fused = FUSED_DENOISE if fused is None else fused
-        fused = fused and Ln <= 16 and E <= 128 and D <= 16 and not multi
+        fused = fused and Ln <= 16 and E <= 128 and Ln * D <= 160 and not multi      # a3d_dn_rest stages L * D trajectory values in a 160-float area
         if multi:
             # multi-round / multi-scale heads: the fine-scale context follows the previous prediction, so nothing but the
             # image encoding is step-invariant -- every step evaluates the full head (no K/V cache, no fused kernels)

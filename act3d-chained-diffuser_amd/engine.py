@@ -95,7 +95,12 @@ class FlatAdamW:
         self.flat, self.betas, self.eps, self.weight_decay = flat, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
-        self.step_count = torch.zeros(1, device=flat.flat.device, dtype=torch.float32)
+        self.step_count = torch.zeros(1, device=flat.flat.device, dtype=torch.float32)     # optimizer.step() calls so far
+        # per-parameter table of the fused kernel: element offsets of the parameters in buffer order, and per parameter
+        # {step (torch's state[p]["step"]), active, lr / bc1, sqrt(bc2)}.  A parameter is updated from the first step in which
+        # its gradient segment holds a non-zero element (torch: .grad is not None) and then every step, all elements
+        self.seg_off = torch.tensor([flat.slices[n][0] for n, _ in flat.order] + [flat.n], dtype=torch.int64, device=flat.flat.device)
+        self.seg_state = torch.zeros((len(flat.order), 4), device=flat.flat.device, dtype=torch.float32)
         self.param_groups = [{"lr": lr, "weight_decay": 0.0}, {"lr": lr, "weight_decay": weight_decay}]
 
     @property
@@ -115,8 +120,18 @@ class FlatAdamW:
     def step(self, grad_scale=1.0):
         f = self.flat
         L.call("a3d_adamw_step", f.flat.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
-               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), f.n, f.n_nodecay, float(self.lr),
+               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.seg_off.data_ptr(), self.seg_state.data_ptr(),
+               len(f.order), f.n, f.n_nodecay, float(self.lr),
                self.betas[0], self.betas[1], self.eps, 0.0, float(self.weight_decay), float(grad_scale), L.stream())
+
+    @property
+    def param_steps(self):
+        """Per-parameter step counts (buffer order): torch.optim.AdamW's state[p]["step"]; 0 = never had a gradient."""
+        return self.seg_state[:, 0]
+
+    def reset_state(self):
+        """Fresh-optimizer state: zero moments and step counts (parameters re-join with their first gradient)."""
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_(); self.seg_state.zero_()
 
     def state_dict(self):
         """torch.optim.AdamW's state_dict layout for the reference's optimizer (engine.py:89-102: two groups over ALL named
@@ -125,17 +140,13 @@ class FlatAdamW:
         backbone, never-used FPN blocks) have no state, exactly like parameters whose .grad stayed None in torch."""
         f = self.flat
         state = {}
-        step = self.step_count.detach().cpu().reshape(()).clone()
-        if float(step) > 0:
-            # a parameter whose second moment is still all zero has never received a gradient: torch writes no state for it
-            touched = torch.stack([self.exp_avg_sq[a:b].abs().max() if b > a else self.exp_avg_sq.new_zeros(())
-                                   for a, b in (f.slices[n] for n, _ in f.order)]).cpu() > 0
-            for (n, p), used in zip(f.order, touched.tolist()):
-                if not used:
-                    continue
-                a, b = f.slices[n]
-                state[f.torch_index[n]] = {"step": step.clone(), "exp_avg": self.exp_avg[a:b].detach().clone().view(p.shape),
-                                           "exp_avg_sq": self.exp_avg_sq[a:b].detach().clone().view(p.shape)}
+        steps = self.param_steps.detach().cpu()
+        for (n, p), st in zip(f.order, steps):
+            if float(st) <= 0:
+                continue               # never received a gradient: torch writes no state for it
+            a, b = f.slices[n]
+            state[f.torch_index[n]] = {"step": st.clone().reshape(()), "exp_avg": self.exp_avg[a:b].detach().clone().view(p.shape),
+                                       "exp_avg_sq": self.exp_avg_sq[a:b].detach().clone().view(p.shape)}
         groups, off = [], 0
         for names, wd in zip(f.torch_groups, (0.0, self.weight_decay)):
             groups.append({"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd,
@@ -149,8 +160,9 @@ class FlatAdamW:
         """Accepts the torch.optim.AdamW layout (a reference checkpoint's "optimizer" entry).  Raises on a layout that does
         not describe this model's parameters (unknown indices, size mismatches, different group sizes).  Parameters WITHOUT
         an entry are legal: torch.optim.AdamW writes no state for parameters whose .grad stayed None (the FPN blocks of maps
-        a configuration never reads, find_unused_parameters=True in engine.py:121-124); their moments stay zero, which the
-        fused kernel leaves alone until the first gradient arrives."""
+        a configuration never reads, find_unused_parameters=True in engine.py:121-124); their moments and step count stay
+        zero and, as in torch, they start at step 1 with the first gradient they receive.  Per-parameter step counts are
+        kept as stored (they may differ between parameters)."""
         f = self.flat
         if not isinstance(sd, dict) or "state" not in sd or "param_groups" not in sd:
             raise ValueError("optimizer state: expected torch.optim.AdamW's {'state', 'param_groups'} layout")
@@ -159,8 +171,9 @@ class FlatAdamW:
             raise ValueError("optimizer state: parameter groups of sizes %s do not match this model's %s "
                              "(reference grouping, engine.py:89-102)" % (sizes, [len(g) for g in f.torch_groups]))
         by_index = {i: n for n, i in f.torch_index.items()}
-        steps = []
-        seen = set()
+        seg_of = {n: i for i, (n, _) in enumerate(f.order)}
+        steps = torch.zeros(len(f.order), dtype=torch.float32)
+        loaded = []
         for idx, st in sd["state"].items():
             n = by_index.get(int(idx))
             if n is None:
@@ -170,28 +183,20 @@ class FlatAdamW:
             a, b = f.slices[n]
             if st["exp_avg"].numel() != b - a:
                 raise ValueError("optimizer state of %s has %d elements, the parameter %d" % (n, st["exp_avg"].numel(), b - a))
+            loaded.append((a, b, st))
+            steps[seg_of[n]] = float(st["step"])
+        self.reset_state()
+        for a, b, st in loaded:
             self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.append(float(st["step"]))
-            seen.add(n)
-        if steps:
-            for n, _ in f.order:
-                if n not in seen:                      # state-less (never-used) parameter: zero moments
-                    a, b = f.slices[n]
-                    self.exp_avg[a:b].zero_()
-                    self.exp_avg_sq[a:b].zero_()
-            if max(steps) != min(steps):
-                raise ValueError("optimizer state: per-parameter steps differ (%g .. %g); the flat optimizer keeps one"
-                                 % (min(steps), max(steps)))
-            self.step_count.fill_(steps[0])
-        else:
-            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
+        self.seg_state[:, 0].copy_(steps)
+        self.step_count.fill_(float(steps.max()) if len(loaded) else 0.0)
         self.lr = sd["param_groups"][0].get("lr", self.lr)
 
 
 def get_optimizer(model, lr=1e-4, active_names=None):
     """engine.py:89-102 on the flat buffers.  Returns (FlatParams, FlatAdamW).  With active_names=None every trainable
-    parameter is placed in the buffer; elements that never receive a gradient are left untouched by the fused AdamW kernel
+    parameter is placed in the buffer; parameters that never receive a gradient are left untouched by the fused AdamW kernel
     (as torch.optim.AdamW skips parameters whose .grad is None -- no weight decay on unused FPN blocks)."""
     flat = FlatParams(model, active_names)
     return flat, FlatAdamW(flat, lr=lr)

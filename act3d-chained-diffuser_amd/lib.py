@@ -104,7 +104,7 @@ SIGNATURES = {
     "a3d_sample_ghost_points": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "a3d_rng_advance": (_i, [_p, _u64, _p]),
     "a3d_philox4x32_10_host": (None, [_p, _p, _p]),
-    "a3d_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _z, _f, _f, _f, _f, _f, _f, _f, _p]),
+    "a3d_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _z, _z, _f, _f, _f, _f, _f, _f, _f, _p]),
     "a3d_dbg_mfma_bf16": (_i, [_p, _p, _p, _p]),
     "a3d_dbg_mfma_f32": (_i, [_p, _p, _p, _p]),
     "a3d_dbg_cvt_pk_bf16": (_i, [_p, _p, _i, _p]),

@@ -133,9 +133,13 @@ if ATTN_MODE not in ("f16", "bf16x3", "fp8"):
 LOG2E = 1.4426950408889634
 
 
-def _use16(drop):
-    """The split-fp16 operand formats feed every pass of the default and the fp8 mode (with and without dropout)."""
-    return ATTN_MODE in ("f16", "fp8")
+ATTN16_BWD_MAX_LQP = 7296     # a3d_attn16_bwd's prep kernel sorts one (b, h)'s query rows in LDS: 12 B per query + 64 KB <= 150 KB
+
+
+def _use16(Lq, need_bwd):
+    """The split-fp16 operand formats feed every pass of the default and the fp8 mode (with and without dropout), except a
+    forward whose backward would exceed the split-fp16 backward's query limit: that block runs on the bf16x3 family."""
+    return ATTN_MODE in ("f16", "fp8") and not (need_bwd and ceil_to(Lq, 64) > ATTN16_BWD_MAX_LQP)
 
 
 PLANE_PARTS = 2       # q / k planes of the backward: hi and lo parts
@@ -409,13 +413,12 @@ class AttnBlockFn(torch.autograd.Function):
               "qk" (query is key, value differs -- :277-303), "none" (three inputs).
     Returns (y, attn_out) where attn_out is the pre-residual attention output (rarely needed).
     """
-    grad_mode = True        # torch.is_grad_enabled() of the caller, recorded by attn_block just before apply()
-
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode,
-                drop=None, site=0):
+                drop=None, site=0, grad_mode=True):
         """drop / site: DropCtx of the pass and this block's site id (attention weights: site, residual branch: site + 1;
-        multihead_custom_attention.py:413, layers.py:146,181)."""
+        multihead_custom_attention.py:413, layers.py:146,181).  grad_mode: torch.is_grad_enabled() of the CALLER (grad mode is
+        always off inside Function.forward, so it has to be handed in; attn_block does)."""
         L.require_gpu(q_in, k_in, v_in, resid)
         if drop is not None and drop.p <= 0:
             drop = None
@@ -429,13 +432,12 @@ class AttnBlockFn(torch.autograd.Function):
             kmask = _c(kmask.to(torch.uint8))
         wp, bp = in_w.data_ptr(), in_b.data_ptr()
         f4 = 4
-        # grad mode is always off inside Function.forward: ask the ctx whether a backward can follow (the in-projection
-        # parameters count -- they get .grad through wgrad even when no input needs a gradient), and the caller's grad mode
-        # (attn_block records it): under torch.no_grad() no backward follows whatever the parameters say
-        need_bwd = AttnBlockFn.grad_mode and (any(ctx.needs_input_grad) or in_w.requires_grad)
+        # whether a backward can follow: the in-projection parameters count (they get .grad through wgrad even when no
+        # input needs a gradient); under torch.no_grad() none follows whatever the parameters say
+        need_bwd = bool(grad_mode) and (any(ctx.needs_input_grad) or in_w.requires_grad)
         if FUSED_PROJ and E % 4 == 0 and E <= 128:
             # ---- projections fused with RoPE + operand formatting: the projected rows never reach HBM
-            fused = attn_operands_fused16 if _use16(drop) else attn_operands_fused
+            fused = attn_operands_fused16 if _use16(Lq, need_bwd) else attn_operands_fused
             Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = fused(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, E, H, dev,
                                                             need_bwd)
         else:
@@ -460,7 +462,7 @@ class AttnBlockFn(torch.autograd.Function):
                     v_pre = linear_raw(v_in.data_ptr(), E, wp + 2 * E * E * f4, E, bp + 2 * E * f4, B * S, E, E, dev)
                     k_ptr, ldk, v_ptr, ldv = k_pre.data_ptr(), E, v_pre.data_ptr(), E
                     keep = (q_pre, k_pre, v_pre)
-            unfused = attn_operands16 if _use16(drop) else attn_operands
+            unfused = attn_operands16 if _use16(Lq, need_bwd) else attn_operands
             Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = unfused(q_ptr, ldq, k_ptr, ldk, v_ptr, ldv, q_xyz, k_xyz, B, Lq,
                                                               S, E, H, dev, need_bwd=need_bwd)
             del keep
@@ -486,6 +488,9 @@ class AttnBlockFn(torch.autograd.Function):
         in_w, in_b, out_w, out_b, ln_g, ln_b = ctx.params
         B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, has_xyz, has_mask = ctx.meta
         dev = dy.device
+        if Qs.dtype == torch.float16 and (ctx.extra is None or ctx.extra[0] is None):
+            raise RuntimeError("AttnBlockFn.backward: the forward ran with grad_mode=False (no backward operand formats were "
+                               "written); call it through ops.attn_block or pass grad_mode=torch.is_grad_enabled()")
         if not has_xyz:
             q_xyz = k_xyz = None
         if not has_mask:
@@ -549,7 +554,7 @@ class AttnBlockFn(torch.autograd.Function):
                 if need_v:
                     d_v_in = dgrad2d(dv_pre, in_w[2 * E:]).view(B, S, E)
         d_resid = dS.view(B, Lq, E) if ctx.needs_input_grad[3] else None
-        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 13
+        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 14
 
 
 SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
@@ -642,9 +647,9 @@ def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=
         mode = "qk"
     else:
         mode = "none"
-    AttnBlockFn.grad_mode = torch.is_grad_enabled()
     return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
-                             mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site)
+                             mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site,
+                             torch.is_grad_enabled())
 
 
 class MLPFn(torch.autograd.Function):

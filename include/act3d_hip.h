@@ -243,10 +243,14 @@ int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds
                             float* out, int B, int Ng, int level, int max_attempts, void* stream);
 int a3d_rng_advance(unsigned long long* state, unsigned long long n, void* stream);
 void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-/* torch.optim.AdamW semantics (engine.py:89-102) on a flat buffer; elements [0, n_nodecay) use wd_nodecay. */
-int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, size_t n, size_t n_nodecay, float lr,
-                   float beta1, float beta2, float eps, float wd_nodecay, float wd_decay, float grad_scale,
-                   void* stream);
+/* torch.optim.AdamW semantics (engine.py:89-102) on a flat buffer; elements [0, n_nodecay) use wd_nodecay.  The decision
+ * "this parameter has no gradient -> skip it" is per PARAMETER, as in torch: seg_off [nseg + 1] (element offsets, ascending,
+ * seg_off[0] = 0, seg_off[nseg] = n) delimits the parameters, seg_state [nseg][4] = {step, active, lr / bc1, sqrt(bc2)} is
+ * the per-parameter step count + scratch (zero-initialised by the caller; step = torch's state[p]["step"]).  A parameter
+ * joins the update from the first call in which its gradient segment has a non-zero element.  step[0] counts calls. */
+int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, const long long* seg_off, float* seg_state,
+                   int nseg, size_t n, size_t n_nodecay, float lr, float beta1, float beta2, float eps, float wd_nodecay,
+                   float wd_decay, float grad_scale, void* stream);
 
 /* ---- DDPM trajectory denoiser (elementwise pieces) ------------------------------------------------------------ */
 /* x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) eps; channels [0,npos) use acp_pos, the rest acp_rot

@@ -234,7 +234,7 @@ def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
             step = E.GraphedStep(fwd_bwd, opt, batches[rank], ddp=ddp, warmup=1)
             # the warm-up step moved the weights: restore the broadcast state (in place) and replay ONE step
             flat.flat.copy_(p0)
-            opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count.zero_()
+            opt.reset_state()
             m._rng_state.copy_(state)
             for (_, a), (_, b) in zip(make(100).backbone.named_buffers(), m.backbone.named_buffers()):
                 b.copy_(a)

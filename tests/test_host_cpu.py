@@ -265,6 +265,7 @@ def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
     opt.exp_avg.copy_(torch.randn(flat.n, generator=g))
     opt.exp_avg_sq.copy_(torch.rand(flat.n, generator=g))
     opt.step_count.fill_(7)
+    opt.seg_state[:, 0] = 7
     path = str(tmp_path / "last.pth")
     a3d.engine.save_checkpoint(path, m, opt, 6, best_loss=1.25)
     d = torch.load(path, weights_only=False)
@@ -340,6 +341,10 @@ def test_reference_state_with_unused_parameters_loads_into_full_buffer_and_lr_re
     n0 = next(n for n in trainable if n not in unused)
     a, b = flat3.slices[n0]
     assert torch.equal(opt3.exp_avg[a:b], ref_opt.state[named2[n0]]["exp_avg"].reshape(-1))
+    # per-parameter step counts: 2 for the trained parameters, 0 (they start at step 1 with their first gradient, as in
+    # torch) for the state-less ones
+    order = [n for n, _ in flat3.order]
+    assert all(float(opt3.param_steps[order.index(n)]) == (0 if n in unused else 2) for n in trainable)
     # the checkpoint's lr (1e-4 in the reference optimizer) is what load_state_dict leaves; the resume path overrides it
     assert opt3.lr == pytest.approx(1e-4)
     opt3.lr = 5e-5
@@ -348,6 +353,18 @@ def test_reference_state_with_unused_parameters_loads_into_full_buffer_and_lr_re
     sd = opt3.state_dict()
     assert len(sd["state"]) == len(trainable) - len(unused)
     ref_opt.load_state_dict(sd)
+    # a parameter that joins later keeps its own step count through a save / load cycle (torch.optim.AdamW's state[p]["step"])
+    late = unused[0]
+    named2[late].grad = torch.randn(named2[late].shape, generator=g)
+    for n in trainable:
+        if n != late and n not in unused:
+            named2[n].grad = torch.randn(named2[n].shape, generator=g)
+    ref_opt.step()
+    opt3.load_state_dict(ref_opt.state_dict())
+    assert float(opt3.param_steps[order.index(late)]) == 1 and float(opt3.param_steps[order.index(n0)]) == 3
+    assert float(opt3.step_count) == 3
+    back = opt3.state_dict()["state"]
+    assert float(back[flat3.torch_index[late]]["step"]) == 1 and float(back[flat3.torch_index[n0]]["step"]) == 3
     # unknown indices / wrong sizes still raise
     bad = ref_opt.state_dict()
     bad["state"][10 ** 6] = bad["state"][next(iter(bad["state"]))]
@@ -580,17 +597,3 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_nslab(1 << 20, 64) == 2048 and lib.a3d_conv1x1_nslab(1000, 64) == 4
     assert lib.a3d_conv1x1_nslab(1 << 20, 1024) == 512 and lib.a3d_conv1x1_nslab(100, 256) == 2
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
-
-
-def test_denoise_sample_groups_partition_the_batch():
-    """diffusion.dn_sample_groups: contiguous, covering, >= 8 samples per group, one group for small batches."""
-    a3d = load_pkg()
-    g = a3d.diffusion.dn_sample_groups
-    assert g(64, 1) == [(0, 64)]
-    assert g(64, 4) == [(0, 16), (16, 32), (32, 48), (48, 64)]
-    assert g(15, 4) == [(0, 15)] and g(16, 4) == [(0, 8), (8, 16)]
-    for B in (16, 22, 37, 64, 100):
-        for want in (1, 2, 3, 4, 8):
-            cuts = g(B, want)
-            assert cuts[0][0] == 0 and cuts[-1][1] == B and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
-            assert len(cuts) <= want and all(b1 - b0 >= 8 for b0, b1 in cuts)

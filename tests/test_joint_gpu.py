@@ -164,7 +164,7 @@ def _worker(rank, world, port, mode, q):
             step = E.GraphedStep(fwd_bwd, topt, tr_batches[rank], ddp=tddp, warmup=1)
             # the warm-up step moved the weights: restore the broadcast state in place and replay ONE step
             tflat.flat.copy_(p0)
-            topt.exp_avg.zero_(); topt.exp_avg_sq.zero_(); topt.step_count.zero_()
+            topt.reset_state()
             _set_drop(tr, seeds[rank])
             for (_, a), (_, b) in zip(_make_planner(a3d, dev, 200, 0).prediction_head.backbone.named_buffers(),
                                       tr.prediction_head.backbone.named_buffers()):
@@ -275,7 +275,7 @@ def _joint_vs_separate(E, joint, ks, ts, kcrit, tcrit, kA, kB, tA, tB, kfA, kfB,
             fb.flat.copy_(fa.flat)
             ob.exp_avg.copy_(oa.exp_avg)
             ob.exp_avg_sq.copy_(oa.exp_avg_sq)
-            ob.step_count.copy_(oa.step_count)
+            ob.step_count.copy_(oa.step_count); ob.seg_state.copy_(oa.seg_state)
         for (_, a), (_, b) in zip(kA.backbone.named_buffers(), kB.backbone.named_buffers()):
             b.copy_(a)
         for (_, a), (_, b) in zip(tA.prediction_head.backbone.named_buffers(), tB.prediction_head.backbone.named_buffers()):

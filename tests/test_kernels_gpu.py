@@ -443,41 +443,45 @@ def test_heads_and_losses(a3d, dev):
 
 
 def test_adamw_matches_torch(a3d, dev):
+    """a3d_adamw_step against torch.optim.AdamW with the reference's two groups (engine.py:89-102), PER-PARAMETER skipping:
+    a matrix with an all-zero gradient row from step 1 on (a dead ReLU unit) is decayed like torch decays it; a tensor whose
+    .grad stays None is left alone; a tensor that joins at step 3 gets the bias correction of its own step count."""
     L = a3d.lib
     g = torch.Generator().manual_seed(2)
-    n0, n1 = 37, 1000
-    p = torch.randn(n0 + n1, generator=g)
-    ref_a = torch.nn.Parameter(p[:n0].clone())
-    ref_b = torch.nn.Parameter(p[n0:].clone())
-    opt = torch.optim.AdamW([{"params": [ref_a], "weight_decay": 0.0}, {"params": [ref_b], "weight_decay": 5e-4}],
-                            lr=1e-4)
-    pd = p.to(dev).clone()
+    shapes = [(37,), (40, 25), (64,), (48,)]            # bias (no decay) | weight with a dead row | never used | joins late
+    ps = [torch.nn.Parameter(torch.randn(sh, generator=g)) for sh in shapes]
+    opt = torch.optim.AdamW([{"params": ps[:1], "weight_decay": 0.0}, {"params": ps[1:], "weight_decay": 5e-4}], lr=1e-4)
+    sizes = [p.numel() for p in ps]
+    off = [0]
+    for k in sizes:
+        off.append(off[-1] + k)
+    n = off[-1]
+    pd = torch.cat([p.detach().reshape(-1) for p in ps]).to(dev)
+    p0 = pd.clone()
     m, v = torch.zeros_like(pd), torch.zeros_like(pd)
     step = torch.zeros(1, device=dev)
-    for it in range(3):
-        gr = torch.randn(n0 + n1, generator=g)
-        ref_a.grad, ref_b.grad = gr[:n0].clone(), gr[n0:].clone()
+    seg_off = torch.tensor(off, dtype=torch.int64, device=dev)
+    seg_state = torch.zeros((len(ps), 4), device=dev)
+    for it in range(5):
+        gr = [torch.randn(sh, generator=g) for sh in shapes]
+        gr[1][7] = 0.0                                   # dead row: exactly zero gradient at every step
+        ps[0].grad, ps[1].grad = gr[0].clone(), gr[1].clone()
+        ps[2].grad = None
+        ps[3].grad = gr[3].clone() if it >= 2 else None
         opt.step()
-        gd = gr.to(dev)
-        L.call("a3d_adamw_step", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr(), n0 + n1,
-               n0, 1e-4, 0.9, 0.999, 1e-8, 0.0, 5e-4, 1.0, L.stream())
-    report("adamw", pd, torch.cat([ref_a.detach(), ref_b.detach()]), 1e-6, 1e-6)
-    assert step.item() == 3.0
-    # a third tensor that never receives a gradient: torch skips it (grad is None) -- no weight decay, no state; in the flat
-    # buffer it is a stretch of elements whose gradient and moments are all still zero
-    ref_c = torch.nn.Parameter(torch.randn(64, generator=g))
-    opt.add_param_group({"params": [ref_c], "weight_decay": 5e-4})
-    pd2 = torch.cat([pd, ref_c.detach().to(dev)])
-    m2, v2 = torch.cat([m, torch.zeros(64, device=dev)]), torch.cat([v, torch.zeros(64, device=dev)])
-    for it in range(2):
-        gr = torch.randn(n0 + n1, generator=g)
-        ref_a.grad, ref_b.grad = gr[:n0].clone(), gr[n0:].clone()
-        opt.step()
-        gd = torch.cat([gr, torch.zeros(64)]).to(dev)
-        L.call("a3d_adamw_step", pd2.data_ptr(), gd.data_ptr(), m2.data_ptr(), v2.data_ptr(), step.data_ptr(), n0 + n1 + 64,
-               n0, 1e-4, 0.9, 0.999, 1e-8, 0.0, 5e-4, 1.0, L.stream())
-    assert torch.equal(pd2[n0 + n1:].cpu(), ref_c.detach()), "unused parameters must not decay"
-    report("adamw (with an unused tensor)", pd2[:n0 + n1], torch.cat([ref_a.detach(), ref_b.detach()]), 1e-6, 1e-6)
+        gd = torch.cat([gr[0].reshape(-1), gr[1].reshape(-1), torch.zeros(sizes[2]),
+                        gr[3].reshape(-1) if it >= 2 else torch.zeros(sizes[3])]).to(dev)
+        L.call("a3d_adamw_step", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr(), seg_off.data_ptr(),
+               seg_state.data_ptr(), len(ps), n, sizes[0], 1e-4, 0.9, 0.999, 1e-8, 0.0, 5e-4, 1.0, L.stream())
+    ref = torch.cat([p.detach().reshape(-1) for p in ps])
+    report("adamw", pd, ref, 1e-6, 1e-6)
+    assert step.item() == 5.0
+    assert seg_state[:, 0].cpu().tolist() == [5.0, 5.0, 0.0, 3.0], "per-parameter step counts (torch's state[p]['step'])"
+    assert [float(opt.state[p]["step"]) if p in opt.state else 0.0 for p in ps] == [5.0, 5.0, 0.0, 3.0]
+    assert torch.equal(pd[off[2]:off[3]], p0[off[2]:off[3]]), "unused parameters must not decay"
+    dead = slice(off[1] + 7 * 25, off[1] + 8 * 25)
+    assert not torch.equal(pd[dead], p0[dead]), "a zero-gradient row of a trained matrix is decayed, as torch does"
+    report("adamw dead row", pd[dead], ref[dead], 1e-7, 1e-6)
 
 
 def test_sampler_matches_cpu_twin(a3d, dev):
