@@ -164,11 +164,15 @@ class Act3D(nn.Module):
         with torch.no_grad():
             feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32,
                                         normalize=self.normalize)
+        out_bias = {}
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):
-                # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row
+                # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row.
+                # The 3x3 output convolutions run bias-free: their bias rides on the token tensor (`row_bias`) and is added
+                # to the rows a level gathers
                 E_ = self.curr_gripper_embed.weight.shape[1]
-                pyr = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64)
+                pyr, out_bias = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64,
+                                                     defer_output_bias=x.is_cuda)
         else:
             pyr = self.feature_pyramid(feats, needed=self._needed_maps())
         tokens = {}
@@ -177,6 +181,7 @@ class Act3D(nn.Module):
             # (cam, h, w, E) rows of the channels-last map: a view, in the FPN's own dtype -- a bf16 map is gathered in place
             # by a3d_build_context_bf16 (no fp32 copy of the 128 x 128 map, of which a level reads 6 % of the rows)
             tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+            tokens[name].row_bias = out_bias.get(name)
         return [tokens[self.feature_map_pyramid[i]] for i in range(self.num_sampling_level)]
 
     # ------------------------------------------------------------------------------------------------ ghost points
@@ -264,7 +269,7 @@ class Act3D(nn.Module):
                 idx = None
             else:
                 idx = O.knn_topk(prev_pos, pcd_pyramid[i], 32 * 32 * ncam)
-            ctx = O.BuildContextFn.apply(feats[i], idx, grip_tok, accum[id(feats[i])])
+            ctx = O.BuildContextFn.apply(feats[i], idx, grip_tok, accum[id(feats[i])], getattr(feats[i], "row_bias", None))
             ctx_xyz = O.gather_rows(pcd_pyramid[i], idx, grip_xyz[:, None])
             topk_pyramid.append(idx)
             if self.use_instruction:

@@ -110,6 +110,31 @@ __device__ __forceinline__ float rope_freq(int k, int E) {
   return expf((float)(2 * k) * (-9.210340371976184f / (float)(E / 3)));
 }
 
+// sin and cos of a RoPE angle (xyz coordinate x frequency <= 1: a few radians).  libm's sincosf costs ~100 VALU instructions
+// per call (Payne-Hanek branch, two separate polynomials behind calls) and was the largest single item of the rotating
+// kernels (7.5 calls per thread and 64-key tile in proj_rope_split / sq_fwd, twice that in sq_bwd).  For |x| < 200:
+// k = rint(x * 2/pi), r = x - k * pi/2 by two FMAs against a two-part pi/2 (the first product is exact inside the fma, so
+// r carries one rounding: |error| < 4e-8), then the Cephes single-precision minimax polynomials on [-pi/4, pi/4] (1 ulp)
+// and a quadrant swap -- 22 instructions, both results within 2 ulp of the correctly rounded values (tests/test_host_cpu.py
+// checks the host mirror a3d_sincos_host against float64 over the range).  Larger arguments take sincosf.
+__host__ __device__ __forceinline__ void sincos_poly(float x, float* sn, float* cs) {
+  const float kf = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf;
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+  if (fabsf(x) < 200.0f) sincos_poly(x, sn, cs);
+  else sincosf(x, sn, cs);
+}
+
 // IEEE round-to-nearest single operations that the compiler may NOT contract into an fma.  (HIP's __fadd_rn /
 // __fmul_rn are plain operators and __fsqrt_rn is the approximate native sqrt unless OCML_BASIC_ROUNDED_OPERATIONS
 // is defined, so they cannot be used where bit-exactness with the CPU oracle is required.)

@@ -201,7 +201,7 @@ __device__ __forceinline__ void wg_rope(float* T, int ld, int col0, int nblk, co
     if (freq && r < L) {
       const int axis = c / third;
       const int k = (c - axis * third) >> 1;
-      sincosf(xyz[r * ldxyz + axis] * freq[k], &sn, &cs);
+      fast_sincos(xyz[r * ldxyz + axis] * freq[k], &sn, &cs);
     }
     for (int bk = 0; bk < nblk; ++bk) {
       float* q = T + r * ld + col0 + bk * E + c;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
       const int k = (c - axis * third) >> 1;
       const float th = traj[((size_t)b * L + r) * D + axis] * p.freq[k];
       float sn, cs;
-      sincosf(th, &sn, &cs);
+      fast_sincos(th, &sn, &cs);
       const float y0 = Pre[r * 16 + j], y1 = Pre[r * 16 + j + 1];
       Pre[r * 16 + j] = y0 * cs - y1 * sn;
       Pre[r * 16 + j + 1] = y1 * cs + y0 * sn;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void rope_rows_f32_kernel(const float* __restr
         const int axis = ce / third;
         const int k = (ce - axis * third) >> 1;
         float sn, cs;
-        sincosf(xyz[m * 3 + axis] * freq[k], &sn, &cs);
+        fast_sincos(xyz[m * 3 + axis] * freq[k], &sn, &cs);
         const float yp = Y[m * ldy + (c ^ 1)] * scale;
         v = (c & 1) ? (y * cs + yp * sn) : (y * cs - yp * sn);
       } else {

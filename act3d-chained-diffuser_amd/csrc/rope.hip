@@ -39,7 +39,7 @@ __device__ __forceinline__ void rope_tile_to_lds(float* T, int ldt, const float*
         const int k = (c - axis * third) >> 1;
         const float th = xyz[m * 3 + axis] * freq[k];
         float sn, cs;
-        sincosf(th, &sn, &cs);
+        fast_sincos(th, &sn, &cs);
         o0 = y0 * cs - y1 * sn;
         o1 = y1 * cs + y0 * sn;
       } else {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void proj_rope_split_kernel(
       const int kf = (c - axis * third) >> 1;
       const float th = blk.xyz[((size_t)b * N + n) * 3 + axis] * freq[kf];
       float sn, cs;
-      sincosf(th, &sn, &cs);
+      fast_sincos(th, &sn, &cs);
       const float y0 = T[r * ldt + c], y1 = T[r * ldt + c + 1];
       T[r * ldt + c] = y0 * cs - y1 * sn;
       T[r * ldt + c + 1] = y1 * cs + y0 * sn;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void rope_merge_bwd_kernel(
       const int k = (c0 - axis * third) >> 1;
       const float th = xyz[m * 3 + axis] * freq[k];
       float sn, cs;
-      sincosf(th, &sn, &cs);
+      fast_sincos(th, &sn, &cs);
       y0 = cs * g0 + sn * g1;
       y1 = cs * g1 - sn * g0;
     }

@@ -342,9 +342,11 @@ __global__ __launch_bounds__(256) void build_context_kernel(
 }
 
 // bf16 token rows (the FPN's channels-last bf16 output read in place: [B][Npts][4 * E4] bf16) -> fp32 context rows
+// `bias` (fp32 [4 * E4] or null) is added to the gathered rows: the bias of the FPN's 3x3 output convolution, applied to the
+// few rows a level reads instead of to the whole map (its gradient = the column sums of d(ctx), a3d_colsum_rows)
 __global__ __launch_bounds__(256) void build_context_bf16_kernel(
     const unsigned short* __restrict__ feat, const long long* __restrict__ idx, const float* __restrict__ extra,
-    float* __restrict__ ctx, int B, int Npts, int k, int X, int E4, int F4) {
+    const float* __restrict__ bias, float* __restrict__ ctx, int B, int Npts, int k, int X, int E4, int F4) {
   const int S = k + X;
   const size_t total = (size_t)B * S * E4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(256) void build_context_bf16_kernel(
       const long long src = idx ? idx[(size_t)b * k + s] : (long long)s;
       const s16x4 h = reinterpret_cast<const s16x4*>(feat)[((size_t)b * Npts + src) * F4 + e];
       v = make_float4(bf2f((unsigned short)h[0]), bf2f((unsigned short)h[1]), bf2f((unsigned short)h[2]), bf2f((unsigned short)h[3]));
+      if (bias) { v.x += bias[4 * e]; v.y += bias[4 * e + 1]; v.z += bias[4 * e + 2]; v.w += bias[4 * e + 3]; }
     } else {
       v = reinterpret_cast<const float4*>(extra)[((size_t)b * X + (s - k)) * E4 + e];
     }
@@ -533,8 +536,8 @@ extern "C" int a3d_build_context_bwd(const float* dctx, const long long* idx, fl
   return check_launch("a3d_build_context_bwd");
 }
 
-extern "C" int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, float* ctx, int B,
-                                      int Npts, int k, int X, int W, void* stream) {
+extern "C" int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, const float* bias,
+                                      float* ctx, int B, int Npts, int k, int X, int W, void* stream) {
   if (!feat || !ctx || B <= 0 || k <= 0 || X < 0 || W <= 0 || (W % 4) != 0 || ldf < W || (ldf % 4) != 0 || (X > 0 && !extra) || (!idx && k != Npts) ||
       ((((uintptr_t)feat) & 7) != 0) || ((((uintptr_t)ctx | (uintptr_t)extra) & 15) != 0)) {
     set_error("a3d_build_context_bf16: bad argument (B=%d Npts=%d k=%d X=%d W=%d; W %% 4 == 0, 8 / 16-byte aligned)", B, Npts, k, X, W);
@@ -543,7 +546,7 @@ extern "C" int a3d_build_context_bf16(const void* feat, int ldf, const long long
   const size_t total = (size_t)B * (k + X) * (W / 4);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(build_context_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)feat, idx,
-                     extra, ctx, B, Npts, k, X, W / 4, ldf / 4);
+                     extra, bias, ctx, B, Npts, k, X, W / 4, ldf / 4);
   return check_launch("a3d_build_context_bf16");
 }
 

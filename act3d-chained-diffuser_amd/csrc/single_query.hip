@@ -63,10 +63,14 @@ __device__ __forceinline__ void sq_stage_weight(float* Ws, const float* __restri
   }
 }
 
-// T[64][SQ_LD] = rope(Xs W^T + bias) for the tile's rows (rows >= S zero); Ws holds W (rows = output channels)
+// T[64][SQ_LD] = rope(Xs W^T + bias) for the tile's rows (rows >= S zero); Ws holds W (rows = output channels).
+// KEEP: the (cos, sin) of the up to 8 (row, pair) items this thread rotates are left in `keep` (registers, constant
+// indexing) for the inverse rotation of the backward, which visits the same items in the same order.
+constexpr int SQ_ROT = 8;      // (row, channel pair) items per thread: 64 rows x E / 2 <= 30 pairs over 256 threads
+template <bool KEEP>
 __device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const float* Ws, const float* __restrict__ bias,
                                                 const float* __restrict__ xyz, const float* __restrict__ freq, int b, int n0,
-                                                int S, int E) {
+                                                int S, int E, float (&keep)[SQ_ROT][2]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   f32x4 acc[SQ_NT];
@@ -80,6 +84,25 @@ __device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const
 #pragma unroll
     for (int nt = 0; nt < SQ_NT; ++nt) acc[nt] = mfma_f32_16x16x4(a, Ws[(nt * 16 + li) * SQ_LD + kk * 4 + g], acc[nt]);
   }
+  // the angles of this thread's items while the MFMAs drain (registers only: no hazard with T)
+  const int half = E >> 1, third = E / 3;
+  float cs_[SQ_ROT], sn_[SQ_ROT];
+  if (xyz) {
+#pragma unroll
+    for (int it = 0; it < SQ_ROT; ++it) {
+      const int idx = t + it * 256;
+      const int r = idx / half, p = idx - r * half;
+      const int n = n0 + r;
+      cs_[it] = 1.f; sn_[it] = 0.f;
+      if (idx < SQ_T * half && n < S) {
+        const int c = 2 * p;
+        const int axis = c / third;
+        const int kf = (c - axis * third) >> 1;
+        fast_sincos(xyz[((size_t)b * S + n) * 3 + axis] * freq[kf], &sn_[it], &cs_[it]);
+      }
+      if (KEEP) { keep[it][0] = cs_[it]; keep[it][1] = sn_[it]; }
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < SQ_NT; ++nt) {
     const int c = nt * 16 + li;
@@ -92,19 +115,14 @@ __device__ __forceinline__ void sq_project_rope(float* T, const float* Xs, const
   }
   __syncthreads();
   if (xyz) {
-    const int half = E >> 1, third = E / 3;
-    for (int idx = t; idx < SQ_T * half; idx += 256) {
-      const int r = idx / half, p = idx - r * half;
-      const int n = n0 + r;
-      if (n >= S) continue;
-      const int c = 2 * p;
-      const int axis = c / third;
-      const int kf = (c - axis * third) >> 1;
-      float sn, cs;
-      sincosf(xyz[((size_t)b * S + n) * 3 + axis] * freq[kf], &sn, &cs);
+#pragma unroll
+    for (int it = 0; it < SQ_ROT; ++it) {
+      const int idx = t + it * 256;
+      if (idx >= SQ_T * half) break;
+      const int r = idx / half, c = 2 * (idx - r * half);
       const float y0 = T[r * SQ_LD + c], y1 = T[r * SQ_LD + c + 1];
-      T[r * SQ_LD + c] = y0 * cs - y1 * sn;
-      T[r * SQ_LD + c + 1] = y1 * cs + y0 * sn;
+      T[r * SQ_LD + c] = y0 * cs_[it] - y1 * sn_[it];
+      T[r * SQ_LD + c + 1] = y1 * cs_[it] + y0 * sn_[it];
     }
     __syncthreads();
   }
@@ -159,7 +177,8 @@ __global__ __launch_bounds__(256) void sq_fwd_kernel(const float* __restrict__ X
     sq_store_rows(Xs, rows);
     if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, false);
     __syncthreads();
-    sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
+    float unused[SQ_ROT][2];
+    sq_project_rope<false>(T, Xs, Ws, bk, xyz, freq, b, n0, S, E, unused);
     sq_rows_times_heads(T, Qm, sS, E);
     __syncthreads();
     float alpha = 1.f;
@@ -290,7 +309,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
 #pragma unroll
   for (int i = 0; i < SQ_NT; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dqa = 0.f;                          // wave = head, lane = channel d < 15
-  const int half = E >> 1, third = E / 3;
+  const int half = E >> 1;
   SqRows rows;
   if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, true);     // column E = 1: the bias gradient rides in dW
   __syncthreads();
@@ -299,7 +318,8 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     sq_store_rows(Xs, rows);
     if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, true);
     __syncthreads();
-    sq_project_rope(T, Xs, Ws, bk, xyz, freq, b, n0, S, E);
+    float rot[SQ_ROT][2];                                    // (cos, sin) of this thread's items, reused by the inverse rotation
+    sq_project_rope<true>(T, Xs, Ws, bk, xyz, freq, b, n0, S, E, rot);
     sq_rows_times_heads(T, Qm, sS, E);                       // scores
     sq_rows_times_heads(Xs, Dm, dS, E);                      // dp = dxbar . x_k
     __syncthreads();
@@ -319,19 +339,18 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     }
     __syncthreads();
     // T <- R_k^T (ds_k (x) q): gradient w.r.t. the projected (un-rotated) key rows
-    for (int idx = t; idx < SQ_T * half; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < SQ_ROT; ++it) {
+      const int idx = t + it * 256;
+      if (idx >= SQ_T * half) break;
       const int r = idx / half, p = idx - r * half;
       const int c0 = 2 * p, c1 = c0 + 1;
       const int h0 = c0 / HD, h1 = c1 / HD;
       const float g0 = dS[h0 * SQ_T + r] * Qm[h0 * SQ_LD + c0];
       const float g1 = dS[h1 * SQ_T + r] * Qm[h1 * SQ_LD + c1];
       float y0 = g0, y1 = g1;
-      const int n = n0 + r;
-      if (xyz && n < S) {
-        const int axis = c0 / third;
-        const int kf = (c0 - axis * third) >> 1;
-        float sn, cs;
-        sincosf(xyz[((size_t)b * S + n) * 3 + axis] * freq[kf], &sn, &cs);
+      if (xyz && n0 + r < S) {
+        const float cs = rot[it][0], sn = rot[it][1];
         y0 = cs * g0 + sn * g1;
         y1 = cs * g1 - sn * g0;
       }

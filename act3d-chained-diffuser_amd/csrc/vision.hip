@@ -15,64 +15,67 @@
 
 namespace a3d {
 
-// grid (nslab); each thread owns 8 consecutive channels (one 16-byte load per row); C / 8 threads span a row and the
-// 256 / (C / 8) row-groups of the workgroup stride over the slab; an LDS tree adds the row-groups.  C % 8 == 0, C <= 2048.
+// grid (nslab, C / CG): a workgroup owns a group of CG = min(C, 256) channels; each thread owns 8 consecutive channels (one
+// 16-byte load per row), tpr = CG / 8 threads span a row segment and the nsub = 256 / tpr row-groups of the workgroup cover
+// a CHUNK of 8 * nsub rows per iteration (eight independent 16-byte loads per thread; the next chunk's loads are issued before
+// the current one is accumulated).  Chunks are dealt to the slabs round-robin (slab i takes chunks i, i + nslab, ...): at any
+// moment the workgroups of the grid read one contiguous stretch of the activation.  Round 3's contiguous slabs started
+// every workgroup at a multiple of rows / nslab * C * 2 bytes (512 KB for the layer-1 maps) and walked in lockstep -- the
+// same HBM channels for the whole grid, 3.1 TB/s against bn_apply's 6.1 on the same tensors.  The assignment is fixed, so
+// the sums are reproducible run to run.  An LDS tree adds the row-groups.  C % 8 == 0, C / 8 divides 256 or C % 256 == 0.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial,
-                                                       size_t rows, int C, int nslab) {
+                                                       size_t rows, int C, int CG, int nslab) {
   __shared__ float red[256 * 16];
-  const int tpr = C >> 3;                  // threads per row
+  const int tpr = CG >> 3;                 // threads per row segment
   const int nsub = 256 / tpr;              // row-groups per workgroup
   const int cp = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
-  const size_t per = (rows + nslab - 1) / nslab;
-  const size_t r0 = (size_t)blockIdx.x * per;
-  const size_t r1 = r0 + per < rows ? r0 + per : rows;
+  const int C8 = C >> 3;
+  const int cvec = blockIdx.y * tpr + cp;  // this thread's 16-byte column of a row
+  const size_t chunk_rows = (size_t)nsub * 8;
+  const size_t nchunk = (rows + chunk_rows - 1) / chunk_rows;
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  if (rsub < nsub) {
-    auto accum = [&](const uint4& v) {
-      const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+  auto accum = [&](const uint4& v) {
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xFFFF0000u);
-        s[2 * j] += a; q[2 * j] += a * a;
-        s[2 * j + 1] += b; q[2 * j + 1] += b * b;
-      }
-    };
-    size_t r = r0 + rsub;
-    const size_t step = (size_t)nsub;
-    // eight independent 16-byte loads in flight per thread (the loop is latency-bound otherwise: 3.1 TB/s with four)
-    for (; r + 7 * step < r1; r += 8 * step) {
-      uint4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = x[(r + u * step) * tpr + cp];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) accum(v[u]);
+    for (int j = 0; j < 4; ++j) {
+      const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xFFFF0000u);
+      s[2 * j] += a; q[2 * j] += a * a;
+      s[2 * j + 1] += b; q[2 * j + 1] += b * b;
     }
-    for (; r + 3 * step < r1; r += 4 * step) {
-      const uint4 v0 = x[r * tpr + cp];
-      const uint4 v1 = x[(r + step) * tpr + cp];
-      const uint4 v2 = x[(r + 2 * step) * tpr + cp];
-      const uint4 v3 = x[(r + 3 * step) * tpr + cp];
-      accum(v0); accum(v1); accum(v2); accum(v3);
+  };
+  auto load = [&](size_t ch, uint4 (&v)[8]) {
+    const size_t r = ch * chunk_rows + rsub;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t ru = r + (size_t)u * nsub;
+      const uint4 t = x[(ru < rows ? ru : rows - 1) * C8 + cvec];        // clamped address + select: no branch around the load
+      v[u] = ru < rows ? t : make_uint4(0, 0, 0, 0);
     }
-    for (; r < r1; r += step) accum(x[r * tpr + cp]);
+  };
+  uint4 cur[8], nxt[8];
+  size_t ch = blockIdx.x;
+  if (ch < nchunk) load(ch, cur);
+  while (ch < nchunk) {
+    const size_t nch = ch + nslab;
+    if (nch < nchunk) load(nch, nxt);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) accum(cur[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    ch = nch;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s[j]; red[threadIdx.x * 16 + 8 + j] = q[j]; }
   __syncthreads();
-  if (rsub == 0) {
-    float* p = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float ss = 0.f, qq = 0.f;
-      for (int u = 0; u < nsub; ++u) {
-        ss += red[(u * tpr + cp) * 16 + j];
-        qq += red[(u * tpr + cp) * 16 + 8 + j];
-      }
-      p[cp * 8 + j] = ss;
-      p[C + cp * 8 + j] = qq;
-    }
+  // 2 * CG sums per workgroup: thread t < 2 * CG adds the nsub row-groups of (statistic t / CG, channel t % CG)
+  for (int o = threadIdx.x; o < 2 * CG; o += 256) {
+    const int which = o / CG, c = o - which * CG;
+    const int tp = c >> 3, j = c & 7;
+    float acc = 0.f;
+    for (int u = 0; u < nsub; ++u) acc += red[(u * tpr + tp) * 16 + which * 8 + j];
+    partial[(size_t)blockIdx.x * 2 * C + (size_t)which * C + blockIdx.y * CG + c] = acc;
   }
 }
 
@@ -251,16 +254,18 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(const uint4* __rest
 }
 
 // FPN top-down step (torchvision FeaturePyramidNetwork: inner_lateral + F.interpolate(last_inner, nearest)) for an exact
-// 2x upsampling, bf16 NHWC, C % 4 == 0 (8-byte vectors; the policy's C = 60 is not a multiple of 8):
-//   fwd  y[n][h][w][:]  = lat[n][h][w][:] + top[n][h/2][w/2][:]
-//   bwd  dtop[n][i][j][:] = sum of the 2x2 dy block (the lateral branch's gradient is dy itself)
-__device__ __forceinline__ uint2 add_bf16x4(uint2 a, uint2 b) {
-  return make_uint2(pack2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16),
-                          __uint_as_float(a.x & 0xFFFF0000u) + __uint_as_float(b.x & 0xFFFF0000u)),
-                    pack2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16),
-                          __uint_as_float(a.y & 0xFFFF0000u) + __uint_as_float(b.y & 0xFFFF0000u)));
+// 2x upsampling, bf16 NHWC, C % 4 == 0 (8-byte vectors; the policy's C = 60 is not a multiple of 8), with the lateral 1x1
+// convolution's BIAS folded in (the convolution itself then runs bias-free: no separate bias-add pass over the map forward,
+// no separate reduction pass over its gradient backward -- 0.5 + 0.7 ms of torch kernels per step at B = 64):
+//   fwd  y[n][h][w][:]  = lat[n][h][w][:] + bias[:] + top[n][h/2][w/2][:]           (one rounding; bias / top may be null)
+//   bwd  dtop[n][i][j][:] = sum of the 2x2 dy block (the lateral branch's gradient is dy itself);
+//        dbias partial[blk][:] = the workgroup's column sums of dy (fixed order; a3d_colsum_reduce adds them)
+__device__ __forceinline__ void bf16x4_to_f32(uint2 a, float (&o)[4]) {
+  o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xFFFF0000u);
+  o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xFFFF0000u);
 }
 __global__ __launch_bounds__(256) void upsample2_add_fwd_kernel(const uint2* __restrict__ lat, const uint2* __restrict__ top,
+                                                                const float* __restrict__ bias, int nbias,
                                                                 uint2* __restrict__ y, int N, int H, int W, int C4) {
   const size_t total = (size_t)N * H * W * C4;
   const int Ht = H >> 1, Wt = W >> 1;
@@ -271,13 +276,24 @@ __global__ __launch_bounds__(256) void upsample2_add_fwd_kernel(const uint2* __r
     pix /= W;
     const int h = (int)(pix % H);
     const int n = (int)(pix / H);
-    y[i] = add_bf16x4(lat[i], top[(((size_t)n * Ht + (h >> 1)) * Wt + (w >> 1)) * C4 + c]);
+    float a[4], t[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16x4_to_f32(lat[i], a);
+    if (top) bf16x4_to_f32(top[(((size_t)n * Ht + (h >> 1)) * Wt + (w >> 1)) * C4 + c], t);
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += (c * 4 + j < nbias) ? bias[c * 4 + j] : 0.f;      // pad channels carry no bias
+    }
+    y[i] = make_uint2(pack2(a[0] + t[0], a[1] + t[1]), pack2(a[2] + t[2], a[3] + t[3]));
   }
 }
-__global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __restrict__ dy, uint2* __restrict__ dtop, int N,
-                                                                int H, int W, int C4) {
+// grid-stride over POOLED pixels x channel quads; with 256 % C4 == 0 a thread keeps its channel quad for the whole loop, so
+// the column sums of dy are per-thread registers + one LDS tree per workgroup (bias_partial [gridDim.x][4 * C4], or null)
+__global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __restrict__ dy, uint2* __restrict__ dtop,
+                                                                float* __restrict__ bias_partial, int N, int H, int W, int C4) {
+  __shared__ float red[256 * 4];
   const int Ht = H >> 1, Wt = W >> 1;
   const size_t total = (size_t)N * Ht * Wt * C4;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
     size_t pix = i / C4;
@@ -290,35 +306,91 @@ __global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __r
     for (int dyy = 0; dyy < 2; ++dyy)
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const uint2 v = dy[(((size_t)n * H + 2 * ht + dyy) * W + 2 * wt + dx) * C4 + c];
-        acc[0] += __uint_as_float(v.x << 16);
-        acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
-        acc[2] += __uint_as_float(v.y << 16);
-        acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+        float v[4];
+        bf16x4_to_f32(dy[(((size_t)n * H + 2 * ht + dyy) * W + 2 * wt + dx) * C4 + c], v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
       }
-    dtop[i] = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
+    if (dtop) dtop[i] = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] += acc[j];
   }
+  if (bias_partial) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = cs[j];
+    __syncthreads();
+    if ((int)threadIdx.x < 4 * C4) {
+      const int c = threadIdx.x >> 2, j = threadIdx.x & 3;
+      float a = 0.f;
+      for (int u = c; u < 256; u += C4) a += red[u * 4 + j];
+      bias_partial[(size_t)blockIdx.x * 4 * C4 + threadIdx.x] = a;
+    }
+  }
+}
+
+// out[c] += sum_i partial[i][c]   (fixed order, one thread per column; rows <= a few thousand)
+__global__ __launch_bounds__(64) void colsum_reduce_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out,
+                                                          int nout) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  for (; i + 3 < nrow; i += 4) {
+    a0 += partial[(size_t)i * C + c];
+    a1 += partial[(size_t)(i + 1) * C + c];
+    a2 += partial[(size_t)(i + 2) * C + c];
+    a3 += partial[(size_t)(i + 3) * C + c];
+  }
+  for (; i < nrow; ++i) a0 += partial[(size_t)i * C + c];
+  if (c < nout) out[c] += (a0 + a1) + (a2 + a3);
+}
+
+// column sums of the fp32 rows a gather's backward sees: rows (b, s), s < k, of src [B][S][ld] -> partial [gridDim.x][C]
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ src, int B, int S, int k, int ld, int C,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;           // C <= 64 columns x 4 row groups
+  const size_t total = (size_t)B * k;
+  float a = 0.f;
+  if (c < C) {
+    for (size_t r = (size_t)blockIdx.x * 4 + rg; r < total; r += (size_t)gridDim.x * 4) {
+      const size_t b = r / k, s = r - b * k;
+      a += src[(b * S + s) * ld + c];
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < C) partial[(size_t)blockIdx.x * C + threadIdx.x] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
 }
 
 }  // namespace a3d
 
 using namespace a3d;
 
+static int bn_channel_group(int C) { return C < 256 ? C : 256; }
+
 extern "C" int a3d_bn_nslab(size_t rows, int C) {
-  // enough slabs to fill the chip with 4 workgroups per CU, at least 64 rows per slab
-  size_t n = 1024;
-  if (n > rows / 64) n = rows / 64;
+  // ~2048 workgroups over (slab, 256-channel group) -- 8 per CU -- with at least one 8-row-per-thread chunk per slab, and at
+  // most 1024 slabs (a3d_bn_finalize reads nslab x 2 x C partial sums)
+  if (C < 8) return 1;
+  const int CG = bn_channel_group(C);
+  const size_t chunk_rows = (size_t)(256 / (CG / 8)) * 8;
+  size_t n = 2048 / (size_t)(C / CG);
+  const size_t nchunk = (rows + chunk_rows - 1) / chunk_rows;
+  if (n > nchunk) n = nchunk;
+  if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
 }
 
 extern "C" int a3d_bn_stats(const void* x, float* partial, size_t rows, int C, int nslab, void* stream) {
-  if (!x || !partial || rows == 0 || C < 8 || (C % 8) != 0 || C > 2048 || (256 % (C / 8)) != 0 || nslab < 1 ||
+  const int CG = bn_channel_group(C);
+  if (!x || !partial || rows == 0 || C < 8 || (C % 8) != 0 || C > 2048 || (256 % (CG / 8)) != 0 || (C % CG) != 0 || nslab < 1 ||
       (((uintptr_t)x) & 15)) {
-    set_error("a3d_bn_stats: bad argument (C=%d must be 8 * a divisor of 256, nslab=%d)", C, nslab);
+    set_error("a3d_bn_stats: bad argument (C=%d must be 8 * a divisor of 256 or a multiple of 256, nslab=%d)", C, nslab);
     return A3D_ERR_ARG;
   }
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, partial, rows, C,
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nslab, C / CG), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, partial, rows, C, CG,
                      nslab);
   return check_launch("a3d_bn_stats");
 }
@@ -364,7 +436,7 @@ extern "C" int a3d_bn_apply_pool2(const void* x, const void* residual, const flo
   return check_launch("a3d_bn_apply_pool2");
 }
 
-static int check_up2(const char* fn, const void* a, const void* b, const void* c, int N, int H, int W, int C) {
+static int check_up2(const char* fn, const void* a, const void* b, const void* c /* may be null */, int N, int H, int W, int C) {
   if (!a || !b || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 4) != 0 ||
       ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 7)) {
     set_error("%s: bad argument (H=%d W=%d must be even, C=%d a multiple of 4, pointers 8-byte aligned)", fn, H, W, C);
@@ -373,24 +445,62 @@ static int check_up2(const char* fn, const void* a, const void* b, const void* c
   return A3D_OK;
 }
 
-extern "C" int a3d_upsample2_add_fwd(const void* lat, const void* top, void* y, int N, int H, int W, int C, void* stream) {
-  int rc = check_up2("a3d_upsample2_add_fwd", lat, top, y, N, H, W, C);
-  if (rc || !y) { if (!rc) set_error("a3d_upsample2_add_fwd: null output"); return A3D_ERR_ARG; }
+extern "C" int a3d_upsample2_add_fwd(const void* lat, const void* top, const float* bias, int nbias, void* y, int N, int H, int W,
+                                     int C, void* stream) {
+  int rc = check_up2("a3d_upsample2_add_fwd", lat, y, top, N, H, W, C);
+  if (rc) return rc;
+  if (bias && (nbias <= 0 || nbias > C)) { set_error("a3d_upsample2_add_fwd: %d bias entries for %d channels", nbias, C); return A3D_ERR_ARG; }
   const size_t total = (size_t)N * H * W * (C / 4);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(upsample2_add_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint2*)lat,
-                     (const uint2*)top, (uint2*)y, N, H, W, C / 4);
+                     (const uint2*)top, bias, nbias, (uint2*)y, N, H, W, C / 4);
   return check_launch("a3d_upsample2_add_fwd");
 }
 
-extern "C" int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, int W, int C, void* stream) {
-  int rc = check_up2("a3d_upsample2_add_bwd", dy, dtop, nullptr, N, H, W, C);
-  if (rc) return rc;
+static int up2_bwd_grid(int N, int H, int W, int C) {
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  return (int)std::min<size_t>((total + 255) / 256, 4096);
+}
+extern "C" size_t a3d_upsample2_add_bwd_ws_floats(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  return (size_t)up2_bwd_grid(N, H, W, C) * C;
+}
+
+extern "C" int a3d_upsample2_add_bwd(const void* dy, void* dtop, float* dbias, int nbias, float* ws, int N, int H, int W, int C,
+                                     void* stream) {
+  int rc = check_up2("a3d_upsample2_add_bwd", dy, dy, dtop, N, H, W, C);
+  if (rc) return rc;
+  if (!dtop && !dbias) { set_error("a3d_upsample2_add_bwd: nothing to compute (dtop and dbias are both null)"); return A3D_ERR_ARG; }
+  if (dbias && (!ws || (256 % (C / 4)) != 0 || nbias <= 0 || nbias > C)) {
+    set_error("a3d_upsample2_add_bwd: the bias gradient needs a workspace, C / 4 = %d dividing 256 and 0 < nbias <= C", C / 4);
+    return A3D_ERR_ARG;
+  }
+  const int grid = up2_bwd_grid(N, H, W, C);
   hipLaunchKernelGGL(upsample2_add_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint2*)dy, (uint2*)dtop,
-                     N, H, W, C / 4);
-  return check_launch("a3d_upsample2_add_bwd");
+                     dbias ? ws : nullptr, N, H, W, C / 4);
+  rc = check_launch("a3d_upsample2_add_bwd");
+  if (rc || !dbias) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, grid, C, dbias, nbias);
+  return check_launch("a3d_upsample2_add_bwd(bias)");
+}
+
+extern "C" size_t a3d_colsum_rows_ws_floats(int B, int k, int C) {
+  if (B <= 0 || k <= 0 || C <= 0) return 0;
+  const size_t nblk = std::min<size_t>(((size_t)B * k + 63) / 64, 1024);
+  return nblk * C;
+}
+
+extern "C" int a3d_colsum_rows(const float* src, int B, int S, int k, int ld, int C, float* out, int nout, float* ws, void* stream) {
+  if (!src || !out || !ws || B <= 0 || S <= 0 || k <= 0 || k > S || C <= 0 || C > 64 || ld < C || nout <= 0 || nout > C) {
+    set_error("a3d_colsum_rows: bad argument (B=%d S=%d k=%d ld=%d C=%d nout=%d; C <= 64, k <= S)", B, S, k, ld, C, nout);
+    return A3D_ERR_ARG;
+  }
+  const int nblk = (int)(a3d_colsum_rows_ws_floats(B, k, C) / C);
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, src, B, S, k, ld, C, ws);
+  int rc = check_launch("a3d_colsum_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out, nout);
+  return check_launch("a3d_colsum_rows(reduce)");
 }
 
 extern "C" int a3d_rgb_normalize_nhwc_bf16(const float* x, const float* mean, const float* stdv, void* y, size_t N, int H, int W,

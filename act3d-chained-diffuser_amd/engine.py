@@ -317,7 +317,9 @@ def _split_backward(tokens, run_hot, on_hot_done):
     uniq, leaves = {}, []
     for t in tokens:
         if id(t) not in uniq:
-            uniq[id(t)] = (t, t.detach().requires_grad_(t.requires_grad))
+            leaf = t.detach().requires_grad_(t.requires_grad)
+            leaf.row_bias = getattr(t, "row_bias", None)      # deferred FPN output bias (Act3D.compute_visual_tokens)
+            uniq[id(t)] = (t, leaf)
         leaves.append(uniq[id(t)][1])
     loss = run_hot(leaves)
     loss.backward()

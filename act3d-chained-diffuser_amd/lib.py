@@ -87,7 +87,9 @@ SIGNATURES = {
     "a3d_traj_nn_topk": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_build_context": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_build_context_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "a3d_build_context_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_build_context_bf16": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "a3d_colsum_rows_ws_floats": (_z, [_i, _i, _i]),
+    "a3d_colsum_rows": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "a3d_build_context_bwd_bf16": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_mask_logits_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "a3d_mask_logits_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -104,6 +106,7 @@ SIGNATURES = {
     "a3d_sample_ghost_points": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "a3d_rng_advance": (_i, [_p, _u64, _p]),
     "a3d_philox4x32_10_host": (None, [_p, _p, _p]),
+    "a3d_sincos_host": (None, [_p, _p, _p, _z]),
     "a3d_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _z, _z, _f, _f, _f, _f, _f, _f, _f, _p]),
     "a3d_dbg_mfma_bf16": (_i, [_p, _p, _p, _p]),
     "a3d_dbg_mfma_f32": (_i, [_p, _p, _p, _p]),
@@ -116,8 +119,9 @@ SIGNATURES = {
     "a3d_bn_apply": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_bn_apply_pool2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rgb_normalize_nhwc_bf16": (_i, [_p, _p, _p, _p, _z, _i, _i, _p]),
-    "a3d_upsample2_add_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
-    "a3d_upsample2_add_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "a3d_upsample2_add_fwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "a3d_upsample2_add_bwd_ws_floats": (_z, [_i, _i, _i, _i]),
+    "a3d_upsample2_add_bwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     # diffusion.hip
     "a3d_ddpm_add_noise": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "a3d_ddpm_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

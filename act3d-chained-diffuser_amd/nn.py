@@ -153,34 +153,63 @@ class ParallelAttention(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ adjacent: vision
 class _Upsample2AddFn(torch.autograd.Function):
-    """lat + F.interpolate(top, 2x, nearest) for bf16 channels_last maps in one kernel; backward: dtop = 2x2 sums."""
+    """lat + bias + F.interpolate(top, 2x, nearest) for bf16 channels_last maps in one kernel; backward: dtop = 2x2 sums of
+    dy and, in the same pass, the column sums of dy = the bias gradient, accumulated straight into bias.grad (as every wgrad
+    kernel of ops.py does).  `bias`: the lateral convolution's fp32 Parameter (<= C entries; the convolution itself runs
+    bias-free) or None; `top` None at the pyramid's top level."""
 
     @staticmethod
-    def forward(ctx, lat, top):
+    def forward(ctx, lat, top, bias):
         N, C, H, W = lat.shape
         y = torch.empty_like(lat)
-        O.L.call("a3d_upsample2_add_fwd", lat.data_ptr(), top.data_ptr(), y.data_ptr(), N, H, W, C, O.L.stream())
+        O.L.call("a3d_upsample2_add_fwd", lat.data_ptr(), None if top is None else top.data_ptr(),
+                 None if bias is None else bias.data_ptr(), 0 if bias is None else bias.numel(), y.data_ptr(), N, H, W, C,
+                 O.L.stream())
+        ctx.bias = bias
+        ctx.has_top = top is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, C, H, W = dy.shape
+        bias = ctx.bias
+        want_top = ctx.has_top and ctx.needs_input_grad[1]
+        want_bias = bias is not None and bias.requires_grad
         dtop = None
-        if ctx.needs_input_grad[1]:
+        if want_top or want_bias:
             dy = dy.contiguous(memory_format=torch.channels_last)
-            dtop = torch.empty((N, C, H // 2, W // 2), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
-            O.L.call("a3d_upsample2_add_bwd", dy.data_ptr(), dtop.data_ptr(), N, H, W, C, O.L.stream())
-        return (dy if ctx.needs_input_grad[0] else None), dtop
+            if want_top:
+                dtop = torch.empty((N, C, H // 2, W // 2), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
+            ws = gb = None
+            if want_bias:
+                ws = torch.empty((O.L.load().a3d_upsample2_add_bwd_ws_floats(N, H, W, C),), device=dy.device, dtype=torch.float32)
+                gb = O.grad_buf(bias)
+            O.L.call("a3d_upsample2_add_bwd", dy.data_ptr(), None if dtop is None else dtop.data_ptr(),
+                     None if gb is None else gb.data_ptr(), 0 if gb is None else gb.numel(), None if ws is None else ws.data_ptr(),
+                     N, H, W, C, O.L.stream())
+        return (dy if ctx.needs_input_grad[0] else None), dtop, None
 
 
-def fpn_top_down(lat, last):
-    """inner_lateral + nearest-upsampled last_inner (torchvision FPN); fused HIP kernel for the exact-2x bf16 NHWC case."""
+def _fused_top_down_ok(lat, last, with_bias=False):
     cl = torch.channels_last
-    if (lat.is_cuda and lat.dtype == torch.bfloat16 and last.dtype == torch.bfloat16 and lat.shape[1] % 4 == 0
-            and lat.shape[-2] == 2 * last.shape[-2] and lat.shape[-1] == 2 * last.shape[-1]
-            and lat.is_contiguous(memory_format=cl) and last.is_contiguous(memory_format=cl)):
-        return _Upsample2AddFn.apply(lat, last)
-    return lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+    ok = (lat.is_cuda and lat.dtype == torch.bfloat16 and lat.shape[1] % 4 == 0 and lat.shape[-2] % 2 == 0 and lat.shape[-1] % 2 == 0
+          and lat.is_contiguous(memory_format=cl))
+    if last is not None:
+        ok = ok and (last.dtype == torch.bfloat16 and lat.shape[-2] == 2 * last.shape[-2] and lat.shape[-1] == 2 * last.shape[-1]
+                     and last.is_contiguous(memory_format=cl))
+    if with_bias:
+        ok = ok and 256 % (lat.shape[1] // 4) == 0
+    return ok
+
+
+def fpn_top_down(lat, last, bias=None):
+    """inner_lateral (+ its convolution's bias, when the convolution ran bias-free) + nearest-upsampled last_inner
+    (torchvision FPN); fused HIP kernel for the exact-2x bf16 NHWC case."""
+    if _fused_top_down_ok(lat, last, bias is not None):
+        return _Upsample2AddFn.apply(lat, last, bias)
+    if bias is not None:
+        lat = lat + F.pad(bias, (0, lat.shape[1] - bias.numel())).to(lat.dtype).view(1, -1, 1, 1)
+    return lat if last is None else lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
 
 
 class FeaturePyramidNetwork(nn.Module):
@@ -198,39 +227,59 @@ class FeaturePyramidNetwork(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, feats, needed=None, pad_to=None):
+    def forward(self, feats, needed=None, pad_to=None, defer_output_bias=False):
         """pad_to: run every convolution with its output (and, for the 3x3 layer blocks, input) channel count zero-padded
         to this width and return the padded maps (pad channels are exact zeros).  MIOpen's bf16 NHWC kernels for C = 60
         are ~2x slower than for C = 64 (measured on MI355X, N = 256 at 128 x 128: forward + backward 5.2 ms vs 2.6 ms);
-        the parameters keep the reference's shapes, the padding is a per-step F.pad that autograd slices back."""
+        the parameters keep the reference's shapes, the padding is a per-step F.pad that autograd slices back.
+
+        Biases (bf16 CUDA maps): the lateral 1x1 convolutions run bias-free and their bias is added by the top-down kernel
+        that reads the lateral map anyway (forward) / reduced by the kernel that reads its gradient anyway (backward).
+        defer_output_bias=True also runs the 3x3 output convolutions bias-free and returns (maps, {name: bias Parameter}):
+        the consumer adds the bias to the token rows it gathers (ops.BuildContextFn) -- a level reads 6 % of the fine map."""
         names = list(feats.keys())
         xs = list(feats.values())
         C = self.inner_blocks[0][0].out_channels
         pad = 0 if pad_to is None else max(0, pad_to - C)
 
-        def inner(i, x):
+        def conv(m, x, wpad, with_bias, **kw):
+            w = F.pad(m.weight, wpad) if pad else m.weight
+            b = None
+            if with_bias:
+                b = F.pad(m.bias, (0, pad)) if pad else m.bias
+            return F.conv2d(x, w, b, **kw)
+
+        def inner(i, x, last):
             m = self.inner_blocks[i][0]
-            if not pad:
-                return m(x)
-            return F.conv2d(x, F.pad(m.weight, (0, 0, 0, 0, 0, 0, 0, pad)), F.pad(m.bias, (0, pad)))
+            wpad = (0, 0, 0, 0, 0, 0, 0, pad)
+            Co = C + pad
+            bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+            fuse = (x.is_cuda and bf16 and Co % 4 == 0 and 256 % (Co // 4) == 0 and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0
+                    and (last is None or (x.shape[-2] == 2 * last.shape[-2] and x.shape[-1] == 2 * last.shape[-1])))
+            if not fuse:
+                lat = conv(m, x, wpad, True)
+                return lat if last is None else fpn_top_down(lat, last)
+            return fpn_top_down(conv(m, x, wpad, False), last, m.bias)      # bias-free convolution, bias in the top-down kernel
+
+        out_bias = {}
 
         def layer(i, x):
             m = self.layer_blocks[i][0]
-            if not pad:
-                return m(x)
-            return F.conv2d(x, F.pad(m.weight, (0, 0, 0, 0, 0, pad, 0, pad)), F.pad(m.bias, (0, pad)), padding=1)
+            defer = defer_output_bias and x.is_cuda
+            if defer:
+                out_bias[names[i]] = m.bias
+            return conv(m, x, (0, 0, 0, 0, 0, pad, 0, pad), not defer, padding=1)
 
-        last = inner(len(xs) - 1, xs[-1])
+        last = inner(len(xs) - 1, xs[-1], None)
         out = {}
         lowest = min(names.index(n) for n in needed) if needed is not None else 0
         if needed is None or names[-1] in needed:
             out[names[-1]] = layer(len(xs) - 1, last)
         for i in range(len(xs) - 2, lowest - 1, -1):
-            lat = inner(i, xs[i])
-            last = fpn_top_down(lat, last)
+            last = inner(i, xs[i], last)
             if needed is None or names[i] in needed:
                 out[names[i]] = layer(i, last)
-        return out
+        return (out, out_bias) if defer_output_bias else out
 
 
 class _Bottleneck(nn.Module):

@@ -826,7 +826,10 @@ class BuildContextFn(torch.autograd.Function):
     channels-last output read in place: no fp32 copy of the map, the gradient goes back as one bf16 map); extra (B, X, E)."""
 
     @staticmethod
-    def forward(ctx, feat, idx, extra, accum=None):
+    def forward(ctx, feat, idx, extra, accum=None, bias=None):
+        """bias: fp32 Parameter (E,) added to the gathered rows of a bf16 map (the deferred bias of the FPN's 3x3 output
+        convolution, nn.FeaturePyramidNetwork.forward(defer_output_bias=True)); its gradient -- the column sums of d(ctx)
+        over the gathered rows -- is accumulated into bias.grad by the backward."""
         L.require_gpu(feat)
         feat, extra = _c(feat), _c(extra)
         B, Npts, ldf = feat.shape
@@ -835,9 +838,11 @@ class BuildContextFn(torch.autograd.Function):
         X = extra.shape[1]
         out = torch.empty((B, k + X, E), device=feat.device, dtype=F32)
         bf = feat.dtype == torch.bfloat16
+        if bias is not None and (not bf or bias.numel() != E or bias.dtype != F32):
+            raise ValueError("BuildContextFn: a deferred row bias needs a bf16 token map and an fp32 bias of %d entries" % E)
         if bf:
             L.call("a3d_build_context_bf16", feat.data_ptr(), ldf, None if idx is None else idx.data_ptr(), extra.data_ptr(),
-                   out.data_ptr(), B, Npts, k, X, E, L.stream())
+                   None if bias is None else bias.data_ptr(), out.data_ptr(), B, Npts, k, X, E, L.stream())
         else:
             if ldf != E:
                 raise ValueError("fp32 token rows must have exactly the context width (%d vs %d)" % (ldf, E))
@@ -845,6 +850,7 @@ class BuildContextFn(torch.autograd.Function):
                    out.data_ptr(), B, Npts, k, X, E, L.stream())
         ctx.idx = idx
         ctx.accum = accum
+        ctx.bias = bias
         if accum is not None:
             accum.pending += 1
         ctx.meta = (B, Npts, k, X, E, bf, ldf)
@@ -857,6 +863,10 @@ class BuildContextFn(torch.autograd.Function):
         idx, accum = ctx.idx, ctx.accum
         dfeat = dextra = None
         accumulate = 0
+        if ctx.bias is not None and ctx.bias.requires_grad:
+            ws = torch.empty((L.load().a3d_colsum_rows_ws_floats(B, k, E),), device=dctx.device, dtype=F32)
+            gb = grad_buf(ctx.bias)
+            L.call("a3d_colsum_rows", dctx.data_ptr(), B, k + X, k, E, E, gb.data_ptr(), E, ws.data_ptr(), L.stream())
         if ctx.needs_input_grad[0]:
             dt = torch.bfloat16 if bf else F32
             if accum is not None and accum.buf is None and accum.pending == 1:
@@ -883,7 +893,7 @@ class BuildContextFn(torch.autograd.Function):
                 dfeat = None                    # a later backward of the same map returns the shared buffer
             else:
                 accum.buf = None
-        return dfeat, None, dextra, None
+        return dfeat, None, dextra, None, None
 
 
 # ------------------------------------------------------------------------------------------------ heads / losses

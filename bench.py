@@ -496,7 +496,10 @@ def main():
         # hot-path-only throughput (pre-computed visual tokens): informational
         try:
             with torch.no_grad():
-                feats = [f.detach() for f in model.compute_visual_tokens(batch["rgbs"])]
+                toks = model.compute_visual_tokens(batch["rgbs"])
+                feats = [f.detach() for f in toks]
+                for f, t in zip(feats, toks):
+                    f.row_bias = getattr(t, "row_bias", None)      # deferred FPN output bias rides on the token tensor
 
             def hot_only():
                 opt.zero_grad()

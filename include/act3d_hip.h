@@ -208,11 +208,17 @@ int a3d_build_context_bwd(const float* dctx, const long long* idx, float* dfeat,
 /* Same with bf16 token rows: `feat` is the FPN's bf16 channels-last output read in place ([B][Npts][ldf] bf16 with the
  * W token channels first -- ldf = 64 when the FPN runs channel-padded for MIOpen -- 8-byte aligned, W, ldf % 4 == 0);
  * ctx / extra stay fp32; the backward accumulates into a bf16 gradient map of the same layout (zero-initialised by the
- * caller and shared by every level that gathers from the map; pad channels are never written). */
-int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, float* ctx, int B, int Npts,
-                           int k, int X, int W, void* stream);
+ * caller and shared by every level that gathers from the map; pad channels are never written).
+ * `bias` (fp32 [W] or NULL) is added to the gathered rows -- the bias of the FPN's 3x3 output convolution applied to the rows a
+ * level reads instead of to the whole map; its gradient is a3d_colsum_rows of d(ctx). */
+int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, const float* extra, const float* bias, float* ctx,
+                           int B, int Npts, int k, int X, int W, void* stream);
 int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, int ldf, float* dextra, int B,
                                int Npts, int k, int X, int W, int accumulate, void* stream);
+/* out[c] += sum over b < B, s < k of src[b][s][c]  (src fp32 [B][S][ld], c < nout <= C <= 64; two launches, fixed summation
+ * order; ws: a3d_colsum_rows_ws_floats(B, k, C) floats). */
+size_t a3d_colsum_rows_ws_floats(int B, int k, int C);
+int a3d_colsum_rows(const float* src, int B, int S, int k, int ld, int C, float* out, int nout, float* ws, void* stream);
 
 /* ---- decoding heads, losses, sampler, optimizer ----------------------------------------------------------- */
 int a3d_mask_logits_fwd(const float* q, const float* F, float* out, int B, int Ng, int E, void* stream);
@@ -243,6 +249,9 @@ int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds
                             float* out, int B, int Ng, int level, int max_attempts, void* stream);
 int a3d_rng_advance(unsigned long long* state, unsigned long long n, void* stream);
 void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Host mirror of the device RoPE sin / cos (a3d_common.h sincos_poly, used for |x| < 200; the rotary code of
+ * position_encodings.py:64-97 evaluated in-kernel): the same fp32 operations, so a CPU test can bound it against float64. */
+void a3d_sincos_host(const float* x, float* sn, float* cs, size_t n);
 /* torch.optim.AdamW semantics (engine.py:89-102) on a flat buffer; elements [0, n_nodecay) use wd_nodecay.  The decision
  * "this parameter has no gradient -> skip it" is per PARAMETER, as in torch: seg_off [nseg + 1] (element offsets, ascending,
  * seg_off[0] = 0, seg_off[nseg] = n) delimits the parameters, seg_state [nseg][4] = {step, active, lr / bc1, sqrt(bc2)} is
@@ -362,10 +371,16 @@ int a3d_bn_apply(const void* x, const void* residual, const float* scale, const 
  * y_full [N][H][W][C] is also written unless NULL.  scale == NULL: identity (plain average pool of x).  H, W even. */
 int a3d_bn_apply_pool2(const void* x, const void* residual, const float* scale, const float* shift, void* y_full,
                        void* y_pool, int N, int H, int W, int C, int relu, void* stream);
-/* FPN top-down step, bf16 NHWC, exact 2x: y = lat + nearest_up2(top)  (torchvision FeaturePyramidNetwork.forward as the
- * reference instantiates it, act3d.py:60-66); backward: dtop = 2x2 block sums of dy (dlat = dy).  H, W: the fine size. */
-int a3d_upsample2_add_fwd(const void* lat, const void* top, void* y, int N, int H, int W, int C, void* stream);
-int a3d_upsample2_add_bwd(const void* dy, void* dtop, int N, int H, int W, int C, void* stream);
+/* FPN top-down step, bf16 NHWC, exact 2x: y = lat + bias + nearest_up2(top)  (torchvision FeaturePyramidNetwork.forward as the
+ * reference instantiates it, act3d.py:60-66, with the lateral 1x1 convolution's bias folded in: the convolution runs
+ * bias-free; bias fp32 [nbias <= C] or NULL, channels >= nbias are MIOpen's zero padding; top NULL at the pyramid's top level).  Backward: dtop = 2x2 block sums of dy (dlat = dy;
+ * dtop NULL at the top level), dbias[c] += column sums of dy when dbias != NULL (ws: a3d_upsample2_add_bwd_ws_floats floats,
+ * C / 4 must divide 256; two-stage, fixed order).  H, W: the fine size, even. */
+int a3d_upsample2_add_fwd(const void* lat, const void* top, const float* bias, int nbias, void* y, int N, int H, int W, int C,
+                          void* stream);
+size_t a3d_upsample2_add_bwd_ws_floats(int N, int H, int W, int C);
+int a3d_upsample2_add_bwd(const void* dy, void* dtop, float* dbias, int nbias, float* ws, int N, int H, int W, int C,
+                          void* stream);
 
 /* y (bf16, [N][H][W][3] = torch channels_last storage) = (x (fp32 [N][3][H][W]) - mean[c]) / std[c]: CLIP's input
  * normalisation (model/utils/clip.py:19, act3d.py:364) fused with the layout change and the cast the bf16 backbone needs. */

@@ -53,8 +53,8 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.a3d_bn_stats(dummy, dummy, 1024, 24, 4, None) == -22                                   # C/8 must divide 256
     assert lib.a3d_bn_apply(dummy, None, dummy, dummy, dummy, 1024, 60, 1, None) == -22               # C % 8
     assert lib.a3d_bn_apply_pool2(dummy, None, None, None, None, dummy, 1, 7, 8, 64, 1, None) == -22  # odd H
-    assert lib.a3d_upsample2_add_fwd(dummy, dummy, dummy, 1, 8, 8, 62, None) == -22                   # C % 4
-    assert lib.a3d_upsample2_add_bwd(dummy, dummy, 1, 8, 9, 60, None) == -22                          # odd W
+    assert lib.a3d_upsample2_add_fwd(dummy, dummy, None, 0, dummy, 1, 8, 8, 62, None) == -22                   # C % 4
+    assert lib.a3d_upsample2_add_bwd(dummy, dummy, None, 0, None, 1, 8, 9, 60, None) == -22                          # odd W
     assert lib.a3d_linear_wgrad_ws(None, 0, None, 0, None, 0, None, 4, 4, 4, None, 0, None) == -22
 
 
@@ -73,7 +73,8 @@ def test_c_abi_host_side_planning_functions():
     assert lib.a3d_linear_wgrad_ws_bytes(0, 60, 60, 1) == 0
     # BatchNorm statistics slabs: >= 64 rows per slab, at most 1024 slabs
     assert lib.a3d_bn_nslab(10, 64) == 1
-    assert lib.a3d_bn_nslab(64 * 100, 64) == 100
+    assert lib.a3d_bn_nslab(64 * 100, 64) == 25                      # 256-row chunks (32 row-groups x 8 loads in flight)
+    assert lib.a3d_bn_nslab(1 << 14, 2048) == 256                    # x 8 channel groups of 256 = 2048 workgroups
     assert lib.a3d_bn_nslab(1 << 22, 32) == 1024
     # attention split-K workspace and k-NN scratch grow linearly
     assert lib.a3d_attn_fwd_ws_floats(2, 4, 64, 4) == 2 * lib.a3d_attn_fwd_ws_floats(1, 4, 64, 4)
@@ -597,3 +598,24 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_nslab(1 << 20, 64) == 2048 and lib.a3d_conv1x1_nslab(1000, 64) == 4
     assert lib.a3d_conv1x1_nslab(1 << 20, 1024) == 512 and lib.a3d_conv1x1_nslab(100, 256) == 2
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
+
+
+def test_rope_sincos_host_mirror_within_1e7_of_float64():
+    """The device RoPE sin / cos (a3d_common.h sincos_poly: two-FMA Cody-Waite reduction + Cephes polynomials, used for
+    |x| < 200 in every rotating kernel) through its host mirror: absolute error <= 1.2e-7 against float64 over the range,
+    at the quadrant boundaries and at multiples of pi / 2 (torch's sin / cos, which the reference's rotary code uses --
+    position_encodings.py:86-95 -- are within 1 ulp = 6e-8 of the same values)."""
+    a3d = load_pkg()
+    lib = a3d.lib.load()
+    rng = np.random.default_rng(0)
+    k = np.arange(-127, 128, dtype=np.float64)
+    x = np.concatenate([rng.uniform(-200, 200, 400000), rng.uniform(-4, 4, 400000), np.linspace(-199.9, 199.9, 200001),
+                        k * np.pi / 2, k * np.pi / 4, np.nextafter((k * np.pi / 4).astype(np.float32), np.float32(1e9)),
+                        [0.0, -0.0, 1e-30, -1e-30, 199.99999]]).astype(np.float32)
+    sn, cs = np.empty_like(x), np.empty_like(x)
+    lib.a3d_sincos_host(x.ctypes.data, sn.ctypes.data, cs.ctypes.data, x.size)
+    xd = x.astype(np.float64)
+    assert np.abs(sn - np.sin(xd)).max() <= 1.2e-7 and np.abs(cs - np.cos(xd)).max() <= 1.2e-7
+    assert np.abs(sn * sn + cs * cs - 1.0).max() <= 3e-7
+    small = np.abs(xd) < 0.5                       # relative accuracy of sin near 0 (the polynomial is odd in r)
+    assert np.abs(sn[small] - np.sin(xd[small])).max() <= 6e-8 and not sn[x == 0].any()

@@ -556,7 +556,7 @@ def test_diffusion_elementwise(a3d, dev):
         report(f"ddpm step t={tstep}", out, ref_prev, 2e-6, 1e-6)
 
 
-@pytest.mark.parametrize("N,C,H", [(4, 32, 16), (3, 64, 24), (2, 256, 8), (2, 2048, 4)])
+@pytest.mark.parametrize("N,C,H", [(4, 32, 16), (3, 64, 24), (2, 256, 8), (2, 2048, 4), (7, 64, 40), (3, 512, 12), (5, 1024, 6)])
 def test_fused_batchnorm_train_relu_residual(a3d, dev, N, C, H):
     """vision.hip BN (batch statistics + running-stat update) + residual + ReLU vs torch's fp32 batch_norm."""
     g = torch.Generator().manual_seed(C + N)
@@ -633,6 +633,76 @@ def test_fpn_top_down_fused(a3d, dev):
     # shapes the fused kernel does not cover fall back to torch
     odd = torch.randn(1, 60, 5, 7, generator=g).to(torch.bfloat16).to(dev)
     assert a3d.nn.fpn_top_down(odd, top[:1, :, :3, :4].contiguous()).shape == odd.shape
+
+
+def test_fpn_with_folded_biases_matches_plain_convolutions(a3d, dev):
+    """nn.FeaturePyramidNetwork on bf16 channels-last maps: the lateral convolutions run bias-free with their bias added by the
+    top-down kernel (forward) and reduced by it (backward), and the output convolutions' bias is deferred to the token
+    gather (ops.BuildContextFn bias, a3d_colsum_rows).  Against the same module evaluated the plain way (F.conv2d with bias,
+    torch add + nearest interpolate, torch gather): outputs within bf16 rounding, every weight / bias gradient within
+    bf16-accumulation noise of its scale."""
+    import copy
+    torch.manual_seed(3)
+    E, Cin, N = 60, [64, 256, 512, 1024, 2048], 3
+    fpn = a3d.nn.FeaturePyramidNetwork(Cin, E).to(dev)
+    with torch.no_grad():
+        for m in fpn.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.copy_(torch.randn_like(m.bias) * 0.3)
+    ref = copy.deepcopy(fpn)
+    g = torch.Generator().manual_seed(4)
+    sizes = [32, 16, 8, 4, 2]
+    feats = {f"res{i + 1}": (torch.randn(N, c, s_, s_, generator=g) * 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+             for i, (c, s_) in enumerate(zip(Cin, sizes))}
+    needed = ["res1", "res3"]
+    k = 37
+    idx = torch.stack([torch.randperm(32 * 32, generator=g)[:k] for _ in range(N)]).to(dev)
+    extra = torch.randn(N, 1, E, generator=g).to(dev)
+    wts = {n: torch.randn(N, (k if n == "res1" else 64) + 1, E, generator=g).to(dev) for n in needed}
+
+    def tokens(fm):
+        n_, C_, h, w = fm.shape
+        return fm.permute(0, 2, 3, 1).reshape(N, h * w, C_)
+
+    # product path
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pyr, ob = fpn(feats, needed=needed, pad_to=64, defer_output_bias=True)
+    assert set(ob) == set(needed) and all(v.dtype == torch.bfloat16 for v in pyr.values())
+    loss = 0
+    outs = {}
+    for n in needed:
+        ctx = a3d.ops.BuildContextFn.apply(tokens(pyr[n]), idx if n == "res1" else None, extra, None, ob[n])
+        outs[n] = ctx
+        loss = loss + (ctx * wts[n]).sum()
+    loss.backward()
+    # plain path: convolutions with bias, torch top-down, torch gather
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xs = list(feats.values())
+        last = ref.inner_blocks[4][0](xs[4])
+        maps = {}
+        for i in range(3, -1, -1):
+            last = ref.inner_blocks[i][0](xs[i]) + torch.nn.functional.interpolate(last, size=xs[i].shape[-2:], mode="nearest")
+            if f"res{i + 1}" in needed:
+                maps[f"res{i + 1}"] = ref.layer_blocks[i][0](last)
+    rloss = 0
+    for n in needed:
+        t = tokens(maps[n]).float()
+        rows = t if n != "res1" else torch.gather(t, 1, idx[..., None].expand(N, k, E))
+        rctx = torch.cat([rows, extra], dim=1)
+        report(f"fpn folded-bias tokens {n}", outs[n], rctx, 2e-2, 1.6e-2)          # bf16 maps: one rounding apart
+        rloss = rloss + (rctx * wts[n]).sum()
+    rloss.backward()
+    used = [f"inner_blocks.{i}.0" for i in range(5)] + ["layer_blocks.0.0", "layer_blocks.2.0"]
+    gp, gr = dict(fpn.named_parameters()), dict(ref.named_parameters())
+    for pre in used:
+        for leaf in ("weight", "bias"):
+            a, b = gp[f"{pre}.{leaf}"].grad, gr[f"{pre}.{leaf}"].grad
+            assert a is not None and b is not None, pre
+            err = (a.float() - b.float()).abs().max().item()
+            sc = b.float().abs().max().item()
+            print(f"[parity] fpn folded-bias grad {pre}.{leaf}: max abs err {err:.3e} (scale {sc:.3e})")
+            assert err <= 3e-2 * sc + 1e-6, (pre, leaf, err, sc)
+    assert gp["layer_blocks.1.0.bias"].grad is None                                    # maps nobody reads stay untouched
 
 
 @pytest.mark.parametrize("mode,B,Lq,S,E,H", [("kv", 2, 37, 131, 60, 4), ("qk", 2, 70, 70, 120, 8), ("none", 1, 5, 64, 60, 4),
