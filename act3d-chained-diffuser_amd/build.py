@@ -20,6 +20,10 @@ EXTRA_FLAGS = {"attention.hip": _ATTN_FLAGS, "attention_bwd.hip": _ATTN_FLAGS, "
                "attention8.hip": _ATTN_FLAGS}
 
 
+# development aid: extra hipcc flags for an A/B build on the GPU box, e.g. A3D_HIPCC_FLAGS="-DA3D_LIBM_SINCOS" python build.py --force
+ENV_FLAGS = os.environ.get("A3D_HIPCC_FLAGS", "").split()
+
+
 def _hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -47,7 +51,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ENV_FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -130,9 +130,16 @@ __host__ __device__ __forceinline__ void sincos_poly(float x, float* sn, float* 
   *sn = (q & 2) ? -s0 : s0;
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
+// out of line: ONE copy of libm's large-argument path per kernel, however often fast_sincos is unrolled (inlined, eight
+// unrolled calls in sq_bwd grew the kernel by 8 x Payne-Hanek and it ran 40 % slower on instruction fetch)
+__device__ __noinline__ static void sincos_libm(float x, float* sn, float* cs) { sincosf(x, sn, cs); }
 __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+#ifdef A3D_LIBM_SINCOS        // A/B build (A3D_HIPCC_FLAGS=-DA3D_LIBM_SINCOS): libm everywhere
+  sincosf(x, sn, cs);
+#else
   if (fabsf(x) < 200.0f) sincos_poly(x, sn, cs);
-  else sincosf(x, sn, cs);
+  else sincos_libm(x, sn, cs);
+#endif
 }
 
 // IEEE round-to-nearest single operations that the compiler may NOT contract into an fma.  (HIP's __fadd_rn /

@@ -221,10 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
             }
             const unsigned int h2 = pk_f16(p0, p1);
             w[T * 2 + pr] = h2;
-            if (PP == 2) {
-              const h16x2 hh = __builtin_bit_cast(h16x2, h2);
-              wl[T * 2 + pr] = pk_f16(p0 - (float)hh[0], p1 - (float)hh[1]);
-            }
+            if (PP == 2) wl[T * 2 + pr] = lo_f16(p0, p1, h2);
           }
         }
         pf[hf] = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});

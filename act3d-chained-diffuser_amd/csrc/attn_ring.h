@@ -29,11 +29,29 @@ __device__ __forceinline__ f32x4 mfma_f16(s16x8 a, s16x8 b, f32x4 c) {
 __device__ __forceinline__ unsigned int pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){a, b}, h16x2));
 }
+// lo = fp16(a - hi.x) | fp16(b - hi.y) for hi = pk_f16(a, b): the low parts of the two-part fp16 operands.  Written out in
+// C++ this is 2 x v_cvt_f32_f16 + 2 x v_sub_f32 + v_cvt_pk_f16_f32 -- 80 of ~140 VALU instructions of the forward's two-tile
+// loop body existed only to form P_lo (round-3 review).  v_fma_mixlo/hi_f16 take the fp16 half straight as an fma operand
+// and round the fp32 result into a half: a * 1.0 - hi is exact in fp32 (hi is a's own rounding), so the one rounding to fp16
+// gives the same bits as the five-instruction sequence.  hipcc emits no mix instruction on its own; A3D_NO_FMA_MIX builds
+// the C++ form for the A/B run.
+__device__ __forceinline__ unsigned int lo_f16(float a, float b, unsigned int hi) {
+#ifdef A3D_NO_FMA_MIX
+  const h16x2 hh = __builtin_bit_cast(h16x2, hi);
+  return pk_f16(a - (float)hh[0], b - (float)hh[1]);
+#else
+  unsigned int lo;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo)
+      : "v"(a), "v"(b), "v"(hi));
+  return lo;
+#endif
+}
 // x = hi + lo, both fp16 pairs: hi = fp16(x) (round to nearest), lo = fp16(x - hi)
 __device__ __forceinline__ void pk_f16_2(float a, float b, unsigned int& hi, unsigned int& lo) {
   hi = pk_f16(a, b);
-  const h16x2 hh = __builtin_bit_cast(h16x2, hi);
-  lo = pk_f16(a - (float)hh[0], b - (float)hh[1]);
+  lo = lo_f16(a, b, hi);
 }
 // x = hi + lo, both bf16 pairs (16 mantissa bits, fp32's exponent range): the operands of the query-axis contractions
 __device__ __forceinline__ void pk_bf16_2(float a, float b, unsigned int& hi, unsigned int& lo) {

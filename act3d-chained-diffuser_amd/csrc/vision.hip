@@ -328,21 +328,33 @@ __global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __r
   }
 }
 
-// out[c] += sum_i partial[i][c]   (fixed order, one thread per column; rows <= a few thousand)
-__global__ __launch_bounds__(64) void colsum_reduce_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out,
-                                                          int nout) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int i = 0;
-  for (; i + 3 < nrow; i += 4) {
-    a0 += partial[(size_t)i * C + c];
-    a1 += partial[(size_t)(i + 1) * C + c];
-    a2 += partial[(size_t)(i + 2) * C + c];
-    a3 += partial[(size_t)(i + 3) * C + c];
+// out[c] += sum_i partial[i][c] in a fixed order: 64 columns x 16 row groups per 1024-thread workgroup, eight independent
+// loads in flight per thread, LDS tree over the row groups (rows <= a few thousand; one thread per column took 145 us for
+// 4096 rows -- a chain of exposed L2 round trips)
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partial, int nrow, int C, float* __restrict__ out,
+                                                            int nout) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (c < C) {
+    int i = rg;
+    for (; i + 7 * 16 < nrow; i += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += partial[(size_t)(i + u * 16) * C + c];
+    }
+    for (; i < nrow; i += 16) a[0] += partial[(size_t)i * C + c];
   }
-  for (; i < nrow; ++i) a0 += partial[(size_t)i * C + c];
-  if (c < nout) out[c] += (a0 + a1) + (a2 + a3);
+  red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (rg == 0 && c < nout) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += red[u][cl];
+    out[c] += s;
+  }
 }
 
 // column sums of the fp32 rows a gather's backward sees: rows (b, s), s < k, of src [B][S][ld] -> partial [gridDim.x][C]
@@ -459,7 +471,7 @@ extern "C" int a3d_upsample2_add_fwd(const void* lat, const void* top, const flo
 
 static int up2_bwd_grid(int N, int H, int W, int C) {
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  return (int)std::min<size_t>((total + 255) / 256, 4096);
+  return (int)std::min<size_t>((total + 255) / 256, 2048);
 }
 extern "C" size_t a3d_upsample2_add_bwd_ws_floats(int N, int H, int W, int C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
@@ -480,7 +492,7 @@ extern "C" int a3d_upsample2_add_bwd(const void* dy, void* dtop, float* dbias, i
                      dbias ? ws : nullptr, N, H, W, C / 4);
   rc = check_launch("a3d_upsample2_add_bwd");
   if (rc || !dbias) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, grid, C, dbias, nbias);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, ws, grid, C, dbias, nbias);
   return check_launch("a3d_upsample2_add_bwd(bias)");
 }
 
@@ -499,7 +511,7 @@ extern "C" int a3d_colsum_rows(const float* src, int B, int S, int k, int ld, in
   hipLaunchKernelGGL(colsum_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, src, B, S, k, ld, C, ws);
   int rc = check_launch("a3d_colsum_rows");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out, nout);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, ws, nblk, C, out, nout);
   return check_launch("a3d_colsum_rows(reduce)");
 }
 

@@ -10,6 +10,17 @@ import math
 import torch
 import torch.nn.functional as F
 
+# Test hook: when set to a list, every ReLU (and planner_loss's L1) appends (site, min |argument|) -- the distance of the
+# evaluation from the nearest kink.  Gradients of a ReLU / L1 network are only comparable between two implementations when
+# no argument is within forward rounding of zero; tests/golden/make_dropout_case.py searches a case with a stated margin.
+KINKS = None
+
+
+def relu(x, site):
+    if KINKS is not None:
+        KINKS.append((site, x.detach().abs().min().item()))
+    return F.relu(x)
+
 
 def rope3d_code(xyz, E):
     """cos, sin tables (B, N, E) for points xyz (B, N, 3).
@@ -89,7 +100,7 @@ def rel_cross_attn_module(P, prefix, n_layers, query, ctx, H, q_xyz=None, ctx_xy
                 P[a + "multihead_attn.out_proj.weight"], P[a + "multihead_attn.out_proj.bias"], H, q_xyz, ctx_xyz)
         x = layer_norm(x + o, P[a + "norm.weight"], P[a + "norm.bias"])
         f = f"{prefix}.ffw_layers.{i}."
-        hdn = F.relu(F.linear(x, P[f + "linear1.weight"], P[f + "linear1.bias"]))
+        hdn = relu(F.linear(x, P[f + "linear1.weight"], P[f + "linear1.bias"]), f + "linear1")
         x = layer_norm(x + F.linear(hdn, P[f + "linear2.weight"], P[f + "linear2.bias"]), P[f + "norm.weight"],
                        P[f + "norm.bias"])
         outs.append(x)
@@ -145,7 +156,7 @@ def parallel_attention_layer(P, prefix, seq1, seq1_mask, seq2, H, seq1_xyz=None,
         seq1 = layer_norm(seq1 + _drop(o, drop, sb + 3), P[prefix + ".norm_1.weight"], P[prefix + ".norm_1.bias"])
     if apply_ffn:
         y = ada_or_id(seq1, "adaln_ff1")
-        hdn = _drop(F.relu(F.linear(y, P[prefix + ".ffn_12.0.weight"], P[prefix + ".ffn_12.0.bias"])), drop, sb + 4)
+        hdn = _drop(relu(F.linear(y, P[prefix + ".ffn_12.0.weight"], P[prefix + ".ffn_12.0.bias"]), prefix + ".ffn_12.0"), drop, sb + 4)
         ffn = _drop(F.linear(hdn, P[prefix + ".ffn_12.3.weight"], P[prefix + ".ffn_12.3.bias"]), drop, sb + 5)
         seq1 = layer_norm(y + ffn, P[prefix + ".norm_122.weight"], P[prefix + ".norm_122.bias"])
     return seq1
@@ -161,7 +172,7 @@ def parallel_attention(P, prefix, n_layers, seq1, seq1_mask, seq2, H, **kw):
 def mlp2(x, P, prefix, i0="0", i1="2", drop=None, name_root="prediction_head."):
     """Linear-ReLU-Linear heads (act3d.py:162-166; diffusion_head.py:41-46 uses indices 0 and 3, with an nn.Dropout(0.1)
     between the ReLU and the second Linear: `drop` applies it, site = (module path, 4))."""
-    hdn = F.relu(F.linear(x, P[f"{prefix}.{i0}.weight"], P[f"{prefix}.{i0}.bias"]))
+    hdn = relu(F.linear(x, P[f"{prefix}.{i0}.weight"], P[f"{prefix}.{i0}.bias"]), f"{prefix}.{i0}")
     if drop is not None:
         hdn = _drop(hdn, drop, drop.site_id(prefix[len(name_root):] if prefix.startswith(name_root) else prefix, 4))
     return F.linear(hdn, P[f"{prefix}.{i1}.weight"], P[f"{prefix}.{i1}.bias"])

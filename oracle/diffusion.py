@@ -267,6 +267,8 @@ def planner_loss(P, sched, gt_trajectory, traj_mask, ctx_feats, ctx_xyz_world, i
     gt, cg, gg = convert_rot(gt), convert_rot(cg), convert_rot(gg)
     noisy = sched.add_noise(gt, noise, timesteps)
     pred = head_forward(P, noisy, traj_mask, timesteps, ctx_feats, cxyz, cg, gg, instruction, H, drop=drop)
+    if OB.KINKS is not None:
+        OB.KINKS.append(("l1", (pred - gt).detach().abs().min().item()))
     loss = 100 * F.l1_loss(pred[..., :3], gt[..., :3]) + 10 * F.l1_loss(pred[..., 3:9], gt[..., 3:9])
     return loss, pred, gt
 

@@ -151,10 +151,11 @@ def test_mlp_with_dropout_vs_twin(a3d, dev):
     report("dropout ffn d ln_g", gd.grad, cg.grad, 1e-4, 1e-4)
 
 
-def _planner_dropout_draw(a3d, dev, r, seed):
+def _planner_dropout_draw(a3d, dev, r, seed, cfg=None, input_seed=None):
     """One draw of the dropout masks (generator seed `seed`): device loss + gradients against the oracle applying the twin's
-    masks.  Returns (model, device loss, oracle loss, {parameter: (max-abs error of scale, relative L2 error)})."""
-    cfg = r["cfg"]
+    masks.  Returns (model, inputs, tokens, device loss, oracle loss, {parameter: (max-abs error of scale, relative L2 error)},
+    the oracle's minimum distance from a ReLU / L1 kink)."""
+    cfg = dict(r["cfg"], image=256) if cfg is None else cfg
     m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
                              use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
                              gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100,
@@ -162,7 +163,8 @@ def _planner_dropout_draw(a3d, dev, r, seed):
     Pc = _diffusion_params(r)
     m.load_state_dict(Pc, strict=False)
     m.to(dev).train()
-    inp = C.trajectory_inputs(r["seed"], cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"])
+    inp = C.trajectory_inputs(r["seed"] if input_seed is None else input_seed, cfg["B"], cfg["L"], cfg["ncam"], cfg["E"],
+                              image=cfg["image"], pad_last=cfg["pad_last"])
     tokens = C.tokens_from_maps(inp["fmap"])
     d = {k: v.to(dev) for k, v in inp.items()}
     for p_ in m.parameters():
@@ -177,9 +179,14 @@ def _planner_dropout_draw(a3d, dev, r, seed):
     pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
     cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
     twin = OS.DropoutTwin(seed, 0, 0.1)
-    oloss, _, _ = OD.planner_loss(P, OD.DDPMSchedules(100), inp["trajectory"], inp["mask"], tokens, None, inp["instr"],
-                                  inp["curr_gripper"], inp["goal_gripper"], bounds, inp["noise"], inp["timesteps"], 8,
-                                  ctx_xyz_norm=cxyz_n, drop=twin)
+    OB.KINKS = []
+    try:
+        oloss, _, _ = OD.planner_loss(P, OD.DDPMSchedules(100), inp["trajectory"], inp["mask"], tokens, None, inp["instr"],
+                                      inp["curr_gripper"], inp["goal_gripper"], bounds, inp["noise"], inp["timesteps"], 8,
+                                      ctx_xyz_norm=cxyz_n, drop=twin)
+        margin = min(v for _, v in OB.KINKS)
+    finally:
+        OB.KINKS = None
     oloss.backward()
     named = dict(m.named_parameters())
     errs = {}
@@ -189,39 +196,48 @@ def _planner_dropout_draw(a3d, dev, r, seed):
         ref, got = p_.grad, named[n].grad.cpu()
         errs[n] = ((got - ref).abs().max().item() / max(1e-3, ref.abs().max().item()),
                    (got - ref).norm().item() / max(1e-6, ref.norm().item()))
-    return m, d, tokens, loss.item(), oloss.item(), errs
+    return m, d, tokens, loss.item(), oloss.item(), errs, margin
 
 
 def test_planner_training_step_with_dropout_vs_oracle(a3d, dev):
-    """DiffusionPlanner.forward in train() with the reference's p = 0.1: loss and EVERY parameter gradient against the oracle
-    applying the twin masks; a second forward pass draws different masks (the generator advanced on the device).
+    """DiffusionPlanner.forward in train() with the reference's p = 0.1 (layers.py:115-218, diffusion_model.py:286-324): loss
+    and EVERY parameter gradient against the oracle applying the twin masks -- ONE draw, no retry.
 
-    Gradients of a ReLU network are only defined away from the kinks: a hidden unit whose pre-activation is within the forward
-    rounding (~1e-6) of zero is ON in one evaluation and OFF in the other, which changes its whole backward contribution
-    (seen as one row of a first-FFN-linear gradient off by 2e-2 and everything upstream of it by 4e-3 ... 2e-2, with the layers
-    behind it at 1e-5).  With ~1e6 hidden units in this step that happens in roughly every second draw of the masks -- between
-    any two correct evaluations, the reference's own CPU and GPU runs included.  Independent draws are independent coin flips,
-    a wrong kernel fails all of them: so the loss must agree on EVERY draw, and the gradients -- relative L2 <= 1.5e-3 on every
-    parameter, max-abs <= 1.5e-2 of scale -- on at least one of up to four draws (each draw's worst numbers are printed)."""
+    Gradients of a ReLU / L1 network are only defined away from the kinks: a hidden unit whose pre-activation is within the
+    forward rounding (~1e-6) of zero is ON in one evaluation and OFF in the other, which changes its whole backward
+    contribution -- between any two correct evaluations, the reference's own CPU and GPU runs included.  So the case is CHOSEN
+    away from the kinks: tests/golden/make_dropout_case.py searched (input seed, dropout seed) pairs on the CPU oracle for a
+    draw whose smallest |ReLU argument| and smallest |pred - target| over the whole step exceed 1e-4 (dropout_case.pt; a 4 x 4
+    feature map keeps the number of hidden units at ~1e5 so that such a draw exists).  The margin is re-measured here with the
+    same oracle hook and asserted, then every parameter must be within 1.5e-3 relative L2 and 1.5e-2 max-abs of scale.
+    The full-size golden shape (1024 context tokens, ~2e6 hidden units: no kink-free draw exists) keeps its LOSS check and a
+    statement of how many parameters a kink flip moved."""
     r = load("diffusion.pt")
-    good = None
-    for seed in (4242, 4243, 4244, 4245):
-        m, d, tokens, loss, oloss, errs = _planner_dropout_draw(a3d, dev, r, seed)
-        print(f"[parity] dropout train loss (draw {seed}): {loss:.6f} vs oracle {oloss:.6f}")
-        assert abs(loss - oloss) <= 1e-3 * max(1.0, abs(oloss))
-        assert abs(oloss - r["train_loss"].item()) > 1e-2, "the dropped loss must differ from the p = 0 golden"
-        worst = max(errs.items(), key=lambda kv: kv[1][1])
-        over = [n for n, (e, l2) in errs.items() if not (e <= 1.5e-2 and l2 <= 1.5e-3)]
-        print(f"[parity] dropout train gradients (draw {seed}): worst relative L2 {worst[1][1]:.3e} ({worst[0]}), worst max-abs "
-              f"{max(e for e, _ in errs.values()):.3e} of scale, {len(over)} of {len(errs)} parameters over the bound")
-        if not over:
-            good = (m, d, tokens, loss)
-            break
-    assert good is not None, "no draw of the masks gave gradients within 1.5e-3 (relative L2) of the oracle"
-    m, d, tokens, loss = good
+    case = load("dropout_case.pt")
+    m, d, tokens, loss, oloss, errs, margin = _planner_dropout_draw(a3d, dev, r, case["drop_seed"], cfg=case["cfg"],
+                                                                    input_seed=case["input_seed"])
+    print(f"[parity] dropout train step (kink-free case: input seed {case['input_seed']}, dropout seed {case['drop_seed']}): loss "
+          f"{loss:.6f} vs oracle {oloss:.6f}; oracle margin from the nearest kink {margin:.3e} (stored {case['margin']:.3e})")
+    assert margin >= 0.5 * case["bound"], "the stored case is no longer away from the ReLU / L1 kinks on this host"
+    assert abs(oloss - case["loss"].item()) <= 1e-4 * abs(oloss), "the oracle does not reproduce the stored case"
+    assert abs(loss - oloss) <= 1e-3 * max(1.0, abs(oloss))
+    worst = max(errs.items(), key=lambda kv: kv[1][1])
+    over = [n for n, (e, l2) in errs.items() if not (e <= 1.5e-2 and l2 <= 1.5e-3)]
+    print(f"[parity] dropout train gradients (one draw): worst relative L2 {worst[1][1]:.3e} ({worst[0]}), worst max-abs "
+          f"{max(e for e, _ in errs.values()):.3e} of scale, {len(over)} of {len(errs)} parameters over the bound")
+    assert len(errs) > 200 and not over, over[:5]
+    # the generator advanced on the device: a second pass draws different masks; eval mode drops nothing
     loss2 = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
               noise=d["noise"], timesteps=d["timesteps"], visual_tokens=tokens.to(dev))
     assert abs(loss2.item() - loss) > 1e-4, "second pass drew the same masks"
+    # ---- the golden shape (B = 2, L = 8, 1024 context tokens): loss on one draw; gradient statistics reported, not gated
+    m, d, tokens, loss, oloss, errs, margin = _planner_dropout_draw(a3d, dev, r, 4242)
+    print(f"[parity] dropout train loss (golden shape, draw 4242): {loss:.6f} vs oracle {oloss:.6f}; oracle margin {margin:.3e}")
+    assert abs(loss - oloss) <= 1e-3 * max(1.0, abs(oloss))
+    assert abs(oloss - r["train_loss"].item()) > 1e-2, "the dropped loss must differ from the p = 0 golden"
+    over = [n for n, (e, l2) in errs.items() if not (e <= 1.5e-2 and l2 <= 1.5e-3)]
+    print(f"[parity] dropout train gradients (golden shape, margin {margin:.1e} < rounding => kink flips possible): {len(over)} of "
+          f"{len(errs)} parameters over the 1.5e-3 bound, worst relative L2 {max(l2 for _, l2 in errs.values()):.3e}")
     m.eval()
     with torch.no_grad():
         le = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],

@@ -478,3 +478,18 @@ def test_fp8_oracle_equals_torch_float8_e4m3fn():
     assert np.array_equal(fp8.e4m3_bytes(np.float32([1000.0, -1e9])), np.uint8([0x7E, 0xFE]))        # saturation
     ek, ev = fp8.attention_scales(np.float32([8.0, 0.3]), np.float32([3.0, 40.0]), np.float32([1.75, 0.01]))
     assert ek.tolist() == [-1, 3] and ev.tolist() == [7, 14]
+
+
+def test_dropout_case_is_away_from_every_relu_and_l1_kink():
+    """tests/golden/dropout_case.pt (tests/golden/make_dropout_case.py): the oracle, re-run with the kink hook of
+    oracle/blocks.py, reproduces the stored loss and keeps every ReLU argument and every L1 residual of the p = 0.1 training
+    step at least `bound` = 1e-4 away from zero -- the precondition of the single-draw gradient test on the GPU."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_dropout_case as MD
+    case = load("dropout_case.pt")
+    P = _diffusion_params(load("diffusion.pt"))
+    with torch.no_grad():
+        loss, margin, site, *_ = MD.oracle_case(P, case["cfg"], case["input_seed"], case["drop_seed"])
+    assert case["bound"] == MD.MARGIN and case["margin"] > case["bound"]
+    assert margin >= 0.5 * case["bound"], (margin, site)
+    assert abs(loss.item() - case["loss"].item()) <= 1e-5 * abs(loss.item())
