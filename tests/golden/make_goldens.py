@@ -623,7 +623,195 @@ def golden_dataset():
     save("dataset.pt", out)
 
 
+# ------------------------------------------------------------------------------------------------------ harness rows (f-4)
+class _DictWriter:
+    """Stand-in for tensorboard's SummaryWriter (absent here): records what the reference's harness logs."""
+
+    def __init__(self):
+        self.scalars, self.images = {}, []
+
+    def add_scalar(self, key, value, step):
+        self.scalars[key] = (float(value), int(step))
+
+    def add_image(self, key, img, step):
+        self.images.append(key)
+
+
+def _init_single_process_group():
+    import tempfile
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="file://" + tempfile.mktemp(), rank=0, world_size=1)
+
+
+def _reference_engine():
+    """The reference's own engine.py (BaseTrainTester.save_checkpoint / load_checkpoint / get_optimizer), imported under
+    another name with torch.utils.tensorboard stubbed (refimport replaces `engine` by an inert placeholder for the model
+    imports)."""
+    import importlib.util
+    import types
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = _DictWriter
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    spec = importlib.util.spec_from_file_location("ref_engine_real", "/root/reference/engine.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def golden_harness():
+    """f-4: records produced by the REFERENCE'S OWN harness code on seeded inputs --
+      keypose:    main_keypose.TrainTester.evaluate_nsteps (main_keypose.py:236-281) over two batches, free-running eval
+                  forward of the reference Act3D (numpy ghost sampler seeded), every scalar it logs + its return value;
+      trajectory: main_trajectory.TrainTester.evaluate_nsteps (main_trajectory.py:206-274) over two batches with two task
+                  names (per-task keys), 100-step sampling with injected noise;
+      checkpoint: engine.BaseTrainTester.get_optimizer + one AdamW step + save_checkpoint (engine.py:89-102,214-230): the
+                  file's structure, every tensor's (sum, abs-sum) and a few whole tensors -- not the 80 MB file.
+    The product's KeyposeTrainTester / TrajectoryTrainTester / engine.save_checkpoint are compared with these on the GPU."""
+    import types
+    _init_single_process_group()
+    out = {}
+    # ---- keypose evaluate_nsteps
+    E, levels, ncam, Ng, B = 60, 2, 1, 48, 2
+    for attempt in range(60):
+        seed, gain = 300 + attempt, 3.0
+        m, _ = build_ref_act3d(E, levels, ncam, Ng, False, seed, gain, Ng_val=Ng)
+        m.eval()
+        batches = [C.keypose_inputs(seed + 1000 * (j + 1), B, ncam, E, levels) for j in range(2)]
+        state = {"j": 0}
+
+        def fake(visible_rgb, visible_pcd, num_cameras, m=m, batches=batches, state=state):
+            import einops
+            inp = batches[state["j"]]
+            pcd = einops.rearrange(visible_pcd, "bt ncam c h w -> (bt ncam) c h w")
+            feats, poss, pcds = [], [], []
+            for i in range(m.num_sampling_level):
+                p_ = F.interpolate(pcd, scale_factor=1. / m.downscaling_factor_pyramid[i], mode='bilinear')
+                p_ = einops.rearrange(p_, "(bt ncam) c h w -> bt (ncam h w) c", ncam=num_cameras)
+                feats.append(inp["feats"][i])
+                poss.append(m.relative_pe_layer(p_))
+                pcds.append(p_)
+            return feats, poss, pcds
+        m._compute_visual_features = fake
+        gaps = []
+        orig_forward = m.forward
+
+        def spy(*a, m=m, orig_forward=orig_forward, gaps=gaps, state=state, **k):
+            o = orig_forward(*a, **k)
+            for masks in o["ghost_pcd_masks_pyramid"]:
+                top2 = masks[-1].topk(2, dim=-1).values
+                gaps.append((top2[:, 0] - top2[:, 1]).min().item())
+            state["j"] += 1
+            return o
+        m.forward = spy
+        loader = [{"rgbs": torch.zeros(B, ncam, 3, 256, 256), "pcds": b_["pcd"], "instr": b_["instr"], "curr_gripper": b_["curr_gripper"],
+                   "action": b_["action"], "task": ["task_a", "task_b"]} for b_ in batches]
+        tester = R.main_keypose.TrainTester.__new__(R.main_keypose.TrainTester)
+        tester.args = types.SimpleNamespace()
+        tester.writer = _DictWriter()
+        crit = R.main_keypose.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query",
+                                             ground_truth_gaussian_spread=0.01)
+        np.random.seed(seed)
+        ret = tester.evaluate_nsteps(m, crit, loader, step_id=7, val_iters=5, split="val")
+        if min(gaps) > 1e-2:
+            break
+    else:
+        raise RuntimeError("no keypose harness seed with a safe top-2 logit gap")
+    print("harness keypose seed", seed, "gaps", gaps, "scalars", len(tester.writer.scalars))
+    out["keypose"] = dict(cfg=dict(E=E, levels=levels, ncam=ncam, Ng=Ng, B=B), seed=seed, gain=gain, batch_seeds=[seed + 1000, seed + 2000],
+                          np_seed=seed, step_id=7, scalars=dict(tester.writer.scalars), returned=ret, gaps=gaps)
+    # ---- trajectory evaluate_nsteps
+    E, B, Ln, ncam = 120, 2, 8, 1
+    m = R.dm.DiffusionPlanner(backbone="clip", image_size=(256, 256), embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2,
+                              num_query_cross_attn_layers=6, use_instruction=True, use_goal=True, use_goal_at_test=True,
+                              feat_scales_to_use=1, attn_rounds=1, weight_tying=True, gripper_loc_bounds=C.DIFFUSION_BOUNDS,
+                              rotation_parametrization="6D", diffusion_timesteps=100)
+    shapes, alias = C.unique_param_shapes(m)
+    seed = 77
+    res = m.load_state_dict(C.expand_aliases(C.seeded_state_dict(shapes, seed, gain=1.5), alias), strict=False)
+    assert not res.unexpected_keys
+    m.eval()
+    tb = [C.trajectory_inputs(seed + 10 * (j + 1), B, Ln, ncam, E, pad_last=2) for j in range(2)]
+    state = {"j": 0}
+
+    def fake_encode_images(rgb, pcd):
+        import einops
+        p_ = einops.rearrange(pcd, "bt ncam c h w -> (bt ncam) c h w")
+        p_ = F.interpolate(p_, scale_factor=1. / 8, mode='bilinear')
+        p_ = einops.rearrange(p_, "(bt ncam) c h w -> bt (ncam h w) c", ncam=ncam)
+        return [tb[state["j"]]["fmap"]], [p_]
+    m.prediction_head.encode_images = fake_encode_images
+    loader = [{"trajectory": b_["trajectory"], "trajectory_mask": b_["mask"], "rgbs": torch.zeros(B, ncam, 3, 256, 256), "pcds": b_["pcd"],
+               "instr": b_["instr"], "curr_gripper": b_["curr_gripper"], "action": b_["goal_gripper"], "task": ["task_a", "task_b"]}
+              for b_ in tb]
+    tester = R.main_trajectory.TrainTester.__new__(R.main_trajectory.TrainTester)
+    tester.args = types.SimpleNamespace()
+    tester.writer = _DictWriter()
+    tester.synchronize_between_processes = lambda d: d          # BaseTrainTester's (engine.py:232-246) is the identity on one process
+    crit = R.main_trajectory.TrajectoryCriterion()
+    orig_forward = m.forward
+
+    def fwd(*a, **k):
+        inp = tb[state["j"]]
+        sn = inp["step_noise"]
+        m.position_noise_scheduler.injected_noise = {t: sn[t][..., :3] for t in range(100)}
+        m.rotation_noise_scheduler.injected_noise = {t: sn[t][..., 3:] for t in range(100)}
+        with patched_rng([inp["init_noise"]], inp["timesteps"]):
+            o = orig_forward(*a, **k)
+        state["j"] += 1
+        return o
+    m.forward = fwd
+    # the matplotlib / cv2 trajectory plot of the first batch is out of scope (cv2 is a stub here): a placeholder image
+    R.main_trajectory.generate_visualizations = lambda pred, gt, mask: np.zeros((3, 4, 4), dtype=np.uint8)
+    ret = tester.evaluate_nsteps(m, crit, loader, step_id=11, val_iters=5, split="val")
+    print("harness trajectory scalars", len(tester.writer.scalars), "returned", ret)
+    out["trajectory"] = dict(cfg=dict(E=E, B=B, L=Ln, ncam=ncam, pad_last=2), seed=seed, gain=1.5, batch_seeds=[seed + 10, seed + 20],
+                             step_id=11, scalars=dict(tester.writer.scalars), returned=ret, images=list(tester.writer.images))
+    # ---- checkpoint written by the reference's engine
+    import tempfile
+    from pathlib import Path
+    RE = _reference_engine()
+    m, _ = build_ref_act3d(60, 2, 1, 48, False, 300, 3.0, Ng_val=48)
+    for p_ in m.backbone.parameters():
+        p_.requires_grad = False
+    bt = RE.BaseTrainTester.__new__(RE.BaseTrainTester)
+    with tempfile.TemporaryDirectory() as td:
+        bt.args = types.SimpleNamespace(lr=1e-4, log_dir=Path(td))
+        opt = bt.get_optimizer(m)
+        g = torch.Generator().manual_seed(5)
+        unused = [n for n, p_ in m.named_parameters() if "feature_pyramid" in n and (".1.0." in n or ".3.0." in n or ".4.0." in n)]
+        for n, p_ in m.named_parameters():
+            if p_.requires_grad and n not in unused:
+                p_.grad = torch.randn(p_.shape, generator=g) * 0.01
+        opt.step()
+        best = bt.save_checkpoint(m, opt, step_id=4, new_loss=None, best_loss=None)
+        files = sorted(os.listdir(td))
+        ck = torch.load(os.path.join(td, "last.pth"), map_location="cpu", weights_only=False)
+    chk = lambda t: (float(t.double().sum()), float(t.double().abs().sum()))
+    names = [n for n, _ in m.named_parameters()]
+    ostate = ck["optimizer"]["state"]
+    # torch.optim state indices -> parameter names, through the optimizer's own groups (engine.py:89-102: "bias" group first)
+    by_id = {id(p_): n for n, p_ in m.named_parameters()}
+    group_names = [[by_id[id(p_)] for p_ in g_["params"]] for g_ in opt.param_groups]
+    index_name = [n for g_ in group_names for n in g_]
+    nb = lambda n: not n.startswith("backbone")
+    out["checkpoint"] = dict(
+        files=files, keys=sorted(ck.keys()), iter=ck["iter"], best_loss=ck["best_loss"], returned_best=best,
+        weight_keys=[k for k in ck["weight"].keys() if nb(k)],
+        weight_checksums={k: chk(v) for k, v in ck["weight"].items() if nb(k) and "feature_pyramid" not in k and v.dtype.is_floating_point},
+        param_group_options=[{k: v for k, v in g_.items() if k != "params"} for g_ in ck["optimizer"]["param_groups"]],
+        group_sizes=[len(g_["params"]) for g_ in ck["optimizer"]["param_groups"]],
+        group_names=[[n for n in g_ if nb(n)] for g_ in group_names],
+        state_by_name={index_name[int(i)]: dict(step=float(st["step"]), exp_avg=chk(st["exp_avg"]), exp_avg_sq=chk(st["exp_avg_sq"]))
+                       for i, st in ostate.items()},
+        named_parameters=[n for n in names if nb(n)], unused=unused, grad_seed=5, grad_scale=0.01,
+        model=dict(E=60, levels=2, ncam=1, Ng=48, seed=300, gain=3.0),
+        samples={k: ck["weight"][k].clone() for k in ("query_embed.weight", "gripper_state_predictor.2.bias")})
+    print("harness checkpoint: files", files, "state entries", len(ostate), "of", len(names))
+    save("harness.pt", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "diffusion_multi", "optimizer", "metrics", "dataset"]
+    which = sys.argv[1:] or ["blocks", "sampling", "act3d", "act3d_cfg1", "act3d_options", "diffusion", "diffusion_multi", "optimizer", "metrics", "dataset", "harness"]
     for w in which:
         globals()["golden_" + w]()

@@ -212,3 +212,149 @@ def test_keypose_train_tester_main_end_to_end(a3d, dev, tmp_path):
         if not n1.startswith("backbone"):
             assert n1 == n2 and torch.equal(p1, p2), n1
     assert "val-losses/mean/pos_l2_final" in tt2.scalars
+
+
+# ---------------------------------------------------------------------------------------------- reference-produced harness records
+def _harness():
+    return torch.load(os.path.join(HERE, "golden", "harness.pt"), weights_only=False)
+
+
+def _ref_seeded_act3d(a3d, dev, hk, train=False, **kw):
+    from test_act3d_gpu import build_model
+    from test_oracle_golden import _act3d_case, act3d_params
+    names = _act3d_case("train_L3_C1_N64")[2]
+    cfg = dict(hk["cfg"], use_instruction=False, image=256)
+    P = act3d_params(cfg, hk["seed"], hk["gain"], names)
+    return build_model(a3d, dev, cfg, P, cfg["Ng"], train, **kw), cfg
+
+
+def test_keypose_evaluate_nsteps_reproduces_the_reference_harness_record(a3d, dev):
+    """tests/golden/harness.pt["keypose"] is what the REFERENCE's main_keypose.TrainTester.evaluate_nsteps (main_keypose.py:236-281)
+    logged and returned for two seeded batches through the reference Act3D (numpy ghost sampler, injected FPN outputs).  The
+    product driver on the same batches, the same parameters and the same numpy seed must log the same keys with the same
+    values at the same step, and return the same thing (None: the reference looks up a key no keypose metric has)."""
+    hk = _harness()["keypose"]
+    m, cfg = _ref_seeded_act3d(a3d, dev, hk, ghost_sampler="numpy")
+    B, ncam, E, levels = cfg["B"], cfg["ncam"], cfg["E"], cfg["levels"]
+    batches, feats = [], []
+    for s_ in hk["batch_seeds"]:
+        inp = C.keypose_inputs(s_, B, ncam, E, levels)
+        maps = [inp["feats"][0]] + [inp["feats"][1]] * (levels - 1)
+        feats.append([C.tokens_from_maps(f.to(dev)) for f in maps])
+        batches.append({"rgbs": torch.zeros(B, ncam, 3, 8, 8, device=dev), "pcds": inp["pcd"].to(dev), "instr": inp["instr"].to(dev),
+                        "curr_gripper": inp["curr_gripper"].to(dev), "action": inp["action"].to(dev), "task": ["task_a", "task_b"]})
+    state = {"j": 0}
+    m.compute_visual_tokens = lambda rgb: feats[state["j"]]
+    m.register_forward_hook(lambda mod, args, out: state.__setitem__("j", state["j"] + 1))
+    crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    tt = a3d.KeyposeTrainTester(types.SimpleNamespace(log_dir=None))
+    np.random.seed(hk["np_seed"])
+    ret = tt.evaluate_nsteps(m, crit, batches, step_id=hk["step_id"], val_iters=5, split="val")
+    assert ret is hk["returned"] is None and state["j"] == 2
+    got = tt.scalars
+    assert set(got) == set(hk["scalars"]), sorted(set(got) ^ set(hk["scalars"]))
+    worst = 0.0
+    for k, (val, step) in hk["scalars"].items():
+        assert got[k][1] == step == hk["step_id"], k
+        err = abs(got[k][0] - val)
+        worst = max(worst, err / max(1.0, abs(val)))
+        assert err <= 1e-3 * max(1.0, abs(val)), (k, got[k][0], val)
+    print(f"[parity] keypose evaluate_nsteps vs the reference harness: {len(got)} scalars, worst error {worst:.2e} of scale")
+
+
+def test_trajectory_evaluate_nsteps_reproduces_the_reference_harness_record(a3d, dev):
+    """harness.pt["trajectory"]: the reference's main_trajectory.TrainTester.evaluate_nsteps (main_trajectory.py:206-274) over two
+    batches with two task names -- 100-step sampling with injected noise, summary + per-task keys, the returned
+    'val-losses/traj_action_mse'.  (Its tensorboard trajectory plot is out of scope.)"""
+    from test_oracle_golden import _diffusion_params, load
+    ht = _harness()["trajectory"]
+    cfg = ht["cfg"]
+    r = load("diffusion.pt")
+    assert (ht["seed"], ht["gain"]) == (r["seed"], r["gain"])          # the same seeded parameters as the diffusion goldens
+    m = a3d.DiffusionPlanner(embedding_dim=cfg["E"], output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100, dropout=0.0)
+    assert not m.load_state_dict(_diffusion_params(r), strict=False).unexpected_keys
+    m.to(dev)
+    batches, inject = [], []
+    for s_ in ht["batch_seeds"]:
+        inp = {k: v.to(dev) for k, v in C.trajectory_inputs(s_, cfg["B"], cfg["L"], cfg["ncam"], cfg["E"], pad_last=cfg["pad_last"]).items()}
+        batches.append({"trajectory": inp["trajectory"], "trajectory_mask": inp["mask"], "rgbs": torch.zeros(cfg["B"], cfg["ncam"], 3, 8, 8, device=dev),
+                        "pcds": inp["pcd"], "instr": inp["instr"], "curr_gripper": inp["curr_gripper"], "action": inp["goal_gripper"],
+                        "task": ["task_a", "task_b"]})
+        inject.append(dict(visual_tokens=C.tokens_from_maps(inp["fmap"]), init_noise=inp["init_noise"], step_noise=inp["step_noise"]))
+    state = {"j": 0}
+    sample_loop = m.compute_trajectory
+
+    def injected(*a, **k):
+        k.update(inject[state["j"]])
+        state["j"] += 1
+        return sample_loop(*a, **k)
+    m.compute_trajectory = injected
+    tt = a3d.TrajectoryTrainTester(types.SimpleNamespace(log_dir=None))
+    ret = tt.evaluate_nsteps(m, a3d.TrajectoryCriterion(), batches, step_id=ht["step_id"], val_iters=5, split="val")
+    got = tt.scalars
+    assert state["j"] == 2 and set(got) == set(ht["scalars"]), sorted(set(got) ^ set(ht["scalars"]))
+    worst = 0.0
+    for k, (val, step) in ht["scalars"].items():
+        assert got[k][1] == step, k
+        tol = 0.13 if "acc" in k else 2e-3 * max(1.0, abs(val))      # accuracies: one of 8-16 binary outcomes may sit on the threshold
+        err = abs(got[k][0] - val)
+        worst = max(worst, 0.0 if "acc" in k else err / max(1.0, abs(val)))
+        assert err <= tol, (k, got[k][0], val)
+    assert abs(ret - ht["returned"]) <= 2e-3 * max(1.0, abs(ht["returned"]))
+    print(f"[parity] trajectory evaluate_nsteps vs the reference harness: {len(got)} scalars, worst error {worst:.2e} of scale")
+
+
+def test_checkpoint_written_here_matches_the_one_the_reference_engine_wrote(a3d, dev, tmp_path):
+    """harness.pt["checkpoint"] describes last.pth as the REFERENCE's engine wrote it (BaseTrainTester.get_optimizer + one
+    torch.optim.AdamW step + save_checkpoint, engine.py:89-102,214-230) for a seeded Act3D and seeded gradients: file names, keys,
+    'iter' / 'best_loss', the two parameter groups (options and membership), which parameters carry optimizer state, every
+    hot-path tensor's (sum, abs-sum) of weight / exp_avg / exp_avg_sq and two whole tensors.  The product, driven the same
+    way (same parameters, same gradients, its own fused AdamW step, KeyposeTrainTester.save_checkpoint), must write the
+    same thing; FPN / backbone VALUES are not compared (the reference model draws them from the unseeded torch RNG)."""
+    hc = _harness()["checkpoint"]
+    m, _ = _ref_seeded_act3d(a3d, dev, dict(cfg=dict(hc["model"], B=2), seed=hc["model"]["seed"], gain=hc["model"]["gain"]), train=True)
+    named = [(n, p) for n, p in m.named_parameters() if not n.startswith("backbone")]
+    assert [n for n, _ in named] == hc["named_parameters"], "parameter names / order differ from the reference model's"
+    flat, opt = a3d.engine.get_optimizer(m, lr=1e-4)
+    g = torch.Generator().manual_seed(hc["grad_seed"])
+    flat.zero_grad()
+    for n, p in named:
+        if p.requires_grad and n not in hc["unused"]:
+            p.grad.copy_((torch.randn(p.shape, generator=g) * hc["grad_scale"]).to(dev))
+    opt.step()
+    tt = a3d.KeyposeTrainTester(types.SimpleNamespace(log_dir=str(tmp_path)))
+    best = tt.save_checkpoint(m, opt, 4, None, None)
+    assert best is hc["returned_best"] is None and sorted(os.listdir(tmp_path)) == hc["files"]
+    ck = torch.load(os.path.join(tmp_path, "last.pth"), map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == hc["keys"] and ck["iter"] == hc["iter"] and ck["best_loss"] == hc["best_loss"]
+    weight = {(k[7:] if k.startswith("module.") else k): v for k, v in ck["weight"].items()}       # DDP's prefix (engine.py:121-124)
+    assert [k for k in weight if not k.startswith("backbone")] == hc["weight_keys"]
+    chk = lambda t: (float(t.double().sum()), float(t.double().abs().sum()))
+    close = lambda a, b: abs(a[0] - b[0]) <= 2e-5 * max(1e-6, b[1]) and abs(a[1] - b[1]) <= 2e-5 * max(1e-6, b[1])
+    for k, ref in hc["weight_checksums"].items():
+        assert close(chk(weight[k]), ref), ("weight", k, chk(weight[k]), ref)
+    for k, t in hc["samples"].items():
+        assert torch.allclose(weight[k], t, rtol=0, atol=2e-6), k
+    groups = ck["optimizer"]["param_groups"]
+    for gp, ref in zip(groups, hc["param_group_options"]):
+        for key in ("weight_decay", "lr", "betas", "eps", "amsgrad"):
+            assert gp[key] == ref[key] or tuple(gp[key]) == tuple(ref[key]), (key, gp[key], ref[key])
+    index_name = [n for grp in flat.torch_groups for n in grp]
+    mine = [[index_name[i] for i in gp["params"] if not index_name[i].startswith("backbone")] for gp in groups]
+    assert mine == hc["group_names"], "AdamW group membership / order differs from the reference optimizer's"
+    state = {index_name[int(i)]: st for i, st in ck["optimizer"]["state"].items()}
+    assert set(state) == set(hc["state_by_name"]), sorted(set(state) ^ set(hc["state_by_name"]))[:6]
+    for n, ref in hc["state_by_name"].items():
+        assert float(state[n]["step"]) == ref["step"] == 1.0, n
+        if "feature_pyramid" in n:
+            continue
+        assert close(chk(state[n]["exp_avg"]), ref["exp_avg"]) and close(chk(state[n]["exp_avg_sq"]), ref["exp_avg_sq"]), n
+    # and the file loads back into a fresh product model + optimizer through the resume path
+    m2, _ = _ref_seeded_act3d(a3d, dev, dict(cfg=dict(hc["model"], B=2), seed=7, gain=1.0), train=True)
+    flat2, opt2 = a3d.engine.get_optimizer(m2, lr=1e-4)
+    it, bl = a3d.engine.load_checkpoint(os.path.join(tmp_path, "last.pth"), m2, opt2)
+    assert it == hc["iter"] and bl is None and torch.equal(flat2.flat, flat.flat) and torch.equal(opt2.exp_avg, opt.exp_avg)
+    assert torch.equal(opt2.param_steps, opt.param_steps)
+    print(f"[parity] checkpoint vs the reference engine's: {len(hc['weight_checksums'])} weight and {len(state)} optimizer-state entries agree")

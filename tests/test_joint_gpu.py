@@ -296,6 +296,8 @@ def _joint_vs_separate(E, joint, ks, ts, kcrit, tcrit, kA, kB, tA, tB, kfA, kfB,
         pd = (fa.flat - fb.flat).abs()
         print(f"[parity] joint vs separate {name}: grad diff {gd:.3e} (scale {gs:.3e}), parameter diff {pd[solid].max().item():.3e} on "
               f"solid-gradient elements, {pd.max().item():.3e} overall")
+        worst = sorted(((fa.grad[a:b] - fb.grad[a:b]).abs().max().item(), n) for n, (a, b) in fb.slices.items())[-3:]
+        print(f"[parity] joint vs separate {name}: largest per-parameter gradient differences " + ", ".join(f"{n} {d:.2e}" for d, n in worst))
         assert gd <= 2e-4 * gs
         assert pd[solid].max().item() <= 1e-6 and pd.max().item() <= 2.01e-4
     assert torch.equal(koA.step_count, koB.step_count) and torch.equal(toA.step_count, toB.step_count)
