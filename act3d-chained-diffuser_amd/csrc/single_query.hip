@@ -433,7 +433,8 @@ extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk
                                float* lse, float* o, int B, int S, int E, int H, int nsplit, void* stream) {
   int rc = sq_check("a3d_sq_attn_fwd", B, S, E, H, nsplit);
   if (rc) return rc;
-  if (!X || !Wk || !Wv || !qrot || !ws || !xbar || !lse || !o || (xyz && !freq) || ((((uintptr_t)X) & 15) != 0)) {
+  // o == NULL: stop after xbar / lse (the value projection runs in the caller's fused layer kernel, a3d_qs_post_fwd)
+  if (!X || !Wk || (o && !Wv) || !qrot || !ws || !xbar || !lse || (xyz && !freq) || ((((uintptr_t)X) & 15) != 0)) {
     set_error("a3d_sq_attn_fwd: null / misaligned pointer");
     return A3D_ERR_ARG;
   }
@@ -450,7 +451,7 @@ extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk
   if (rc) return rc;
   hipLaunchKernelGGL(sq_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, xbar, lse, B, H, E, nsplit);
   rc = check_launch("a3d_sq_attn_fwd(combine)");
-  if (rc) return rc;
+  if (rc || !o) return rc;
   hipLaunchKernelGGL(sq_vproj_kernel, dim3(cdiv(B * E, 256)), dim3(256), 0, s, xbar, Wv, ldwv, bv, o, B, H, E);
   return check_launch("a3d_sq_attn_fwd(vproj)");
 }
@@ -465,7 +466,8 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
                                int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
   int rc = sq_check("a3d_sq_attn_bwd", B, S, E, H, nsplit);
   if (rc) return rc;
-  if (!X || !Wk || !Wv || !qrot || !xbar || !lse || !dO || !ws || !dX || !dqp || !dWk || !dbk || !dWv || (xyz && !freq) ||
+  // dO == NULL: ws already holds dxbar | cD (written by a3d_qs_post_bwd, which also owns the value projection's gradients)
+  if (!X || !Wk || (dO && (!Wv || !dWv)) || !qrot || !xbar || !lse || !ws || !dX || !dqp || !dWk || !dbk || (xyz && !freq) ||
       ((((uintptr_t)X) & 15) != 0)) {
     set_error("a3d_sq_attn_bwd: null / misaligned pointer");
     return A3D_ERR_ARG;
@@ -474,9 +476,11 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
   float* dxbar = ws;
   float* cD = dxbar + (size_t)B * H * E;
   float* wpart = cD + (size_t)B * H;
-  hipLaunchKernelGGL(sq_vproj_bwd_kernel, dim3(B * H + E), dim3(64), 0, s, dO, xbar, Wv, ldwv, dxbar, cD, dWv, lddwv, dbv, B, H, E);
-  rc = check_launch("a3d_sq_attn_bwd(vproj)");
-  if (rc) return rc;
+  if (dO) {
+    hipLaunchKernelGGL(sq_vproj_bwd_kernel, dim3(B * H + E), dim3(64), 0, s, dO, xbar, Wv, ldwv, dxbar, cD, dWv, lddwv, dbv, B, H, E);
+    rc = check_launch("a3d_sq_attn_bwd(vproj)");
+    if (rc) return rc;
+  }
   const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

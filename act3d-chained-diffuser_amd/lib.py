@@ -33,6 +33,10 @@ DnTailParams = _struct("DnTailParams", [(n, _p) for n in (
     "pos_w0", "pos_b0", "pos_w1", "pos_b1", "rot_w0", "rot_b0", "rot_w1", "rot_b1", "noise", "cond_data", "cond_mask", "coef_pos",
     "coef_rot")])
 
+# parameter / gradient blocks of the fused query-stream layer (a3d_qs_params / a3d_qs_grads)
+QsParams = _struct("QsParams", [(n, _p) for n in ("wv", "bv", "wo", "bo", "g1", "b1", "w1", "c1", "w2", "c2", "g2", "b2")])
+QsGrads = _struct("QsGrads", [(n, _p) for n in ("dwv", "dbv", "dwo", "dbo", "dg1", "db1", "dw1", "dc1", "dw2", "dc2", "dg2", "db2")])
+
 # name -> (restype, argtypes); mirrors include/act3d_hip.h one to one
 SIGNATURES = {
     "a3d_version": (_i, []),
@@ -70,6 +74,11 @@ SIGNATURES = {
     "a3d_sq_bwd_ws_floats": (_z, [_i, _i, _i, _i]),
     "a3d_sq_attn_bwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
                              _i, _p]),
+    "a3d_qs_pre_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
+    "a3d_qs_pre_bwd": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "a3d_qs_save_floats": (_z, [_i, _i]),
+    "a3d_qs_post_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "a3d_qs_post_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_sq_wgrad_reduce": (_i, [_p, _i, _p, _i, _p, _i, _p]),
     "a3d_dn_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "a3d_dn_cross_ws_floats": (_z, [_i, _i, _i]),

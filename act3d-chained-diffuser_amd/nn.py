@@ -68,7 +68,15 @@ class RelativeCrossAttentionModule(nn.Module):
         """Returns the list of per-layer outputs (layers.py:345-351), batch-first."""
         output = []
         for attn, ffw in zip(self.attn_layers, self.ffw_layers):
-            query = ffw(attn(query, value, query_xyz, value_xyz))
+            mha = attn.multihead_attn
+            if O.query_layer_applicable(query, value, mha.embed_dim, attn.num_heads, ffw.linear1.out_features):
+                # the one-query stream: attention block + FFN of a layer as the fused launches of csrc/query_stream.hip
+                query = O.QueryLayerFn.apply(query, value, query_xyz, value_xyz, mha.in_proj_weight, mha.in_proj_bias,
+                                             mha.out_proj.weight, mha.out_proj.bias, attn.norm.weight, attn.norm.bias,
+                                             ffw.linear1.weight, ffw.linear1.bias, ffw.linear2.weight, ffw.linear2.bias,
+                                             ffw.norm.weight, ffw.norm.bias, attn.num_heads)
+            else:
+                query = ffw(attn(query, value, query_xyz, value_xyz))
             output.append(query)
         return output
 

@@ -631,6 +631,102 @@ class SingleQueryAttnBlockFn(torch.autograd.Function):
         return (d_q_in, dX if ctx.needs_input_grad[1] else None, dS.view(B, 1, E) if ctx.needs_input_grad[2] else None) + (None,) * 9
 
 
+QUERY_STREAM_FUSED = os.environ.get("A3D_QS_FUSED", "1") == "1"
+
+
+class QueryLayerFn(torch.autograd.Function):
+    """One layer of Act3D's query stream -- RelativeCrossAttentionLayer + FeedforwardLayer on ONE query per sample
+    (act3d.py:467-480, layers.py:293-351):  y = LN2(x1 + W2 relu(W1 x1)),  x1 = LN1(x + out_proj(MHA(x, ctx, ctx)))  -- as
+    csrc/query_stream.hip's fused launches around the key-streaming kernels of csrc/single_query.hip: 4 launches forward
+    (q projection + RoPE | keys | combine | everything after) and 4 backward, instead of 10 + 16 single-workgroup ones.
+    Same arithmetic as SingleQueryAttnBlockFn followed by MLPFn (exact-f32 MFMA products; summation order differs)."""
+
+    @staticmethod
+    def forward(ctx, x, kv_in, q_xyz, k_xyz, in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, H):
+        L.require_gpu(x, kv_in)
+        x, kv_in = _c(x), _c(kv_in)
+        B, _, E = x.shape
+        S = kv_in.shape[1]
+        dev = x.device
+        f4 = 4
+        if q_xyz is not None:
+            q_xyz, k_xyz = _c(q_xyz.to(F32)), _c(k_xyz.to(F32))
+        freq = rope_freq(E, dev)
+        scale = float(E // H) ** -0.5
+        wp, bp = in_w.data_ptr(), in_b.data_ptr()
+        nz = lambda t: None if t is None else t.data_ptr()
+        st = L.stream()
+        lib = L.load()
+        qrot = torch.empty((B, H, 1, 16), device=dev, dtype=F32)
+        L.call("a3d_qs_pre_fwd", x.data_ptr(), wp, bp, nz(q_xyz), freq.data_ptr(), scale, qrot.data_ptr(), B, E, H, st)
+        nsplit = max(1, min((S + 63) // 64, 1024 // B))
+        ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)
+        xbar = torch.empty((B, H, E), device=dev, dtype=F32)
+        lse = torch.empty((B, H), device=dev, dtype=F32)
+        L.call("a3d_sq_attn_fwd", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, None, E, None, qrot.data_ptr(),
+               freq.data_ptr(), ws.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, B, S, E, H, nsplit, st)
+        save = torch.empty((lib.a3d_qs_save_floats(B, E),), device=dev, dtype=F32)
+        y = torch.empty((B, 1, E), device=dev, dtype=F32)
+        qp = QueryLayerFn._params(in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, E)
+        L.call("a3d_qs_post_fwd", xbar.data_ptr(), x.data_ptr(), C_byref(qp), save.data_ptr(), y.data_ptr(), B, E, H, st)
+        ctx.save_for_backward(x, kv_in, qrot, xbar, lse, save,
+                              q_xyz if q_xyz is not None else torch.empty(0, device=dev),
+                              k_xyz if k_xyz is not None else torch.empty(0, device=dev))
+        ctx.params = (in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2)
+        ctx.meta = (B, S, E, H, scale, nsplit, q_xyz is not None)
+        return y
+
+    @staticmethod
+    def _params(in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, E):
+        f4 = 4
+        return L.QsParams(wv=in_w.data_ptr() + 2 * E * E * f4, bv=in_b.data_ptr() + 2 * E * f4, wo=out_w.data_ptr(), bo=out_b.data_ptr(),
+                          g1=g1.data_ptr(), b1=b1.data_ptr(), w1=w1.data_ptr(), c1=c1.data_ptr(), w2=w2.data_ptr(), c2=c2.data_ptr(),
+                          g2=g2.data_ptr(), b2=b2.data_ptr())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kv_in, qrot, xbar, lse, save, q_xyz, k_xyz = ctx.saved_tensors
+        in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2 = ctx.params
+        B, S, E, H, scale, nsplit, has_xyz = ctx.meta
+        dev = dy.device
+        f4 = 4
+        if not has_xyz:
+            q_xyz = k_xyz = None
+        freq = rope_freq(E, dev)
+        nz = lambda t: None if t is None else t.data_ptr()
+        st = L.stream()
+        lib = L.load()
+        gW, gb = grad_buf(in_w), grad_buf(in_b)
+        wp, bp = in_w.data_ptr(), in_b.data_ptr()
+        qp = QueryLayerFn._params(in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, E)
+        gr = L.QsGrads(dwv=gW.data_ptr() + 2 * E * E * f4, dbv=gb.data_ptr() + 2 * E * f4, dwo=grad_buf(out_w).data_ptr(),
+                       dbo=grad_buf(out_b).data_ptr(), dg1=grad_buf(g1).data_ptr(), db1=grad_buf(b1).data_ptr(),
+                       dw1=grad_buf(w1).data_ptr(), dc1=grad_buf(c1).data_ptr(), dw2=grad_buf(w2).data_ptr(), dc2=grad_buf(c2).data_ptr(),
+                       dg2=grad_buf(g2).data_ptr(), db2=grad_buf(b2).data_ptr())
+        ws = torch.empty((lib.a3d_sq_bwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)    # dxbar | cD | weight-gradient partials
+        dx = torch.empty((B, 1, E), device=dev, dtype=F32)
+        L.call("a3d_qs_post_bwd", _c(dy).data_ptr(), x.data_ptr(), xbar.data_ptr(), save.data_ptr(), C_byref(qp), C_byref(gr),
+               ws.data_ptr(), ws.data_ptr() + B * H * E * f4, dx.data_ptr(), B, E, H, st)
+        dX = torch.empty((B, S, E), device=dev, dtype=F32)
+        dqp = torch.empty((nsplit, B, H, 1, 16), device=dev, dtype=F32)
+        L.call("a3d_sq_attn_bwd", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, None, E, qrot.data_ptr(),
+               freq.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, ws.data_ptr(), dX.data_ptr(), dqp.data_ptr(),
+               gW.data_ptr() + E * E * f4, E, gb.data_ptr() + E * f4, None, E, None, B, S, E, H, nsplit, st)
+        L.call("a3d_qs_pre_bwd", dqp.data_ptr(), nsplit, nz(q_xyz), freq.data_ptr(), scale, x.data_ptr(), wp, gW.data_ptr(), gb.data_ptr(),
+               dx.data_ptr(), B, E, H, st)
+        return (dx if ctx.needs_input_grad[0] else None, dX if ctx.needs_input_grad[1] else None) + (None,) * 15
+
+
+def C_byref(struct):
+    import ctypes
+    return ctypes.byref(struct)
+
+
+def query_layer_applicable(query, value, E, H, hidden):
+    return (QUERY_STREAM_FUSED and SINGLE_QUERY and query.is_cuda and query.shape[1] == 1 and E <= 60 and E % 12 == 0 and H <= 4 and
+            H * 15 == E and hidden == E and value.dtype == F32 and query.dtype == F32)
+
+
 def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=None, site=0):
     """mha: module with in_proj_weight/in_proj_bias/out_proj; norm: LayerNorm-like with weight/bias.
 

@@ -171,13 +171,15 @@ int a3d_attn_bwd_bf16_dropout(const void* Qs, const void* Qt, const void* Ks, co
  *      materialised: o[b][h*15+d] = W_v[h*15+d] . xbar[b][h] + b_v with xbar = softmax-weighted mean of the raw context rows
  *      X [B][S][E] (16-byte aligned); the key projection W_k x + b_k (rows E..2E of in_proj), rotated by xyz (NULL: none), is
  *      recomputed per tile.  qrot: [B][H][16] rotated, scaled query (a3d_rope_rows_f32 with N = Npad = 1).  E = 15 H <= 60.
- *      Outputs xbar [B][H][E], lse [B][H] (saved for backward), o [B][E].  ws >= a3d_sq_fwd_ws_floats floats. ------------- */
+ *      Outputs xbar [B][H][E], lse [B][H] (saved for backward), o [B][E] (o NULL: skipped -- the fused layer kernel
+ *      a3d_qs_post_fwd projects the values).  ws >= a3d_sq_fwd_ws_floats floats. ------------- */
 size_t a3d_sq_fwd_ws_floats(int B, int H, int E, int nsplit);
 int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
                     const float* bv, const float* qrot, const float* freq, float* ws, float* xbar, float* lse, float* o, int B,
                     int S, int E, int H, int nsplit, void* stream);
 /* Backward: dX [B][S][E] (written), dqp [nsplit][B][H][16] (rotated-query gradient partials: a3d_rope_merge_bwd layout with
- * Npad = 1), dWk / dbk / dWv / dbv accumulated (+=).  ws >= a3d_sq_bwd_ws_floats floats. */
+ * Npad = 1), dWk / dbk / dWv / dbv accumulated (+=).  ws >= a3d_sq_bwd_ws_floats floats = dxbar [B][H][E] | cD [B][H] | weight
+ * gradient partials; dO NULL: the caller (a3d_qs_post_bwd) has already written dxbar and cD there and owns dWv / dbv. */
 size_t a3d_sq_bwd_ws_floats(int B, int H, int E, int nsplit);
 int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
                     const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
@@ -260,6 +262,36 @@ void a3d_sincos_host(const float* x, float* sn, float* cs, size_t n);
 int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, const long long* seg_off, float* seg_state,
                    int nseg, size_t n, size_t n_nodecay, float lr, float beta1, float beta2, float eps, float wd_nodecay,
                    float wd_decay, float grad_scale, void* stream);
+
+/* ---- Act3D query stream, fused per layer (csrc/query_stream.hip; act3d.py:467-480, layers.py:293-351) -------------------------
+ * One RelativeCrossAttentionLayer + FeedforwardLayer of the ONE-query-per-sample stream as four launches around a3d_sq_attn_fwd /
+ * a3d_sq_attn_bwd's key-streaming kernels.  E <= 60, E % 12 == 0, H = E / 15 <= 4, FFN hidden = E; all matrices row-major with
+ * row stride E (views into in_proj_weight etc.), fp32. */
+typedef struct {
+  const float *wv, *bv;            /* value rows [2E, 3E) of in_proj_weight / in_proj_bias */
+  const float *wo, *bo;            /* out_proj */
+  const float *g1, *b1;            /* RelativeCrossAttentionLayer.norm */
+  const float *w1, *c1, *w2, *c2;  /* FeedforwardLayer.linear1 / linear2 (weight, bias) */
+  const float *g2, *b2;            /* FeedforwardLayer.norm */
+} a3d_qs_params;
+typedef struct {                   /* gradient buffers of the same parameters, accumulated into (+=) */
+  float *dwv, *dbv, *dwo, *dbo, *dg1, *db1, *dw1, *dc1, *dw2, *dc2, *dg2, *db2;
+} a3d_qs_grads;
+/* qrot [B][H][16] = RoPE((W_q x + b_q) * scale, xyz): the rotated, scaled query a3d_sq_attn_fwd takes (xyz NULL: no rotation) */
+int a3d_qs_pre_fwd(const float* x, const float* wq, const float* bq, const float* xyz, const float* freq, float scale, float* qrot,
+                   int B, int E, int H, void* stream);
+/* from a3d_sq_attn_bwd's dqp [nsplit][B][H][16]: dW_q += dq^T x, db_q += sum dq, dx += dq W_q  (dx [B][E] in / out) */
+int a3d_qs_pre_bwd(const float* dqp, int nsplit, const float* xyz, const float* freq, float scale, const float* x, const float* wq,
+                   float* dwq, float* dbq, float* dx, int B, int E, int H, void* stream);
+/* xbar [B][H][E] (a3d_sq_attn_fwd) + resid [B][E] (the layer's input) -> y [B][E] = the layer's output; `save`
+ * (a3d_qs_save_floats(B, E) floats) keeps o | Y | y1 | h | o2 | LayerNorm statistics per row for the backward */
+size_t a3d_qs_save_floats(int B, int E);
+int a3d_qs_post_fwd(const float* xbar, const float* resid, const a3d_qs_params* p, float* save, float* y, int B, int E, int H,
+                    void* stream);
+/* dy [B][E] -> every parameter gradient of `p` (+=), dxbar [B][H][E] and cD [B][H] (= dxbar . xbar) for a3d_sq_attn_bwd's key
+ * pass, dresid [B][E] = the gradient of the residual branch w.r.t. the layer input */
+int a3d_qs_post_bwd(const float* dy, const float* resid, const float* xbar, const float* save, const a3d_qs_params* p,
+                    const a3d_qs_grads* gr, float* dxbar, float* cD, float* dresid, int B, int E, int H, void* stream);
 
 /* ---- DDPM trajectory denoiser (elementwise pieces) ------------------------------------------------------------ */
 /* x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) eps; channels [0,npos) use acp_pos, the rest acp_rot

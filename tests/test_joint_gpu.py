@@ -266,10 +266,12 @@ def test_joint_iteration_equals_the_two_steps_run_separately(a3d, dev):
 
 
 def _joint_vs_separate(E, joint, ks, ts, kcrit, tcrit, kA, kB, tA, tB, kfA, kfB, tfA, tfB, koA, koB, toA, toB):
-    # one settling iteration on both sides (MIOpen algorithm selection), then both put into the same state
-    joint(ks, ts)
-    E.train_one_step(kB, kcrit, koB, 0, ks)
-    E.train_one_step_trajectory(tB, tcrit, toB, 0, ts)
+    # two settling iterations on both sides (MIOpen may change a configuration's algorithm between its first calls: seen once as
+    # a 1e-2 bf16-accumulation-order difference of the FPN weight gradients in a full-suite run), then both into the same state
+    for _ in range(2):
+        joint(ks, ts)
+        E.train_one_step(kB, kcrit, koB, 0, ks)
+        E.train_one_step_trajectory(tB, tcrit, toB, 0, ts)
     with torch.no_grad():
         for fa, fb, oa, ob in ((kfA, kfB, koA, koB), (tfA, tfB, toA, toB)):
             fb.flat.copy_(fa.flat)

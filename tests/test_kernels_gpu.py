@@ -250,6 +250,59 @@ def test_attn_block_fwd_bwd(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
     report_grad(a3d, "attn_block d ln_b", norm.bias.grad, cb.grad, gtol * sc, 2e-3)
 
 
+@pytest.mark.parametrize("B,S,rope", [(3, 200, False), (70, 130, True), (64, 4097, True)])
+def test_query_stream_module_fused_layers_vs_oracle(a3d, dev, B, S, rope):
+    """nn.RelativeCrossAttentionModule on ONE query per sample (Act3D's query stream, act3d.py:467-480): the fused per-layer
+    launches of csrc/query_stream.hip (ops.QueryLayerFn) against oracle.rel_cross_attn_module -- both layers' outputs, the
+    gradients of the query, the context and every parameter -- and against the op-by-op device path it replaces
+    (SingleQueryAttnBlockFn + MLPFn; A3D_QS_FUSED=0).  B = 70 crosses the 64-row block of the single workgroup."""
+    O = a3d.ops
+    E, H, NL = 60, 4, 2
+    g = torch.Generator().manual_seed(B + S)
+    mod = a3d.nn.RelativeCrossAttentionModule(E, H, NL)
+    with torch.no_grad():
+        for n, p_ in mod.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.1 if p_.dim() == 1 else 1.4 / math.sqrt(p_.shape[-1])))
+            if n.endswith("norm.weight"):
+                p_.add_(1.0)
+    P = {"m." + n: p_.detach().clone().requires_grad_() for n, p_ in mod.named_parameters()}
+    q = torch.randn(B, 1, E, generator=g)
+    ctx = torch.randn(B, S, E, generator=g)
+    q_xyz = torch.rand(B, 1, 3, generator=g) * 2 - 0.5 if rope else None
+    k_xyz = torch.rand(B, S, 3, generator=g) * 2 - 0.5 if rope else None
+    cq, cc = q.clone().requires_grad_(), ctx.clone().requires_grad_()
+    outs = OB.rel_cross_attn_module(P, "m", NL, cq, cc, H, q_xyz, k_xyz)
+    dys = [torch.randn(B, 1, E, generator=g) for _ in range(NL)]
+    sum((o * d).sum() for o, d in zip(outs, dys)).backward()
+
+    def run(fused):
+        old = O.QUERY_STREAM_FUSED
+        O.QUERY_STREAM_FUSED = fused
+        try:
+            m = a3d.nn.RelativeCrossAttentionModule(E, H, NL).to(dev)
+            m.load_state_dict(mod.state_dict())
+            dq, dc = q.to(dev).requires_grad_(), ctx.to(dev).requires_grad_()
+            got = m(dq, dc, None if q_xyz is None else q_xyz.to(dev), None if k_xyz is None else k_xyz.to(dev))
+            sum((o * d.to(dev)).sum() for o, d in zip(got, dys)).backward()
+            return m, dq, dc, got
+        finally:
+            O.QUERY_STREAM_FUSED = old
+
+    m, dq, dc, got = run(True)
+    m0, dq0, dc0, got0 = run(False)
+    for i in range(NL):
+        report(f"query stream layer {i} fwd", got[i], outs[i], 1e-4)
+        report(f"query stream layer {i} fwd (fused vs op-by-op)", got[i], got0[i], 2e-5)
+    gtol = 5e-4
+    report_grad(a3d, "query stream d query", dq.grad, cq.grad, gtol, 1e-3)
+    report_grad(a3d, "query stream d context", dc.grad, cc.grad, gtol, 1e-3)
+    sc = max(1.0, math.sqrt(B * S) / 8)
+    named0 = dict(m0.named_parameters())
+    for n, p_ in m.named_parameters():
+        report_grad(a3d, f"query stream d {n}", p_.grad, P["m." + n].grad, gtol * sc, 2e-3)
+        report_grad(a3d, f"query stream d {n} (fused vs op-by-op)", p_.grad, named0[n].grad, 1e-4 * sc, 5e-4)
+
+
 @pytest.mark.parametrize("B,Lq,S,E,H,rope,masked,mode", [(2, 37, 131, 60, 4, True, False, "kv"), (2, 16, 70, 120, 8, True, True, "qk"),
                                                           (1, 130, 4097, 60, 4, True, False, "kv")])
 def test_attn_block_fwd_bwd_split_bf16_family(a3d, dev, B, Lq, S, E, H, rope, masked, mode):
