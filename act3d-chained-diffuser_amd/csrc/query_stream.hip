@@ -28,19 +28,57 @@ constexpr int QS_TILE = QS_R * QS_LD;
 // per-row record the forward leaves for the backward: o | Y | y1 | h | o2 (E each) | mean1 rstd1 mean2 rstd2
 __host__ __device__ constexpr int qs_save_width(int E) { return 5 * E + 4; }
 
-// T[64][QS_LD] <- rows r0.. of src (row stride ld, `cols` valid columns), zero beyond nrows / cols
-__device__ __forceinline__ void qs_load_rows(float* T, const float* __restrict__ src, int ld, int r0, int nrows, int cols) {
-  for (int i = threadIdx.x; i < QS_R * 64; i += blockDim.x) {
-    const int r = i >> 6, c = i & 63;
-    T[r * QS_LD + c] = (r0 + r < nrows && c < cols) ? src[(size_t)(r0 + r) * ld + c] : 0.f;
+// Tile loads are split into FETCH (global -> registers: every load of the tile issued back to back, branch-free clamped
+// addresses, so a tile costs ONE memory round trip; the first version's guarded scalar loop exposed sixteen -- 80-160 us per
+// kernel) and COMMIT (registers -> LDS), so that the next stage's tiles travel while the current stage computes.
+struct QsRows { float4 v[4]; };       // rows of a 64 x 64 activation tile: thread -> row t >> 2 (+ 64 rows / ... ), 16-byte columns
+struct QsWeight { float v[16]; };     // a 64 x 64 weight tile: only 4-byte aligned inside the flat parameter buffer
+
+// rows r0 .. r0 + 63 of src (row stride ld floats, `cols` valid columns, cols % 4 == 0, 16-byte aligned rows); zero elsewhere
+__device__ __forceinline__ QsRows qs_fetch_rows(const float* __restrict__ src, int ld, int r0, int nrows, int cols) {
+  QsRows q;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    const bool ok = r0 + r < nrows && c < cols;
+    const float4 t = *reinterpret_cast<const float4*>(src + (size_t)(ok ? r0 + r : 0) * ld + (ok ? c : 0));
+    q.v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  return q;
+}
+__device__ __forceinline__ void qs_commit_rows(float* T, const QsRows& q) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    *reinterpret_cast<float4*>(&T[(idx >> 4) * QS_LD + (idx & 15) * 4]) = q.v[i];
   }
 }
-// W[N][K] (row stride ldw, only 4-byte aligned inside the flat parameter buffer) -> T, zero padded to 64 x 64
-__device__ __forceinline__ void qs_load_weight(float* T, const float* __restrict__ W, int ldw, int N, int K) {
-  for (int i = threadIdx.x; i < QS_R * 64; i += blockDim.x) {
-    const int n = i >> 6, k = i & 63;
-    T[n * QS_LD + k] = (n < N && k < K) ? W[(size_t)n * ldw + k] : 0.f;
+__device__ __forceinline__ void qs_load_rows(float* T, const float* __restrict__ src, int ld, int r0, int nrows, int cols) {
+  qs_commit_rows(T, qs_fetch_rows(src, ld, r0, nrows, cols));
+}
+// W[N][K] (row stride ldw) zero padded to 64 x 64
+__device__ __forceinline__ QsWeight qs_fetch_weight(const float* __restrict__ W, int ldw, int N, int K) {
+  QsWeight w;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int n = idx >> 6, k = idx & 63;
+    const bool ok = n < N && k < K;
+    const float t = W[ok ? (size_t)n * ldw + k : 0];
+    w.v[i] = ok ? t : 0.f;
   }
+  return w;
+}
+__device__ __forceinline__ void qs_commit_weight(float* T, const QsWeight& w) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    T[(idx >> 6) * QS_LD + (idx & 63)] = w.v[i];
+  }
+}
+__device__ __forceinline__ void qs_load_weight(float* T, const float* __restrict__ W, int ldw, int N, int K) {
+  qs_commit_weight(T, qs_fetch_weight(W, ldw, N, K));
 }
 // acc[nt] (rows wave*16 + g*4 + r, column nt*16 + li) = sum_k X[row][k] W[col][k]     (y = x W^T)
 __device__ __forceinline__ void qs_gemm_nt(const float* Xs, const float* Ws, f32x4 (&acc)[4]) {
@@ -65,7 +103,7 @@ __device__ __forceinline__ void qs_gemm_nn(const float* Ds, const float* Ws, f32
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 4
   for (int kk = 0; kk < 16; ++kk) {
     const int n = kk * 4 + g;
     const float a = (n >= nlo && n < nhi) ? Ds[(wave * 16 + li) * QS_LD + n] : 0.f;
@@ -76,7 +114,7 @@ __device__ __forceinline__ void qs_gemm_nn(const float* Ds, const float* Ws, f32
 // wacc[ct] (rows n = wave*16 + g*4 + r, column ct*16 + li) += sum_rows D[row][n] X[row][col]     (dW += dY^T X)
 __device__ __forceinline__ void qs_wgrad(const float* Ds, const float* Xs, f32x4 (&wacc)[4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-#pragma unroll
+#pragma unroll 4
   for (int kk = 0; kk < 16; ++kk) {
     const int row = kk * 4 + g;
     const float a = Ds[row * QS_LD + wave * 16 + li];
@@ -250,7 +288,8 @@ __global__ __launch_bounds__(256) void qs_pre_bwd_kernel(const float* __restrict
   float* Ws = smem;
   float* Xs = Ws + QS_TILE;
   float* D = Xs + QS_TILE;
-  float* red = D + QS_TILE;
+  float* Q = D + QS_TILE;
+  float* red = Q + QS_TILE;
   qs_load_weight(Ws, wq, E, E, E);
   const int half = E >> 1, third = E / 3;
   f32x4 wacc[4];
@@ -258,19 +297,35 @@ __global__ __launch_bounds__(256) void qs_pre_bwd_kernel(const float* __restrict
   for (int i = 0; i < 4; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float pb = 0.f;
   for (int r0 = 0; r0 < B; r0 += QS_R) {
-    qs_load_rows(Xs, x, E, r0, B, E);
-    for (int i = threadIdx.x; i < QS_R * 64; i += blockDim.x) {
-      const int r = i >> 6, p = i & 63;
-      if (p >= 32) continue;
+    const QsRows xr = qs_fetch_rows(x, E, r0, B, E);
+    // sum of the key-split partials of the rotated-query gradient: Q[row][h * 16 + d] (H * 16 = 64 columns), every thread's
+    // 16 elements x nsplit loads issued in batches of eight
+    for (int j = 0; j < 16; ++j) {
+      const int i = threadIdx.x + j * 256;
+      const int r = i >> 6, c = i & 63;
+      const bool ok = r0 + r < B && c < H * 16;
+      const float* src = dqp + ((size_t)(ok ? r0 + r : 0) * H) * 16 + (ok ? c : 0);
+      float a = 0.f;
+      int sp = 0;
+      for (; sp + 7 < nsplit; sp += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(sp + u) * B * H * 16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += t[u];
+      }
+      for (; sp < nsplit; ++sp) a += src[(size_t)sp * B * H * 16];
+      Q[r * QS_LD + c] = ok ? a : 0.f;
+    }
+    qs_commit_rows(Xs, xr);
+    __syncthreads();
+    for (int i = threadIdx.x; i < QS_R * 32; i += blockDim.x) {
+      const int r = i >> 5, p = i & 31;
       const int c0 = 2 * p, c1 = c0 + 1;
       float y0 = 0.f, y1 = 0.f;
       if (p < half && r0 + r < B) {
         const int h0 = c0 / HD, h1 = c1 / HD;
-        float g0 = 0.f, g1 = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-          g0 += dqp[(((size_t)s * B + r0 + r) * H + h0) * 16 + (c0 - h0 * HD)];
-          g1 += dqp[(((size_t)s * B + r0 + r) * H + h1) * 16 + (c1 - h1 * HD)];
-        }
+        const float g0 = Q[r * QS_LD + h0 * 16 + (c0 - h0 * HD)], g1 = Q[r * QS_LD + h1 * 16 + (c1 - h1 * HD)];
         y0 = g0; y1 = g1;
         if (xyz) {
           const int axis = c0 / third;
@@ -492,7 +547,7 @@ __global__ __launch_bounds__(256) void qs_post_bwd_kernel(const float* __restric
         // weight gradient of the head's 15 rows: the A operand is dO restricted to them (other rows of the tile add zero)
         const int nrow = wave * 16 + li;
         const bool mine = nrow >= h * HD && nrow < (h + 1) * HD;
-#pragma unroll
+#pragma unroll 4
         for (int kk = 0; kk < 16; ++kk) {
           const int row = kk * 4 + g;
           const float a = mine ? G[row * QS_LD + nrow] : 0.f;
@@ -553,7 +608,7 @@ extern "C" int a3d_qs_pre_fwd(const float* x, const float* wq, const float* bq, 
                               float* qrot, int B, int E, int H, void* stream) {
   int rc = qs_check("a3d_qs_pre_fwd", B, E, H);
   if (rc) return rc;
-  if (!x || !wq || !qrot || (xyz && !freq)) { set_error("a3d_qs_pre_fwd: null pointer"); return A3D_ERR_ARG; }
+  if (!x || !wq || !qrot || (xyz && !freq) || (((uintptr_t)x) & 15)) { set_error("a3d_qs_pre_fwd: null / misaligned pointer (x: 16 bytes)"); return A3D_ERR_ARG; }
   static bool once = false;
   if (!once) { qs_allow_lds(qs_pre_fwd_kernel); qs_allow_lds(qs_pre_bwd_kernel); qs_allow_lds(qs_post_fwd_kernel); qs_allow_lds(qs_post_bwd_kernel); once = true; }
   hipLaunchKernelGGL(qs_pre_fwd_kernel, dim3(1), dim3(256), 3 * QS_TILE * sizeof(float), (hipStream_t)stream, x, wq, bq, xyz, freq, scale,
@@ -565,10 +620,13 @@ extern "C" int a3d_qs_pre_bwd(const float* dqp, int nsplit, const float* xyz, co
                               const float* wq, float* dwq, float* dbq, float* dx, int B, int E, int H, void* stream) {
   int rc = qs_check("a3d_qs_pre_bwd", B, E, H);
   if (rc) return rc;
-  if (!dqp || nsplit < 1 || !x || !wq || !dwq || !dbq || !dx || (xyz && !freq)) { set_error("a3d_qs_pre_bwd: bad argument"); return A3D_ERR_ARG; }
+  if (!dqp || nsplit < 1 || !x || !wq || !dwq || !dbq || !dx || (xyz && !freq) || (((uintptr_t)x) & 15)) {
+    set_error("a3d_qs_pre_bwd: bad argument (x 16-byte aligned)");
+    return A3D_ERR_ARG;
+  }
   static bool once = false;
   if (!once) { qs_allow_lds(qs_pre_bwd_kernel); once = true; }
-  hipLaunchKernelGGL(qs_pre_bwd_kernel, dim3(1), dim3(256), (3 * QS_TILE + 256) * sizeof(float), (hipStream_t)stream, dqp, nsplit, xyz,
+  hipLaunchKernelGGL(qs_pre_bwd_kernel, dim3(1), dim3(256), (4 * QS_TILE + 256) * sizeof(float), (hipStream_t)stream, dqp, nsplit, xyz,
                      freq, scale, x, wq, dwq, dbq, dx, B, E, H);
   return check_launch("a3d_qs_pre_bwd");
 }
@@ -581,7 +639,10 @@ extern "C" int a3d_qs_post_fwd(const float* xbar, const float* resid, const a3d_
                                int H, void* stream) {
   int rc = qs_check("a3d_qs_post_fwd", B, E, H);
   if (rc) return rc;
-  if (!xbar || !resid || !qs_params_ok(p) || !save || !y) { set_error("a3d_qs_post_fwd: null pointer"); return A3D_ERR_ARG; }
+  if (!xbar || !resid || !qs_params_ok(p) || !save || !y || ((((uintptr_t)xbar) | ((uintptr_t)resid) | ((uintptr_t)save)) & 15)) {
+    set_error("a3d_qs_post_fwd: null / misaligned pointer (xbar, resid, save: 16 bytes)");
+    return A3D_ERR_ARG;
+  }
   static bool once = false;
   if (!once) { qs_allow_lds(qs_post_fwd_kernel); once = true; }
   hipLaunchKernelGGL(qs_post_fwd_kernel, dim3(1), dim3(256), (4 * QS_TILE + 2 * QS_R) * sizeof(float), (hipStream_t)stream, xbar, resid, *p,
@@ -594,8 +655,9 @@ extern "C" int a3d_qs_post_bwd(const float* dy, const float* resid, const float*
   int rc = qs_check("a3d_qs_post_bwd", B, E, H);
   if (rc) return rc;
   if (!dy || !resid || !xbar || !save || !qs_params_ok(p) || !gr || !gr->dwv || !gr->dbv || !gr->dwo || !gr->dbo || !gr->dg1 || !gr->db1 ||
-      !gr->dw1 || !gr->dc1 || !gr->dw2 || !gr->dc2 || !gr->dg2 || !gr->db2 || !dxbar || !cD || !dresid) {
-    set_error("a3d_qs_post_bwd: null pointer");
+      !gr->dw1 || !gr->dc1 || !gr->dw2 || !gr->dc2 || !gr->dg2 || !gr->db2 || !dxbar || !cD || !dresid ||
+      ((((uintptr_t)dy) | ((uintptr_t)resid) | ((uintptr_t)xbar) | ((uintptr_t)save)) & 15)) {
+    set_error("a3d_qs_post_bwd: null / misaligned pointer (dy, resid, xbar, save: 16 bytes)");
     return A3D_ERR_ARG;
   }
   static bool once = false;

@@ -195,124 +195,313 @@ __device__ __forceinline__ void hist_add_wave(unsigned int* hist, unsigned int b
   if (pred) atomicAdd(&hist[bin], 1u);
 }
 
-// Same selection as knn_topk_kernel with each thread's ITEMS distances held in registers (N <= 1024 * ITEMS): no scratch
-// round trips through L2 in the seven passes, wave-aggregated histogram atomics.
-template <int ITEMS>
-__global__ __launch_bounds__(TK_THREADS) void knn_topk_reg_kernel(
-    const float* __restrict__ pos, const float* __restrict__ xyz, long long* __restrict__ idx_out,
-    float* __restrict__ dist_out, int N, int k, int kpad, int npos, int squared) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned int sh_prefix, sh_krem, sh_count, sh_neq;
-  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-launch selection for the shapes of the training step (N = 65 536 fine-map points, k = 4096; one 1024-thread workgroup
+// per sample took 206 us on 64 of 256 CUs -- round-3 review): the distance pass and a first, coarse histogram are spread over
+// KN_PARTS workgroups per sample; the second launch needs only cheap passes over the stored bit patterns and a sort that
+// keeps most of its exchange stages inside the wave.
+//   knn_dist_hist_kernel   grid (KN_PARTS, B): distances (IEEE, reference operation order) -> ws_dist [B][N] uint32; histogram
+//                          of bits [30:20] (8 exponent + 3 mantissa bits: 2048 bins, wave-aggregated LDS atomics) -> plain
+//                          stores into ws_hist [B][KN_PARTS][2048] (no global atomics, nothing to zero)
+//   knn_select_sort_kernel grid (B): sums the part histograms, scans them for the bin holding the k-th smallest; one pass over
+//                          ws_dist puts every element of a LOWER bin straight into the key array ("definitely in") and the
+//                          elements OF that bin into a candidate list in LDS; radix passes over the candidates' remaining 20
+//                          value bits (then index bits among ties of the threshold value) pick exactly the missing ones;
+//                          bitonic sort of the k 64-bit (distance, index) keys with four keys per thread -- strides 1, 2 in
+//                          registers, 4 .. 128 by lane exchange inside the wave, only strides >= 256 through LDS (10 barrier
+//                          stages for 4096 keys instead of 78).  A candidate list that overflows its LDS budget (a dense
+//                          shell of equidistant points) falls back to radix passes over ws_dist filtered by the bin.
+// Same result as knn_topk_kernel: ascending (distance, index), bit for bit.
+constexpr int KN_PARTS = 8;
+constexpr int KN_BINS = 2048;
+constexpr int KN_SHIFT = 20;
+
+__global__ __launch_bounds__(TK_THREADS) void knn_dist_hist_kernel(const float* __restrict__ pos, const float* __restrict__ xyz,
+                                                                   unsigned int* __restrict__ ws_dist, unsigned int* __restrict__ ws_hist,
+                                                                   int N, int npos, int squared) {
+  __shared__ unsigned int hist[KN_BINS];
+  const int b = blockIdx.y, part = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const float* qp = pos + (size_t)b * npos * 3;
   const float* pts = xyz + (size_t)b * N * 3;
-
-  unsigned int dv[ITEMS];     // element i of this thread is point t + i * 1024 (0xFFFFFFFF beyond N: never selected, k <= N)
-#pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    const int n = t + i * TK_THREADS;
-    dv[i] = (n < N) ? __float_as_uint(nn_dist(qp, npos, squared, pts + (size_t)n * 3)) : 0xFFFFFFFFu;
-  }
-  if (t == 0) { sh_prefix = 0; sh_krem = (unsigned int)k; }
+  for (int i = t; i < KN_BINS; i += TK_THREADS) hist[i] = 0;
   __syncthreads();
+  const int per = (N + KN_PARTS - 1) / KN_PARTS;
+  const int n0 = part * per, n1 = min(N, n0 + per);
+  for (int base = n0; base < n1; base += TK_THREADS) {          // wave-uniform trip count
+    const int n = base + t;
+    const bool ok = n < n1;
+    unsigned int v = 0;
+    if (ok) {
+      v = __float_as_uint(nn_dist(qp, npos, squared, pts + (size_t)n * 3));
+      ws_dist[(size_t)b * N + n] = v;
+    }
+    hist_add_wave(hist, v >> KN_SHIFT, ok, lane);
+  }
+  __syncthreads();
+  unsigned int* out = ws_hist + ((size_t)b * KN_PARTS + part) * KN_BINS;
+  for (int i = t; i < KN_BINS; i += TK_THREADS) out[i] = hist[i];
+}
 
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    if (t < 256) hist[t] = 0;
-    __syncthreads();
-    const unsigned int prefix = sh_prefix;
-    const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+// wave 0: the bin (of 256) in which the running count reaches krem; res = {bin, count below the bin, count in the bin}
+__device__ __forceinline__ void select_bin256(const unsigned int* hist, unsigned int krem, unsigned int* res) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const unsigned int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+  const unsigned int mine = h0 + h1 + h2 + h3;
+  unsigned int incl = mine;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const bool in = (t + i * TK_THREADS < N) && ((dv[i] & himask) == prefix);
-      hist_add_wave(hist, (dv[i] >> shift) & 255u, in, lane);
-    }
-    __syncthreads();
-    if (t == 0) {
-      unsigned int krem = sh_krem, cum = 0;
-      int bin = 0;
-      for (; bin < 256; ++bin) {
-        if (cum + hist[bin] >= krem) break;
-        cum += hist[bin];
-      }
-      if (bin > 255) bin = 255;
-      sh_krem = krem - cum;
-      sh_prefix = prefix | ((unsigned int)bin << shift);
-      sh_neq = hist[bin];
-    }
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  const unsigned int T = sh_prefix;       // k-th smallest value
-  unsigned int need = sh_krem;            // how many elements == T are wanted
-  unsigned int idx_thr = 0xFFFFFFFFu;     // elements == T with idx <= idx_thr are taken
-  if (sh_neq != need) {
-    __syncthreads();
-    if (t == 0) { sh_prefix = 0; sh_krem = need; }
-    __syncthreads();
-    for (int pass = 0; pass < 3; ++pass) {
-      const int shift = 16 - 8 * pass;
-      if (t < 256) hist[t] = 0;
-      __syncthreads();
-      const unsigned int prefix = sh_prefix;
-      const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-#pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
-        const unsigned int n = (unsigned int)(t + i * TK_THREADS);
-        const bool in = (n < (unsigned int)N) && dv[i] == T && ((n & himask) == prefix);
-        hist_add_wave(hist, (n >> shift) & 255u, in, lane);
-      }
-      __syncthreads();
-      if (t == 0) {
-        unsigned int krem = sh_krem, cum = 0;
-        int bin = 0;
-        for (; bin < 256; ++bin) {
-          if (cum + hist[bin] >= krem) break;
-          cum += hist[bin];
+  const unsigned int excl = incl - mine;
+  const unsigned int total = __shfl(incl, 63, 64);
+  const bool own = (excl < krem && krem <= incl) || (lane == 63 && krem > total);      // krem > total cannot happen for k <= N
+  if (own) {
+    unsigned int cum = excl;
+    int bin = 4 * lane;
+    const unsigned int hs[4] = {h0, h1, h2, h3};
+    int j = 0;
+    for (; j < 3; ++j) {
+      if (cum + hs[j] >= krem) break;
+      cum += hs[j];
+    }
+    res[0] = (unsigned int)(bin + j);
+    res[1] = cum;
+    res[2] = hs[j];
+  }
+}
+
+// 64-bit key exchange inside the wave
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  const unsigned int lo = __shfl_xor((unsigned int)v, mask, 64), hi = __shfl_xor((unsigned int)(v >> 32), mask, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// bitonic sort of keys[0, kpad) (kpad a power of two >= 4096 uses the register scheme; smaller arrays the plain LDS network)
+__device__ __forceinline__ void wg_bitonic_sort(unsigned long long* keys, int kpad) {
+  const int t = threadIdx.x;
+  if (kpad < 4 * TK_THREADS) {
+    for (int size = 2; size <= kpad; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = t; i < (kpad >> 1); i += TK_THREADS) {
+          const int lo = (i / stride) * (stride << 1) + (i % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const unsigned long long a = keys[lo], c = keys[hi];
+          if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
         }
-        if (bin > 255) bin = 255;
-        sh_krem = krem - cum;
-        sh_prefix = prefix | ((unsigned int)bin << shift);
+        __syncthreads();
       }
-      __syncthreads();
     }
-    idx_thr = sh_prefix;
+    return;
   }
-  // ---- collect survivors (one LDS atomic per wave-instruction: lanes take consecutive slots)
-  if (t == 0) sh_count = 0;
+  // thread t owns keys [g * 4096 + 4 t, + 4) of every 4096-key group g; all threads walk the same (size, stride) sequence
+  const int ngroup = kpad / (4 * TK_THREADS);
+  for (int grp = 0; grp < ngroup; ++grp) {
+    unsigned long long v[4];
+    const int base = grp * 4 * TK_THREADS + 4 * t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = keys[base + j];
+    for (int size = 2; size <= 4 * TK_THREADS; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (stride >= 256) {
+          // partner in another wave: through LDS
+#pragma unroll
+          for (int j = 0; j < 4; ++j) keys[base + j] = v[j];
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = base + j;
+            const unsigned long long o = keys[i ^ stride];
+            const bool up = ((i & size) == 0), lower = ((i & stride) == 0);
+            const unsigned long long mn = v[j] < o ? v[j] : o, mx = v[j] < o ? o : v[j];
+            v[j] = (lower == up) ? mn : mx;
+          }
+          __syncthreads();
+        } else if (stride >= 4) {
+          const int lm = stride >> 2;             // partner lane = lane ^ (stride / 4), same register slot
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = base + j;
+            const unsigned long long o = shfl_xor_u64(v[j], lm);
+            const bool up = ((i & size) == 0), lower = ((i & stride) == 0);
+            const unsigned long long mn = v[j] < o ? v[j] : o, mx = v[j] < o ? o : v[j];
+            v[j] = (lower == up) ? mn : mx;
+          }
+        } else {
+          // stride 1 or 2: both keys in this thread's registers
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pj = j ^ stride;
+            if (pj > j) {
+              const bool up = (((base + j) & size) == 0);
+              const unsigned long long a = v[j], c = v[pj];
+              if ((a > c) == up) { v[j] = c; v[pj] = a; }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keys[base + j] = v[j];
+  }
+  __syncthreads();
+  // merge the sorted 4096-key groups (kpad > 4096 only): remaining bitonic stages over the whole array through LDS
+  if (ngroup > 1) {
+    // groups were sorted ascending / descending alternately by the (i & size) rule with size = 4096 on absolute indices
+    for (int size = 8 * TK_THREADS; size <= kpad; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = t; i < (kpad >> 1); i += TK_THREADS) {
+          const int lo = (i / stride) * (stride << 1) + (i % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const unsigned long long a = keys[lo], c = keys[hi];
+          if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void knn_select_sort_kernel(const unsigned int* __restrict__ ws_dist,
+                                                                     const unsigned int* __restrict__ ws_hist,
+                                                                     long long* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                                     int N, int k, int kpad, int cand_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];        // [kpad] then cand [cand_cap]
+  __shared__ unsigned int hist[KN_BINS];
+  __shared__ unsigned int wsum[16];
+  __shared__ unsigned int sel[3];
+  __shared__ unsigned int sh_count, sh_ccount, sh_kbin, sh_cbelow, sh_cbin;
+  unsigned long long* cand = keys + kpad;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned int* dw = ws_dist + (size_t)b * N;
+  // ---- part histograms -> hist; the bin holding the k-th smallest element
+  for (int i = t; i < KN_BINS; i += TK_THREADS) {
+    unsigned int s = 0;
+#pragma unroll
+    for (int p = 0; p < KN_PARTS; ++p) s += ws_hist[((size_t)b * KN_PARTS + p) * KN_BINS + i];
+    hist[i] = s;
+  }
+  if (t == 0) { sh_count = 0; sh_ccount = 0; }
+  __syncthreads();
+  {
+    const unsigned int h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    const unsigned int mine = h0 + h1;
+    unsigned int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned int off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    const unsigned int excl = off + incl - mine;
+    if (excl < (unsigned int)k && (unsigned int)k <= excl + mine) {           // exactly one thread
+      if (excl + h0 >= (unsigned int)k) { sh_kbin = 2 * t; sh_cbelow = excl; sh_cbin = h0; }
+      else { sh_kbin = 2 * t + 1; sh_cbelow = excl + h0; sh_cbin = h1; }
+    }
+  }
   for (int i = t; i < kpad; i += TK_THREADS) keys[i] = 0xFFFFFFFFFFFFFFFFull;
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    const unsigned int n = (unsigned int)(t + i * TK_THREADS);
-    const unsigned int v = dv[i];
-    const bool take = (n < (unsigned int)N) && (v < T || (v == T && n <= idx_thr));
-    const unsigned long long m = __ballot(take);
-    if (m != 0ull) {
-      const int leader = __ffsll((long long)m) - 1;
-      unsigned int base = 0;
-      if (lane == leader) base = atomicAdd(&sh_count, (unsigned int)__popcll(m));
-      base = __builtin_amdgcn_readlane(base, leader);
-      if (take) {
-        const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (slot < (unsigned int)kpad) keys[slot] = ((unsigned long long)v << 32) | n;
-      }
+  const unsigned int kbin = sh_kbin, need_total = (unsigned int)k - sh_cbelow, cbin = sh_cbin;
+  const bool in_lds = cbin <= (unsigned int)cand_cap;
+  // ---- one pass over the distances: lower bins -> keys, the k-th bin -> candidates
+  for (int base = 0; base < N; base += TK_THREADS) {
+    const int n = base + t;
+    const unsigned int v = n < N ? dw[n] : 0xFFFFFFFFu;
+    const unsigned int bin = v >> KN_SHIFT;
+    const bool take = n < N && bin < kbin, cnd = in_lds && n < N && bin == kbin;
+    const unsigned long long mt = __ballot(take), mc = __ballot(cnd);
+    if (mt != 0ull) {
+      const int leader = __ffsll((long long)mt) - 1;
+      unsigned int bs = 0;
+      if (lane == leader) bs = atomicAdd(&sh_count, (unsigned int)__popcll(mt));
+      bs = __builtin_amdgcn_readlane(bs, leader);
+      if (take) keys[bs + (unsigned int)__popcll(mt & ((1ull << lane) - 1ull))] = ((unsigned long long)v << 32) | (unsigned int)n;
+    }
+    if (mc != 0ull) {
+      const int leader = __ffsll((long long)mc) - 1;
+      unsigned int bs = 0;
+      if (lane == leader) bs = atomicAdd(&sh_ccount, (unsigned int)__popcll(mc));
+      bs = __builtin_amdgcn_readlane(bs, leader);
+      if (cnd) cand[bs + (unsigned int)__popcll(mc & ((1ull << lane) - 1ull))] = ((unsigned long long)v << 32) | (unsigned int)n;
     }
   }
   __syncthreads();
-  // ---- bitonic sort of kpad 64-bit keys (value major, index minor)
-  for (int size = 2; size <= kpad; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = t; i < (kpad >> 1); i += TK_THREADS) {
-        const int lo = (i / stride) * (stride << 1) + (i % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = keys[lo], c = keys[hi];
-        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+  // ---- the `need_total` smallest (value, index) pairs of the k-th bin.  Items: the candidate list, or (overflow) ws_dist
+  // filtered by the bin.  Radix passes over the low 20 value bits (8 + 8 + 4), then 3 passes over the index among the ties.
+  const int nitems = in_lds ? (int)cbin : N;
+  auto item = [&](int i, unsigned int& v, unsigned int& n) -> bool {
+    if (in_lds) { const unsigned long long c = cand[i]; v = (unsigned int)(c >> 32); n = (unsigned int)c; return true; }
+    v = dw[i]; n = (unsigned int)i;
+    return (v >> KN_SHIFT) == kbin;
+  };
+  unsigned int prefix = kbin << KN_SHIFT, krem = need_total, neq = cbin;
+  const int shifts[3] = {12, 4, 0};
+  const unsigned int widths[3] = {8, 8, 4};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = shifts[pass];
+    const unsigned int himask = 0xFFFFFFFFu << (shift + widths[pass]);
+    for (int i = t; i < 256; i += TK_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int base = 0; base < nitems; base += TK_THREADS) {
+      const int i = base + t;
+      unsigned int v = 0, n = 0;
+      const bool ok = i < nitems && item(i, v, n) && ((v & himask) == prefix);
+      hist_add_wave(hist, (v >> shift) & ((1u << widths[pass]) - 1u), ok, lane);
+    }
+    __syncthreads();
+    select_bin256(hist, krem, sel);
+    __syncthreads();
+    prefix |= sel[0] << shift;
+    krem -= sel[1];
+    neq = sel[2];
+    __syncthreads();
+  }
+  const unsigned int T = prefix;            // k-th smallest value
+  unsigned int idx_thr = 0xFFFFFFFFu;       // elements == T with index <= idx_thr are taken
+  if (neq != krem) {
+    unsigned int ipre = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 16 - 8 * pass;
+      const unsigned int himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = t; i < 256; i += TK_THREADS) hist[i] = 0;
+      __syncthreads();
+      for (int base = 0; base < nitems; base += TK_THREADS) {
+        const int i = base + t;
+        unsigned int v = 0, n = 0;
+        const bool ok = i < nitems && item(i, v, n) && v == T && ((n & himask) == ipre);
+        hist_add_wave(hist, (n >> shift) & 255u, ok, lane);
       }
       __syncthreads();
+      select_bin256(hist, krem, sel);
+      __syncthreads();
+      ipre |= sel[0] << shift;
+      krem -= sel[1];
+      __syncthreads();
+    }
+    idx_thr = ipre;
+  }
+  for (int base = 0; base < nitems; base += TK_THREADS) {
+    const int i = base + t;
+    unsigned int v = 0, n = 0;
+    const bool take = i < nitems && item(i, v, n) && (v < T || (v == T && n <= idx_thr));
+    const unsigned long long mt = __ballot(take);
+    if (mt != 0ull) {
+      const int leader = __ffsll((long long)mt) - 1;
+      unsigned int bs = 0;
+      if (lane == leader) bs = atomicAdd(&sh_count, (unsigned int)__popcll(mt));
+      bs = __builtin_amdgcn_readlane(bs, leader);
+      const unsigned int slot = bs + (unsigned int)__popcll(mt & ((1ull << lane) - 1ull));
+      if (take && slot < (unsigned int)kpad) keys[slot] = ((unsigned long long)v << 32) | n;
     }
   }
+  __syncthreads();
+  wg_bitonic_sort(keys, kpad);
   for (int i = t; i < k; i += TK_THREADS) {
     const unsigned long long kk = keys[i];
     idx_out[(size_t)b * k + i] = (long long)(kk & 0xFFFFFFFFull);
@@ -462,7 +651,10 @@ extern "C" int a3d_pcd_downsample(const float* pcd, float* out_xyz, int B, int C
   return check_launch("a3d_pcd_downsample");
 }
 
-extern "C" size_t a3d_knn_topk_ws_bytes(int B, int N) { return (size_t)B * N * sizeof(unsigned int); }
+extern "C" size_t a3d_knn_topk_ws_bytes(int B, int N) {
+  // distance bit patterns [B][N] + the part histograms of the two-launch selection [B][KN_PARTS][KN_BINS]
+  return ((size_t)B * N + (size_t)B * KN_PARTS * KN_BINS) * sizeof(unsigned int);
+}
 
 static int nn_topk_launch(const char* fn, const float* pos, int npos, int squared, const float* xyz, void* ws,
                           long long* idx_out, float* dist_out, int B, int N, int k, void* stream) {
@@ -472,24 +664,29 @@ static int nn_topk_launch(const char* fn, const float* pos, int npos, int square
   }
   int kpad = 2;
   while (kpad < k) kpad <<= 1;
-  const size_t lds = (size_t)kpad * sizeof(unsigned long long);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)knn_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    (void)hipFuncSetAttribute((const void*)knn_topk_reg_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    (void)hipFuncSetAttribute((const void*)knn_select_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
     attr_set = true;
   }
-  static const bool use_ws = getenv("A3D_KNN_WS") && atoi(getenv("A3D_KNN_WS")) != 0;   // A/B switch: scratch-based kernel
-  if (!use_ws && N <= 16 * TK_THREADS)
-    hipLaunchKernelGGL(knn_topk_reg_kernel<16>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
-                       dist_out, N, k, kpad, npos, squared);
-  else if (!use_ws && N <= 64 * TK_THREADS)
-    hipLaunchKernelGGL(knn_topk_reg_kernel<64>, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz, idx_out,
-                       dist_out, N, k, kpad, npos, squared);
-  else
-    hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), lds, (hipStream_t)stream, pos, xyz,
-                       (unsigned int*)ws, idx_out, dist_out, N, k, kpad, npos, squared);
+  unsigned int* ws_dist = (unsigned int*)ws;
+  static const bool one_wg = getenv("A3D_KNN_WS") && atoi(getenv("A3D_KNN_WS")) != 0;   // A/B switch: one workgroup per sample
+  // candidate list of the k-th histogram bin: what is left of 136 KB of dynamic LDS after the key array, at most 6144 entries
+  const long long cand_room = (136 * 1024 - (long long)kpad * 8) / 8;
+  if (one_wg || cand_room < 1024) {
+    hipLaunchKernelGGL(knn_topk_kernel, dim3(B), dim3(TK_THREADS), (size_t)kpad * sizeof(unsigned long long), (hipStream_t)stream, pos, xyz,
+                       ws_dist, idx_out, dist_out, N, k, kpad, npos, squared);
+    return check_launch(fn);
+  }
+  const int cand_cap = (int)std::min<long long>(cand_room, 6144);
+  unsigned int* ws_hist = ws_dist + (size_t)B * N;
+  hipLaunchKernelGGL(knn_dist_hist_kernel, dim3(KN_PARTS, B), dim3(TK_THREADS), 0, (hipStream_t)stream, pos, xyz, ws_dist, ws_hist, N, npos,
+                     squared);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  hipLaunchKernelGGL(knn_select_sort_kernel, dim3(B), dim3(TK_THREADS), (size_t)(kpad + cand_cap) * sizeof(unsigned long long),
+                     (hipStream_t)stream, ws_dist, ws_hist, idx_out, dist_out, N, k, kpad, cand_cap);
   return check_launch(fn);
 }
 

@@ -875,7 +875,7 @@ def knn_topk(pos, xyz, k, return_dist=False):
     L.require_gpu(pos, xyz)
     pos, xyz = _c(pos.to(F32)).view(-1, 3), _c(xyz.to(F32))
     B, N, _ = xyz.shape
-    ws = torch.empty((B * N,), device=xyz.device, dtype=torch.int32)
+    ws = torch.empty((L.load().a3d_knn_topk_ws_bytes(B, N) // 4,), device=xyz.device, dtype=torch.int32)
     idx = torch.empty((B, k), device=xyz.device, dtype=torch.int64)
     dist = torch.empty((B, k), device=xyz.device, dtype=F32) if return_dist else None
     L.call("a3d_knn_topk", pos.data_ptr(), xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(),
@@ -889,7 +889,7 @@ def traj_nn_topk(traj_xyz, xyz, k):
     L.require_gpu(traj_xyz, xyz)
     traj_xyz, xyz = _c(traj_xyz.detach().to(F32)), _c(xyz.to(F32))
     B, N, _ = xyz.shape
-    ws = torch.empty((B * N,), device=xyz.device, dtype=torch.int32)
+    ws = torch.empty((L.load().a3d_knn_topk_ws_bytes(B, N) // 4,), device=xyz.device, dtype=torch.int32)
     idx = torch.empty((B, k), device=xyz.device, dtype=torch.int64)
     L.call("a3d_traj_nn_topk", traj_xyz.data_ptr(), traj_xyz.shape[1], xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(), None,
            B, N, k, L.stream())

@@ -174,7 +174,12 @@ def kernel_rooflines(a3d, device, B):
     tiles = B * H * (Lqp // 16) * (Sp // 64)
     x_fwd = tiles * per_fwd * 16384.0
     x_bwd = tiles * per_bwd * 16384.0
-    return {
+    extra_k = {}
+    try:
+        extra_k = other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq)
+    except Exception as e:                                   # a missing entry must not take the bench line down
+        extra_k = {"error": repr(e)[:200]}
+    return {**extra_k, **{
         "attn_fwd": {"bound": "mfma", "achieved": f_fwd / (t_fwd * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "ms": t_fwd, "nsplit": ns, "launches_per_step": 6, "dtype": dt, "family": O.ATTN_MODE,
                      "executed_tflops": x_fwd / (t_fwd * 1e-3) / 1e12, "mfma_util_executed": x_fwd / (t_fwd * 1e-3) / 2.5e15},
@@ -183,7 +188,65 @@ def kernel_rooflines(a3d, device, B):
                      "executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12, "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15},
         "kv_proj_rope": {"bound": "hbm", "achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "ms": t_proj, "launches_per_step": 6},
-    }
+    }}
+
+
+def other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq):
+    """HBM rooflines of the other hand-written hot-path kernels the round-3 review named, timed live at the workload's shapes
+    (algorithmic bytes per launch):
+      sq_fwd / sq_bwd   single-query attention over the S = 4097 context rows: forward reads X (4 S E B) + xyz (12 S B);
+                        the backward reads them again and writes dX (4 S E B)
+      knn_topk          12 N B bytes of points (N = 65 536), k = 4096 sorted indices out (8 k B)
+      bn_stats          one read of a bf16 activation (the layer-1 map: 256 images x 64 x 64 x 256 channels)"""
+    O, Lb = a3d.ops, a3d.ops.L
+    lib = Lb.load()
+    E, H = 60, 4
+    S = x.shape[1]
+    f4 = 4
+    out = {}
+    qrot = torch.randn(B, H, 1, 16, device=device)
+    nsplit = max(1, min((S + 63) // 64, 1024 // B))
+    ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=device)
+    xbar, lse = torch.empty((B, H, E), device=device), torch.empty((B, H), device=device)
+    wp, bp = w.data_ptr(), bb.data_ptr()
+
+    def sq_fwd():
+        Lb.call("a3d_sq_attn_fwd", x.data_ptr(), k_xyz.data_ptr(), wp + E * E * f4, E, bp + E * f4, None, E, None, qrot.data_ptr(),
+                freq.data_ptr(), ws.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, B, S, E, H, nsplit, Lb.stream())
+    t = time_kernel(sq_fwd)
+    by = B * S * (E * 4.0 + 12.0)
+    out["sq_fwd"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                     "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 6, "note": "keys + combine (2 launches)"}
+    wsb = torch.zeros((lib.a3d_sq_bwd_ws_floats(B, H, E, nsplit),), device=device)
+    dX = torch.empty((B, S, E), device=device)
+    dqp = torch.empty((nsplit, B, H, 1, 16), device=device)
+    gW, gb = torch.zeros(3 * E, E, device=device), torch.zeros(3 * E, device=device)
+
+    def sq_bwd():
+        Lb.call("a3d_sq_attn_bwd", x.data_ptr(), k_xyz.data_ptr(), wp + E * E * f4, E, bp + E * f4, None, E, qrot.data_ptr(),
+                freq.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, wsb.data_ptr(), dX.data_ptr(), dqp.data_ptr(),
+                gW.data_ptr() + E * E * f4, E, gb.data_ptr() + E * f4, None, E, None, B, S, E, H, nsplit, Lb.stream())
+    t = time_kernel(sq_bwd)
+    by = B * S * (2 * E * 4.0 + 12.0)
+    out["sq_bwd"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                     "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 6, "note": "keys + weight-gradient reduce (2 launches)"}
+    N, k = 65536, 4096
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(B, N, 3, generator=g).to(device)
+    pos = torch.rand(B, 3, generator=g).to(device)
+    t = time_kernel(lambda: O.knn_topk(pos, pts, k))
+    by = B * (N * 12.0 + k * 8.0)
+    out["knn_topk"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                       "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 2, "note": "latency / sort bound: 2 launches (distances + histogram | select + sort)"}
+    rows, C = 4 * B * 64 * 64, 256
+    act = torch.randn(rows, C, device=device).to(torch.bfloat16)
+    nslab = lib.a3d_bn_nslab(rows, C)
+    partial = torch.empty((nslab, 2, C), device=device)
+    t = time_kernel(lambda: Lb.call("a3d_bn_stats", act.data_ptr(), partial.data_ptr(), rows, C, nslab, Lb.stream()))
+    by = rows * C * 2.0
+    out["bn_stats"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                       "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 55, "note": "layer-1 map (537 MB); 55 launches of 17 - 537 MB per step"}
+    return out
 
 
 def pmc_record(B):
@@ -519,7 +582,11 @@ def main():
             res["hot_path_only"] = {"error": repr(e)[:200]}
         try:
             ks = kernel_rooflines(a3d, device, B)
-            dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
+            if "error" in ks:
+                res["kernels_error"] = ks.pop("error")
+            # dominant hand-written kernel by (duration x launches per step) among the kernels whose launches all have the
+            # timed shape (bn_stats' 55 launches per step range from 17 to 537 MB: its entry is the largest one)
+            dom = max((k for k in ks if k != "bn_stats"), key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
             r = dict(ks[dom])
             r["kernel"] = dom
             r["frac"] = r["achieved"] / r["peak"]

@@ -78,7 +78,7 @@ def test_c_abi_host_side_planning_functions():
     assert lib.a3d_bn_nslab(1 << 22, 32) == 1024
     # attention split-K workspace and k-NN scratch grow linearly
     assert lib.a3d_attn_fwd_ws_floats(2, 4, 64, 4) == 2 * lib.a3d_attn_fwd_ws_floats(1, 4, 64, 4)
-    assert lib.a3d_knn_topk_ws_bytes(3, 1000) == 3 * 1000 * 4
+    assert lib.a3d_knn_topk_ws_bytes(3, 1000) == (3 * 1000 + 3 * 8 * 2048) * 4       # distances + 8 part histograms of 2048 bins per sample
 
 
 def test_product_ops_refuse_cpu_tensors():

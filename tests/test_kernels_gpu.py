@@ -376,7 +376,8 @@ def test_pcd_downsample_bit_exact(a3d, dev, f, H):
     assert torch.equal(got, ref), f"pcd_downsample f={f}: max diff {(got - ref).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("B,N,k", [(3, 16384, 1024), (2, 65536, 4096), (2, 49152, 3072), (1, 500, 500), (2, 1000, 7)])
+@pytest.mark.parametrize("B,N,k", [(3, 16384, 1024), (2, 65536, 4096), (2, 49152, 3072), (1, 500, 500), (2, 1000, 7), (1, 40000, 9000),
+                                   (1, 40000, 16384)])
 def test_knn_topk_indices_exact(a3d, dev, B, N, k):
     """Bit-exact against the oracle (IEEE fp32 distances, (distance, index) order).  Against torch.topk on CPU the
     index sequence must agree wherever neighbouring distances are not within 2 ulp: torch's CPU sqrt (MKL VML) is not
@@ -401,6 +402,23 @@ def test_knn_topk_indices_exact(a3d, dev, B, N, k):
     assert strict.float().mean().item() > 0.9
     for b in range(B):
         assert set(idx[b, :-2].tolist()) <= set(tv.indices[b].tolist()) | set(idx[b, -4:].tolist())
+
+
+def test_knn_topk_dense_shell_overflows_the_candidate_list(a3d, dev):
+    """30 000 points within 1e-4 of distance 1 share ONE bin of the coarse histogram (bin width 2^-3 there): the k-th bin's
+    candidate list cannot hold them in LDS and the selection runs its radix passes over the stored distances instead; k = 5000
+    also takes the sort through two 4096-key register groups + the LDS merge.  Bit-exact against the oracle, as everywhere."""
+    from oracle import sampling as OS
+    g = torch.Generator().manual_seed(11)
+    N, k = 30000, 5000
+    d = torch.randn(2, N, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True) * (1.0 + 1e-4 * torch.rand(2, N, 1, generator=g))
+    d[:, :100] *= 0.5                                   # a few points in lower bins ("definitely in")
+    d[1, 5000:5200] = d[1, 4999]                        # exact ties around the threshold region
+    pos = torch.zeros(2, 3)
+    idx, dist = a3d.ops.knn_topk(pos.to(dev), d.to(dev), k, return_dist=True)
+    o_idx, o_dist = OS.knn_topk(pos.numpy(), d.numpy(), k)
+    assert np.array_equal(dist.cpu().numpy(), o_dist) and np.array_equal(idx.cpu().numpy(), o_idx)
 
 
 def test_knn_topk_ties(a3d, dev):
