@@ -160,22 +160,192 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const unsigned short* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Streaming variant for the HBM-bound shapes (layer 1 / layer 2 of the CLIP ResNet: M = 2^18 .. 2^20 rows, K, N <= 512): the
+// workgroup's weight block W[BN][K] is staged ONCE and stays in LDS while the workgroup walks its M tiles -- the kernel above
+// re-stages it for every tile and K step, which for K = 64 -> N = 256 is four times the bytes of the activation tile it is
+// multiplied with (LDS writes and L2 reads, not HBM, bounded it: 15.5 vs 11.9 ms for the whole backbone in round 3) -- and the
+// (tile, K step) pairs of a workgroup form one flat sequence of steps whose activation chunks are fetched D steps ahead into
+// registers (~32 KB in flight per workgroup, unconditional clamped loads), one barrier per step, two LDS buffers.
+//   LDS: W KS x BN x 64 B (8 - 64 KB) | X 2 x BM x 64 B | the producer's BatchNorm scale / shift (K floats each)
+template <int WN, int KS>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                             const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                             int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial,
+                                                             long long M, int N) {
+  constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN, K = KS * 32;
+  constexpr int XL = BM * 4 / 256;                                // 16-byte segments each thread stages per step: 1, 2 or 4
+  constexpr int D = 8 / XL;                                       // steps in flight: 8 x 16 B per thread = 32 KB per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_c1[];
+  unsigned short* Ws = smem_c1;                                   // [KS][BN * 32]
+  unsigned short* Xs = Ws + KS * BN * 32;                         // [2][BM * 32]
+  float* scS = reinterpret_cast<float*>(Xs + 2 * BM * 32);        // [K] scale | [K] shift
+  __shared__ float redS[4][64], redQ[4][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.y * BN;
+  const long long mtiles = (M + BM - 1) / BM;
+  for (int i = t; i < KS * BN * 4; i += 256) {
+    const int ks = i / (BN * 4), rem = i - ks * (BN * 4), row = rem >> 2, seg = rem & 3;
+    *reinterpret_cast<uint4*>(&Ws[ks * BN * 32 + plane_off(row, seg)]) =
+        *reinterpret_cast<const uint4*>(w + (size_t)(n0 + row) * K + ks * C1_BK + seg * 8);
+  }
+  if (in_scale)
+    for (int i = t; i < K; i += 256) { scS[i] = in_scale[i]; scS[K + i] = in_shift[i]; }
+  float ssum[4][4], ssq[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
+  const long long my_tiles = blockIdx.x < mtiles ? (mtiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const long long total = my_tiles * KS;                          // flat steps: s -> (tile blockIdx.x + (s / KS) gridDim.x, K step s % KS)
+  auto load = [&](long long s, uint4 (&r)[XL]) {
+    const long long m0 = (blockIdx.x + (s / KS) * gridDim.x) * BM;
+    const int ks = (int)(s % KS);
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+      const long long m = m0 + row < M ? m0 + row : M - 1;        // clamped: tail rows are masked at the store
+      r[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks * C1_BK + seg * 8);
+    }
+  };
+  auto stage = [&](int buf, int ks, const uint4 (&r)[XL]) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
+      uint4 v = r[i];
+      if (in_scale) {
+        const int k0 = ks * C1_BK + seg * 8;
+        unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = __uint_as_float(u[j] << 16) * scS[k0 + 2 * j] + scS[K + k0 + 2 * j];
+          float b = __uint_as_float(u[j] & 0xFFFF0000u) * scS[k0 + 2 * j + 1] + scS[K + k0 + 2 * j + 1];
+          if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+          u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+        }
+        v = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+      *reinterpret_cast<uint4*>(&Xs[buf * BM * 32 + plane_off(row, seg)]) = v;
+    }
+  };
+  if (total > 0) {
+    uint4 xr[D][XL];
+#pragma unroll
+    for (int j = 0; j < D; ++j) load(j < total ? j : total - 1, xr[j]);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                              // W, scale / shift staged
+    for (long long s0 = 0; s0 < total; s0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const long long s = s0 + j;
+        if (s >= total) break;                                    // workgroup-uniform
+        const int ks = (int)(s % KS), buf = (int)(s & 1);
+        stage(buf, ks, xr[j]);
+        load(s + D < total ? s + D : total - 1, xr[j]);           // unconditional: D steps ahead (the tail re-fetches the last chunk)
+        __syncthreads();                                          // stage(s) visible; every wave is past its reads of step s - 1's other buffer
+        s16x8 xa[4], wb[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          xa[tm] = *reinterpret_cast<const s16x8*>(&Xs[buf * BM * 32 + plane_off(wm * 64 + tm * 16 + li, g)]);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + plane_off(wn * 64 + tn * 16 + li, g)]);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
+        if (ks == KS - 1) {
+          // tile done: round once, 8-byte stores (4 consecutive channels of one row), statistics of the rounded values
+          const long long m0 = (blockIdx.x + (s / KS) * gridDim.x) * BM;
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) {
+            const long long m = m0 + wm * 64 + tm * 16 + li;
+            const bool ok = m < M;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+              unsigned short h[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                h[r] = f2bf(acc[tn][tm][r]);
+                if (ok) {
+                  const float v = bf2f(h[r]);
+                  ssum[tn][r] += v;
+                  ssq[tn][r] += v * v;
+                }
+                acc[tn][tm][r] = 0.f;
+              }
+              if (ok) {
+                const uint2 pk = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
+                *reinterpret_cast<uint2*>(y + (size_t)m * N + n0 + wn * 64 + tn * 16 + g * 4) = pk;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv = ssum[tn][r], q = ssq[tn][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); q += __shfl_xor(q, o, 64); }
+      if (li == 0) { redS[wave][tn * 16 + g * 4 + r] = sv; redQ[wave][tn * 16 + g * 4 + r] = q; }
+    }
+  __syncthreads();
+  for (int i = t; i < BN; i += 256) {
+    const int wn_i = i >> 6, c = i & 63;
+    float sv = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < WM; ++j) { sv += redS[j * WN + wn_i][c]; q += redQ[j * WN + wn_i][c]; }
+    float* p = partial + (size_t)blockIdx.x * 2 * N;
+    p[n0 + i] = sv;
+    p[N + n0 + i] = q;
+  }
+}
+
 }  // namespace a3d
 
 using namespace a3d;
 
-static int c1_slabs(size_t M, int N) {
-  const int wn = N >= 256 ? 4 : (N >= 128 ? 2 : 1);
+static int c1_wn(int N) { return N >= 256 ? 4 : (N >= 128 ? 2 : 1); }
+// dynamic LDS of the streaming kernel: W block + two X buffers + scale / shift
+static size_t c1_stream_lds(int K, int N) {
+  const int wn = c1_wn(N), bn = 64 * wn, bm = 64 * (4 / wn);
+  return (size_t)(K / 32) * bn * 64 + (size_t)2 * bm * 64 + (size_t)2 * K * sizeof(float);
+}
+// the shapes the resident-weight kernel serves: K in {64, 128, 256}, its LDS block within 96 KB (two workgroups per CU up to 78 KB)
+static bool c1_streams(int K, int N) {
+  return (K == 64 || K == 128 || K == 256) && (N % 64) == 0 && (N < 256 || (N % 256) == 0) && c1_stream_lds(K, N) <= 96 * 1024;
+}
+static int c1_slabs(size_t M, int K, int N) {
+  const int wn = c1_wn(N);
   const int bm = 64 * (4 / wn);
   const size_t mtiles = (M + bm - 1) / bm;
   const int ntiles = N / (64 * wn);
+  if (c1_streams(K, N)) {
+    // persistent: as many workgroups as are resident at once (LDS-limited), each walking its share of the M tiles
+    const size_t lds = c1_stream_lds(K, N) + 2048;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));      // 248 registers per lane: two workgroups per CU
+    return (int)std::min<size_t>(mtiles, (size_t)std::max(1, 256 * per_cu / ntiles));
+  }
   size_t cap = (size_t)std::max(1, 2048 / ntiles);               // ~8 workgroups per CU over the whole grid
   return (int)std::min(mtiles, cap);
 }
 
-extern "C" int a3d_conv1x1_nslab(size_t M, int N) {
-  if (M == 0 || N <= 0) return 0;
-  return c1_slabs(M, N);
+extern "C" int a3d_conv1x1_streams(int K, int N) { return (K > 0 && N > 0 && c1_streams(K, N)) ? 1 : 0; }
+
+extern "C" int a3d_conv1x1_nslab(size_t M, int K, int N) {
+  if (M == 0 || N <= 0 || K <= 0) return 0;
+  return c1_slabs(M, K, N);
 }
 
 extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu,
@@ -190,7 +360,29 @@ extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_
   const unsigned short* xs = (const unsigned short*)x;
   const unsigned short* ws = (const unsigned short*)w;
   unsigned short* ys = (unsigned short*)y;
-  const int slabs = c1_slabs(M, N);
+  const int slabs = c1_slabs(M, K, N);
+  if (c1_streams(K, N)) {
+    const size_t lds = c1_stream_lds(K, N);
+    const dim3 grid(slabs, N >= 256 ? N / 256 : 1);
+#define A3D_C1S(WNV, KSV)                                                                                                         \
+    do {                                                                                                                           \
+      static bool once = false;                                                                                                    \
+      if (!once) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<WNV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); once = true; } \
+      hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV>), grid, dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, N); \
+    } while (0)
+    const int wn = c1_wn(N), ks = K / 32;
+    if (wn == 4 && ks == 2) A3D_C1S(4, 2);
+    else if (wn == 4 && ks == 4) A3D_C1S(4, 4);
+    else if (wn == 2 && ks == 2) A3D_C1S(2, 2);
+    else if (wn == 2 && ks == 4) A3D_C1S(2, 4);
+    else if (wn == 2 && ks == 8) A3D_C1S(2, 8);
+    else if (wn == 1 && ks == 2) A3D_C1S(1, 2);
+    else if (wn == 1 && ks == 4) A3D_C1S(1, 4);
+    else if (wn == 1 && ks == 8) A3D_C1S(1, 8);
+    else { set_error("a3d_conv1x1_bn_fwd: no streaming instance for K=%d N=%d", K, N); return A3D_ERR_ARG; }
+#undef A3D_C1S
+    return check_launch("a3d_conv1x1_bn_fwd(stream)");
+  }
   if (N >= 256)
     hipLaunchKernelGGL(conv1x1_kernel<4>, dim3(slabs, N / 256), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
   else if (N == 128)

@@ -493,10 +493,12 @@ __device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, co
   float4 wq[WGRP][WCH];
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int r0 = 0; r0 < nrounds; r0 += WGRP) {
+    // unconditional (a guarded load ends its basic block with s_waitcnt vmcnt(0): the rounds would be fetched one after the
+    // other); rounds past the end re-fetch the last one
 #pragma unroll
     for (int u = 0; u < WGRP; ++u) {
-      const int r = r0 + u;
-      if (r < nrounds) loadw(wave + (r / nchunk) * nwave, r % nchunk, wq[u]);
+      const int r = min(r0 + u, nrounds - 1);
+      loadw(wave + (r / nchunk) * nwave, r % nchunk, wq[u]);
     }
 #pragma unroll
     for (int u = 0; u < WGRP; ++u) {

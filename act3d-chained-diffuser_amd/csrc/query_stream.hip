@@ -218,16 +218,24 @@ __device__ __forceinline__ void qs_colsum(const float* T, float& pb) {
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   for (int r = rg * 16; r < rg * 16 + 16; ++r) pb += T[r * QS_LD + c];
 }
-// dst[c] += the four row groups' partials (red: 256 floats of LDS)
-__device__ __forceinline__ void qs_flush_vec(float* __restrict__ dst, float p, float* red, int n) {
+// The gradient buffers are ADDED to (tied modules accumulate over the pyramid levels).  A read-add-store exposes one memory
+// round trip per flush -- twelve of them were a third of the first version's backward kernel; a returnless
+// global_atomic_add_f32 is fire-and-forget, and with ONE workgroup per launch and one add per address per launch the result
+// does not depend on any ordering (stream order separates the launches): deterministic.
+// vectors: NV per-thread partials p[0..NV) (thread = (column t & 63, row group t >> 6)) -> dst[v][c] += sum over the row groups
+template <int NV>
+__device__ __forceinline__ void qs_flush_vecs(float* const (&dst)[NV], const float (&p)[NV], float* red, int n) {
   __syncthreads();
-  red[threadIdx.x] = p;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) red[v * 256 + threadIdx.x] = p[v];
   __syncthreads();
-  if ((int)threadIdx.x < n) dst[threadIdx.x] += (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+  for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
+    const int v = i >> 6, c = i & 63;
+    if (c < n) atomicAdd(&dst[v][c], (red[v * 256 + c] + red[v * 256 + 64 + c]) + (red[v * 256 + 128 + c] + red[v * 256 + 192 + c]));
+  }
 }
 // dW[n][k] += wacc (rows n < N, columns k < K)
-__device__ __forceinline__ void qs_flush_wgrad(float* __restrict__ dW, int ldw, const f32x4 (&wacc)[4], int N, int K, int nlo = 0,
-                                               int nhi = 64) {
+__device__ __forceinline__ void qs_flush_wgrad(float* __restrict__ dW, int ldw, const f32x4 (&wacc)[4], int N, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -236,7 +244,7 @@ __device__ __forceinline__ void qs_flush_wgrad(float* __restrict__ dW, int ldw, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = wave * 16 + g * 4 + r;
-      if (n < N && n >= nlo && n < nhi) dW[(size_t)n * ldw + k] += wacc[ct][r];
+      if (n < N) atomicAdd(&dW[(size_t)n * ldw + k], wacc[ct][r]);
     }
   }
 }
@@ -359,7 +367,9 @@ __global__ __launch_bounds__(256) void qs_pre_bwd_kernel(const float* __restrict
     __syncthreads();
   }
   qs_flush_wgrad(dwq, E, wacc, E, E);
-  qs_flush_vec(dbq, pb, red, E);
+  float* const dst[1] = {dbq};
+  const float pv[1] = {pb};
+  qs_flush_vecs<1>(dst, pv, red, E);
 }
 
 // ------------------------------------------------------------------------------------------------ post: forward
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256) void qs_post_bwd_kernel(const float* __restric
   float* G = D + QS_TILE;             // produced gradient
   float* st = G + QS_TILE;            // [64][2] saved LayerNorm statistics
   float* rowst = st + 2 * QS_R;       // [64][2]
-  float* red = rowst + 2 * QS_R;      // [256]
+  float* red = rowst + 2 * QS_R;      // [8][256]
   const int SW = qs_save_width(E);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   f32x4 w2a[4], w1a[4], woa[4], wva[4];
@@ -578,14 +588,9 @@ __global__ __launch_bounds__(256) void qs_post_bwd_kernel(const float* __restric
   qs_flush_wgrad(gr.dw1, E, w1a, E, E);
   qs_flush_wgrad(gr.dwo, E, woa, E, E);
   qs_flush_wgrad(gr.dwv, E, wva, E, E);
-  qs_flush_vec(gr.dg2, pg2, red, E);
-  qs_flush_vec(gr.db2, pb2, red, E);
-  qs_flush_vec(gr.dc2, pc2, red, E);
-  qs_flush_vec(gr.dc1, pc1, red, E);
-  qs_flush_vec(gr.dg1, pg1, red, E);
-  qs_flush_vec(gr.db1, pb1, red, E);
-  qs_flush_vec(gr.dbo, pbo, red, E);
-  qs_flush_vec(gr.dbv, pbv, red, E);
+  float* const dst[8] = {gr.dg2, gr.db2, gr.dc2, gr.dc1, gr.dg1, gr.db1, gr.dbo, gr.dbv};
+  const float pv[8] = {pg2, pb2, pc2, pc1, pg1, pb1, pbo, pbv};
+  qs_flush_vecs<8>(dst, pv, red, E);
 }
 
 }  // namespace a3d
@@ -662,7 +667,7 @@ extern "C" int a3d_qs_post_bwd(const float* dy, const float* resid, const float*
   }
   static bool once = false;
   if (!once) { qs_allow_lds(qs_post_bwd_kernel); once = true; }
-  hipLaunchKernelGGL(qs_post_bwd_kernel, dim3(1), dim3(256), (5 * QS_TILE + 4 * QS_R + 256) * sizeof(float), (hipStream_t)stream, dy, resid,
+  hipLaunchKernelGGL(qs_post_bwd_kernel, dim3(1), dim3(256), (5 * QS_TILE + 4 * QS_R + 8 * 256) * sizeof(float), (hipStream_t)stream, dy, resid,
                      xbar, save, *p, *gr, dxbar, cD, dresid, B, E, H);
   return check_launch("a3d_qs_post_bwd");
 }

@@ -406,7 +406,7 @@ def conv1x1_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
     y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
     partial = None
     if want_stats:
-        partial = torch.empty((O.L.load().a3d_conv1x1_nslab(M, Cout), 2, Cout), device=x.device, dtype=torch.float32)
+        partial = torch.empty((O.L.load().a3d_conv1x1_nslab(M, K, Cout), 2, Cout), device=x.device, dtype=torch.float32)
     O.L.call("a3d_conv1x1_bn_fwd", x.data_ptr(), w2.data_ptr(), None if in_scale is None else in_scale[0].data_ptr(),
              None if in_scale is None else in_scale[1].data_ptr(), 1 if in_relu else 0, y.data_ptr(),
              None if partial is None else partial.data_ptr(), M, K, Cout, O.L.stream())
@@ -466,12 +466,20 @@ def fused_frozen_backbone_forward(bb, x):
     blocks = [blk for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for blk in layer]
     last_of_layer = {id(layer[-1]) for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4)}
     x_pooled = None                                    # AvgPool2d(2)(x), when the producer of x already emitted it
-    fuse = FUSED_CONV1X1
+    fuse = FUSED_CONV1X1          # "stream": only where the resident-weight streaming GEMM serves the shape; True / "all": every 1x1
+
+    def fused_ok(m, t):
+        """the 1x1 convolution m on input t goes through a3d_conv1x1_bn_fwd"""
+        if not fuse or m.kernel_size != (1, 1) or m.stride != (1, 1):
+            return False
+        K, Nc = t.shape[1], m.weight.shape[0]
+        if K % 32 or Nc % 64 or (Nc >= 256 and Nc % 256):
+            return False
+        return fuse != "stream" or bool(O.L.load().a3d_conv1x1_streams(K, Nc))
 
     def conv1(m, t, **kw):
         """1x1 convolution + the partial statistics of its output (None on the MIOpen path)"""
-        if fuse and m.kernel_size == (1, 1) and m.stride == (1, 1) and t.shape[1] % 32 == 0 and m.weight.shape[0] % 64 == 0 \
-                and (m.weight.shape[0] < 256 or m.weight.shape[0] % 256 == 0):
+        if fused_ok(m, t):
             return conv1x1_bn(t, m, **kw)
         return conv(m, t), None
 
@@ -480,7 +488,7 @@ def fused_frozen_backbone_forward(bb, x):
         out = bn_act(c1, blk.bn1, partial=p1)
         c2 = conv(blk.conv2, out)
         no_pool = isinstance(blk.avgpool, nn.Identity) or (isinstance(blk.avgpool, nn.AvgPool2d) and blk.avgpool.kernel_size in (1, (1, 1)))
-        if fuse and no_pool and blk.conv3.weight.shape[0] % 256 == 0:
+        if no_pool and fused_ok(blk.conv3, c2):
             # BatchNorm-apply + ReLU of bn2 ride on conv3's operand load: c2 is never rewritten
             o3, p3 = conv1x1_bn(c2, blk.conv3, in_scale=bn_scale_shift(c2, blk.bn2), in_relu=True, want_stats=blk.bn3.training)
         else:
@@ -519,9 +527,12 @@ def fused_frozen_backbone_forward(bb, x):
 
 
 FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
-# opt-in (round 2: correctness-tested, not yet timed inside the step): the backbone's 1x1 convolutions through
-# a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the consumer folded into the GEMM
-FUSED_CONV1X1 = os.environ.get("A3D_FUSED_CONV1X1", "0") == "1"
+# The backbone's 1x1 convolutions through a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the
+# consumer folded into the GEMM.  "stream" (default): the shapes the resident-weight streaming kernel serves (the HBM-bound
+# layers 1-2, where removing the BatchNorm passes pays: profiles/r04_conv1x1_layers.json); "all": every 1x1 convolution (the
+# re-staging kernel loses to MIOpen on the deep layers); "0": MIOpen everywhere
+_fc = os.environ.get("A3D_FUSED_CONV1X1", "stream")
+FUSED_CONV1X1 = False if _fc in ("0", "", "off") else ("stream" if _fc == "stream" else True)
 
 
 def normalize_to_nhwc_bf16(x, normalize):

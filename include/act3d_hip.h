@@ -428,9 +428,12 @@ int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream);
 /* ---- frozen backbone: 1x1 convolutions as a bf16 MFMA GEMM with the neighbouring BatchNorm work folded in ---------------
  * (CLIP ModifiedResNet bottleneck conv1 / conv3 / downsample, model/utils/clip.py:28-43.)
  * y [M][N] bf16 = f(x [M][K] bf16) w[N][K]^T with f(x) = relu?(x * in_scale[k] + in_shift[k]) (the producer's BatchNorm-apply;
- * in_scale NULL: identity); partial (or NULL): [a3d_conv1x1_nslab(M, N)][2][N] per-workgroup (sum, sum of squares) of the
- * rounded outputs = the input a3d_bn_finalize expects for the BatchNorm that follows.  K % 32 == 0, N in {64, 128, 256 j}. */
-int a3d_conv1x1_nslab(size_t M, int N);
+ * in_scale NULL: identity); partial (or NULL): [a3d_conv1x1_nslab(M, K, N)][2][N] per-workgroup (sum, sum of squares) of the
+ * rounded outputs = the input a3d_bn_finalize expects for the BatchNorm that follows.  K % 32 == 0, N in {64, 128, 256 j}.
+ * a3d_conv1x1_streams(K, N) == 1: the shape is served by the resident-weight streaming kernel (K <= 256, weight block + activation
+ * buffers within 96 KB of LDS) -- the HBM-bound layers, where the fusion pays; other shapes run the re-staging kernel. */
+int a3d_conv1x1_streams(int K, int N);
+int a3d_conv1x1_nslab(size_t M, int K, int N);
 int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
                        float* partial, size_t M, int K, int N, void* stream);
 

@@ -958,7 +958,11 @@ def test_option_head_kernels(a3d, dev):
 
 
 @pytest.mark.parametrize("M,K,N,pro", [(1000, 256, 64, True), (4096, 64, 256, False), (777, 512, 128, True),
-                                       (2048, 1024, 512, True), (64, 2048, 1024, False), (16, 128, 256, True)])
+                                       (2048, 1024, 512, True), (64, 2048, 1024, False), (16, 128, 256, True),
+                                       # the resident-weight streaming kernel: every (waves along N, K steps) instance, workgroups
+                                       # with fewer steps than the prefetch depth and with many tiles, a ragged last tile
+                                       (5000, 64, 64, True), (3000, 256, 128, True), (70001, 128, 512, False), (100000, 64, 256, True),
+                                       (400003, 64, 256, False), (150000, 128, 128, True), (9000, 64, 128, False), (33000, 128, 64, True)])
 def test_conv1x1_gemm_with_folded_batchnorm(a3d, dev, M, K, N, pro):
     """a3d_conv1x1_bn_fwd: y = bf16(f(x) w^T) with f = the producer's BatchNorm-apply + ReLU (rounded to bf16 as the unfused
     path materialises it), fp32 accumulation, and the per-slab (sum, sum of squares) of the rounded outputs."""
@@ -973,7 +977,7 @@ def _check_conv1x1(a3d, dev, M, K, N, pro):
     sh = (0.2 * torch.randn(K, generator=g)) if pro else None
     xd, wd = x.to(dev), w.to(dev)
     y = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-    nslab = a3d.lib.load().a3d_conv1x1_nslab(M, N)
+    nslab = a3d.lib.load().a3d_conv1x1_nslab(M, K, N)
     part = torch.zeros((nslab, 2, N), device=dev, dtype=torch.float32)
     scd = None if sc is None else sc.to(dev).contiguous()
     shd = None if sh is None else sh.to(dev).contiguous()
@@ -1003,22 +1007,24 @@ def test_backbone_with_fused_1x1_convolutions_matches_miopen_path(a3d, dev):
     import copy
     torch.manual_seed(0)
     bb32 = a3d.nn.SyntheticCLIPResNet50().to(dev).train()
-    nets = {False: copy.deepcopy(bb32), True: copy.deepcopy(bb32)}
+    nets = {False: copy.deepcopy(bb32), "stream": copy.deepcopy(bb32), True: copy.deepcopy(bb32)}
     x = torch.rand(4, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
     outs = {}
+    keep = a3d.nn.FUSED_CONV1X1
     with torch.no_grad():
         ref = bb32(x)
         for flag, net in nets.items():
-            a3d.nn.FUSED_CONV1X1 = flag
+            a3d.nn.FUSED_CONV1X1 = flag          # False: MIOpen; "stream": the streaming kernel's shapes (default); True: every 1x1
             try:
                 outs[flag] = a3d.nn.run_frozen_backbone(net, x.clone(), torch.bfloat16)
             finally:
-                a3d.nn.FUSED_CONV1X1 = False
+                a3d.nn.FUSED_CONV1X1 = keep
     rms = lambda t: t.float().pow(2).mean().sqrt().item()
     for k in ref:
-        e_f, e_d, sc = rms(outs[True][k] - ref[k]), rms(outs[False][k] - ref[k]), rms(ref[k])
-        print(f"[parity] backbone {k}: rms_err fused-1x1={e_f:.3e} default={e_d:.3e} ref_rms={sc:.3e}")
+        e_s, e_f, e_d, sc = rms(outs["stream"][k] - ref[k]), rms(outs[True][k] - ref[k]), rms(outs[False][k] - ref[k]), rms(ref[k])
+        print(f"[parity] backbone {k}: rms_err fused-1x1 stream={e_s:.3e} all={e_f:.3e} default={e_d:.3e} ref_rms={sc:.3e}")
         assert torch.isfinite(outs[True][k]).all() and e_f <= 1.25 * e_d + 1e-3 * sc, k
+        assert torch.isfinite(outs["stream"][k]).all() and e_s <= 1.25 * e_d + 1e-3 * sc, k
     for (n, p), (_, q) in zip(bb32.named_buffers(), nets[True].named_buffers()):
         if n.endswith("num_batches_tracked"):
             assert torch.equal(p, q), n
