@@ -14,9 +14,8 @@
 //   32-key half interleaved (tile T row i <-> key (i>>2)*8 + (i&3) + 4T) so that after exp() every lane
 //   already holds, in order, the 8 consecutive keys the P operand of the PV MFMA wants: P never touches LDS.
 //   PV = V_hi P_hi + V_hi P_lo + V_lo P_hi (3 MFMAs per 32 keys).
-// Backward (attn_bwd_dq_kernel / attn_bwd_dkv_kernel): recompute-based, exact f32 MFMA (16x16x4), operands
-//   reconstructed as hi + lo from the same split tensors the forward consumed.  The transposed formulation
-//   (S^T for dQ, S for dK/dV) puts P / dS directly in B-operand layout, so again no LDS transposes of scores.
+// Backward: attention_bwd.hip (split-bf16 MFMA on the same operand formats; the exact-f32 MFMA backward that preceded it was
+//   deleted in round 4 -- one A/B reference per kernel).
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
 #include <stdlib.h>
@@ -301,230 +300,6 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(
   }
 }
 
-// dOh[b][h][q][16] (head-padded copy of dO, rows >= Lq zero) and D[b][h][q] = sum_d dO * O
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(
-    const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ dOh,
-    float* __restrict__ D, int B, int H, int Lq, int Lqp) {
-  const size_t rows = (size_t)B * H * Lqp;
-  const int E = H * HD;
-  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
-       row += (size_t)gridDim.x * blockDim.x) {
-    const int q = (int)(row % Lqp);
-    const size_t bh = row / Lqp;
-    const int h = (int)(bh % H), b = (int)(bh / H);
-    float dsum = 0.f;
-    float v[HDP];
-#pragma unroll
-    for (int d = 0; d < HDP; ++d) v[d] = 0.f;
-    if (q < Lq) {
-      const size_t base = ((size_t)b * Lq + q) * E + h * HD;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) {
-        v[d] = dO[base + d];
-        dsum += v[d] * O[base + d];
-      }
-    }
-#pragma unroll
-    for (int d4 = 0; d4 < 4; ++d4)
-      *reinterpret_cast<float4*>(&dOh[row * HDP + d4 * 4]) = make_float4(v[d4 * 4], v[d4 * 4 + 1], v[d4 * 4 + 2], v[d4 * 4 + 3]);
-    D[row] = dsum;
-  }
-}
-
-// q / k rows: p -> 4 hi at p[0..3], 4 lo at p[16..19], 4 lo2 at p[32..35]; x = hi + (lo + lo2)
-__device__ __forceinline__ float4 load_split4(const unsigned short* p) {
-  const s16x4 hi = *reinterpret_cast<const s16x4*>(p);
-  const s16x4 lo = *reinterpret_cast<const s16x4*>(p + 16);
-  const s16x4 l2 = *reinterpret_cast<const s16x4*>(p + 32);
-  return make_float4(bf2f((unsigned short)hi[0]) + (bf2f((unsigned short)lo[0]) + bf2f((unsigned short)l2[0])),
-                     bf2f((unsigned short)hi[1]) + (bf2f((unsigned short)lo[1]) + bf2f((unsigned short)l2[1])),
-                     bf2f((unsigned short)hi[2]) + (bf2f((unsigned short)lo[2]) + bf2f((unsigned short)l2[2])),
-                     bf2f((unsigned short)hi[3]) + (bf2f((unsigned short)lo[3]) + bf2f((unsigned short)l2[3])));
-}
-
-// stage 64 keys of K (from QK format) and V (from VT format) as fp32 [64][FLD]
-__device__ __forceinline__ void stage_kv_f32(float* Kf, float* Vf, float* biasS,
-                                             const unsigned short* __restrict__ Ks,
-                                             const unsigned short* __restrict__ Vt,
-                                             const unsigned char* __restrict__ kmask, size_t bh, int b,
-                                             int c, int S, int Sp) {
-  const int t = threadIdx.x;
-  {
-    const int row = t >> 2, qd = t & 3;
-    const float4 v = load_split4(Ks + (bh * Sp + (size_t)c * KC + row) * QKW + qd * 4);
-    *reinterpret_cast<float4*>(&Kf[row * FLD + qd * 4]) = v;
-  }
-  {
-    const int key = t & 63, dq = t >> 6;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = dq * 4 + e;
-      const float hi = bf2f(Vt[((bh * 2 + 0) * 16 + d) * Sp + (size_t)c * KC + key]);
-      const float lo = bf2f(Vt[((bh * 2 + 1) * 16 + d) * Sp + (size_t)c * KC + key]);
-      Vf[key * FLD + d] = hi + lo;
-    }
-  }
-  if (t < KC) {
-    const int key = c * KC + t;
-    bool valid = key < S;
-    if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
-    biasS[t] = valid ? 0.f : -INFINITY;
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
-    const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
-    const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
-    const float* __restrict__ dOh, const float* __restrict__ LSE, const float* __restrict__ D,
-    float* __restrict__ dQp, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit) {
-  __shared__ __attribute__((aligned(16))) float Kf[KC * FLD];
-  __shared__ __attribute__((aligned(16))) float Vf[KC * FLD];
-  __shared__ __attribute__((aligned(16))) float biasS[KC];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z / nsplit, sp = blockIdx.z - b * nsplit;
-  const int h = blockIdx.y;
-  const size_t bh = (size_t)b * H + h;
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  const bool active = q0 < Lqp;
-  const int q = q0 + li;
-
-  float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), dof = qf;
-  float lse_q = INFINITY, d_q = 0.f;
-  if (active) {
-    qf = load_split4(Qs + (bh * Lqp + q) * QKW + g * 4);
-    dof = *reinterpret_cast<const float4*>(&dOh[(bh * Lqp + q) * HDP + g * 4]);
-    if (q < Lq) {
-      lse_q = LSE[bh * Lqp + q];
-      if (lse_q == -INFINITY) lse_q = INFINITY;
-      d_q = D[bh * Lqp + q];
-    }
-  }
-  const int nch = Sp / KC;
-  const int cps = (nch + nsplit - 1) / nsplit;
-  const int c_beg = sp * cps, c_end = min(nch, c_beg + cps);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int c = c_beg; c < c_end; ++c) {
-    stage_kv_f32(Kf, Vf, biasS, Ks, Vt, kmask, bh, b, c, S, Sp);
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int T = 0; T < 4; ++T) {
-        const float4 ka = *reinterpret_cast<const float4*>(&Kf[(T * 16 + li) * FLD + g * 4]);
-        const float4 va = *reinterpret_cast<const float4*>(&Vf[(T * 16 + li) * FLD + g * 4]);
-        f32x4 sT = *reinterpret_cast<const f32x4*>(&biasS[T * 16 + g * 4]);
-        sT = mfma_f32_16x16x4(ka.x, qf.x, sT);
-        sT = mfma_f32_16x16x4(ka.y, qf.y, sT);
-        sT = mfma_f32_16x16x4(ka.z, qf.z, sT);
-        sT = mfma_f32_16x16x4(ka.w, qf.w, sT);
-        f32x4 dpT = {0.f, 0.f, 0.f, 0.f};
-        dpT = mfma_f32_16x16x4(va.x, dof.x, dpT);
-        dpT = mfma_f32_16x16x4(va.y, dof.y, dpT);
-        dpT = mfma_f32_16x16x4(va.z, dof.z, dpT);
-        dpT = mfma_f32_16x16x4(va.w, dof.w, dpT);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(sT[r] - lse_q);
-          const float ds = p * (dpT[r] - d_q);
-          const float kd = Kf[(T * 16 + g * 4 + r) * FLD + li];
-          acc = mfma_f32_16x16x4(kd, ds, acc);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (active) {
-    const size_t row = (((size_t)sp * B + b) * H + h) * Lqp + q;
-    *reinterpret_cast<f32x4*>(&dQp[row * HDP + g * 4]) = acc;
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
-    const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks,
-    const unsigned short* __restrict__ Vt, const unsigned char* __restrict__ kmask,
-    const float* __restrict__ dOh, const float* __restrict__ LSE, const float* __restrict__ D,
-    float* __restrict__ dK, float* __restrict__ dV, int B, int H, int Lq, int Lqp, int S, int Sp) {
-  __shared__ __attribute__((aligned(16))) float Qf[64 * FLD];
-  __shared__ __attribute__((aligned(16))) float Of[64 * FLD];
-  __shared__ __attribute__((aligned(16))) float lseS[64];
-  __shared__ __attribute__((aligned(16))) float dS_[64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const size_t bh = (size_t)b * H + h;
-  const int key = blockIdx.x * 64 + wave * 16 + li;   // < Sp always
-
-  const float4 kf = load_split4(Ks + (bh * Sp + key) * QKW + g * 4);
-  float4 vf;
-  {
-    float tmp[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = g * 4 + e;
-      tmp[e] = bf2f(Vt[((bh * 2 + 0) * 16 + d) * Sp + key]) + bf2f(Vt[((bh * 2 + 1) * 16 + d) * Sp + key]);
-    }
-    vf = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-  }
-  bool valid = key < S;
-  if (valid && kmask) valid = kmask[(size_t)b * S + key] == 0;
-  const float bias_k = valid ? 0.f : -INFINITY;
-
-  f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-  for (int qc = 0; qc < Lqp; qc += 64) {
-    {
-      const int row = t >> 2, qd = t & 3;
-      const int q = qc + row;
-      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ov = qv;
-      if (q < Lqp) {
-        qv = load_split4(Qs + (bh * Lqp + q) * QKW + qd * 4);
-        ov = *reinterpret_cast<const float4*>(&dOh[(bh * Lqp + q) * HDP + qd * 4]);
-      }
-      *reinterpret_cast<float4*>(&Qf[row * FLD + qd * 4]) = qv;
-      *reinterpret_cast<float4*>(&Of[row * FLD + qd * 4]) = ov;
-      if (t < 64) {
-        const int qq = qc + t;
-        float l = INFINITY, dd = 0.f;
-        if (qq < Lq) {
-          l = LSE[bh * Lqp + qq];
-          if (l == -INFINITY) l = INFINITY;
-          dd = D[bh * Lqp + qq];
-        }
-        lseS[t] = l;
-        dS_[t] = dd;
-      }
-    }
-    __syncthreads();
-    const int ntile = min(4, (Lqp - qc) >> 4);
-    for (int T = 0; T < ntile; ++T) {
-      const float4 qa = *reinterpret_cast<const float4*>(&Qf[(T * 16 + li) * FLD + g * 4]);
-      const float4 oa = *reinterpret_cast<const float4*>(&Of[(T * 16 + li) * FLD + g * 4]);
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      s = mfma_f32_16x16x4(qa.x, kf.x, s);
-      s = mfma_f32_16x16x4(qa.y, kf.y, s);
-      s = mfma_f32_16x16x4(qa.z, kf.z, s);
-      s = mfma_f32_16x16x4(qa.w, kf.w, s);
-      dp = mfma_f32_16x16x4(oa.x, vf.x, dp);
-      dp = mfma_f32_16x16x4(oa.y, vf.y, dp);
-      dp = mfma_f32_16x16x4(oa.z, vf.z, dp);
-      dp = mfma_f32_16x16x4(oa.w, vf.w, dp);
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lseS[T * 16 + g * 4]);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&dS_[T * 16 + g * 4]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[r] + bias_k - l4[r]);
-        const float ds = p * (dp[r] - d4[r]);
-        const float od = Of[(T * 16 + g * 4 + r) * FLD + li];
-        const float qd_ = Qf[(T * 16 + g * 4 + r) * FLD + li];
-        dv = mfma_f32_16x16x4(od, p, dv);
-        dk = mfma_f32_16x16x4(qd_, ds, dk);
-      }
-    }
-    __syncthreads();
-  }
-  *reinterpret_cast<f32x4*>(&dK[(bh * Sp + key) * HDP + g * 4]) = dk;
-  *reinterpret_cast<f32x4*>(&dV[(bh * Sp + key) * HDP + g * 4]) = dv;
-}
-
 }  // namespace a3d
 
 using namespace a3d;
@@ -604,31 +379,4 @@ extern "C" int a3d_attn_fwd_dropout(const void* Qs, const void* Ks, const void* 
 extern "C" size_t a3d_attn_fwd_ws_floats(int B, int H, int Lqp, int nsplit) {
   if (nsplit <= 1) return 0;
   return (size_t)nsplit * B * H * Lqp * (HDP + 2);
-}
-
-extern "C" int a3d_attn_bwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask,
-                            const float* O, const float* dO, const float* LSE, float* dOh, float* D,
-                            float* dQp, float* dK, float* dV, int B, int H, int Lq, int Lqp, int S, int Sp,
-                            int nsplit, void* stream) {
-  int rc = check_attn_args("a3d_attn_bwd", B, H, Lq, Lqp, S, Sp, nsplit);
-  if (rc) return rc;
-  if (!Qs || !Ks || !Vt || !O || !dO || !LSE || !dOh || !D || !dQp || !dK || !dV) {
-    set_error("a3d_attn_bwd: null pointer");
-    return A3D_ERR_ARG;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  const size_t rows = (size_t)B * H * Lqp;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((int)std::min<size_t>((rows + 255) / 256, 4096)), dim3(256), 0,
-                     s, dO, O, dOh, D, B, H, Lq, Lqp);
-  rc = check_launch("a3d_attn_bwd(prep)");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Lqp, 64), H, B * nsplit), dim3(256), 0, s,
-                     (const unsigned short*)Qs, (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, dOh,
-                     LSE, D, dQp, B, H, Lq, Lqp, S, Sp, nsplit);
-  rc = check_launch("a3d_attn_bwd(dq)");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(Sp / KC, H, B), dim3(256), 0, s, (const unsigned short*)Qs,
-                     (const unsigned short*)Ks, (const unsigned short*)Vt, kmask, dOh, LSE, D, dK, dV, B, H, Lq,
-                     Lqp, S, Sp);
-  return check_launch("a3d_attn_bwd(dkv)");
 }

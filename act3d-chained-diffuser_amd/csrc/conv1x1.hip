@@ -5,12 +5,14 @@
 //   optional epilogue: per-workgroup partial (sum, sum of squares) of the ROUNDED outputs per channel, in the layout
 //   a3d_bn_finalize reduces ([slab][2][N]) -- the statistics pass of the BatchNorm that follows the convolution.
 // Folding BatchNorm-apply + ReLU of the PRODUCER into the A-operand load and the statistics of the CONSUMER's BatchNorm
-// into the epilogue removes one read + one write and one read of the activation per fused layer; the GEMM itself is
-// HBM-bound (K, N <= 2048: 2 (M K + M N) bytes for 2 M N K FLOP).
+// into the epilogue removes one read + one write and one read of the activation per fused layer.  It pays where the GEMM is
+// HBM-bound -- layers 1 and 2 (M = 2^18 .. 2^20 rows, K <= 256): there MIOpen's convolution already runs at 4.8 - 5.5 TB/s
+// (profiles/r04_conv_layers.json), so the only thing to win is the BatchNorm traffic, and the kernel has to match MIOpen's
+// bandwidth to keep it.  On the deep layers (K, N up to 2048 at M = 2^14 .. 2^16) the convolution is compute-bound and MIOpen /
+// CK reach 0.6 - 1.0 PFLOP/s; the round-2/3 re-staging kernel that served them lost by 3x (profiles/r04_conv1x1_layers.json) and
+// was deleted in round 4: those shapes stay on MIOpen.
 // Tiling: 256 threads = 4 waves in a WM x WN grid, 64 x 64 outputs per wave (16 MFMA 16x16x32 tiles, computed TRANSPOSED --
-// A operand = w rows, B operand = x rows -- so that a lane owns 4 consecutive channels of one row: 8-byte stores, full
-// 32-byte sectors).  32-channel K steps staged through LDS (swizzled [rows][32] tiles, a3d_common.h plane_off),
-// register-prefetched one step ahead; workgroups walk the M tiles persistently so that there are few statistic slabs.
+// A operand = w rows, B operand = x rows -- so that a lane owns consecutive channels of one row).
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
 
@@ -18,152 +20,8 @@ namespace a3d {
 
 constexpr int C1_BK = 32;
 
-template <int WN>     // waves along N (1, 2 or 4); WM = 4 / WN waves along M
-__global__ __launch_bounds__(256) void conv1x1_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
-                                                      const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                      int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial,
-                                                      long long M, int K, int N) {
-  constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN;
-  constexpr int XL = BM * 4 / 256, WL = BN * 4 / 256;            // 16-byte segments each thread stages per K step
-  __shared__ __attribute__((aligned(16))) unsigned short Xs[2][BM * 32];
-  __shared__ __attribute__((aligned(16))) unsigned short Ws[2][BN * 32];
-  __shared__ float redS[4][64], redQ[4][64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.y * BN;
-  const long long mtiles = (M + BM - 1) / BM;
-  const int ksteps = K / C1_BK;
-  float ssum[4][4], ssq[4][4];                                    // [tn][r]: channel n0 + wn * 64 + tn * 16 + g * 4 + r
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
-
-  for (long long mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
-    const long long m0 = mt * BM;
-    uint4 xr[XL], wr[WL];
-    auto load = [&](int ks) {
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
-        const long long m = m0 + row < M ? m0 + row : M - 1;                   // clamped: tail rows are masked at the store
-        xr[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks * C1_BK + seg * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
-        wr[i] = *reinterpret_cast<const uint4*>(w + (size_t)(n0 + row) * K + ks * C1_BK + seg * 8);
-      }
-    };
-    auto stage = [&](int buf, int ks) {
-#pragma unroll
-      for (int i = 0; i < XL; ++i) {
-        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
-        uint4 v = xr[i];
-        if (in_scale) {
-          // producer's BatchNorm-apply (+ ReLU) on the 8 channels of this segment, rounded back to bf16 like the
-          // activation the unfused path materialises
-          const int k0 = ks * C1_BK + seg * 8;
-          const float4 s0 = *reinterpret_cast<const float4*>(in_scale + k0), s1 = *reinterpret_cast<const float4*>(in_scale + k0 + 4);
-          const float4 h0 = *reinterpret_cast<const float4*>(in_shift + k0), h1 = *reinterpret_cast<const float4*>(in_shift + k0 + 4);
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-          unsigned int u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a = __uint_as_float(u[j] << 16) * sc[2 * j] + sh[2 * j];
-            float b = __uint_as_float(u[j] & 0xFFFF0000u) * sc[2 * j + 1] + sh[2 * j + 1];
-            if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-            u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
-          }
-          v = make_uint4(u[0], u[1], u[2], u[3]);
-        }
-        *reinterpret_cast<uint4*>(&Xs[buf][plane_off(row, seg)]) = v;
-      }
-#pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int idx = t + i * 256, row = idx >> 2, seg = idx & 3;
-        *reinterpret_cast<uint4*>(&Ws[buf][plane_off(row, seg)]) = wr[i];
-      }
-    };
-
-    f32x4 acc[4][4];                                              // [tn][tm]: D[n = g * 4 + r][m = li]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load(0);
-    __syncthreads();                                              // previous tile's LDS reads are done
-    stage(0, 0);
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int buf = ks & 1;
-      if (ks + 1 < ksteps) load(ks + 1);
-      __syncthreads();                                            // stage(buf) visible; reads of buf ^ 1 (step ks - 1) done
-      s16x8 xa[4], wb[4];
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-        xa[tm] = *reinterpret_cast<const s16x8*>(&Xs[buf][plane_off(wm * 64 + tm * 16 + li, g)]);
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-        wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[buf][plane_off(wn * 64 + tn * 16 + li, g)]);
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
-      if (ks + 1 < ksteps) stage(buf ^ 1, ks + 1);
-    }
-    // ---- epilogue: round once, 8-byte stores (4 consecutive channels of one row), statistics of the rounded values
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      const long long m = m0 + wm * 64 + tm * 16 + li;
-      const bool ok = m < M;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = f2bf(acc[tn][tm][r]);
-          if (ok) {
-            const float v = bf2f(h[r]);
-            ssum[tn][r] += v;
-            ssq[tn][r] += v * v;
-          }
-        }
-        if (ok) {
-          const uint2 pk = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
-          *reinterpret_cast<uint2*>(y + (size_t)m * N + n0 + wn * 64 + tn * 16 + g * 4) = pk;
-        }
-      }
-    }
-  }
-  if (!partial) return;
-  // ---- per-workgroup partial statistics: sum over the 16 rows a lane group holds, then over the WM waves along M
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = ssum[tn][r], q = ssq[tn][r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (li == 0) { redS[wave][tn * 16 + g * 4 + r] = s; redQ[wave][tn * 16 + g * 4 + r] = q; }
-    }
-  __syncthreads();
-  for (int i = t; i < BN; i += 256) {
-    const int wn_i = i >> 6, c = i & 63;
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int j = 0; j < WM; ++j) { s += redS[j * WN + wn_i][c]; q += redQ[j * WN + wn_i][c]; }
-    float* p = partial + (size_t)blockIdx.x * 2 * N;
-    p[n0 + i] = s;
-    p[N + n0 + i] = q;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Streaming variant for the HBM-bound shapes (layer 1 / layer 2 of the CLIP ResNet: M = 2^18 .. 2^20 rows, K, N <= 512): the
-// workgroup's weight block W[BN][K] is staged ONCE and stays in LDS while the workgroup walks its M tiles -- the kernel above
-// re-stages it for every tile and K step, which for K = 64 -> N = 256 is four times the bytes of the activation tile it is
+// The workgroup's weight block W[BN][K] is staged ONCE and stays in LDS while the workgroup walks its M tiles -- the first kernel
+// re-staged it for every tile and K step, which for K = 64 -> N = 256 is four times the bytes of the activation tile it is
 // multiplied with (LDS writes and L2 reads, not HBM, bounded it: 15.5 vs 11.9 ms for the whole backbone in round 3) -- and the
 // (tile, K step) pairs of a workgroup form one flat sequence of steps whose activation chunks are fetched D steps ahead into
 // registers (~32 KB in flight per workgroup, unconditional clamped loads), one barrier per step, two LDS buffers.
@@ -255,18 +113,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
           xa[tm] = *reinterpret_cast<const s16x8*>(&Xs[buf * BM * 32 + plane_off(wm * 64 + tm * 16 + li, g)]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-          wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + plane_off(wn * 64 + tn * 16 + li, g)]);
+          wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + plane_off(wn * 64 + (li >> 2) * 16 + tn * 4 + (li & 3), g)]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
         if (ks == KS - 1) {
-          // tile done: round once, 8-byte stores (4 consecutive channels of one row), statistics of the rounded values
+          // tile done: round once; the weight rows were fed to the MFMA permuted (tile tn row i <-> channel (i >> 2) * 16 + tn * 4 +
+          // (i & 3) of the wave's 64), so a lane holds 16 CONSECUTIVE channels of its row: 32-byte stores, and the four lane groups
+          // of a row write one full 128-byte line (8-byte stores of 4 channels reached 3.25 TB/s on the 64 -> 256 layers against
+          // MIOpen's 5.2); statistics of the rounded values
           const long long m0 = (blockIdx.x + (s / KS) * gridDim.x) * BM;
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm) {
             const long long m = m0 + wm * 64 + tm * 16 + li;
             const bool ok = m < M;
+            unsigned int pk[8];
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
               unsigned short h[4];
@@ -280,10 +142,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
                 }
                 acc[tn][tm][r] = 0.f;
               }
-              if (ok) {
-                const uint2 pk = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
-                *reinterpret_cast<uint2*>(y + (size_t)m * N + n0 + wn * 64 + tn * 16 + g * 4) = pk;
-              }
+              pk[2 * tn] = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
+              pk[2 * tn + 1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+            }
+            if (ok) {
+              uint4* dst = reinterpret_cast<uint4*>(y + (size_t)m * N + n0 + wn * 64 + g * 16);
+              dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+              dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
           }
         }
@@ -298,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
       float sv = ssum[tn][r], q = ssq[tn][r];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); q += __shfl_xor(q, o, 64); }
-      if (li == 0) { redS[wave][tn * 16 + g * 4 + r] = sv; redQ[wave][tn * 16 + g * 4 + r] = q; }
+      if (li == 0) { redS[wave][g * 16 + tn * 4 + r] = sv; redQ[wave][g * 16 + tn * 4 + r] = q; }      // the permuted channel of (tn, g, r)
     }
   __syncthreads();
   for (int i = t; i < BN; i += 256) {
@@ -331,29 +196,25 @@ static int c1_slabs(size_t M, int K, int N) {
   const int bm = 64 * (4 / wn);
   const size_t mtiles = (M + bm - 1) / bm;
   const int ntiles = N / (64 * wn);
-  if (c1_streams(K, N)) {
-    // persistent: as many workgroups as are resident at once (LDS-limited), each walking its share of the M tiles
-    const size_t lds = c1_stream_lds(K, N) + 2048;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));      // 248 registers per lane: two workgroups per CU
-    return (int)std::min<size_t>(mtiles, (size_t)std::max(1, 256 * per_cu / ntiles));
-  }
-  size_t cap = (size_t)std::max(1, 2048 / ntiles);               // ~8 workgroups per CU over the whole grid
-  return (int)std::min(mtiles, cap);
+  // persistent: as many workgroups as are resident at once (LDS-limited), each walking its share of the M tiles
+  const size_t lds = c1_stream_lds(K, N) + 2048;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));      // 180 registers per lane: two workgroups per CU
+  return (int)std::min<size_t>(mtiles, (size_t)std::max(1, 256 * per_cu / ntiles));
 }
 
 extern "C" int a3d_conv1x1_streams(int K, int N) { return (K > 0 && N > 0 && c1_streams(K, N)) ? 1 : 0; }
 
 extern "C" int a3d_conv1x1_nslab(size_t M, int K, int N) {
-  if (M == 0 || N <= 0 || K <= 0) return 0;
+  if (M == 0 || N <= 0 || K <= 0 || !c1_streams(K, N)) return 0;
   return c1_slabs(M, K, N);
 }
 
 extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu,
                                   void* y, float* partial, size_t M, int K, int N, void* stream) {
-  if (!x || !w || !y || M == 0 || K <= 0 || N <= 0 || (K % 32) != 0 || (N % 64) != 0 || (N >= 256 && (N % 256) != 0) ||
-      (in_scale && !in_shift) || ((((uintptr_t)x | (uintptr_t)w) & 15) != 0) || (((uintptr_t)y) & 7) != 0 ||
-      (in_scale && ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0))) {
-    set_error("a3d_conv1x1_bn_fwd: bad argument (M=%zu K=%d N=%d; K %% 32 == 0, N in {64, 128, 256 j}, 16-byte aligned operands)", M, K, N);
+  if (!x || !w || !y || M == 0 || K <= 0 || N <= 0 || !c1_streams(K, N) || (in_scale && !in_shift) ||
+      ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
+    set_error("a3d_conv1x1_bn_fwd: bad argument (M=%zu K=%d N=%d; served shapes: K in {64, 128, 256}, N in {64, 128, 256 j}, weight block "
+              "+ buffers within 96 KB of LDS -- a3d_conv1x1_streams; 16-byte aligned operands)", M, K, N);
     return A3D_ERR_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -361,33 +222,24 @@ extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_
   const unsigned short* ws = (const unsigned short*)w;
   unsigned short* ys = (unsigned short*)y;
   const int slabs = c1_slabs(M, K, N);
-  if (c1_streams(K, N)) {
-    const size_t lds = c1_stream_lds(K, N);
-    const dim3 grid(slabs, N >= 256 ? N / 256 : 1);
+  const size_t lds = c1_stream_lds(K, N);
+  const dim3 grid(slabs, N >= 256 ? N / 256 : 1);
 #define A3D_C1S(WNV, KSV)                                                                                                         \
-    do {                                                                                                                           \
-      static bool once = false;                                                                                                    \
-      if (!once) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<WNV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); once = true; } \
-      hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV>), grid, dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, N); \
-    } while (0)
-    const int wn = c1_wn(N), ks = K / 32;
-    if (wn == 4 && ks == 2) A3D_C1S(4, 2);
-    else if (wn == 4 && ks == 4) A3D_C1S(4, 4);
-    else if (wn == 2 && ks == 2) A3D_C1S(2, 2);
-    else if (wn == 2 && ks == 4) A3D_C1S(2, 4);
-    else if (wn == 2 && ks == 8) A3D_C1S(2, 8);
-    else if (wn == 1 && ks == 2) A3D_C1S(1, 2);
-    else if (wn == 1 && ks == 4) A3D_C1S(1, 4);
-    else if (wn == 1 && ks == 8) A3D_C1S(1, 8);
-    else { set_error("a3d_conv1x1_bn_fwd: no streaming instance for K=%d N=%d", K, N); return A3D_ERR_ARG; }
+  do {                                                                                                                           \
+    static bool once = false;                                                                                                    \
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<WNV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); once = true; } \
+    hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV>), grid, dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, N); \
+  } while (0)
+  const int wn = c1_wn(N), ks = K / 32;
+  if (wn == 4 && ks == 2) A3D_C1S(4, 2);
+  else if (wn == 4 && ks == 4) A3D_C1S(4, 4);
+  else if (wn == 2 && ks == 2) A3D_C1S(2, 2);
+  else if (wn == 2 && ks == 4) A3D_C1S(2, 4);
+  else if (wn == 2 && ks == 8) A3D_C1S(2, 8);
+  else if (wn == 1 && ks == 2) A3D_C1S(1, 2);
+  else if (wn == 1 && ks == 4) A3D_C1S(1, 4);
+  else if (wn == 1 && ks == 8) A3D_C1S(1, 8);
+  else { set_error("a3d_conv1x1_bn_fwd: no streaming instance for K=%d N=%d", K, N); return A3D_ERR_ARG; }
 #undef A3D_C1S
-    return check_launch("a3d_conv1x1_bn_fwd(stream)");
-  }
-  if (N >= 256)
-    hipLaunchKernelGGL(conv1x1_kernel<4>, dim3(slabs, N / 256), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
-  else if (N == 128)
-    hipLaunchKernelGGL(conv1x1_kernel<2>, dim3(slabs, 1), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
-  else
-    hipLaunchKernelGGL(conv1x1_kernel<1>, dim3(slabs, 1), dim3(256), 0, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, K, N);
   return check_launch("a3d_conv1x1_bn_fwd");
 }

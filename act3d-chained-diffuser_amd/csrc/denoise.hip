@@ -43,18 +43,76 @@ constexpr int WCH = 8;            // 16-channel blocks per register chunk
 
 // (The fragment loads are branch-free -- clamped addresses + selects: a per-lane guarded load compiles to one basic block
 // and one s_waitcnt vmcnt(0) per load, i.e. one exposed L2 round trip per 16 channels.)
-// Round 4: a wave's (tile, chunk) ROUNDS are fetched four at a time -- 32 float4 per lane in flight -- before their 128 MFMAs
-// issue.  Round 3 prefetched one round ahead, but a round computes for ~0.4 us against 1.5-3 us of L2 / HBM latency, so every
-// round still exposed a round trip: 13 per layer remainder (the FFN's two layers are four rounds per wave each, A3D_DN_PROF:
-// 20 of the remainder's 61 us).  With groups of four a dense layer exposes ceil(rounds / 4) round trips: 6 per remainder.
-constexpr int WGRP = 4;           // rounds fetched together
-template <bool VEC>
-__device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, const float* bias,
-                                             int N, float* Ys, int ldy, int act);
 template <int ACT, bool VEC>
 __device__ __forceinline__ void wg_linear_impl(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                                const float* __restrict__ bias, int N, float* Ys, int ldy) {
-  wg_linear_rt<VEC>(Xs, ldx, K, W, ldw, bias, N, Ys, ldy, ACT);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
+  const int nchunk = (nblk + WCH - 1) / WCH;
+  auto loadw = [&](int ct, int c, float4 (&w)[WCH]) {
+    const int n = ct * 16 + li;
+    const float* wrow = W + (size_t)min(n, N - 1) * ldw;
+    const bool row_ok = n < N;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int k0 = (c * WCH + i) * 16 + 4 * g;
+      float4 wv;
+      if (VEC) {                                             // K % 4 == 0, rows 16-byte aligned
+        wv = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
+        if (!(row_ok && k0 < K)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        wv.x = wrow[min(k0 + 0, K - 1)];
+        wv.y = wrow[min(k0 + 1, K - 1)];
+        wv.z = wrow[min(k0 + 2, K - 1)];
+        wv.w = wrow[min(k0 + 3, K - 1)];
+        wv.x = (row_ok && k0 + 0 < K) ? wv.x : 0.f;
+        wv.y = (row_ok && k0 + 1 < K) ? wv.y : 0.f;
+        wv.z = (row_ok && k0 + 2 < K) ? wv.z : 0.f;
+        wv.w = (row_ok && k0 + 3 < K) ? wv.w : 0.f;
+      }
+      w[i] = wv;
+    }
+  };
+  float4 wc[WCH], wn[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) wn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ct = wave, c = 0;
+  if (ct < ntile) loadw(ct, 0, wc);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  while (ct < ntile) {
+    int nct = ct, nc = c + 1;
+    if (nc == nchunk) { nc = 0; nct = ct + nwave; }
+    if (nct < ntile) loadw(nct, nc, wn);                     // wave-uniform condition
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int blk = min(c * WCH + i, nblk - 1);            // blocks past the end multiply zero weights
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
+      acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
+      acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
+      acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
+      acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
+    }
+    if (c == nchunk - 1) {
+      const int n = ct * 16 + li;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc0[r] + acc1[r] + bv;
+          if (ACT == 1) v = fmaxf(v, 0.f);
+          Ys[(g * 4 + r) * ldy + n] = v;
+        }
+      }
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wc[i] = wn[i];
+    ct = nct;
+    c = nc;
+  }
+  __syncthreads();
 }
 
 template <int ACT>
@@ -456,6 +514,10 @@ struct DnOp {
 };
 struct DnOpTable { int n; DnOp op[13]; };
 
+// Round 4 measured a deeper weight fetch here -- a wave's rounds fetched four at a time (32 float4 per lane in flight) before
+// their MFMAs, on the hypothesis that every round exposes an L2 round trip: 0.913 ms per denoise step with guarded loads, 1.10 ms
+// with unconditional ones (redundant re-fetches for waves with fewer than four rounds), against 0.86 ms for the one-round-ahead
+// pipeline below (gpurun r04e / r04f, cfg-3).  The hypothesis is refuted; the pipeline stays.
 template <bool VEC>
 __device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, const float* bias,
                                              int N, float* Ys, int ldy, int act) {
@@ -471,7 +533,7 @@ __device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, co
     for (int i = 0; i < WCH; ++i) {
       const int k0 = (c * WCH + i) * 16 + 4 * g;
       float4 wv;
-      if (VEC) {                                             // K % 4 == 0, rows 16-byte aligned
+      if (VEC) {
         wv = *reinterpret_cast<const float4*>(wrow + min(k0, K - 4));
         if (!(row_ok && k0 < K)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
@@ -487,48 +549,43 @@ __device__ __forceinline__ void wg_linear_rt(const float* Xs, int ldx, int K, co
       w[i] = wv;
     }
   };
-  // this wave's rounds, tile-major: round r = (tile wave + (r / nchunk) * nwave, chunk r % nchunk); all conditions wave-uniform
-  const int tiles_w = wave < ntile ? (ntile - wave + nwave - 1) / nwave : 0;
-  const int nrounds = tiles_w * nchunk;
-  float4 wq[WGRP][WCH];
+  float4 wc[WCH], wn[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) wn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ct = wave, c = 0;
+  if (ct < ntile) loadw(ct, 0, wc);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int r0 = 0; r0 < nrounds; r0 += WGRP) {
-    // unconditional (a guarded load ends its basic block with s_waitcnt vmcnt(0): the rounds would be fetched one after the
-    // other); rounds past the end re-fetch the last one
+  while (ct < ntile) {
+    int nct = ct, nc = c + 1;
+    if (nc == nchunk) { nc = 0; nct = ct + nwave; }
+    if (nct < ntile) loadw(nct, nc, wn);
 #pragma unroll
-    for (int u = 0; u < WGRP; ++u) {
-      const int r = min(r0 + u, nrounds - 1);
-      loadw(wave + (r / nchunk) * nwave, r % nchunk, wq[u]);
+    for (int i = 0; i < WCH; ++i) {
+      const int blk = min(c * WCH + i, nblk - 1);
+      const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
+      acc0 = mfma_f32_16x16x4(a.x, wc[i].x, acc0);
+      acc1 = mfma_f32_16x16x4(a.y, wc[i].y, acc1);
+      acc0 = mfma_f32_16x16x4(a.z, wc[i].z, acc0);
+      acc1 = mfma_f32_16x16x4(a.w, wc[i].w, acc1);
     }
+    if (c == nchunk - 1) {
+      const int n = ct * 16 + li;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int u = 0; u < WGRP; ++u) {
-      const int r = r0 + u;
-      if (r >= nrounds) break;
-      const int ct = wave + (r / nchunk) * nwave, c = r % nchunk;
-#pragma unroll
-      for (int i = 0; i < WCH; ++i) {
-        const int blk = min(c * WCH + i, nblk - 1);          // blocks past the end multiply zero weights
-        const float4 a = *reinterpret_cast<const float4*>(&Xs[li * ldx + blk * 16 + 4 * g]);
-        acc0 = mfma_f32_16x16x4(a.x, wq[u][i].x, acc0);
-        acc1 = mfma_f32_16x16x4(a.y, wq[u][i].y, acc1);
-        acc0 = mfma_f32_16x16x4(a.z, wq[u][i].z, acc0);
-        acc1 = mfma_f32_16x16x4(a.w, wq[u][i].w, acc1);
-      }
-      if (c == nchunk - 1) {
-        const int n = ct * 16 + li;
-        if (n < N) {
-          const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            float v = acc0[rr] + acc1[rr] + bv;
-            if (act == 1) v = fmaxf(v, 0.f);
-            Ys[(g * 4 + rr) * ldy + n] = v;
-          }
+        for (int r = 0; r < 4; ++r) {
+          float v = acc0[r] + acc1[r] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          Ys[(g * 4 + r) * ldy + n] = v;
         }
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = acc0;
       }
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = acc0;
     }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wc[i] = wn[i];
+    ct = nct;
+    c = nc;
   }
   __syncthreads();
 }

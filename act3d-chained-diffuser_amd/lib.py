@@ -54,7 +54,6 @@ SIGNATURES = {
     "a3d_rope_merge_bwd": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_fwd_ws_floats": (_z, [_i, _i, _i, _i]),
-    "a3d_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn_bwd_bf16": (_i, [_p] * 15 + [_i] * 7 + [_p]),
     "a3d_rope_split16": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_proj_rope_split16": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _p, _p, _i, _p, _f, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),

@@ -466,16 +466,12 @@ def fused_frozen_backbone_forward(bb, x):
     blocks = [blk for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4) for blk in layer]
     last_of_layer = {id(layer[-1]) for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4)}
     x_pooled = None                                    # AvgPool2d(2)(x), when the producer of x already emitted it
-    fuse = FUSED_CONV1X1          # "stream": only where the resident-weight streaming GEMM serves the shape; True / "all": every 1x1
+    fuse = FUSED_CONV1X1
 
     def fused_ok(m, t):
-        """the 1x1 convolution m on input t goes through a3d_conv1x1_bn_fwd"""
-        if not fuse or m.kernel_size != (1, 1) or m.stride != (1, 1):
-            return False
-        K, Nc = t.shape[1], m.weight.shape[0]
-        if K % 32 or Nc % 64 or (Nc >= 256 and Nc % 256):
-            return False
-        return fuse != "stream" or bool(O.L.load().a3d_conv1x1_streams(K, Nc))
+        """the 1x1 convolution m on input t goes through a3d_conv1x1_bn_fwd (the shapes its streaming kernel serves)"""
+        return bool(fuse and m.kernel_size == (1, 1) and m.stride == (1, 1) and
+                    O.L.load().a3d_conv1x1_streams(t.shape[1], m.weight.shape[0]))
 
     def conv1(m, t, **kw):
         """1x1 convolution + the partial statistics of its output (None on the MIOpen path)"""
@@ -527,12 +523,10 @@ def fused_frozen_backbone_forward(bb, x):
 
 
 FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
-# The backbone's 1x1 convolutions through a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the
-# consumer folded into the GEMM.  "stream" (default): the shapes the resident-weight streaming kernel serves (the HBM-bound
-# layers 1-2, where removing the BatchNorm passes pays: profiles/r04_conv1x1_layers.json); "all": every 1x1 convolution (the
-# re-staging kernel loses to MIOpen on the deep layers); "0": MIOpen everywhere
-_fc = os.environ.get("A3D_FUSED_CONV1X1", "stream")
-FUSED_CONV1X1 = False if _fc in ("0", "", "off") else ("stream" if _fc == "stream" else True)
+# The backbone's 1x1 convolutions of the HBM-bound layers (1 and 2: K <= 256, the shapes a3d_conv1x1_streams accepts) through
+# a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the consumer folded into the GEMM; the deep,
+# compute-bound layers stay on MIOpen (profiles/r04_conv1x1_layers.json).  A3D_FUSED_CONV1X1=0: MIOpen everywhere (A/B).
+FUSED_CONV1X1 = os.environ.get("A3D_FUSED_CONV1X1", "1") not in ("0", "", "off")
 
 
 def normalize_to_nhwc_bf16(x, normalize):

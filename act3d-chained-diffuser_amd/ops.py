@@ -356,9 +356,6 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, si
     return O, LSE
 
 
-BWD_F32 = os.environ.get("A3D_BWD_F32", "0") == "1"     # A/B switch: exact-f32 MFMA reference backward (attention.hip)
-
-
 def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, extra=None, drop=None, site=0):
     dev = Qs.device
     dropping = drop is not None and drop.p > 0
@@ -377,24 +374,18 @@ def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, e
                dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, drop.state.data_ptr() if dropping else None,
                int(site), drop.p if dropping else 0.0, L.stream())
         return dQp, dK, dV
-    if extra is None or extra[0] is None or BWD_F32:
-        if dropping:
-            raise NotImplementedError("attention-weight dropout is implemented in the split-bf16 backward only")
-        dOh = torch.empty((B, H, Lqp, 16), device=dev, dtype=F32)
-        L.call("a3d_attn_bwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), km, O.data_ptr(), dO.data_ptr(),
-               LSE.data_ptr(), dOh.data_ptr(), D.data_ptr(), dQp.data_ptr(), dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp,
-               S, Sp, nsplit, L.stream())
+    if extra is None or extra[0] is None:
+        raise RuntimeError("attn_core_bwd: the forward wrote no backward operand formats (it ran with need_bwd=False)")
+    Qt, Kt, Vs = extra
+    dOs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
+    dOt = torch.empty((B, H, 2, 16, Lqp), device=dev, dtype=torch.bfloat16)
+    args = (Qs.data_ptr(), Qt.data_ptr(), Ks.data_ptr(), Kt.data_ptr(), Vs.data_ptr(), km,
+            O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOs.data_ptr(), dOt.data_ptr(), D.data_ptr(), dQp.data_ptr(),
+            dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit)
+    if dropping:
+        L.call("a3d_attn_bwd_bf16_dropout", *args, drop.state.data_ptr(), int(site), drop.p, L.stream())
     else:
-        Qt, Kt, Vs = extra
-        dOs = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.bfloat16)
-        dOt = torch.empty((B, H, 2, 16, Lqp), device=dev, dtype=torch.bfloat16)
-        args = (Qs.data_ptr(), Qt.data_ptr(), Ks.data_ptr(), Kt.data_ptr(), Vs.data_ptr(), km,
-                O.data_ptr(), dO.data_ptr(), LSE.data_ptr(), dOs.data_ptr(), dOt.data_ptr(), D.data_ptr(), dQp.data_ptr(),
-                dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit)
-        if dropping:
-            L.call("a3d_attn_bwd_bf16_dropout", *args, drop.state.data_ptr(), int(site), drop.p, L.stream())
-        else:
-            L.call("a3d_attn_bwd_bf16", *args, L.stream())
+        L.call("a3d_attn_bwd_bf16", *args, L.stream())
     return dQp, dK, dV
 
 

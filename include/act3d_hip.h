@@ -90,13 +90,8 @@ int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz, const floa
 int a3d_attn_fwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, float* O, float* LSE,
                  float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
 size_t a3d_attn_fwd_ws_floats(int B, int H, int Lqp, int nsplit);
-/* Backward of the above.  Scratch: dOh [B][H][Lqp][16], D [B][H][Lqp].  Outputs (grad w.r.t. rotated rows):
- * dQp [nsplit][B][H][Lqp][16], dK [B][H][Sp][16], dV [B][H][Sp][16]. */
-int a3d_attn_bwd(const void* Qs, const void* Ks, const void* Vt, const unsigned char* kmask, const float* O,
-                 const float* dO, const float* LSE, float* dOh, float* D, float* dQp, float* dK, float* dV, int B,
-                 int H, int Lq, int Lqp, int S, int Sp, int nsplit, void* stream);
-
-/* Same gradients on split-bf16 MFMA (default path).  Needs both formats of q, k, v: rows Qs, Ks (48-wide), Vs (32-wide)
+/* Backward of the above on split-bf16 MFMA: outputs (gradients w.r.t. the rotated rows) dQp [nsplit][B][H][Lqp][16], dK / dV
+ * [B][H][Sp][16].  Needs both formats of q, k, v: rows Qs, Ks (48-wide), Vs (32-wide)
  * and planes Qt, Kt (a3d_rope_split writes both).  Scratch: dOs [B][H][Lqp][32] bf16, dOt [B][H][2][16][Lqp] bf16,
  * D [B][H][Lqp].  Lqp % 64 == 0. */
 int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void* Kt, const void* Vs,
@@ -429,9 +424,10 @@ int a3d_dbg_cvt_pk_bf16(const float* in, void* out, int npairs, void* stream);
  * (CLIP ModifiedResNet bottleneck conv1 / conv3 / downsample, model/utils/clip.py:28-43.)
  * y [M][N] bf16 = f(x [M][K] bf16) w[N][K]^T with f(x) = relu?(x * in_scale[k] + in_shift[k]) (the producer's BatchNorm-apply;
  * in_scale NULL: identity); partial (or NULL): [a3d_conv1x1_nslab(M, K, N)][2][N] per-workgroup (sum, sum of squares) of the
- * rounded outputs = the input a3d_bn_finalize expects for the BatchNorm that follows.  K % 32 == 0, N in {64, 128, 256 j}.
- * a3d_conv1x1_streams(K, N) == 1: the shape is served by the resident-weight streaming kernel (K <= 256, weight block + activation
- * buffers within 96 KB of LDS) -- the HBM-bound layers, where the fusion pays; other shapes run the re-staging kernel. */
+ * rounded outputs = the input a3d_bn_finalize expects for the BatchNorm that follows.
+ * Served shapes (a3d_conv1x1_streams(K, N) == 1): K in {64, 128, 256}, N in {64, 128, 256 j}, weight block + activation buffers
+ * within 96 KB of LDS -- the HBM-bound layers 1-2 of the ResNet, where the fusion pays; other shapes are refused (A3D_ERR_ARG,
+ * a3d_conv1x1_nslab 0): the compute-bound deep layers stay on MIOpen.  Operands 16-byte aligned. */
 int a3d_conv1x1_streams(int K, int N);
 int a3d_conv1x1_nslab(size_t M, int K, int N);
 int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,

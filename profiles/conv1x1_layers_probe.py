@@ -50,7 +50,7 @@ for cin, cout, hw, count, pos in SHAPES:
     sc = torch.rand(2, cin, device=dev) + 0.5
     nslab = lib.a3d_bn_nslab(M, cout)
     part = torch.empty(nslab, 2, cout, device=dev)
-    nslab_c = lib.a3d_conv1x1_nslab(M, cin, cout)
+    nslab_c = max(1, lib.a3d_conv1x1_nslab(M, cin, cout))
     part_c = torch.empty(nslab_c, 2, cout, device=dev)
     st = L.stream()
     t_conv = timeit(lambda: F.conv2d(x, w))
@@ -68,7 +68,7 @@ for cin, cout, hw, count, pos in SHAPES:
         L.call("a3d_conv1x1_bn_fwd", x.data_ptr(), w2.data_ptr(), sc[0].data_ptr() if pos == "conv3" else None,
                sc[1].data_ptr() if pos == "conv3" else None, 1 if pos == "conv3" else 0, y.data_ptr(), part_c.data_ptr(), M, cin, cout, st)
 
-    ok = cin % 32 == 0 and cout % 64 == 0 and (cout < 256 or cout % 256 == 0)
+    ok = bool(lib.a3d_conv1x1_streams(cin, cout))
     t_unf = timeit(unfused)
     t_f = timeit(fused) if ok else float("nan")
     mb = 2.0 * (x.numel() + y.numel()) / 1e6

@@ -595,11 +595,10 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, None, 1, dummy, None, 128, 64, 64, None) == -22     # scale without shift
     assert b"a3d_conv1x1_bn_fwd" in lib.a3d_last_error_string()
     # slab planning is pure host code and consistent with the tile table (64 / 128 / >= 256 output channels)
-    assert lib.a3d_conv1x1_nslab(1 << 20, 512, 64) == 2048 and lib.a3d_conv1x1_nslab(1000, 512, 64) == 4
-    assert lib.a3d_conv1x1_nslab(1 << 20, 512, 1024) == 512 and lib.a3d_conv1x1_nslab(100, 512, 256) == 2
-    # the resident-weight streaming kernel (K <= 256, LDS block <= 96 KB): persistent grid of up to two workgroups per CU
+    # the resident-weight streaming kernel serves K <= 256 with an LDS block <= 96 KB; other shapes are refused (MIOpen's)
     assert lib.a3d_conv1x1_streams(64, 256) == 1 and lib.a3d_conv1x1_streams(256, 128) == 1 and lib.a3d_conv1x1_streams(128, 512) == 1
     assert lib.a3d_conv1x1_streams(256, 512) == 0 and lib.a3d_conv1x1_streams(512, 128) == 0 and lib.a3d_conv1x1_streams(96, 64) == 0
+    assert lib.a3d_conv1x1_nslab(1 << 20, 512, 64) == 0 and lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 512, 128, None) == -22
     assert lib.a3d_conv1x1_nslab(1 << 20, 64, 256) == 512 and lib.a3d_conv1x1_nslab(1 << 18, 128, 512) == 256 and lib.a3d_conv1x1_nslab(100, 64, 64) == 1
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
 
