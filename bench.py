@@ -252,7 +252,7 @@ def other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq):
 def pmc_record(B):
     """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
     counters cannot be read from inside this process).  None when no record exists for this batch size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_pmc_B{B}.json")   # B = 64 (round 3 kernels)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r04_pmc_B{B}.json")   # B = 64 (round 4 kernels)
     try:
         with open(path) as fh:
             return json.load(fh)["kernels"]
@@ -593,11 +593,14 @@ def main():
             pmc = pmc_record(B) or {}
             r["traffic"] = pmc.get(dom, {}).get("hbm_bytes")
             if dom in pmc:
-                r["traffic_source"] = f"profiles/r03_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
+                r["traffic_source"] = f"profiles/r04_pmc_B{B}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch)"
                 r["pmc"] = pmc[dom].get("pmc")
             res["roofline"] = r
             res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
-                                  **({"mfma_util_executed": v["mfma_util_executed"]} if "mfma_util_executed" in v else {})}
+                                  "launches_per_step": v.get("launches_per_step"),
+                                  **({"mfma_util_executed": v["mfma_util_executed"]} if "mfma_util_executed" in v else {}),
+                                  **({"traffic": pmc[k]["hbm_bytes"]} if k in pmc else {}),
+                                  **({"pmc": pmc[k]["pmc"]} if k in pmc and pmc[k].get("pmc") else {})}
                               for k, v in ks.items()}
         except Exception as e:
             res["roofline"] = {"error": repr(e)[:300]}

@@ -136,9 +136,18 @@ def training_attention_roofline(a3d, B, Ln, S, dev):
     tf = _time(lambda: O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Ln, Lqp, S, Sp, ns), 20)
     tb = _time(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Ln, Lqp, S, Sp, ns, extra=extra), 20)
     fl = 14.0 * Ln * S * E * B
-    return {"bound": "mfma", "kernel": "attn_fwd + attn_bwd (trajectory -> context cross-attention)",
+    traffic, src = None, None
+    try:          # HBM bytes of the same micro-benchmark from the committed counter passes (profiles/pmc_json_cmd.sh)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r04_pmc_diffusion_attn_B{B}_L{Ln}.json")
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]
+        traffic = k["attn_fwd"]["hbm_bytes"] + k["attn_bwd"]["hbm_bytes"]
+        src = f"profiles/r04_pmc_diffusion_attn_B{B}_L{Ln}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, forward + backward launch)"
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "attn_fwd + attn_bwd (trajectory -> context cross-attention)", "traffic_source": src,
             "achieved": fl / (tf + tb) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / (tf + tb) / 1e12 / 2500.0,
-            "ms": (tf + tb) * 1e3, "ms_fwd": tf * 1e3, "ms_bwd": tb * 1e3, "traffic": None, "launches_per_step": 8,
+            "ms": (tf + tb) * 1e3, "ms_fwd": tf * 1e3, "ms_bwd": tb * 1e3, "traffic": traffic, "launches_per_step": 8,
             "dtype": "fp16 / bf16 MFMA on two-part operands" if f16 else "bf16 (split operands)", "family": O.ATTN_MODE}
 
 
@@ -237,7 +246,8 @@ def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"])
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "attn"],
+                    help="attn: only the trajectory -> context attention micro-benchmark of the training roofline (for counter passes)")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--cams", type=int, default=3)
@@ -248,7 +258,9 @@ def main():
     torch.backends.cudnn.benchmark = True
     a3d = importlib.import_module("act3d-chained-diffuser_amd")
     a3d.lib.load()
-    if args.mode == "sample":
+    if args.mode == "attn":
+        res = training_attention_roofline(a3d, args.batch or 22, args.horizon or 50, args.cams * 1024 + 2, dev)
+    elif args.mode == "sample":
         res = sampling_bench(a3d, dev, args.batch or 64, args.horizon or 16, args.cams, args.reps, not args.no_graph)
     else:
         res = training_bench(a3d, dev, args.batch or 22, args.horizon or 50, args.cams, args.reps, 3, not args.no_graph)
