@@ -278,107 +278,6 @@ __global__ __launch_bounds__(256) void proj_rope_split_kernel(
   else write_operand_formats(T, ldt, blk.rows, blk.rows_width, blk.planes, b, n0, Npad, H);
 }
 
-// Persistent variant for K <= 64 and E <= 64 (the Act3D shapes: E = K = 60).  The kernel above is a chain per 64-row tile --
-// global loads -> LDS -> barrier -> MFMA -> LDS -> barrier -> rotation -> barrier -> format stores -- with nothing in flight
-// while it waits, and it re-stages the 16 KB weight block for every tile: 8 us per workgroup, 30 % of HBM peak (round-3 review).
-// Here a workgroup keeps its weight block in LDS and walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (block,
-// sample) with the NEXT tile's rows already travelling in registers (unconditional clamped loads); the tile buffer T has its
-// own LDS so that the weights survive the epilogue.  Same arithmetic (exact-f32 MFMA in k order), same outputs.
-template <int NT>
-__global__ __launch_bounds__(256) void proj_rope_split_res_kernel(
-    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ bias, int K,
-    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E, int H, int fmt16) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                               // [64][PR_LD]
-  float* Ws = Xs + RT_ROWS * PR_LD;               // [NT * 16][PR_LD]
-  float* T = Ws + NT * 16 * PR_LD;                // [64][E + 1]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z;
-  const ProjBlock blk = blockIdx.y ? blk1 : blk0;
-  const float* Wb = W + (size_t)blockIdx.y * E * ldw;
-  const float* bb = bias ? bias + blockIdx.y * E : nullptr;
-  const bool w_vec = ((((uintptr_t)Wb) & 15) == 0) && ((ldw & 3) == 0);
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int idx = t + i * 256;
-    const int j = idx >> 4, c = (idx & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < E && c < K) {
-      const float* wp = Wb + (size_t)j * ldw + c;
-      v = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
-    }
-    *reinterpret_cast<float4*>(&Ws[j * PR_LD + c]) = v;
-  }
-  const int ntile = Npad / RT_ROWS;
-  auto fetch = [&](int tile, float4 (&xr)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = t + i * 256;
-      const int r = idx >> 4, c = (idx & 15) * 4;
-      const int n = tile * RT_ROWS + r;
-      const bool ok = n < N && c < K;
-      const float4 v = *reinterpret_cast<const float4*>(X + ((size_t)b * N + (ok ? n : 0)) * ldx + (ok ? c : 0));
-      xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  float4 xr[4];
-  int tile = blockIdx.x;
-  if (tile >= ntile) return;
-  fetch(tile, xr);
-  const int ksteps = (K + 3) >> 2;
-  const int ldt = E + 1;
-  for (; tile < ntile; tile += gridDim.x) {
-    const int n0 = tile * RT_ROWS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = t + i * 256;
-      *reinterpret_cast<float4*>(&Xs[(idx >> 4) * PR_LD + (idx & 15) * 4]) = xr[i];
-    }
-    __syncthreads();                              // rows (and, first time, weights) staged; the previous tile's T readers are done
-    fetch(min(tile + (int)gridDim.x, ntile - 1), xr);
-    f32x4 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < ksteps; ++kk) {
-      const float a = Xs[(wave * 16 + li) * PR_LD + kk * 4 + g];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f32_16x16x4(a, Ws[(nt * 16 + li) * PR_LD + kk * 4 + g], acc[nt]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int c = nt * 16 + li;
-      if (c >= E) continue;
-      const float bv = bb ? bb[c] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wave * 16 + g * 4 + r;
-        T[row * ldt + c] = (n0 + row < N) ? (acc[nt][r] + bv) * blk.scale : 0.f;
-      }
-    }
-    __syncthreads();
-    if (blk.xyz) {
-      const int half = E >> 1, third = E / 3;
-      for (int idx = t; idx < RT_ROWS * half; idx += 256) {
-        const int r = idx / half, p = idx - r * half;
-        const int n = n0 + r;
-        if (n >= N) continue;
-        const int c = 2 * p;
-        const int axis = c / third;
-        const int kf = (c - axis * third) >> 1;
-        float sn, cs;
-        fast_sincos(blk.xyz[((size_t)b * N + n) * 3 + axis] * freq[kf], &sn, &cs);
-        const float y0 = T[r * ldt + c], y1 = T[r * ldt + c + 1];
-        T[r * ldt + c] = y0 * cs - y1 * sn;
-        T[r * ldt + c + 1] = y1 * cs + y0 * sn;
-      }
-      __syncthreads();
-    }
-    if (fmt16) write_operand_formats16(T, ldt, blk.rows, blk.planes, blk.rows_width, b, n0, Npad, H);   // rows_width = plane parts
-    else write_operand_formats(T, ldt, blk.rows, blk.rows_width, blk.planes, b, n0, Npad, H);
-  }
-}
-
 // dY[m][c] = scale * R(xyz)^T * sum_s dR[s][b][h][n][d]   (R^T = inverse rotation; identity when xyz == null)
 __global__ __launch_bounds__(256) void rope_merge_bwd_kernel(
     const float* __restrict__ dR, int nsplit, const float* __restrict__ xyz, const float* __restrict__ freq,
@@ -505,16 +404,8 @@ static int proj_rope_split_launch(const char* fn, const float* X, int ldx, const
   ProjBlock b0{xyz0, scale0, (unsigned short*)rows0, rows0_width, (unsigned short*)planes0};
   ProjBlock b1{xyz1, scale1, (unsigned short*)rows1, rows1_width, (unsigned short*)planes1};
   const int NT = E <= 64 ? 4 : 8;
-  static const bool res_off = getenv("A3D_PROJ_RES") && atoi(getenv("A3D_PROJ_RES")) == 0;      // A/B switch: the per-tile kernel
-  if (NT == 4 && K <= PR_KC && !res_off) {
-    // persistent, weight-resident variant: ~3 workgroups per CU over the whole grid, each walking its share of the tiles
-    const int ntile = Npad / RT_ROWS;
-    const int gx = std::max(1, std::min(ntile, 768 / ((two ? 2 : 1) * B)));
-    const size_t lds_res = ((size_t)(RT_ROWS + NT * 16) * PR_LD + (size_t)RT_ROWS * (E + 1)) * sizeof(float);
-    hipLaunchKernelGGL(proj_rope_split_res_kernel<4>, dim3(gx, two ? 2 : 1, B), dim3(256), lds_res, (hipStream_t)stream, X, ldx, W, ldw,
-                       bias, K, b0, b1, freq, B, N, Npad, E, H, fmt16);
-    return check_launch(fn);
-  }
+  // (round 4 measured a persistent, weight-resident variant of this kernel for K <= 64 -- weights kept in LDS, next tile's rows
+  // prefetched in registers: 0.149 ms against 0.138 ms for the k|v block of the bench shape, gpurun r04h; deleted.)
   dim3 grid(Npad / RT_ROWS, two ? 2 : 1, B);
   const size_t lds = std::max((size_t)(RT_ROWS + NT * 16) * PR_LD, (size_t)RT_ROWS * (E + 1)) * sizeof(float);
   static bool attr_set = false;

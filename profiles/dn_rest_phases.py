@@ -21,18 +21,12 @@ torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 18)()
 a3d.lib.call("a3d_dbg_dn_prof", ctypes.cast(buf, ctypes.c_void_p).value)
 t = [buf[i] for i in range(18)]
-straight = os.environ.get("A3D_DN_REST") == "straight"
-if straight:
-    names = ["stage vectors + warm-up of the weights", "load x rows", "combine key splits", "linear c_out (120->120)", "add+LN", "AdaLN (self)",
-             "linear q|k (120->240)", "linear v (120->120)", "RoPE", "16x16 self-attention", "linear s_out (120->120)", "add+LN",
-             "AdaLN (ffn)", "zero pad", "linear ffn1 (120->480, relu)", "linear ffn2 (480->120)", "add+LN", "store"]
-    marks = list(range(18))
-else:           # dn_rest_loop_kernel: marks 0, 1, 2, then one per operation (3 .. 15), 17 at the end
-    names = ["stage vectors + warm-up of the weights", "load x rows + pads + combine key splits", "linear c_out (120->120)", "add+LN",
-             "AdaLN (self)", "linear q|k (120->240)", "linear v (120->120)", "RoPE", "16x16 self-attention", "linear s_out (120->120)",
-             "add+LN", "AdaLN (ffn)", "linear ffn1 (120->480, relu)", "linear ffn2 (480->120)", "add+LN", "store"]
-    marks = list(range(16)) + [17]
-out = {"kernel": "dn_rest_kernel (straight-line)" if straight else "dn_rest_loop_kernel", "eager_ms_per_denoise_step": r.get("ms_per_denoise_step"),
+# dn_rest_loop_kernel: marks 0, 1, 2, then one per operation (3 .. 15), 17 at the end (the straight-line kernel of round 3 is gone)
+names = ["stage vectors + warm-up of the weights", "load x rows + pads + combine key splits", "linear c_out (120->120)", "add+LN",
+         "AdaLN (self)", "linear q|k (120->240)", "linear v (120->120)", "RoPE", "16x16 self-attention", "linear s_out (120->120)",
+         "add+LN", "AdaLN (ffn)", "linear ffn1 (120->480, relu)", "linear ffn2 (480->120)", "add+LN", "store"]
+marks = list(range(16)) + [17]
+out = {"kernel": "dn_rest_loop_kernel", "eager_ms_per_denoise_step": r.get("ms_per_denoise_step"),
        "total_us": (t[17] - t[0]) * 0.01,
        "phases_us": {f"{i:02d} {names[i]}": round((t[marks[i + 1]] - t[marks[i]]) * 0.01, 2) for i in range(len(marks) - 1)}}
 print(json.dumps(out, indent=1))
