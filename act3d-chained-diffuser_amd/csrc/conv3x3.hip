@@ -1,0 +1,269 @@
+// 3x3 (stride 1, padding 1) convolutions of the frozen backbone's narrow layers as a bf16 MFMA implicit GEMM with the
+// neighbouring BatchNorm work folded in (CLIP ModifiedResNet: the stem's conv2 / conv3 and layer1's conv2,
+// model/utils/clip.py:22-43 -- 32 -> 32 and 32 -> 64 channels at 128 x 128, 64 -> 64 at 64 x 64 for 256 x 256 images).
+//   y[n][oy][ox][co] = sum_{kh, kw, ci} f(x[n][oy + kh - 1][ox + kw - 1][ci]) * w[co][kh][kw][ci]      (0 outside the image)
+//   f(v) = relu?(v * in_scale[ci] + in_shift[ci]) rounded to bf16 (identity when in_scale == NULL): BatchNorm-apply + ReLU of
+//   the PRODUCER, which the unfused path materialises with a3d_bn_apply;   x, y bf16 NHWC;  w bf16 [Cout][3][3][Cin] (the
+//   channels_last layout of the torch weight);  fp32 accumulation, one rounding;  optional epilogue: per-workgroup partial
+//   (sum, sum of squares) of the ROUNDED outputs per channel, in the layout a3d_bn_finalize reduces ([slab][2][Cout]).
+// Why these layers: at <= 64 channels the library convolutions reach 0.3 - 0.5 PFLOP/s and 1.7 - 2.3 TB/s -- neither roof
+// (profiles/r04_conv_layers.json: 238 / 349 / 155 us against 67 / 101 / 34 us of HBM time) -- and each is surrounded by a
+// BatchNorm-apply pass over its input (read + write) and a statistics pass over its output that this kernel absorbs.  From 128
+// channels on the weights (9 Cin Cout bf16 >= 288 KB) do not fit LDS and CK is compute-bound at 0.7 - 1.0 PFLOP/s: MIOpen.
+// Structure (the streaming scheme of conv1x1.hip): a persistent workgroup keeps ALL weights in LDS and walks 8 x 32-pixel output
+// tiles; the (tile, 32-channel half) pairs form one flat sequence of steps whose 10 x 34-pixel halo tiles are fetched D steps
+// ahead into registers (unconditional clamped loads), normalised and zero-padded on their way into one of two LDS buffers, one
+// barrier per step.  Per step and wave: 9 taps x (4 pixel fragments + Cout/16 weight fragments) -> 36 Cout/16 MFMA 16x16x32,
+// computed TRANSPOSED (A = weight rows, B = pixels) with the weight rows permuted so that a lane owns 8 / 16 consecutive
+// channels of its pixel (16 / 32-byte stores, full lines per pixel).
+// LDS rows are 64 bytes (32 channels) with the 16-byte segment g of row p stored at g ^ ((p >> 1) & 3): conflict-free
+// ds_read_b128 for 16 consecutive rows from ANY base row (the tap shifts make the base arbitrary; plane_off is only
+// conflict-free from aligned bases).
+#include "a3d_common.h"
+#include "../../include/act3d_hip.h"
+
+namespace a3d {
+
+constexpr int C3_TH = 8, C3_TW = 32;                              // output tile
+constexpr int C3_HW = C3_TW + 2, C3_HP = (C3_TH + 2) * C3_HW;     // halo tile: 10 x 34 = 340 pixels
+constexpr int C3_XL = (C3_HP * 4 + 255) / 256;                    // 16-byte segments each thread stages per step: 6
+
+__device__ __forceinline__ int c3_off(int row, int seg) { return row * 32 + ((seg ^ ((row >> 1) & 3)) << 3); }
+
+template <int HALVES, int NT, int D, bool ROLL>
+__global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ in_scale,
+    const float* __restrict__ in_shift, int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial, int nimg, int H,
+    int W) {
+  constexpr int CIN = 32 * HALVES, COUT = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_c3[];
+  unsigned short* Ws = smem_c3;                                   // [HALVES][9][COUT] rows of 32 channels
+  unsigned short* Xs = Ws + HALVES * 9 * COUT * 32;               // [2][C3_HP] rows of 32 channels
+  float* scS = reinterpret_cast<float*>(Xs + 2 * C3_HP * 32);     // [CIN] scale | [CIN] shift
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  // workgroups of one XCD (blockIdx.x mod 8) take consecutive tiles, so that the halo rows neighbours share meet in one L2
+  const int nwg = gridDim.x;
+  const int lb = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tiles_x = W / C3_TW, tiles_y = H / C3_TH;
+  const int ntiles = nimg * tiles_x * tiles_y;                    // < 2^31 / 2: checked by the host
+  for (int i = t; i < HALVES * 9 * COUT * 4; i += 256) {
+    const int seg = i & 3, r = i >> 2, co = r % COUT, tap = (r / COUT) % 9, h = r / (COUT * 9);
+    *reinterpret_cast<uint4*>(&Ws[c3_off((h * 9 + tap) * COUT + co, seg)]) =
+        *reinterpret_cast<const uint4*>(w + ((size_t)co * 9 + tap) * CIN + h * 32 + seg * 8);
+  }
+  if (in_scale)
+    for (int i = t; i < CIN; i += 256) { scS[i] = in_scale[i]; scS[CIN + i] = in_shift[i]; }
+  // this thread's halo segments: pixel hp = (t + 256 i) / 4 of the 10 x 34 tile, 16-byte segment (t & 3)
+  const int seg_t = t & 3;
+  int hy[C3_XL], hx[C3_XL];
+#pragma unroll
+  for (int i = 0; i < C3_XL; ++i) {
+    const int hp = (t + i * 256) >> 2;
+    hy[i] = hp / C3_HW;
+    hx[i] = hp - hy[i] * C3_HW;
+  }
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
+  const int my_tiles = lb < ntiles ? (ntiles - lb + nwg - 1) / nwg : 0;
+  const int total = my_tiles * HALVES;                            // flat steps: s -> (tile lb + (s / HALVES) nwg, half s % HALVES)
+  auto tile_of = [&](int s, int& img, int& y0, int& x0) {
+    const int tile = lb + (s / HALVES) * nwg;
+    img = tile / (tiles_x * tiles_y);
+    const int rem = tile - img * (tiles_x * tiles_y);
+    y0 = (rem / tiles_x) * C3_TH;
+    x0 = (rem % tiles_x) * C3_TW;
+  };
+  auto load = [&](int s, uint4 (&r)[C3_XL]) {
+    int img, y0, x0;
+    tile_of(s, img, y0, x0);
+    const int half = s % HALVES;
+    const unsigned short* base = x + (size_t)img * H * W * CIN + half * 32 + seg_t * 8;
+#pragma unroll
+    for (int i = 0; i < C3_XL; ++i) {
+      const int iy = min(max(y0 - 1 + hy[i], 0), H - 1), ix = min(max(x0 - 1 + hx[i], 0), W - 1);   // clamped: masked at the stage
+      r[i] = *reinterpret_cast<const uint4*>(base + ((size_t)iy * W + ix) * CIN);
+    }
+  };
+  auto stage = [&](int buf, int s, const uint4 (&r)[C3_XL]) {
+    int img, y0, x0;
+    tile_of(s, img, y0, x0);
+    const int k0 = (s % HALVES) * 32 + seg_t * 8;
+#pragma unroll
+    for (int i = 0; i < C3_XL; ++i) {
+      const int hp = (t + i * 256) >> 2;
+      const int iy = y0 - 1 + hy[i], ix = x0 - 1 + hx[i];
+      const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      uint4 v = r[i];
+      if (in_scale) {
+        unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = __uint_as_float(u[j] << 16) * scS[k0 + 2 * j] + scS[CIN + k0 + 2 * j];
+          float b = __uint_as_float(u[j] & 0xFFFF0000u) * scS[k0 + 2 * j + 1] + scS[CIN + k0 + 2 * j + 1];
+          if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+          u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+        }
+        v = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+      if (!inside) v = make_uint4(0u, 0u, 0u, 0u);                 // the convolution's zero padding (of the NORMALISED map)
+      if (hp < C3_HP) *reinterpret_cast<uint4*>(&Xs[buf * C3_HP * 32 + c3_off(hp, seg_t)]) = v;
+    }
+  };
+  // fragment addressing.  Pixels: m-tile tm of this wave = tile row 2 wave + (tm >> 1), columns (tm & 1) 16 + li; tap (kh, kw)
+  // reads halo pixel (row + kh) 34 + col + kw.  Weights: MFMA tile tn row i <-> channel (i >> 2) 4 NT + tn 4 + (i & 3), so the
+  // result rows g 4 + r of tile tn are the channels g 4 NT + tn 4 + r: a lane holds 4 NT consecutive channels of its pixel
+  int xbase[4], woff[NT];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) xbase[tm] = (2 * wave + (tm >> 1)) * C3_HW + (tm & 1) * 16 + li;
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) woff[tn] = c3_off((li >> 2) * (4 * NT) + tn * 4 + (li & 3), g);
+  if (total > 0) {
+    uint4 xr[D][C3_XL];
+#pragma unroll
+    for (int j = 0; j < D; ++j) load(j < total ? j : total - 1, xr[j]);
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                              // W, scale / shift staged
+    for (int s0 = 0; s0 < total; s0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int s = s0 + j;
+        if (s >= total) break;                                    // workgroup-uniform
+        const int half = s % HALVES, buf = s & 1;
+        stage(buf, s, xr[j]);
+        load(s + D < total ? s + D : total - 1, xr[j]);           // unconditional: D steps ahead (the tail re-fetches the last tile)
+        __syncthreads();                                          // stage(s) visible; every wave is past its reads of the other buffer
+        const unsigned short* Xb = Xs + buf * C3_HP * 32;
+        const unsigned short* Wb = Ws + half * 9 * COUT * 32;
+        auto taps_of_row = [&](int kh) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            s16x8 xa[4], wb[NT];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) xa[tm] = *reinterpret_cast<const s16x8*>(&Xb[c3_off(xbase[tm] + kh * C3_HW + kw, g)]);
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) wb[tn] = *reinterpret_cast<const s16x8*>(&Wb[(kh * 3 + kw) * COUT * 32 + woff[tn]]);
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
+          }
+        };
+        if constexpr (ROLL) {                                     // two workgroups per CU: the 256-register budget does not hold 9 taps of hoisted fragments
+#pragma unroll 1
+          for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
+        } else {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
+        }
+        if (half == HALVES - 1) {
+          // tile done: round once, statistics of the rounded values, 4 NT consecutive channels per lane and pixel
+          int img, y0, x0;
+          tile_of(s, img, y0, x0);
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) {
+            const int oy = y0 + 2 * wave + (tm >> 1), ox = x0 + (tm & 1) * 16 + li;
+            unsigned int pk[2 * NT];
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+              unsigned short h[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                h[r] = f2bf(acc[tn][tm][r]);
+                const float v = bf2f(h[r]);
+                ssum[tn][r] += v;
+                ssq[tn][r] += v * v;
+                acc[tn][tm][r] = 0.f;
+              }
+              pk[2 * tn] = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
+              pk[2 * tn + 1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+            }
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4* dst = reinterpret_cast<u32x4*>(y + (((size_t)img * H + oy) * W + ox) * COUT + g * (4 * NT));
+#pragma unroll
+            for (int q = 0; q < NT / 2; ++q) dst[q] = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+          }
+        }
+      }
+    }
+  }
+  if (!partial) return;
+  __syncthreads();                                                // every wave is past its last fragment reads: Xs is free
+  float* redS = reinterpret_cast<float*>(Xs);                     // [4 waves][COUT] sums | [4][COUT] sums of squares
+  float* redQ = redS + 4 * COUT;
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv = ssum[tn][r], q = ssq[tn][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); q += __shfl_xor(q, o, 64); }
+      if (li == 0) { redS[wave * COUT + g * (4 * NT) + tn * 4 + r] = sv; redQ[wave * COUT + g * (4 * NT) + tn * 4 + r] = q; }
+    }
+  __syncthreads();
+  if (t < COUT) {
+    float sv = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sv += redS[j * COUT + t]; q += redQ[j * COUT + t]; }
+    float* p = partial + (size_t)blockIdx.x * 2 * COUT;
+    p[t] = sv;
+    p[COUT + t] = q;
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+static size_t c3_lds(int Cin, int Cout) { return (size_t)(Cin / 32) * 9 * Cout * 64 + (size_t)2 * C3_HP * 64 + (size_t)2 * Cin * sizeof(float); }
+// served: 32 -> 32, 32 -> 64, 64 -> 64 channels on maps of 8 j x 32 k pixels
+static bool c3_serves(int Cin, int Cout, int H, int W) {
+  const bool ch = (Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && Cout == 64);
+  return ch && H > 0 && W > 0 && (H % C3_TH) == 0 && (W % C3_TW) == 0;
+}
+static int c3_slabs(size_t nimg, int H, int W, int Cin, int Cout) {
+  const size_t ntiles = nimg * (size_t)(H / C3_TH) * (size_t)(W / C3_TW);
+  const int per_cu = (2 * c3_lds(Cin, Cout) <= 160 * 1024 && Cin == 32) ? 2 : 1;      // resident workgroups (LDS-limited)
+  return (int)std::min<size_t>(ntiles, (size_t)256 * per_cu);
+}
+
+extern "C" int a3d_conv3x3_serves(int Cin, int Cout, int H, int W) { return c3_serves(Cin, Cout, H, W) ? 1 : 0; }
+
+extern "C" int a3d_conv3x3_nslab(size_t nimg, int H, int W, int Cin, int Cout) {
+  if (nimg == 0 || !c3_serves(Cin, Cout, H, W)) return 0;
+  return c3_slabs(nimg, H, W, Cin, Cout);
+}
+
+extern "C" int a3d_conv3x3_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
+                                  float* partial, size_t nimg, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x || !w || !y || nimg == 0 || nimg * (size_t)(H > 0 ? H : 1) * (size_t)(W > 0 ? W : 1) / 128 > (size_t)(1 << 30) || !c3_serves(Cin, Cout, H, W) || (in_scale && !in_shift) ||
+      ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
+    set_error("a3d_conv3x3_bn_fwd: bad argument (images=%zu H=%d W=%d Cin=%d Cout=%d; served: 32 -> 32, 32 -> 64, 64 -> 64 channels, "
+              "H a multiple of 8, W a multiple of 32 -- a3d_conv3x3_serves; 16-byte aligned operands)", nimg, H, W, Cin, Cout);
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* xs = (const unsigned short*)x;
+  const unsigned short* ws = (const unsigned short*)w;
+  unsigned short* ys = (unsigned short*)y;
+  const int slabs = c3_slabs(nimg, H, W, Cin, Cout);
+  const size_t lds = c3_lds(Cin, Cout);
+#define A3D_C3S(HV, NTV, DV, RV)                                                                                                    \
+  do {                                                                                                                           \
+    static bool once = false;                                                                                                    \
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<HV, NTV, DV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; } \
+    hipLaunchKernelGGL((conv3x3_stream_kernel<HV, NTV, DV, RV>), dim3(slabs), dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (int)nimg, H, W); \
+  } while (0)
+  if (Cin == 32 && Cout == 32) A3D_C3S(1, 2, 3, false);
+  else if (Cin == 32 && Cout == 64) A3D_C3S(1, 4, 2, true);
+  else A3D_C3S(2, 4, 2, false);
+#undef A3D_C3S
+  return check_launch("a3d_conv3x3_bn_fwd");
+}

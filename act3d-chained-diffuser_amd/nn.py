@@ -413,6 +413,34 @@ def conv1x1_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
     return y, partial
 
 
+def conv3x3_serves(x, conv):
+    """the 3x3 convolution `conv` on the bf16 channels_last map x is one a3d_conv3x3_bn_fwd serves (stride 1, padding 1, no bias,
+    32 -> 32 / 32 -> 64 / 64 -> 64 channels, H % 8 == 0, W % 32 == 0)"""
+    return bool(conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
+                conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and
+                O.L.load().a3d_conv3x3_serves(x.shape[1], conv.weight.shape[0], x.shape[2], x.shape[3]))
+
+
+def conv3x3_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
+    """3x3 stride-1 padding-1 convolution of a bf16 channels_last activation as the implicit GEMM of csrc/conv3x3.hip: optional
+    BatchNorm-apply (+ ReLU) of the producer on the input (`in_scale` = bn_scale_shift of that layer; the zero padding is applied
+    after it, as F.conv2d pads the normalised map), and the partial statistics of the output for the BatchNorm that follows.
+    Returns (y, partial or None)."""
+    N, Cin, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    assert x.is_contiguous(memory_format=torch.channels_last) and conv3x3_serves(x, conv)
+    wt = conv.weight
+    assert wt.is_contiguous(memory_format=torch.channels_last)        # [Cout][3][3][Cin] in memory
+    y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    partial = None
+    if want_stats:
+        partial = torch.empty((O.L.load().a3d_conv3x3_nslab(N, H, W, Cin, Cout), 2, Cout), device=x.device, dtype=torch.float32)
+    O.L.call("a3d_conv3x3_bn_fwd", x.data_ptr(), wt.data_ptr(), None if in_scale is None else in_scale[0].data_ptr(),
+             None if in_scale is None else in_scale[1].data_ptr(), 1 if in_relu else 0, y.data_ptr(),
+             None if partial is None else partial.data_ptr(), N, H, W, Cin, Cout, O.L.stream())
+    return y, partial
+
+
 def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
     bf16 channels_last activation (vision.hip).  Three launches: stats (skipped when the producer left `partial` sums),
@@ -453,13 +481,23 @@ def fused_frozen_backbone_forward(bb, x):
     folded into the BatchNorm-apply kernel that produces its input (the block output also feeds the next block's
     downsample branch pooled, so that kernel emits both)."""
     conv = lambda m, t: F.conv2d(t, m.weight, None, m.stride, m.padding)
-    x = bn_act(conv(bb.conv1, x), bb.bn1)
-    x = bn_act(conv(bb.conv2, x), bb.bn2)
-    c3 = conv(bb.conv3, x)
+    fuse3 = FUSED_CONV3X3
+
+    def conv3(m, t, bn_in, p_in, want_stats):
+        """3x3 convolution m of relu(bn_in(t)) (t = the raw output of the previous convolution, p_in its partial statistics or
+        None) + the partial statistics of its own output: one a3d_conv3x3_bn_fwd where it serves the shape -- relu(bn_in(t)) is
+        then never materialised -- else BatchNorm-apply + MIOpen"""
+        if fuse3 and conv3x3_serves(t, m):
+            return conv3x3_bn(t, m, in_scale=bn_scale_shift(t, bn_in, p_in), in_relu=True, want_stats=want_stats)
+        return conv(m, bn_act(t, bn_in, partial=p_in)), None
+
+    c1 = conv(bb.conv1, x)
+    c2, p2 = conv3(bb.conv2, c1, bb.bn1, None, bb.bn2.training)
+    c3, p3 = conv3(bb.conv3, c2, bb.bn2, p2, bb.bn3.training)
     if _pool2_ok(bb.avgpool, c3):
-        x0, x = bn_act(c3, bb.bn3, pool=True)
+        x0, x = bn_act(c3, bb.bn3, pool=True, partial=p3)
     else:
-        x0 = bn_act(c3, bb.bn3)
+        x0 = bn_act(c3, bb.bn3, partial=p3)
         x = bb.avgpool(x0)
     outs = [x0]
     bns = [bb.bn1, bb.bn2, bb.bn3]
@@ -481,17 +519,16 @@ def fused_frozen_backbone_forward(bb, x):
 
     for bi, blk in enumerate(blocks):
         c1, p1 = conv1(blk.conv1, x, want_stats=blk.bn1.training)
-        out = bn_act(c1, blk.bn1, partial=p1)
-        c2 = conv(blk.conv2, out)
+        c2, p2 = conv3(blk.conv2, c1, blk.bn1, p1, blk.bn2.training)
         no_pool = isinstance(blk.avgpool, nn.Identity) or (isinstance(blk.avgpool, nn.AvgPool2d) and blk.avgpool.kernel_size in (1, (1, 1)))
         if no_pool and fused_ok(blk.conv3, c2):
             # BatchNorm-apply + ReLU of bn2 ride on conv3's operand load: c2 is never rewritten
-            o3, p3 = conv1x1_bn(c2, blk.conv3, in_scale=bn_scale_shift(c2, blk.bn2), in_relu=True, want_stats=blk.bn3.training)
+            o3, p3 = conv1x1_bn(c2, blk.conv3, in_scale=bn_scale_shift(c2, blk.bn2, p2), in_relu=True, want_stats=blk.bn3.training)
         else:
             if _pool2_ok(blk.avgpool, c2):
-                out = bn_act(c2, blk.bn2, pool=True, keep_full=False)[1]
+                out = bn_act(c2, blk.bn2, pool=True, keep_full=False, partial=p2)[1]
             else:
-                out = blk.avgpool(bn_act(c2, blk.bn2))
+                out = blk.avgpool(bn_act(c2, blk.bn2, partial=p2))
             o3, p3 = conv1(blk.conv3, out, want_stats=blk.bn3.training)
         if blk.downsample is not None:
             dpool = blk.downsample[0]
@@ -527,6 +564,9 @@ FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
 # a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the consumer folded into the GEMM; the deep,
 # compute-bound layers stay on MIOpen (profiles/r04_conv1x1_layers.json).  A3D_FUSED_CONV1X1=0: MIOpen everywhere (A/B).
 FUSED_CONV1X1 = os.environ.get("A3D_FUSED_CONV1X1", "1") not in ("0", "", "off")
+# The 3x3 convolutions with <= 64 channels (the stem's conv2 / conv3, layer1's conv2) through a3d_conv3x3_bn_fwd, with BatchNorm-apply
+# of the producer and the statistics of the consumer folded in; wider layers stay on MIOpen.  A3D_FUSED_CONV3X3=0: MIOpen (A/B).
+FUSED_CONV3X3 = os.environ.get("A3D_FUSED_CONV3X3", "1") not in ("0", "", "off")
 
 
 def normalize_to_nhwc_bf16(x, normalize):

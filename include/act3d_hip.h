@@ -433,6 +433,19 @@ int a3d_conv1x1_nslab(size_t M, int K, int N);
 int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
                        float* partial, size_t M, int K, int N, void* stream);
 
+/* 3x3 stride-1 padding-1 convolution of the frozen backbone's narrow layers (the stem's conv2 / conv3, layer1's conv2:
+ * model/utils/clip.py:22-43, torch.nn.Conv2d(.., 3, padding=1, bias=False)) as a bf16 MFMA implicit GEMM with the BatchNorm work
+ * around it folded in, like a3d_conv1x1_bn_fwd:  x [images][H][W][Cin] bf16 (NHWC), w [Cout][3][3][Cin] bf16 (the channels_last
+ * layout of the torch weight), y [images][H][W][Cout] bf16;  in_scale / in_shift (or NULL): BatchNorm-apply (+ ReLU when in_relu)
+ * of the producer applied to x on load, rounded to bf16 as a3d_bn_apply materialises it, zero padding applied AFTER it;
+ * partial (or NULL): [a3d_conv3x3_nslab(..)][2][Cout] per-workgroup (sum, sum of squares) of the rounded outputs for
+ * a3d_bn_finalize.  Served shapes (a3d_conv3x3_serves == 1): 32 -> 32, 32 -> 64 and 64 -> 64 channels, H a multiple of 8, W a
+ * multiple of 32; anything else is refused (wider layers are compute-bound library convolutions).  16-byte aligned operands. */
+int a3d_conv3x3_serves(int Cin, int Cout, int H, int W);
+int a3d_conv3x3_nslab(size_t images, int H, int W, int Cin, int Cout);
+int a3d_conv3x3_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
+                       float* partial, size_t images, int H, int W, int Cin, int Cout, void* stream);
+
 /* ---- data plane ----------------------------------------------------------------------------------------
  * The `Resize` augmentation of datasets/utils.py:40-100 (nearest resize by a random scale, reflect-pad right/bottom, random
  * crop back to H x W; RGB and XYZ share the draws) as one gather pass over the collated batch on the device.

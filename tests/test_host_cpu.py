@@ -601,6 +601,14 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_nslab(1 << 20, 512, 64) == 0 and lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 512, 128, None) == -22
     assert lib.a3d_conv1x1_nslab(1 << 20, 64, 256) == 512 and lib.a3d_conv1x1_nslab(1 << 18, 128, 512) == 256 and lib.a3d_conv1x1_nslab(100, 64, 64) == 1
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
+    # the 3x3 implicit GEMM serves the narrow layers only (weights resident in LDS), on maps of 8 j x 32 k pixels
+    assert lib.a3d_conv3x3_serves(32, 32, 128, 128) == 1 and lib.a3d_conv3x3_serves(32, 64, 128, 128) == 1 and lib.a3d_conv3x3_serves(64, 64, 64, 64) == 1
+    assert lib.a3d_conv3x3_serves(64, 32, 64, 64) == 0 and lib.a3d_conv3x3_serves(128, 128, 64, 64) == 0 and lib.a3d_conv3x3_serves(64, 64, 60, 64) == 0
+    assert lib.a3d_conv3x3_serves(64, 64, 64, 48) == 0 and lib.a3d_conv3x3_serves(3, 32, 256, 256) == 0
+    assert lib.a3d_conv3x3_nslab(256, 128, 128, 32, 32) == 512 and lib.a3d_conv3x3_nslab(256, 128, 128, 32, 64) == 512
+    assert lib.a3d_conv3x3_nslab(256, 64, 64, 64, 64) == 256 and lib.a3d_conv3x3_nslab(1, 16, 32, 64, 64) == 2 and lib.a3d_conv3x3_nslab(4, 64, 64, 128, 128) == 0
+    assert lib.a3d_conv3x3_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 4, 64, 64, 128, 128, None) == -22
+    assert b"a3d_conv3x3_bn_fwd" in lib.a3d_last_error_string()
 
 
 def test_rope_sincos_host_mirror_within_1e7_of_float64():

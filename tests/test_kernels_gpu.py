@@ -999,6 +999,46 @@ def _check_conv1x1(a3d, dev, M, K, N, pro):
     report("sum of squares", s[1], (got * got).sum(0), 1e-2, 1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 32, 32, 32), (3, 24, 64, 32, 64), (2, 16, 32, 64, 64), (5, 8, 96, 64, 64),
+                                            (1, 64, 64, 32, 32)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_conv3x3_gemm_with_folded_batchnorm(a3d, dev, N, H, W, Cin, Cout, pro):
+    """a3d_conv3x3_bn_fwd: y = bf16(conv3x3(f(x), w)) with f = the producer's BatchNorm-apply + ReLU (rounded to bf16 as the
+    unfused path materialises it), zero padding of the NORMALISED map, fp32 accumulation, and the per-slab (sum, sum of squares)
+    of the rounded outputs; the reference is F.conv2d in float64 on the same bf16 operands (clip.py:22-43: padding=1, no bias)."""
+    g = torch.Generator().manual_seed(N * 1000 + H + W + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16)
+    sc = (1.0 + 0.3 * torch.randn(Cin, generator=g)) if pro else None
+    sh = (0.2 * torch.randn(Cin, generator=g)) if pro else None      # non-zero shift: a wrongly padded border would show relu(shift)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=False).to(dev).to(torch.bfloat16)
+    conv.weight.data = w.to(dev).contiguous(memory_format=torch.channels_last)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    scale = None if not pro else torch.stack([sc, sh]).to(dev).contiguous()
+    assert a3d.nn.conv3x3_serves(xd, conv)
+    y, part = a3d.nn.conv3x3_bn(xd, conv, in_scale=scale, in_relu=pro, want_stats=True)
+    torch.cuda.synchronize()
+    assert y.shape == (N, Cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    assert part.shape == (a3d.lib.load().a3d_conv3x3_nslab(N, H, W, Cin, Cout), 2, Cout)
+    xf = x.float()
+    if pro:
+        # x * scale + shift as ONE rounding (the kernel's fma, the same expression a3d_bn_apply evaluates on the unfused path)
+        xf = torch.relu((xf.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()).to(torch.bfloat16).float()
+    ref = F.conv2d(xf.double(), w.double(), padding=1)
+    got = y.float().cpu()
+    err = (got.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-3          # one bf16 rounding of an fp32-accumulated sum
+    assert torch.isfinite(got).all()
+    assert (err <= tol).all(), f"max err {err.max().item():.3e} at {torch.nonzero(err > tol)[:3].tolist()}"
+    print(f"[parity] conv3x3 {Cin}->{Cout} {N}x{H}x{W} pro={pro}: max_abs_err={err.max().item():.3e} ref_absmax={ref.abs().max().item():.3e}")
+    s = part.sum(0).cpu()
+    report("conv3x3 sum", s[0], got.sum((0, 2, 3)), 1e-2, 1e-4)
+    report("conv3x3 sum of squares", s[1], (got * got).sum((0, 2, 3)), 1e-2, 1e-4)
+    # without the statistics epilogue: same map
+    y2, p2 = a3d.nn.conv3x3_bn(xd, conv, in_scale=scale, in_relu=pro, want_stats=False)
+    assert p2 is None and torch.equal(y2, y)
+
+
 def test_backbone_with_fused_1x1_convolutions_matches_miopen_path(a3d, dev):
     """The backbone path with the layer-1 / layer-2 1x1 convolutions through a3d_conv1x1_bn_fwd (bn2-apply folded into conv3's
     operand load, output statistics from the GEMM epilogue; default) must be as close to the fp32 module as the all-MIOpen bf16
@@ -1007,23 +1047,26 @@ def test_backbone_with_fused_1x1_convolutions_matches_miopen_path(a3d, dev):
     import copy
     torch.manual_seed(0)
     bb32 = a3d.nn.SyntheticCLIPResNet50().to(dev).train()
-    nets = {False: copy.deepcopy(bb32), True: copy.deepcopy(bb32)}
+    nets = {False: copy.deepcopy(bb32), True: copy.deepcopy(bb32), "1x1": copy.deepcopy(bb32)}
     x = torch.rand(4, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
     outs = {}
-    keep = a3d.nn.FUSED_CONV1X1
+    keep = a3d.nn.FUSED_CONV1X1, a3d.nn.FUSED_CONV3X3
     with torch.no_grad():
         ref = bb32(x)
         for flag, net in nets.items():
-            a3d.nn.FUSED_CONV1X1 = flag          # False: MIOpen everywhere; True (default): the streaming GEMM on the shapes it serves
+            # False: MIOpen everywhere; True (default): the streaming 1x1 GEMM and the 3x3 implicit GEMM on the shapes they serve;
+            # "1x1": only the 1x1 GEMM (the round-4 path before conv3x3.hip)
+            a3d.nn.FUSED_CONV1X1, a3d.nn.FUSED_CONV3X3 = bool(flag), flag is True
             try:
                 outs[flag] = a3d.nn.run_frozen_backbone(net, x.clone(), torch.bfloat16)
             finally:
-                a3d.nn.FUSED_CONV1X1 = keep
+                a3d.nn.FUSED_CONV1X1, a3d.nn.FUSED_CONV3X3 = keep
     rms = lambda t: t.float().pow(2).mean().sqrt().item()
     for k in ref:
-        e_f, e_d, sc = rms(outs[True][k] - ref[k]), rms(outs[False][k] - ref[k]), rms(ref[k])
-        print(f"[parity] backbone {k}: rms_err fused-1x1={e_f:.3e} default={e_d:.3e} ref_rms={sc:.3e}")
+        e_f, e_1, e_d, sc = rms(outs[True][k] - ref[k]), rms(outs["1x1"][k] - ref[k]), rms(outs[False][k] - ref[k]), rms(ref[k])
+        print(f"[parity] backbone {k}: rms_err fused-1x1+3x3={e_f:.3e} fused-1x1={e_1:.3e} all-MIOpen={e_d:.3e} ref_rms={sc:.3e}")
         assert torch.isfinite(outs[True][k]).all() and e_f <= 1.25 * e_d + 1e-3 * sc, k
+        assert e_1 <= 1.25 * e_d + 1e-3 * sc, k
     for (n, p), (_, q) in zip(bb32.named_buffers(), nets[True].named_buffers()):
         if n.endswith("num_batches_tracked"):
             assert torch.equal(p, q), n
