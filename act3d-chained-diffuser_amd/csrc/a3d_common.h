@@ -30,6 +30,13 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
   unsigned int r = u + 0x7FFFu + ((u >> 16) & 1u);
   return (unsigned short)(r >> 16);
 }
+// two fp32 -> packed bf16 pair (a in the low half) with the gfx950 hardware conversion v_cvt_pk_bf16_f32: round-to-nearest-even,
+// the same bits as f2bf for finite inputs
+__device__ __forceinline__ unsigned int pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 __device__ __forceinline__ float bf2f(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }

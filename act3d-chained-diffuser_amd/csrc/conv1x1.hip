@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
       r[i] = *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks * C1_BK + seg * 8);
     }
   };
+  const float relu_lo = in_relu ? 0.f : -INFINITY;
   auto stage = [&](int buf, int ks, const uint4 (&r)[XL]) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -80,8 +81,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
         for (int j = 0; j < 4; ++j) {
           float a = __uint_as_float(u[j] << 16) * scS[k0 + 2 * j] + scS[K + k0 + 2 * j];
           float b = __uint_as_float(u[j] & 0xFFFF0000u) * scS[k0 + 2 * j + 1] + scS[K + k0 + 2 * j + 1];
-          if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-          u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
+          a = fmaxf(a, relu_lo);
+          b = fmaxf(b, relu_lo);
+          u[j] = pk_bf16(a, b);                                   // v_cvt_pk_bf16_f32: RNE, the bits of f2bf
         }
         v = make_uint4(u[0], u[1], u[2], u[3]);
       }
@@ -131,19 +133,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
             unsigned int pk[8];
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
-              unsigned short h[4];
+              // the software rounding (5 VALU per value + packing) made this epilogue ~770 VALU instructions per 32 MFMA; the hardware
+              // pair conversion is RNE with the same bits
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                h[r] = f2bf(acc[tn][tm][r]);
+              for (int r2 = 0; r2 < 2; ++r2) {
+                const unsigned int u = pk_bf16(acc[tn][tm][2 * r2], acc[tn][tm][2 * r2 + 1]);
                 if (ok) {
-                  const float v = bf2f(h[r]);
-                  ssum[tn][r] += v;
-                  ssq[tn][r] += v * v;
+                  const float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xFFFF0000u);
+                  ssum[tn][2 * r2] += v0;
+                  ssq[tn][2 * r2] += v0 * v0;
+                  ssum[tn][2 * r2 + 1] += v1;
+                  ssq[tn][2 * r2 + 1] += v1 * v1;
                 }
-                acc[tn][tm][r] = 0.f;
+                pk[2 * tn + r2] = u;
               }
-              pk[2 * tn] = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
-              pk[2 * tn + 1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+              acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (ok) {
               uint4* dst = reinterpret_cast<uint4*>(y + (size_t)m * N + n0 + wn * 64 + g * 16);

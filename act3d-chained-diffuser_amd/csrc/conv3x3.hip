@@ -16,9 +16,10 @@
 // barrier per step.  Per step and wave: 9 taps x (4 pixel fragments + Cout/16 weight fragments) -> 36 Cout/16 MFMA 16x16x32,
 // computed TRANSPOSED (A = weight rows, B = pixels) with the weight rows permuted so that a lane owns 8 / 16 consecutive
 // channels of its pixel (16 / 32-byte stores, full lines per pixel).
-// LDS rows are 64 bytes (32 channels) with the 16-byte segment g of row p stored at g ^ ((p >> 1) & 3): conflict-free
-// ds_read_b128 for 16 consecutive rows from ANY base row (the tap shifts make the base arbitrary; plane_off is only
-// conflict-free from aligned bases).
+// The kernel's first version was VALU-bound (172 / 296 / 134 us on the three layers, gpurun r04i: ~1100 VALU instructions per
+// wave and step against 72 - 144 MFMA): software bf16 rounding, per-read swizzle arithmetic and three integer divisions per step.
+// This one rounds with v_cvt_pk_bf16_f32, normalises with packed fma, reads fragments at precomputed offsets and walks its
+// tiles with a carry-propagating cursor.
 #include "a3d_common.h"
 #include "../../include/act3d_hip.h"
 
@@ -28,7 +29,28 @@ constexpr int C3_TH = 8, C3_TW = 32;                              // output tile
 constexpr int C3_HW = C3_TW + 2, C3_HP = (C3_TH + 2) * C3_HW;     // halo tile: 10 x 34 = 340 pixels
 constexpr int C3_XL = (C3_HP * 4 + 255) / 256;                    // 16-byte segments each thread stages per step: 6
 
-__device__ __forceinline__ int c3_off(int row, int seg) { return row * 32 + ((seg ^ ((row >> 1) & 3)) << 3); }
+// LDS rows are 64 bytes (32 channels).  Weight row r (aligned blocks of Cout rows): 16-byte segment g stored at g ^ ((r >> 1) & 3).
+// Halo pixel hp = hy 34 + hx: segment g stored at g ^ ((hx >> 1) & 3) -- keyed on the COLUMN, so that a tap's row shift (kh 34
+// pixels) is a constant byte offset of the read while 16 consecutive pixels from any base stay conflict-free for ds_read_b128
+// (checked by enumeration over the instruction's lane groups for every base and row offset).
+__device__ __forceinline__ int c3_woff(int row, int seg) { return row * 32 + ((seg ^ ((row >> 1) & 3)) << 3); }
+__device__ __forceinline__ int c3_xoff(int hp, int hx, int seg) { return hp * 32 + ((seg ^ ((hx >> 1) & 3)) << 3); }
+
+typedef float c3_f32x2 __attribute__((ext_vector_type(2)));
+typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int c3_u32x4 __attribute__((ext_vector_type(4)));
+
+// tile cursor (workgroup-uniform): tile = (img tiles_y + ty) tiles_x + tx, advanced by the grid size with carries -- no division per step
+struct C3Cursor {
+  int img, ty, tx;
+  __device__ __forceinline__ void advance(int dimg, int dty, int dtx, int tiles_y, int tiles_x) {
+    tx += dtx;
+    if (tx >= tiles_x) { tx -= tiles_x; ++ty; }
+    ty += dty;
+    if (ty >= tiles_y) { ty -= tiles_y; ++img; }
+    img += dimg;
+  }
+};
 
 template <int HALVES, int NT, int D, bool ROLL>
 __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_kernel(
@@ -36,6 +58,7 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
     const float* __restrict__ in_shift, int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial, int nimg, int H,
     int W) {
   constexpr int CIN = 32 * HALVES, COUT = 16 * NT;
+  static_assert(D % HALVES == 0, "the half of a step must be a compile-time function of its slot");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_c3[];
   unsigned short* Ws = smem_c3;                                   // [HALVES][9][COUT] rows of 32 channels
   unsigned short* Xs = Ws + HALVES * 9 * COUT * 32;               // [2][C3_HP] rows of 32 channels
@@ -45,15 +68,14 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
   // workgroups of one XCD (blockIdx.x mod 8) take consecutive tiles, so that the halo rows neighbours share meet in one L2
   const int nwg = gridDim.x;
   const int lb = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int tiles_x = W / C3_TW, tiles_y = H / C3_TH;
-  const int ntiles = nimg * tiles_x * tiles_y;                    // < 2^31 / 2: checked by the host
+  const int tiles_x = W / C3_TW, tiles_y = H / C3_TH, tpi = tiles_x * tiles_y;
+  const int ntiles = nimg * tpi;                                  // < 2^30: checked by the host
   for (int i = t; i < HALVES * 9 * COUT * 4; i += 256) {
     const int seg = i & 3, r = i >> 2, co = r % COUT, tap = (r / COUT) % 9, h = r / (COUT * 9);
-    *reinterpret_cast<uint4*>(&Ws[c3_off((h * 9 + tap) * COUT + co, seg)]) =
+    *reinterpret_cast<uint4*>(&Ws[c3_woff((h * 9 + tap) * COUT + co, seg)]) =
         *reinterpret_cast<const uint4*>(w + ((size_t)co * 9 + tap) * CIN + h * 32 + seg * 8);
   }
-  if (in_scale)
-    for (int i = t; i < CIN; i += 256) { scS[i] = in_scale[i]; scS[CIN + i] = in_shift[i]; }
+  for (int i = t; i < CIN; i += 256) { scS[i] = in_scale ? in_scale[i] : 1.f; scS[CIN + i] = in_scale ? in_shift[i] : 0.f; }
   // this thread's halo segments: pixel hp = (t + 256 i) / 4 of the 10 x 34 tile, 16-byte segment (t & 3)
   const int seg_t = t & 3;
   int hy[C3_XL], hx[C3_XL];
@@ -63,68 +85,82 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
     hy[i] = hp / C3_HW;
     hx[i] = hp - hy[i] * C3_HW;
   }
-  float ssum[NT][4], ssq[NT][4];
+  c3_f32x2 ssum[NT][2], ssq[NT][2];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
+    for (int r = 0; r < 2; ++r) { ssum[a][r] = c3_f32x2{0.f, 0.f}; ssq[a][r] = c3_f32x2{0.f, 0.f}; }
   const int my_tiles = lb < ntiles ? (ntiles - lb + nwg - 1) / nwg : 0;
-  const int total = my_tiles * HALVES;                            // flat steps: s -> (tile lb + (s / HALVES) nwg, half s % HALVES)
-  auto tile_of = [&](int s, int& img, int& y0, int& x0) {
-    const int tile = lb + (s / HALVES) * nwg;
-    img = tile / (tiles_x * tiles_y);
-    const int rem = tile - img * (tiles_x * tiles_y);
-    y0 = (rem / tiles_x) * C3_TH;
-    x0 = (rem % tiles_x) * C3_TW;
-  };
-  auto load = [&](int s, uint4 (&r)[C3_XL]) {
-    int img, y0, x0;
-    tile_of(s, img, y0, x0);
-    const int half = s % HALVES;
-    const unsigned short* base = x + (size_t)img * H * W * CIN + half * 32 + seg_t * 8;
+  const int total = my_tiles * HALVES;                            // flat steps: step s = (this workgroup's tile s / HALVES, half s % HALVES)
+  // one-time divisions: the first tile and the per-tile advance (grid size) in (image, tile row, tile column) digits
+  const int dimg = nwg / tpi, dty = (nwg - dimg * tpi) / tiles_x, dtx = nwg - dimg * tpi - dty * tiles_x;
+  C3Cursor cl;                                                    // the LOAD stream's tile (D steps ahead of the compute stream's)
+  cl.img = lb / tpi;
+  cl.ty = (lb - cl.img * tpi) / tiles_x;
+  cl.tx = lb - cl.img * tpi - cl.ty * tiles_x;
+  C3Cursor cc = cl;                                               // the compute stream's tile
+  int lk = 0, lhalf = 0;                                          // load stream: tile ordinal, half
+  auto load_next = [&](uint4 (&r)[C3_XL]) {
+    const int y0 = cl.ty * C3_TH, x0 = cl.tx * C3_TW;
+    // uniform 64-bit image base + 32-bit byte offset per lane (one image is at most 2^31 bytes: checked by the host)
+    const char* base = reinterpret_cast<const char*>(x + (size_t)cl.img * H * W * CIN + lhalf * 32);
 #pragma unroll
     for (int i = 0; i < C3_XL; ++i) {
       const int iy = min(max(y0 - 1 + hy[i], 0), H - 1), ix = min(max(x0 - 1 + hx[i], 0), W - 1);   // clamped: masked at the stage
-      r[i] = *reinterpret_cast<const uint4*>(base + ((size_t)iy * W + ix) * CIN);
+      const unsigned int off = (unsigned int)((iy * W + ix) * CIN + seg_t * 8) * 2u;
+      r[i] = *reinterpret_cast<const uint4*>(base + off);
+    }
+    if (++lhalf == HALVES) {
+      lhalf = 0;
+      if (lk + 1 < my_tiles) { ++lk; cl.advance(dimg, dty, dtx, tiles_y, tiles_x); }   // past the end: the last tile again (never staged)
     }
   };
-  auto stage = [&](int buf, int s, const uint4 (&r)[C3_XL]) {
-    int img, y0, x0;
-    tile_of(s, img, y0, x0);
-    const int k0 = (s % HALVES) * 32 + seg_t * 8;
+  // BatchNorm-apply + ReLU of the producer on 8 channels: packed fma, hardware bf16 rounding (v_cvt_pk_bf16_f32, RNE), ReLU as a
+  // packed signed-integer max on the bf16 pairs (negative floats are negative int16; lower bound -32768 = no ReLU)
+  const c3_s16x2 relu_lo = in_relu ? c3_s16x2{0, 0} : c3_s16x2{(short)-32768, (short)-32768};
+  auto stage = [&](int buf, int half, const uint4 (&r)[C3_XL]) {
+    const int y0 = cc.ty * C3_TH, x0 = cc.tx * C3_TW;
+    const int k0 = half * 32 + seg_t * 8;
+    c3_f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = c3_f32x2{scS[k0 + 2 * j], scS[k0 + 2 * j + 1]};
+      sh[j] = c3_f32x2{scS[CIN + k0 + 2 * j], scS[CIN + k0 + 2 * j + 1]};
+    }
 #pragma unroll
     for (int i = 0; i < C3_XL; ++i) {
       const int hp = (t + i * 256) >> 2;
       const int iy = y0 - 1 + hy[i], ix = x0 - 1 + hx[i];
       const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      uint4 v = r[i];
-      if (in_scale) {
-        unsigned int u[4] = {v.x, v.y, v.z, v.w};
+      unsigned int u[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float a = __uint_as_float(u[j] << 16) * scS[k0 + 2 * j] + scS[CIN + k0 + 2 * j];
-          float b = __uint_as_float(u[j] & 0xFFFF0000u) * scS[k0 + 2 * j + 1] + scS[CIN + k0 + 2 * j + 1];
-          if (in_relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-          u[j] = (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16);
-        }
-        v = make_uint4(u[0], u[1], u[2], u[3]);
+      for (int j = 0; j < 4; ++j) {
+        c3_f32x2 v = {__uint_as_float(u[j] << 16), __uint_as_float(u[j] & 0xFFFF0000u)};
+        v = v * sc[j] + sh[j];
+        const c3_s16x2 pk = __builtin_elementwise_max(__builtin_bit_cast(c3_s16x2, pk_bf16(v.x, v.y)), relu_lo);
+        u[j] = inside ? __builtin_bit_cast(unsigned int, pk) : 0u;      // the convolution's zero padding (of the NORMALISED map)
       }
-      if (!inside) v = make_uint4(0u, 0u, 0u, 0u);                 // the convolution's zero padding (of the NORMALISED map)
-      if (hp < C3_HP) *reinterpret_cast<uint4*>(&Xs[buf * C3_HP * 32 + c3_off(hp, seg_t)]) = v;
+      if (hp < C3_HP) *reinterpret_cast<c3_u32x4*>(&Xs[buf * C3_HP * 32 + c3_xoff(hp, hx[i], seg_t)]) = c3_u32x4{u[0], u[1], u[2], u[3]};
     }
   };
   // fragment addressing.  Pixels: m-tile tm of this wave = tile row 2 wave + (tm >> 1), columns (tm & 1) 16 + li; tap (kh, kw)
-  // reads halo pixel (row + kh) 34 + col + kw.  Weights: MFMA tile tn row i <-> channel (i >> 2) 4 NT + tn 4 + (i & 3), so the
-  // result rows g 4 + r of tile tn are the channels g 4 NT + tn 4 + r: a lane holds 4 NT consecutive channels of its pixel
-  int xbase[4], woff[NT];
+  // reads halo pixel (row + kh) 34 + col + kw: xo[tm][kw] + kh 34 rows of 64 B (the segment swizzle depends on li + kw only).
+  // Weights: MFMA tile tn row i <-> channel (i >> 2) 4 NT + tn 4 + (i & 3), so the result rows g 4 + r of tile tn are the channels
+  // g 4 NT + tn 4 + r: a lane holds 4 NT consecutive channels of its pixel
+  int xo[4][3], woff[NT];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) xbase[tm] = (2 * wave + (tm >> 1)) * C3_HW + (tm & 1) * 16 + li;
+  for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-  for (int tn = 0; tn < NT; ++tn) woff[tn] = c3_off((li >> 2) * (4 * NT) + tn * 4 + (li & 3), g);
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = (tm & 1) * 16 + li + kw;
+      xo[tm][kw] = c3_xoff((2 * wave + (tm >> 1)) * C3_HW + col, col, g);
+    }
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) woff[tn] = c3_woff((li >> 2) * (4 * NT) + tn * 4 + (li & 3), g);
   if (total > 0) {
     uint4 xr[D][C3_XL];
 #pragma unroll
-    for (int j = 0; j < D; ++j) load(j < total ? j : total - 1, xr[j]);
+    for (int j = 0; j < D; ++j) load_next(xr[j]);
     f32x4 acc[NT][4];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -136,9 +172,9 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
       for (int j = 0; j < D; ++j) {
         const int s = s0 + j;
         if (s >= total) break;                                    // workgroup-uniform
-        const int half = s % HALVES, buf = s & 1;
-        stage(buf, s, xr[j]);
-        load(s + D < total ? s + D : total - 1, xr[j]);           // unconditional: D steps ahead (the tail re-fetches the last tile)
+        const int half = j % HALVES, buf = s & 1;                 // s0 is a multiple of D, D of HALVES
+        stage(buf, half, xr[j]);
+        load_next(xr[j]);                                         // unconditional: D steps ahead
         __syncthreads();                                          // stage(s) visible; every wave is past its reads of the other buffer
         const unsigned short* Xb = Xs + buf * C3_HP * 32;
         const unsigned short* Wb = Ws + half * 9 * COUT * 32;
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
           for (int kw = 0; kw < 3; ++kw) {
             s16x8 xa[4], wb[NT];
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) xa[tm] = *reinterpret_cast<const s16x8*>(&Xb[c3_off(xbase[tm] + kh * C3_HW + kw, g)]);
+            for (int tm = 0; tm < 4; ++tm) xa[tm] = *reinterpret_cast<const s16x8*>(&Xb[xo[tm][kw] + kh * (C3_HW * 32)]);
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) wb[tn] = *reinterpret_cast<const s16x8*>(&Wb[(kh * 3 + kw) * COUT * 32 + woff[tn]]);
 #pragma unroll
@@ -164,32 +200,30 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
           for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
         }
         if (half == HALVES - 1) {
-          // tile done: round once, statistics of the rounded values, 4 NT consecutive channels per lane and pixel
-          int img, y0, x0;
-          tile_of(s, img, y0, x0);
+          // tile done: round once (RNE), statistics of the rounded values, 4 NT consecutive channels per lane and pixel
+          const int y0 = cc.ty * C3_TH, x0 = cc.tx * C3_TW;
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm) {
             const int oy = y0 + 2 * wave + (tm >> 1), ox = x0 + (tm & 1) * 16 + li;
             unsigned int pk[2 * NT];
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
-              unsigned short h[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                h[r] = f2bf(acc[tn][tm][r]);
-                const float v = bf2f(h[r]);
-                ssum[tn][r] += v;
-                ssq[tn][r] += v * v;
-                acc[tn][tm][r] = 0.f;
+              for (int r2 = 0; r2 < 2; ++r2) {
+                const unsigned int u = pk_bf16(acc[tn][tm][2 * r2], acc[tn][tm][2 * r2 + 1]);
+                const c3_f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+                ssum[tn][r2] += v;
+                ssq[tn][r2] += v * v;
+                pk[2 * tn + r2] = u;
               }
-              pk[2 * tn] = (unsigned int)h[0] | ((unsigned int)h[1] << 16);
-              pk[2 * tn + 1] = (unsigned int)h[2] | ((unsigned int)h[3] << 16);
+              acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            u32x4* dst = reinterpret_cast<u32x4*>(y + (((size_t)img * H + oy) * W + ox) * COUT + g * (4 * NT));
+            char* ybase = reinterpret_cast<char*>(y + (size_t)cc.img * H * W * COUT);
+            c3_u32x4* dst = reinterpret_cast<c3_u32x4*>(ybase + (unsigned int)((oy * W + ox) * COUT + g * (4 * NT)) * 2u);
 #pragma unroll
-            for (int q = 0; q < NT / 2; ++q) dst[q] = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+            for (int q = 0; q < NT / 2; ++q) dst[q] = c3_u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
           }
+          cc.advance(dimg, dty, dtx, tiles_y, tiles_x);
         }
       }
     }
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
   for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float sv = ssum[tn][r], q = ssq[tn][r];
+      float sv = ssum[tn][r >> 1][r & 1], q = ssq[tn][r >> 1][r & 1];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); q += __shfl_xor(q, o, 64); }
       if (li == 0) { redS[wave * COUT + g * (4 * NT) + tn * 4 + r] = sv; redQ[wave * COUT + g * (4 * NT) + tn * 4 + r] = q; }
@@ -243,7 +277,7 @@ extern "C" int a3d_conv3x3_nslab(size_t nimg, int H, int W, int Cin, int Cout) {
 
 extern "C" int a3d_conv3x3_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
                                   float* partial, size_t nimg, int H, int W, int Cin, int Cout, void* stream) {
-  if (!x || !w || !y || nimg == 0 || nimg * (size_t)(H > 0 ? H : 1) * (size_t)(W > 0 ? W : 1) / 128 > (size_t)(1 << 30) || !c3_serves(Cin, Cout, H, W) || (in_scale && !in_shift) ||
+  if (!x || !w || !y || nimg == 0 || nimg * (size_t)(H > 0 ? H : 1) * (size_t)(W > 0 ? W : 1) / 256 >= (size_t)(1 << 30) || (size_t)(H > 0 ? H : 1) * (size_t)(W > 0 ? W : 1) * 128 >= ((size_t)1 << 31) || !c3_serves(Cin, Cout, H, W) || (in_scale && !in_shift) ||
       ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
     set_error("a3d_conv3x3_bn_fwd: bad argument (images=%zu H=%d W=%d Cin=%d Cout=%d; served: 32 -> 32, 32 -> 64, 64 -> 64 channels, "
               "H a multiple of 8, W a multiple of 32 -- a3d_conv3x3_serves; 16-byte aligned operands)", nimg, H, W, Cin, Cout);

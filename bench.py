@@ -246,6 +246,26 @@ def other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq):
     by = rows * C * 2.0
     out["bn_stats"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
                        "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 55, "note": "layer-1 map (537 MB); 55 launches of 17 - 537 MB per step"}
+    del act
+    # the backbone's own convolutions (bf16 MFMA implicit GEMMs with BatchNorm folded in): algorithmic bytes = one read of the
+    # input map + one write of the output map; flops = 2 x pixels x taps x Cin x Cout, against the dense bf16 MFMA peak
+    nimg = 4 * B
+    for name, (cin, cout, hw, k, per_step) in {"conv3x3_64_64": (64, 64, 64, 3, 3), "conv3x3_32_64": (32, 64, 128, 3, 1),
+                                               "conv1x1_64_256": (64, 256, 64, 1, 4)}.items():
+        xin = torch.randn(nimg, cin, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False).to(device).to(torch.bfloat16)
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        scale = torch.stack([1.0 + 0.1 * torch.randn(cin), 0.1 * torch.randn(cin)]).to(device).contiguous()
+        fn = a3d.nn.conv3x3_bn if k == 3 else a3d.nn.conv1x1_bn
+        with torch.no_grad():
+            t = time_kernel(lambda: fn(xin, conv, in_scale=scale, in_relu=True, want_stats=True))
+        px = nimg * hw * hw
+        by, fl = px * (cin + cout) * 2.0, 2.0 * px * k * k * cin * cout
+        out[name] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                     "frac": by / (t * 1e-3) / 8e12, "mfma_TFLOPs": fl / (t * 1e-3) / 1e12, "mfma_frac": fl / (t * 1e-3) / 2.5e15,
+                     "launches_per_step": per_step,
+                     "note": f"{cin} -> {cout} channels, {nimg} maps of {hw} x {hw}; BatchNorm-apply of the producer and statistics of the output folded in"}
+        del xin
     return out
 
 
