@@ -13,7 +13,7 @@
 // Structure (the streaming scheme of conv1x1.hip): a persistent workgroup keeps ALL weights in LDS and walks 8 x 32-pixel output
 // tiles; the (tile, 32-channel half) pairs form one flat sequence of steps whose 10 x 34-pixel halo tiles are fetched D steps
 // ahead into registers (unconditional clamped loads), normalised and zero-padded on their way into one of two LDS buffers, one
-// barrier per step.  Per step and wave: 9 taps x (4 pixel fragments + Cout/16 weight fragments) -> 36 Cout/16 MFMA 16x16x32,
+// barrier per step.  Per step and wave: 9 taps x (4 pixel fragments + COUT/16 weight fragments) -> 36 COUT/16 MFMA 16x16x32,
 // computed TRANSPOSED (A = weight rows, B = pixels) with the weight rows permuted so that a lane owns 8 / 16 consecutive
 // channels of its pixel (16 / 32-byte stores, full lines per pixel).
 // The kernel's first version was VALU-bound (172 / 296 / 134 us on the three layers, gpurun r04i: ~1100 VALU instructions per
@@ -52,12 +52,19 @@ struct C3Cursor {
   }
 };
 
-template <int HALVES, int NT, int D, bool ROLL>
-__global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_kernel(
+// dynamic LDS of one workgroup: weights + two halo buffers + scale / shift
+constexpr int c3_lds_bytes(int halves, int nt) { return halves * 9 * 16 * nt * 64 + 2 * C3_HP * 64 + 2 * 32 * halves * 4; }
+
+// COUT = 16 NT output channels per workgroup: blockIdx.y selects the block of COUT channels of the layer's `ctot` (64 -> 64 runs as
+// two 32-channel blocks: half the weights per workgroup = two workgroups per CU instead of one, which hides the per-step barrier /
+// LDS / global-load latencies a single wave per SIMD exposes: 105 -> see profiles/r04_conv3x3_probe.json)
+template <int HALVES, int NT, int D>
+__global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 2 : 1)) void conv3x3_stream_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial, int nimg, int H,
-    int W) {
+    int W, int ctot) {
   constexpr int CIN = 32 * HALVES, COUT = 16 * NT;
+  const int co0 = blockIdx.y * COUT;
   static_assert(D % HALVES == 0, "the half of a step must be a compile-time function of its slot");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_c3[];
   unsigned short* Ws = smem_c3;                                   // [HALVES][9][COUT] rows of 32 channels
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
   for (int i = t; i < HALVES * 9 * COUT * 4; i += 256) {
     const int seg = i & 3, r = i >> 2, co = r % COUT, tap = (r / COUT) % 9, h = r / (COUT * 9);
     *reinterpret_cast<uint4*>(&Ws[c3_woff((h * 9 + tap) * COUT + co, seg)]) =
-        *reinterpret_cast<const uint4*>(w + ((size_t)co * 9 + tap) * CIN + h * 32 + seg * 8);
+        *reinterpret_cast<const uint4*>(w + ((size_t)(co0 + co) * 9 + tap) * CIN + h * 32 + seg * 8);
   }
   for (int i = t; i < CIN; i += 256) { scS[i] = in_scale ? in_scale[i] : 1.f; scS[CIN + i] = in_scale ? in_shift[i] : 0.f; }
   // this thread's halo segments: pixel hp = (t + 256 i) / 4 of the 10 x 34 tile, 16-byte segment (t & 3)
@@ -192,13 +199,8 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
               for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma_bf16_16x16x32(wb[tn], xa[tm], acc[tn][tm]);
           }
         };
-        if constexpr (ROLL) {                                     // two workgroups per CU: the 256-register budget does not hold 9 taps of hoisted fragments
-#pragma unroll 1
-          for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
-        } else {
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
-        }
+        for (int kh = 0; kh < 3; ++kh) taps_of_row(kh);
         if (half == HALVES - 1) {
           // tile done: round once (RNE), statistics of the rounded values, 4 NT consecutive channels per lane and pixel
           const int y0 = cc.ty * C3_TH, x0 = cc.tx * C3_TW;
@@ -218,8 +220,8 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
               }
               acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            char* ybase = reinterpret_cast<char*>(y + (size_t)cc.img * H * W * COUT);
-            c3_u32x4* dst = reinterpret_cast<c3_u32x4*>(ybase + (unsigned int)((oy * W + ox) * COUT + g * (4 * NT)) * 2u);
+            char* ybase = reinterpret_cast<char*>(y + (size_t)cc.img * H * W * ctot + co0);
+            c3_u32x4* dst = reinterpret_cast<c3_u32x4*>(ybase + (unsigned int)((oy * W + ox) * ctot + g * (4 * NT)) * 2u);
 #pragma unroll
             for (int q = 0; q < NT / 2; ++q) dst[q] = c3_u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
           }
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
     float sv = 0.f, q = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sv += redS[j * COUT + t]; q += redQ[j * COUT + t]; }
-    float* p = partial + (size_t)blockIdx.x * 2 * COUT;
+    float* p = partial + (size_t)blockIdx.x * 2 * ctot + co0;
     p[t] = sv;
-    p[COUT + t] = q;
+    p[ctot + t] = q;
   }
 }
 
@@ -256,7 +258,12 @@ __global__ __launch_bounds__(256, (HALVES == 1 ? 2 : 1)) void conv3x3_stream_ker
 
 using namespace a3d;
 
-static size_t c3_lds(int Cin, int Cout) { return (size_t)(Cin / 32) * 9 * Cout * 64 + (size_t)2 * C3_HP * 64 + (size_t)2 * Cin * sizeof(float); }
+// output channels per workgroup: 64 -> 64 splits into two blocks of 32 (two workgroups per CU)
+static int c3_cblock(int Cin, int Cout) {
+  static const bool split = !(getenv("A3D_C3_SPLIT") && atoi(getenv("A3D_C3_SPLIT")) == 0);      // A/B switch: 0 = one 64-channel block
+  return (Cin == 64 && Cout == 64 && split) ? 32 : Cout;
+}
+static size_t c3_lds(int Cin, int Cout) { return (size_t)c3_lds_bytes(Cin / 32, c3_cblock(Cin, Cout) / 16); }
 // served: 32 -> 32, 32 -> 64, 64 -> 64 channels on maps of 8 j x 32 k pixels
 static bool c3_serves(int Cin, int Cout, int H, int W) {
   const bool ch = (Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && Cout == 64);
@@ -264,8 +271,9 @@ static bool c3_serves(int Cin, int Cout, int H, int W) {
 }
 static int c3_slabs(size_t nimg, int H, int W, int Cin, int Cout) {
   const size_t ntiles = nimg * (size_t)(H / C3_TH) * (size_t)(W / C3_TW);
-  const int per_cu = (2 * c3_lds(Cin, Cout) <= 160 * 1024 && Cin == 32) ? 2 : 1;      // resident workgroups (LDS-limited)
-  return (int)std::min<size_t>(ntiles, (size_t)256 * per_cu);
+  const int per_cu = 2 * c3_lds(Cin, Cout) <= 160 * 1024 ? 2 : 1;                    // resident workgroups (LDS-limited)
+  const int yblocks = Cout / c3_cblock(Cin, Cout);
+  return (int)std::min<size_t>(ntiles, (size_t)std::max(8, 256 * per_cu / yblocks));
 }
 
 extern "C" int a3d_conv3x3_serves(int Cin, int Cout, int H, int W) { return c3_serves(Cin, Cout, H, W) ? 1 : 0; }
@@ -289,15 +297,16 @@ extern "C" int a3d_conv3x3_bn_fwd(const void* x, const void* w, const float* in_
   unsigned short* ys = (unsigned short*)y;
   const int slabs = c3_slabs(nimg, H, W, Cin, Cout);
   const size_t lds = c3_lds(Cin, Cout);
-#define A3D_C3S(HV, NTV, DV, RV)                                                                                                    \
+#define A3D_C3S(HV, NTV, DV)                                                                                                        \
   do {                                                                                                                           \
     static bool once = false;                                                                                                    \
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<HV, NTV, DV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; } \
-    hipLaunchKernelGGL((conv3x3_stream_kernel<HV, NTV, DV, RV>), dim3(slabs), dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (int)nimg, H, W); \
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<HV, NTV, DV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; } \
+    hipLaunchKernelGGL((conv3x3_stream_kernel<HV, NTV, DV>), dim3(slabs, Cout / c3_cblock(Cin, Cout)), dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (int)nimg, H, W, Cout); \
   } while (0)
-  if (Cin == 32 && Cout == 32) A3D_C3S(1, 2, 3, false);
-  else if (Cin == 32 && Cout == 64) A3D_C3S(1, 4, 2, true);
-  else A3D_C3S(2, 4, 2, false);
+  if (Cin == 32 && Cout == 32) A3D_C3S(1, 2, 3);
+  else if (Cin == 32 && Cout == 64) A3D_C3S(1, 4, 2);
+  else if (c3_cblock(Cin, Cout) == 32) A3D_C3S(2, 2, 2);
+  else A3D_C3S(2, 4, 2);
 #undef A3D_C3S
   return check_launch("a3d_conv3x3_bn_fwd");
 }

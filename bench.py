@@ -619,6 +619,7 @@ def main():
             res["kernels"] = {k: {"ms": v["ms"], "achieved": v["achieved"], "unit": v["unit"], "frac": v["achieved"] / v["peak"],
                                   "launches_per_step": v.get("launches_per_step"),
                                   **({"mfma_util_executed": v["mfma_util_executed"]} if "mfma_util_executed" in v else {}),
+                                  **{f: v[f] for f in ("mfma_TFLOPs", "mfma_frac", "note") if f in v},
                                   **({"traffic": pmc[k]["hbm_bytes"]} if k in pmc else {}),
                                   **({"pmc": pmc[k]["pmc"]} if k in pmc and pmc[k].get("pmc") else {})}
                               for k, v in ks.items()}
