@@ -170,8 +170,13 @@ __global__ __launch_bounds__(256) void rgb_normalize_kernel(const float* __restr
 }
 
 // 8 channels (16 B) per thread
+// RBN: the residual is itself a raw convolution output with its own BatchNorm (the bottleneck's downsample branch,
+// clip.py:28-43: identity = downsample(x) = bn(conv(avgpool(x)))): y = relu?(x * scale + shift + (res * rscale + rshift)) -- the
+// branch's normalised map is never materialised (one read + one write of a 4 * planes map less per layer)
+template <bool RBN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__ x, const uint4* __restrict__ res,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                        uint4* __restrict__ y, size_t nvec, int C8, int relu) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C8) * 8;
@@ -186,8 +191,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
       float a = __uint_as_float(vw[j] << 16) * scale[c + 2 * j] + shift[c + 2 * j];
       float b = __uint_as_float(vw[j] & 0xFFFF0000u) * scale[c + 2 * j + 1] + shift[c + 2 * j + 1];
       if (res) {
-        a += __uint_as_float(rw[j] << 16);
-        b += __uint_as_float(rw[j] & 0xFFFF0000u);
+        float ra = __uint_as_float(rw[j] << 16), rb = __uint_as_float(rw[j] & 0xFFFF0000u);
+        if (RBN) {
+          ra = ra * rscale[c + 2 * j] + rshift[c + 2 * j];
+          rb = rb * rscale[c + 2 * j + 1] + rshift[c + 2 * j + 1];
+        }
+        a += ra;
+        b += rb;
       }
       if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
       ow[j] = pack2(a, b);
@@ -419,17 +429,21 @@ extern "C" int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int
   return check_launch("a3d_bn_finalize");
 }
 
-extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y,
-                            size_t rows, int C, int relu, void* stream) {
-  if (!x || !scale || !shift || !y || rows == 0 || C <= 0 || (C % 8) != 0 ||
+extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,
+                            const float* shift, void* y, size_t rows, int C, int relu, void* stream) {
+  if (!x || !scale || !shift || !y || rows == 0 || C <= 0 || (C % 8) != 0 || (res_scale && (!res_shift || !residual)) ||
       ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15)) {
-    set_error("a3d_bn_apply: bad argument (C=%d must be a multiple of 8, pointers 16-byte aligned)", C);
+    set_error("a3d_bn_apply: bad argument (C=%d must be a multiple of 8, pointers 16-byte aligned, res_scale needs res_shift and a residual)", C);
     return A3D_ERR_ARG;
   }
   const size_t nvec = rows * (size_t)(C / 8);
   const int grid = (int)std::min<size_t>((nvec + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
-                     scale, shift, (uint4*)y, nvec, C / 8, relu);
+  if (res_scale)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
+                       scale, shift, res_scale, res_shift, (uint4*)y, nvec, C / 8, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
+                       scale, shift, (const float*)nullptr, (const float*)nullptr, (uint4*)y, nvec, C / 8, relu);
   return check_launch("a3d_bn_apply");
 }
 

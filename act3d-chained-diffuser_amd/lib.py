@@ -128,7 +128,7 @@ SIGNATURES = {
     "a3d_conv3x3_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "a3d_bn_stats": (_i, [_p, _p, _z, _i, _i, _p]),
     "a3d_bn_finalize": (_i, [_p, _i, _z, _i, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
-    "a3d_bn_apply": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _p]),
+    "a3d_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_bn_apply_pool2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rgb_normalize_nhwc_bf16": (_i, [_p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_upsample2_add_fwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),

@@ -390,9 +390,10 @@ int a3d_bn_stats(const void* x, float* partial /* [nslab][2][C] */, size_t rows,
 int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int C, float eps, float momentum, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float* scale, float* shift, int train,
                     void* stream);
-/* y = relu?(x * scale[c] + shift[c] (+ residual)) */
-int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, size_t rows, int C,
-                 int relu, void* stream);
+/* y = relu?(x * scale[c] + shift[c] (+ residual)); res_scale / res_shift (or NULL): the residual is a raw convolution output with
+ * its own BatchNorm (the bottleneck's downsample branch, clip.py:28-43) and enters as residual * res_scale[c] + res_shift[c] */
+int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,
+                 const float* shift, void* y, size_t rows, int C, int relu, void* stream);
 /* Same, followed by the nn.AvgPool2d(2) that the CLIP bottleneck / stem applies to the activation (model/utils/clip.py
  * Bottleneck.avgpool, downsample[0], ModifiedResNet.avgpool): y_pool [N][H/2][W/2][C] = mean of the 2x2 bf16 activations;
  * y_full [N][H][W][C] is also written unless NULL.  scale == NULL: identity (plain average pool of x).  H, W even. */
