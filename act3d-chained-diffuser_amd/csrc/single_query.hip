@@ -273,6 +273,14 @@ __global__ __launch_bounds__(64) void sq_vproj_bwd_kernel(const float* __restric
   }
 }
 
+// Phase timestamps (wall_clock64, 100 MHz) of workgroup (0, 0) of the last sq_bwd launch while a3d_dbg_sq_prof(1, ..) is armed:
+// development aid (profiles/sq_bwd_phases.py), no effect on results.  Marks: 0 entry, 1 weights / query / dxbar staged, then for
+// the workgroup's LAST tile 2 rows in LDS, 3 keys projected + rotated, 4 scores and dp, 5 p and ds, 6 rotated-query gradient,
+// 7 inverse rotation, 8 dX tile stored, 9 dW accumulated; 10 exit; 11 = tiles this workgroup walked.
+__device__ long long g_sq_prof[16];
+__device__ int g_sq_prof_on;
+#define SQ_MARK(i) do { if (prof_on && threadIdx.x == 0) g_sq_prof[i] = wall_clock64(); } while (0)
+
 // ------------------------------------------------------------------------------------------------ backward
 // grid (nsplit, B).  dX [B][S][E] (written, every row once); wpart [B * nsplit][E][E + 1] (dW_k | db_k partials);
 // dqp [nsplit][B][H][1][16] (rotated-query gradient partials, the layout a3d_rope_merge_bwd reads with Npad = 1)
@@ -294,6 +302,8 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, sp = blockIdx.x;
+  const bool prof_on = g_sq_prof_on != 0 && blockIdx.x == 0 && blockIdx.y == 0;
+  SQ_MARK(0);
   sq_stage_weight(Ws, Wk, ldw, E);
   for (int idx = t; idx < 16 * SQ_LD; idx += 256) {
     const int h = idx / SQ_LD, c = idx - h * SQ_LD;
@@ -313,16 +323,20 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   SqRows rows;
   if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, true);     // column E = 1: the bias gradient rides in dW
   __syncthreads();
+  SQ_MARK(1);
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int n0 = tile * SQ_T;
     sq_store_rows(Xs, rows);
     if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, true);
     __syncthreads();
+    SQ_MARK(2);
     float rot[SQ_ROT][2];                                    // (cos, sin) of this thread's items, reused by the inverse rotation
     sq_project_rope<true>(T, Xs, Ws, bk, xyz, freq, b, n0, S, E, rot);
+    SQ_MARK(3);
     sq_rows_times_heads(T, Qm, sS, E);                       // scores
     sq_rows_times_heads(Xs, Dm, dS, E);                      // dp = dxbar . x_k
     __syncthreads();
+    SQ_MARK(4);
     if (wave < H) {
       const bool ok = n0 + lane < S && lse_h != -INFINITY;
       const float p = ok ? __expf(sS[wave * SQ_T + lane] - lse_h) : 0.f;
@@ -330,6 +344,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       dS[wave * SQ_T + lane] = p * (dS[wave * SQ_T + lane] - cd_h);
     }
     __syncthreads();
+    SQ_MARK(5);
     // rotated-query gradient: dq_h[d] += sum_k ds_k,h k_k[h*15 + d]   (T still holds the rotated keys)
     if (wave < H && lane < HD) {
       float a = 0.f;
@@ -338,6 +353,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       dqa += a;
     }
     __syncthreads();
+    SQ_MARK(6);
     // T <- R_k^T (ds_k (x) q): gradient w.r.t. the projected (un-rotated) key rows
 #pragma unroll
     for (int it = 0; it < SQ_ROT; ++it) {
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       T[r * SQ_LD + c1] = y1;
     }
     __syncthreads();
+    SQ_MARK(7);
     // dX tile = T W_k (dgrad, contraction over the projection's output channels) + sum_h p_h dxbar_h
     {
       f32x4 acc[SQ_NT];
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
         }
       }
     }
+    SQ_MARK(8);
     // dW_k | db_k += T^T [Xs | 1]   (contraction over the tile's keys; wave -> output rows n = wave*16 .. +15)
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       }
     }
     __syncthreads();
+    SQ_MARK(9);
   }
   const int KE = E + 1;
   float* wp = wpart + ((size_t)b * nsplit + sp) * E * KE;
@@ -411,6 +430,8 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     }
   }
   if (wave < H && lane < 16) dqp[(((size_t)sp * B + b) * H + wave) * 16 + lane] = lane < HD ? dqa : 0.f;
+  SQ_MARK(10);
+  if (prof_on && threadIdx.x == 0) g_sq_prof[11] = t_end - t_beg;
 }
 
 }  // namespace a3d
@@ -492,4 +513,14 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
   rc = check_launch("a3d_sq_attn_bwd");
   if (rc) return rc;
   return a3d_sq_wgrad_reduce(wpart, B * nsplit, dWk, lddwk, dbk, E, stream);
+}
+
+// development aid: arm (on != 0) / disarm the phase timestamps of sq_bwd_kernel's workgroup (0, 0) and read the 12 values of
+// the last armed launch back (out12 may be NULL when only arming)
+extern "C" int a3d_dbg_sq_prof(int on, long long* out12) {
+  const int v = on ? 1 : 0;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_sq_prof_on), &v, sizeof(int));
+  if (e == hipSuccess && out12) e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_sq_prof), 12 * sizeof(long long));
+  if (e != hipSuccess) { set_error("a3d_dbg_sq_prof: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  return A3D_OK;
 }

@@ -377,6 +377,9 @@ int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* tra
                 float* traj_out, int B, int L, int E, int t_step, void* stream);
 /* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dbg_dn_prof(long long* out18);
+/* development aid: arm / disarm the phase timestamps (100 MHz ticks) of workgroup (0, 0) of a3d_sq_attn_bwd's key pass and read the
+ * 12 values of the last armed launch (host buffer; NULL = only arm) */
+int a3d_dbg_sq_prof(int on, long long* out12);
 /* out[b][h][n][16] fp32 = rope3d(Y[b, n, :E] * scale, xyz) split into heads (column 15 and rows >= N zero): the K cache */
 int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B, int N,
                       int Npad, int E, int H, void* stream);
