@@ -23,6 +23,18 @@ constexpr int SQ_T = 64;       // keys per tile
 constexpr int SQ_LD = 68;      // LDS row stride (floats) of the [64][<=64] tiles
 constexpr int SQ_NT = 4;       // 16-column tiles of a row (E <= 64)
 
+// round-5 candidates for the backward key pass, each an A/B switch at build time (A3D_HIPCC_FLAGS="-DSQ_DX_LDS=0 ..."):
+//   SQ_DX_LDS  the dX tile leaves through an LDS tile as coalesced float4 rows (a tile is ONE contiguous 64 E-float block of dX),
+//              with sum_h p_h dxbar_h as a fifth k-step of its GEMM instead of 128 LDS reads + 64 fma per lane; before: 16 guarded
+//              4-byte stores per lane
+//   SQ_DQ_PAR  the rotated-query gradient on all 64 lanes of the head's wave (key quarters) instead of a 64-step chain on 15 lanes
+#ifndef SQ_DX_LDS
+#define SQ_DX_LDS 1
+#endif
+#ifndef SQ_DQ_PAR
+#define SQ_DQ_PAR 1
+#endif
+
 // context rows n0 .. n0+63 of sample b (zero beyond S / E; column E := 1 for valid rows if `ones`): global -> registers
 // (issued one tile ahead, so the HBM round trip hides behind the previous tile's arithmetic) -> Xs[64][SQ_LD]
 struct SqRows { float4 v[4]; };
@@ -284,7 +296,7 @@ __device__ int g_sq_prof_on;
 // ------------------------------------------------------------------------------------------------ backward
 // grid (nsplit, B).  dX [B][S][E] (written, every row once); wpart [B * nsplit][E][E + 1] (dW_k | db_k partials);
 // dqp [nsplit][B][H][1][16] (rotated-query gradient partials, the layout a3d_rope_merge_bwd reads with Npad = 1)
-__global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
+__global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                      const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                      const float* __restrict__ qrot, const float* __restrict__ freq,
                                                      const float* __restrict__ lse, const float* __restrict__ dxbar,
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   float* Dm = Qm + 16 * SQ_LD;             // [16][SQ_LD]: row h = dxbar[b][h]
   float* sS = Dm + 16 * SQ_LD;             // [4][64] scores -> p
   float* dS = sS + 4 * SQ_T;               // [4][64] dp -> ds
+  float* Ys = dS + 4 * SQ_T;               // [64][SQ_LD] the dX tile on its way out (SQ_DX_LDS)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, sp = blockIdx.x;
@@ -324,8 +337,23 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, true);     // column E = 1: the bias gradient rides in dW
   __syncthreads();
   SQ_MARK(1);
+  int ys_n0 = -1;                            // first row of the dX tile waiting in Ys (-1: none)
+  auto flush_dx = [&]() {                    // Ys -> dX rows ys_n0 .. +63: one contiguous block of dX, float4 per thread and pass
+#if SQ_DX_LDS
+    if (ys_n0 >= 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = t + i * 256;
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        if (ys_n0 + r < S && c < E)
+          *reinterpret_cast<float4*>(dX + ((size_t)b * S + ys_n0 + r) * E + c) = *reinterpret_cast<const float4*>(&Ys[r * SQ_LD + c]);
+      }
+    }
+#endif
+  };
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int n0 = tile * SQ_T;
+    flush_dx();                              // the previous tile's dX (its closing barrier made Ys complete)
     sq_store_rows(Xs, rows);
     if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, true);
     __syncthreads();
@@ -346,12 +374,21 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     __syncthreads();
     SQ_MARK(5);
     // rotated-query gradient: dq_h[d] += sum_k ds_k,h k_k[h*15 + d]   (T still holds the rotated keys)
+#if SQ_DQ_PAR
+    if (wave < H && li < HD) {                  // lane = (key quarter g, channel li): partial sums, reduced over g after the loop
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < SQ_T / 4; ++k) a += dS[wave * SQ_T + g * (SQ_T / 4) + k] * T[(g * (SQ_T / 4) + k) * SQ_LD + wave * HD + li];
+      dqa += a;
+    }
+#else
     if (wave < H && lane < HD) {
       float a = 0.f;
 #pragma unroll 8
       for (int k = 0; k < SQ_T; ++k) a += dS[wave * SQ_T + k] * T[k * SQ_LD + wave * HD + lane];
       dqa += a;
     }
+#endif
     __syncthreads();
     SQ_MARK(6);
     // T <- R_k^T (ds_k (x) q): gradient w.r.t. the projected (un-rotated) key rows
@@ -386,6 +423,19 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
 #pragma unroll
         for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(a, Ws[(kk * 4 + g) * SQ_LD + ct * 16 + li], acc[ct]);
       }
+#if SQ_DX_LDS
+      {
+        // + sum_h p_h dxbar_h as one more k-step: A[row][k = head g] = p, B[k = head g][col] = dxbar (rows >= H of both are zero)
+        const float pa = sS[g * SQ_T + wave * 16 + li];
+#pragma unroll
+        for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(pa, Dm[g * SQ_LD + ct * 16 + li], acc[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < SQ_NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ys[(wave * 16 + g * 4 + r) * SQ_LD + ct * 16 + li] = acc[ct][r];
+      ys_n0 = n0;                               // stored after the tile's closing barrier (top of the next iteration / after the loop)
+#else
 #pragma unroll
       for (int ct = 0; ct < SQ_NT; ++ct) {
         const int c = ct * 16 + li;
@@ -400,6 +450,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
           dX[((size_t)b * S + n) * E + c] = v;
         }
       }
+#endif
     }
     SQ_MARK(8);
     // dW_k | db_k += T^T [Xs | 1]   (contraction over the tile's keys; wave -> output rows n = wave*16 .. +15)
@@ -417,6 +468,11 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     __syncthreads();
     SQ_MARK(9);
   }
+  flush_dx();                                // the last tile
+#if SQ_DQ_PAR
+  dqa += __shfl_xor(dqa, 16, 64);            // the four key quarters of a channel
+  dqa += __shfl_xor(dqa, 32, 64);
+#endif
   const int KE = E + 1;
   float* wp = wpart + ((size_t)b * nsplit + sp) * E * KE;
 #pragma unroll
@@ -489,7 +545,7 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
   if (rc) return rc;
   // dO == NULL: ws already holds dxbar | cD (written by a3d_qs_post_bwd, which also owns the value projection's gradients)
   if (!X || !Wk || (dO && (!Wv || !dWv)) || !qrot || !xbar || !lse || !ws || !dX || !dqp || !dWk || !dbk || (xyz && !freq) ||
-      ((((uintptr_t)X) & 15) != 0)) {
+      ((((uintptr_t)X | (uintptr_t)dX) & 15) != 0)) {
     set_error("a3d_sq_attn_bwd: null / misaligned pointer");
     return A3D_ERR_ARG;
   }
@@ -502,7 +558,7 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
     rc = check_launch("a3d_sq_attn_bwd(vproj)");
     if (rc) return rc;
   }
-  const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
+  const size_t lds = (size_t)((3 + SQ_DX_LDS) * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
