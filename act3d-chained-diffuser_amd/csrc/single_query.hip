@@ -160,10 +160,14 @@ __device__ __forceinline__ void sq_rows_times_heads(const float* A, const float*
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (nsplit, B); partial [B][nsplit][H][E + 2] = {m, l, xbar[E]} per head
+// EC: E as a compile-time constant (60 = Act3D; 0 = run-time E): the rotation loops divide by E / 2 and E / 3 per item
+// (rope.hip's proj_rope_split_kernel has the numbers)
+template <int EC>
 __global__ __launch_bounds__(256) void sq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                      const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                      const float* __restrict__ qrot, const float* __restrict__ freq,
-                                                     float* __restrict__ part, int B, int S, int E, int H, int nsplit) {
+                                                     float* __restrict__ part, int B, int S, int E_rt, int H_rt, int nsplit) {
+  const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
   float* Ws = Xs + SQ_T * SQ_LD;
@@ -296,13 +300,15 @@ __device__ int g_sq_prof_on;
 // ------------------------------------------------------------------------------------------------ backward
 // grid (nsplit, B).  dX [B][S][E] (written, every row once); wpart [B * nsplit][E][E + 1] (dW_k | db_k partials);
 // dqp [nsplit][B][H][1][16] (rotated-query gradient partials, the layout a3d_rope_merge_bwd reads with Npad = 1)
+template <int EC>
 __global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                      const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                      const float* __restrict__ qrot, const float* __restrict__ freq,
                                                      const float* __restrict__ lse, const float* __restrict__ dxbar,
                                                      const float* __restrict__ cD, float* __restrict__ dX,
-                                                     float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E,
-                                                     int H, int nsplit) {
+                                                     float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E_rt,
+                                                     int H_rt, int nsplit) {
+  const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
   float* Ws = Xs + SQ_T * SQ_LD;
@@ -519,11 +525,14 @@ extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk
   const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 16 * SQ_LD + 4 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(sq_fwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
+  if (E == 60 && H == 4)
+    hipLaunchKernelGGL(sq_fwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
+  else
+    hipLaunchKernelGGL(sq_fwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
   rc = check_launch("a3d_sq_attn_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(sq_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, xbar, lse, B, H, E, nsplit);
@@ -561,11 +570,16 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
   const size_t lds = (size_t)((3 + SQ_DX_LDS) * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(sq_bwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX, wpart,
-                     dqp, B, S, E, H, nsplit);
+  if (E == 60 && H == 4)
+    hipLaunchKernelGGL(sq_bwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
+                       wpart, dqp, B, S, E, H, nsplit);
+  else
+    hipLaunchKernelGGL(sq_bwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
+                       wpart, dqp, B, S, E, H, nsplit);
   rc = check_launch("a3d_sq_attn_bwd");
   if (rc) return rc;
   return a3d_sq_wgrad_reduce(wpart, B * nsplit, dWk, lddwk, dbk, E, stream);
