@@ -341,6 +341,67 @@ __global__ __launch_bounds__(256) void rope_merge_bwd_kernel(
   }
 }
 
+// The same, one THREAD per row for the two models' widths (EC = 60 / 120 channels, H = EC / 15 heads).  The kernel above spends
+// its time on four 64-bit integer divisions per channel pair (item -> row / pair / sample) and reads each head's 15 channels of a
+// row as a separate 60-byte piece; here a thread sums its row's H x 16-float records over the splits with float4 loads
+// (consecutive threads = consecutive rows = consecutive 64-byte records of a head plane), rotates the EC / 2 pairs in registers
+// (no index arithmetic left: every channel index is a constant after unrolling) and writes the row as EC / 4 float4.
+template <int EC>
+__global__ __launch_bounds__(256) void rope_merge_bwd_rows_kernel(
+    const float* __restrict__ dR, int nsplit, const float* __restrict__ xyz, const float* __restrict__ freq,
+    float scale, float* __restrict__ dY, int ldy, int B, int N, int Npad) {
+  constexpr int H = EC / HD, third = EC / 3, NF = third / 2;
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const size_t split_stride = (size_t)B * H * Npad * HDP;
+  float g[EC];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* src = dR + (((size_t)b * H + h) * Npad + n) * HDP;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 4);
+    for (int s = 1; s < nsplit; ++s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(src + s * split_stride + q * 4);
+        v[q].x += w.x; v[q].y += w.y; v[q].z += w.z; v[q].w += w.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < HD) g[h * HD + q * 4 + j] = e[j];
+    }
+  }
+  const size_t m = (size_t)b * N + n;
+  if (xyz) {
+    float fr[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) fr[k] = freq[k];
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+      const float x = xyz[m * 3 + axis];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int c0 = axis * third + 2 * k;
+        float sn, cs;
+        fast_sincos(x * fr[k], &sn, &cs);
+        const float g0 = g[c0], g1 = g[c0 + 1];
+        g[c0] = cs * g0 + sn * g1;
+        g[c0 + 1] = cs * g1 - sn * g0;
+      }
+    }
+  }
+  float* dst = dY + m * ldy;
+#pragma unroll
+  for (int q = 0; q < EC / 4; ++q)
+    *reinterpret_cast<float4*>(dst + q * 4) = make_float4(g[q * 4] * scale, g[q * 4 + 1] * scale, g[q * 4 + 2] * scale, g[q * 4 + 3] * scale);
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -402,6 +463,18 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
     set_error("a3d_rope_merge_bwd: bad argument (B=%d N=%d Npad=%d E=%d H=%d nsplit=%d)", B, N, Npad, E, H,
               nsplit);
     return A3D_ERR_ARG;
+  }
+  // the row-per-thread kernel serves the two models' widths when rows of dY can be written as float4 (dR is HDP = 16 floats per
+  // record, 16-byte aligned by construction of the attention backward's partial buffers)
+  const bool rows_ok = ((E == 60 && H == 4) || (E == 120 && H == 8)) && (ldy & 3) == 0 && ((((uintptr_t)dY) | ((uintptr_t)dR)) & 15) == 0 &&
+                       (Npad * HDP) % 4 == 0;
+  if (rows_ok) {
+    const dim3 grid(cdiv(N, 256), B);
+    if (E == 60)
+      hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<60>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    else
+      hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<120>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    return check_launch("a3d_rope_merge_bwd");
   }
   const size_t total = (size_t)B * N * (E / 2);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
