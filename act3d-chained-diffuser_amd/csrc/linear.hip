@@ -39,7 +39,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K, bool v
   return v;
 }
 
-// act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad]
+// act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad], 3 Y += result [a gradient accumulated in place]
 // One 64x64 output tile per workgroup; the next K-chunk is prefetched into registers while the current one is
 // multiplied, so a chunk costs one HBM round trip, not two barriers + a dependent load.
 template <bool WT>
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
       float v = acc[nt][r] + bv;
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = (mask[(size_t)m * ldm + n] > 0.f) ? v : 0.f;
+      else if (act == 3) v += Y[(size_t)m * ldy + n];
       Y[(size_t)m * ldy + n] = v;
     }
   }

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict_
                                                      const float* __restrict__ lse, const float* __restrict__ dxbar,
                                                      const float* __restrict__ cD, float* __restrict__ dX,
                                                      float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E_rt,
-                                                     int H_rt, int nsplit) {
+                                                     int H_rt, int nsplit, int acc_dx) {
   const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
@@ -351,8 +351,15 @@ __global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict_
       for (int i = 0; i < 4; ++i) {
         const int idx = t + i * 256;
         const int r = idx >> 4, c = (idx & 15) * 4;
-        if (ys_n0 + r < S && c < E)
-          *reinterpret_cast<float4*>(dX + ((size_t)b * S + ys_n0 + r) * E + c) = *reinterpret_cast<const float4*>(&Ys[r * SQ_LD + c]);
+        if (ys_n0 + r < S && c < E) {
+          float4* dst = reinterpret_cast<float4*>(dX + ((size_t)b * S + ys_n0 + r) * E + c);
+          float4 v = *reinterpret_cast<const float4*>(&Ys[r * SQ_LD + c]);
+          if (acc_dx) {                        // the context's gradient summed in place (several consumers, one buffer)
+            const float4 o = *dst;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *dst = v;
+        }
       }
     }
 #endif
@@ -453,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict_
           if (n >= S) continue;
           float v = acc[ct][r];
           for (int h = 0; h < H; ++h) v += sS[h * SQ_T + row] * Dm[h * SQ_LD + c];
+          if (acc_dx) v += dX[((size_t)b * S + n) * E + c];
           dX[((size_t)b * S + n) * E + c] = v;
         }
       }
@@ -546,10 +554,10 @@ extern "C" size_t a3d_sq_bwd_ws_floats(int B, int H, int E, int nsplit) {
   return (size_t)B * H * E + (size_t)B * H + (size_t)B * nsplit * E * (E + 1);      // dxbar | cD | weight-gradient partials
 }
 
-extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
-                               int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
-                               const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
-                               int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
+static int sq_attn_bwd_impl(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                            int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                            const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
+                            int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, int acc_dx, void* stream) {
   int rc = sq_check("a3d_sq_attn_bwd", B, S, E, H, nsplit);
   if (rc) return rc;
   // dO == NULL: ws already holds dxbar | cD (written by a3d_qs_post_bwd, which also owns the value projection's gradients)
@@ -576,13 +584,31 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
   }
   if (E == 60 && H == 4)
     hipLaunchKernelGGL(sq_bwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
-                       wpart, dqp, B, S, E, H, nsplit);
+                       wpart, dqp, B, S, E, H, nsplit, acc_dx);
   else
     hipLaunchKernelGGL(sq_bwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
-                       wpart, dqp, B, S, E, H, nsplit);
+                       wpart, dqp, B, S, E, H, nsplit, acc_dx);
   rc = check_launch("a3d_sq_attn_bwd");
   if (rc) return rc;
   return a3d_sq_wgrad_reduce(wpart, B * nsplit, dWk, lddwk, dbk, E, stream);
+}
+
+extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                               int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                               const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
+                               int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
+  return sq_attn_bwd_impl(X, xyz, Wk, ldw, bk, Wv, ldwv, qrot, freq, xbar, lse, dO, ws, dX, dqp, dWk, lddwk, dbk, dWv, lddwv, dbv, B, S,
+                          E, H, nsplit, 0, stream);
+}
+
+// the same with dX += (accumulate_dX != 0): the context's gradient summed in place by its consumers
+extern "C" int a3d_sq_attn_bwd_acc(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                                   int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                                   const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk,
+                                   float* dWv, int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, int accumulate_dX,
+                                   void* stream) {
+  return sq_attn_bwd_impl(X, xyz, Wk, ldw, bk, Wv, ldwv, qrot, freq, xbar, lse, dO, ws, dX, dqp, dWk, lddwk, dbk, dWv, lddwv, dbv, B, S,
+                          E, H, nsplit, accumulate_dX ? 1 : 0, stream);
 }
 
 // development aid: arm (on != 0) / disarm the phase timestamps of sq_bwd_kernel's workgroup (0, 0) and read the 12 values of

@@ -74,6 +74,8 @@ SIGNATURES = {
     "a3d_sq_bwd_ws_floats": (_z, [_i, _i, _i, _i]),
     "a3d_sq_attn_bwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
                              _i, _p]),
+    "a3d_sq_attn_bwd_acc": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
+                                 _i, _i, _p]),
     "a3d_qs_pre_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
     "a3d_qs_pre_bwd": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_qs_save_floats": (_z, [_i, _i]),

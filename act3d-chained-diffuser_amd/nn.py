@@ -37,10 +37,11 @@ class RelativeCrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(embedding_dim)
         self.num_heads = num_heads
 
-    def forward(self, query, value, query_xyz=None, value_xyz=None, pad_mask=None):
-        """query (B, Lq, E), value (B, S, E) batch-first; xyz instead of materialised rotary codes."""
+    def forward(self, query, value, query_xyz=None, value_xyz=None, pad_mask=None, sink=None):
+        """query (B, Lq, E), value (B, S, E) batch-first; xyz instead of materialised rotary codes.  sink: the GradSink of
+        `value` when its consumers share one gradient buffer (ops.GradSink)."""
         return O.attn_block(query, value, value, query, query_xyz, value_xyz, pad_mask, self.multihead_attn, self.norm,
-                            self.num_heads)
+                            self.num_heads, sink=sink)
 
 
 class FeedforwardLayer(nn.Module):
@@ -67,6 +68,7 @@ class RelativeCrossAttentionModule(nn.Module):
     def forward(self, query, value, query_xyz=None, value_xyz=None):
         """Returns the list of per-layer outputs (layers.py:345-351), batch-first."""
         output = []
+        sink = getattr(value, "_a3d_sink", None)      # the context's shared gradient buffer (act3d.py attaches it), or None
         for attn, ffw in zip(self.attn_layers, self.ffw_layers):
             mha = attn.multihead_attn
             if O.query_layer_applicable(query, value, mha.embed_dim, attn.num_heads, ffw.linear1.out_features):
@@ -74,9 +76,9 @@ class RelativeCrossAttentionModule(nn.Module):
                 query = O.QueryLayerFn.apply(query, value, query_xyz, value_xyz, mha.in_proj_weight, mha.in_proj_bias,
                                              mha.out_proj.weight, mha.out_proj.bias, attn.norm.weight, attn.norm.bias,
                                              ffw.linear1.weight, ffw.linear1.bias, ffw.linear2.weight, ffw.linear2.bias,
-                                             ffw.norm.weight, ffw.norm.bias, attn.num_heads)
+                                             ffw.norm.weight, ffw.norm.bias, attn.num_heads, sink)
             else:
-                query = ffw(attn(query, value, query_xyz, value_xyz))
+                query = ffw(attn(query, value, query_xyz, value_xyz, sink=sink))
             output.append(query)
         return output
 

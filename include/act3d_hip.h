@@ -37,7 +37,8 @@ const char* a3d_last_error_string(void);
 
 /* ---- dense layers ------------------------------------------------------------------------------------ */
 /* Y[m,n] = act(sum_k X[m,k] * W(n,k) + bias[n]);  W(n,k) = W[n*ldw+k], or W[k*ldw+n] if w_transposed (dgrad).
- * act: 0 none, 1 relu, 2 multiply by (mask[m*ldm+n] > 0) (ReLU backward fused into dgrad).
+ * act: 0 none, 1 relu, 2 multiply by (mask[m*ldm+n] > 0) (ReLU backward fused into dgrad), 3 Y += result (a gradient summed in place:
+ * the tensor's consumers accumulate into one buffer instead of autograd adding their outputs).
  * Replaces F.linear at multihead_custom_attention.py:246-303,447; layers.py:88-94,313-332; diffusion_head.py:41-49. */
 int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                    const float* mask, int ldm, int M, int N, int K, int act, int w_transposed, void* stream);
@@ -180,6 +181,11 @@ int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, 
                     const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
                     float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv, int lddwv, float* dbv, int B, int S,
                     int E, int H, int nsplit, void* stream);
+/* the same with dX += instead of dX = when accumulate_dX != 0 (the context's gradient summed in place by its consumers) */
+int a3d_sq_attn_bwd_acc(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
+                        const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
+                        float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv, int lddwv, float* dbv, int B, int S,
+                        int E, int H, int nsplit, int accumulate_dX, void* stream);
 /* dW[n][k] += sum_z partial[z][n][k], db[n] += sum_z partial[z][n][E] for partial [nsplit][E][E + 1] (fixed order) */
 int a3d_sq_wgrad_reduce(const float* partial, int nsplit, float* dW, int lddw, float* db, int E, void* stream);
 
