@@ -139,13 +139,27 @@ __host__ __device__ __forceinline__ void sincos_poly(float x, float* sn, float* 
 }
 // out of line: ONE copy of libm's large-argument path per kernel, however often fast_sincos is unrolled (inlined, eight
 // unrolled calls in sq_bwd grew the kernel by 8 x Payne-Hanek and it ran 40 % slower on instruction fetch)
-__device__ __noinline__ static void sincos_libm(float x, float* sn, float* cs) { sincosf(x, sn, cs); }
+// -- and returning BY VALUE: with pointer results the callers' result arrays had their address passed to a real call and were
+// kept in scratch memory (80 bytes per lane in sq_fwd / sq_bwd: a scratch store + load per item on the fast path too)
+__device__ __noinline__ static float2 sincos_libm(float x) {
+  float2 r;
+  sincosf(x, &r.x, &r.y);
+  return r;
+}
 __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
 #ifdef A3D_LIBM_SINCOS        // A/B build (A3D_HIPCC_FLAGS=-DA3D_LIBM_SINCOS): libm everywhere
   sincosf(x, sn, cs);
 #else
-  if (fabsf(x) < 200.0f) sincos_poly(x, sn, cs);
-  else sincos_libm(x, sn, cs);
+  float s_, c_;
+  if (fabsf(x) < 200.0f) {
+    sincos_poly(x, &s_, &c_);
+  } else {
+    const float2 r = sincos_libm(x);
+    s_ = r.x;
+    c_ = r.y;
+  }
+  *sn = s_;
+  *cs = c_;
 #endif
 }
 

@@ -384,17 +384,64 @@ __global__ __launch_bounds__(256) void attn16_bwd_prep_kernel(
     keyS[q] = ((live ? (unsigned int)(300 - e) : 0xFFFFu) << 16) | (unsigned int)q;          // e in [-100, 128] -> 172 .. 400
   }
   __syncthreads();
-  // ---- B: rank of every (distinct) key by counting the smaller ones: one barrier, deterministic
-  for (int q = t; q < Lqp; q += 256) {
-    const unsigned int k = keyS[q];
-    int pos = 0;
-    for (int j = 0; j < Lqp; j += 4) {
-      const u32x4_ o = *reinterpret_cast<const u32x4_*>(keyS + j);
-      pos += (o[0] < k) + (o[1] < k) + (o[2] < k) + (o[3] < k);
+  // ---- B: ascending key order = a STABLE counting sort by the key's high half (230 possible values: 300 - e of a live row, then the
+  // dead rows), rows ascending inside a value because the placement walks the rows in order -- the same order as ranking every key
+  // by counting the smaller ones, which this replaces: that is Lqp^2 / 4 vector compares on ONE CU (Lqp = 3136, the trajectory
+  // model's context rows: 2.5 M per workgroup, ~200 us of the 54 us AVERAGE this kernel shows in the diffusion training trace).
+  {
+    constexpr int NB = 230;                                      // live: 172 .. 400 -> 0 .. 228; dead (0xFFFF) -> 229
+    int* base = reinterpret_cast<int*>(qrowS);                   // [NB] next free position of each value (qrowS is idle until pass C)
+    int* wcnt = base + NB;                                       // [4][NB] rows of the current 256-row round, per wave
+    auto bucket_of = [](unsigned int key) { return (int)min(key >> 16, 401u) - 172; };
+    const int lane = t & 63, wave = t >> 6;
+    for (int i = t; i < 5 * NB; i += 256) base[i] = 0;
+    __syncthreads();
+    for (int q = t; q < Lqp; q += 256) atomicAdd(&base[bucket_of(keyS[q])], 1);
+    __syncthreads();
+    if (t < 64) {                                                // exclusive scan of the 230 counts: 4 per lane + a wave scan
+      int v[4], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = (4 * t + j < NB) ? base[4 * t + j] : 0; sum += v[j]; }
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nb;
+      }
+      int run = incl - sum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * t + j < NB) { base[4 * t + j] = run; run += v[j]; }
     }
-    sortS[pos] = k;
+    __syncthreads();
+    for (int q0 = 0; q0 < Lqp; q0 += 256) {
+      const int q = q0 + t;
+      const bool valid = q < Lqp;
+      const unsigned int key = valid ? keyS[q] : 0u;
+      const int bk = valid ? bucket_of(key) : 255;               // 8 bits; 255 never matches a real value
+      unsigned long long same = ~0ull;                            // lanes of this wave holding the same value: 8 ballots
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool on = (bk >> bit) & 1;
+        const unsigned long long bl = __ballot(on);
+        same &= on ? bl : ~bl;
+      }
+      const int before = __popcll(same & ((1ull << lane) - 1ull));
+      if (valid && before == 0) wcnt[wave * NB + bk] = __popcll(same);
+      __syncthreads();
+      if (valid) {
+        int pos = base[bk] + before;
+        for (int w = 0; w < wave; ++w) pos += wcnt[w * NB + bk];
+        sortS[pos] = key;
+      }
+      __syncthreads();
+      for (int i = t; i < NB; i += 256) {
+        base[i] += wcnt[i] + wcnt[NB + i] + wcnt[2 * NB + i] + wcnt[3 * NB + i];
+        wcnt[i] = 0; wcnt[NB + i] = 0; wcnt[2 * NB + i] = 0; wcnt[3 * NB + i] = 0;
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
   const unsigned int rank0 = sortS[0] >> 16;                                                   // the largest row's 300 - e
   // ---- C: one pack per 64 sorted rows, PREP_GROUP chunks per staging round
   const int nch = Lqp / 64;

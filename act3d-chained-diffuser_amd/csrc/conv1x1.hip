@@ -20,6 +20,11 @@ namespace a3d {
 
 constexpr int C1_BK = 32;
 
+// weight rows in LDS: 64 bytes per row and K step, 16-byte segment g stored at g ^ (bit 1 | bit 4 << 1 of the row): conflict-free
+// ds_read_b128 for the PERMUTED row order the fragments use (plane_off, which the activation tile keeps, is 2-way conflicted for it;
+// tests/test_conv3x3_layout_cpu.py enumerates both)
+__device__ __forceinline__ int c1_woff(int row, int seg) { return row * 32 + ((seg ^ (((row >> 1) & 1) | (((row >> 4) & 1) << 1))) << 3); }
+
 // The workgroup's weight block W[BN][K] is staged ONCE and stays in LDS while the workgroup walks its M tiles -- the first kernel
 // re-staged it for every tile and K step, which for K = 64 -> N = 256 is four times the bytes of the activation tile it is
 // multiplied with (LDS writes and L2 reads, not HBM, bounded it: 15.5 vs 11.9 ms for the whole backbone in round 3) -- and the
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
   const long long mtiles = (M + BM - 1) / BM;
   for (int i = t; i < KS * BN * 4; i += 256) {
     const int ks = i / (BN * 4), rem = i - ks * (BN * 4), row = rem >> 2, seg = rem & 3;
-    *reinterpret_cast<uint4*>(&Ws[ks * BN * 32 + plane_off(row, seg)]) =
+    *reinterpret_cast<uint4*>(&Ws[ks * BN * 32 + c1_woff(row, seg)]) =
         *reinterpret_cast<const uint4*>(w + (size_t)(n0 + row) * K + ks * C1_BK + seg * 8);
   }
   if (in_scale)
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
           xa[tm] = *reinterpret_cast<const s16x8*>(&Xs[buf * BM * 32 + plane_off(wm * 64 + tm * 16 + li, g)]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-          wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + plane_off(wn * 64 + (li >> 2) * 16 + tn * 4 + (li & 3), g)]);
+          wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + c1_woff(wn * 64 + (li >> 2) * 16 + tn * 4 + (li & 3), g)]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll

@@ -29,11 +29,13 @@ constexpr int C3_TH = 8, C3_TW = 32;                              // output tile
 constexpr int C3_HW = C3_TW + 2, C3_HP = (C3_TH + 2) * C3_HW;     // halo tile: 10 x 34 = 340 pixels
 constexpr int C3_XL = (C3_HP * 4 + 255) / 256;                    // 16-byte segments each thread stages per step: 6
 
-// LDS rows are 64 bytes (32 channels).  Weight row r (aligned blocks of Cout rows): 16-byte segment g stored at g ^ ((r >> 1) & 3).
+// LDS rows are 64 bytes (32 channels).  Weight row r (aligned blocks of Cout rows): 16-byte segment g stored at g ^ (bit 1 | bit 4 << 1 of r)
+// -- the fragments read the PERMUTED rows (i >> 2) 4 NT + tn 4 + (i & 3), for which this keying is conflict-free and (r >> 1) & 3 is 2-way
+// conflicted (tests/test_conv3x3_layout_cpu.py).
 // Halo pixel hp = hy 34 + hx: segment g stored at g ^ ((hx >> 1) & 3) -- keyed on the COLUMN, so that a tap's row shift (kh 34
 // pixels) is a constant byte offset of the read while 16 consecutive pixels from any base stay conflict-free for ds_read_b128
 // (checked by enumeration over the instruction's lane groups for every base and row offset).
-__device__ __forceinline__ int c3_woff(int row, int seg) { return row * 32 + ((seg ^ ((row >> 1) & 3)) << 3); }
+__device__ __forceinline__ int c3_woff(int row, int seg) { return row * 32 + ((seg ^ (((row >> 1) & 1) | (((row >> 4) & 1) << 1))) << 3); }
 __device__ __forceinline__ int c3_xoff(int hp, int hx, int seg) { return hp * 32 + ((seg ^ ((hx >> 1) & 3)) << 3); }
 
 typedef float c3_f32x2 __attribute__((ext_vector_type(2)));

@@ -78,6 +78,46 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict_
   }
 }
 
+// The same with the rows of a sample split over gridDim.x workgroups and float4 lanes (E % 4 == 0, E <= 1024): E / 4 lanes per row,
+// 256 / (E / 4) rows per pass, the per-workgroup column sums reduced in LDS and added to dmod (zeroed by the launcher) with one
+// atomic per column and workgroup.  The kernel above walks ALL L rows of a sample with E of its 256 threads in ONE workgroup --
+// B = 22 workgroups on 256 CUs, 3074 dependent-latency steps for the trajectory model's context rows (22 us average, 0.7 ms of a
+// diffusion training step).
+__global__ __launch_bounds__(256) void adaln_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ mod,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              float* __restrict__ dmod, int L, int E, int rows_per_wg) {
+  extern __shared__ float red_ad[];                               // [rows per pass][2 E]
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int lpr = E >> 2, rpp = 256 / lpr;                        // lanes per row, rows per pass
+  const int rg = t / lpr, l4 = t - rg * lpr;                      // row group, float4 column
+  const bool act = rg < rpp;
+  const int c = l4 * 4;
+  float4 ds = make_float4(0.f, 0.f, 0.f, 0.f), dh = ds;
+  if (act) {
+    const float4 m = *reinterpret_cast<const float4*>(mod + (size_t)b * 2 * E + c);
+    const float4 sc = make_float4(1.0f + m.x, 1.0f + m.y, 1.0f + m.z, 1.0f + m.w);
+    const int l_beg = blockIdx.x * rows_per_wg, l_end = min(L, l_beg + rows_per_wg);
+    for (int l = l_beg + rg; l < l_end; l += rpp) {
+      const size_t i = ((size_t)b * L + l) * E + c;
+      const float4 g = *reinterpret_cast<const float4*>(dy + i);
+      const float4 xv = *reinterpret_cast<const float4*>(x + i);
+      ds.x += g.x * xv.x; ds.y += g.y * xv.y; ds.z += g.z * xv.z; ds.w += g.w * xv.w;
+      dh.x += g.x; dh.y += g.y; dh.z += g.z; dh.w += g.w;
+      *reinterpret_cast<float4*>(dx + i) = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
+    }
+    float* r = red_ad + (size_t)rg * 2 * E;
+    *reinterpret_cast<float4*>(r + c) = ds;
+    *reinterpret_cast<float4*>(r + E + c) = dh;
+  }
+  __syncthreads();
+  for (int j = t; j < 2 * E; j += 256) {
+    float a = 0.f;
+    for (int u = 0; u < rpp; ++u) a += red_ad[(size_t)u * 2 * E + j];
+    if (gridDim.x == 1) dmod[(size_t)b * 2 * E + j] = a;
+    else atomicAdd(&dmod[(size_t)b * 2 * E + j], a);
+  }
+}
+
 __global__ void sinusoidal_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int E) {
   const int half = E / 2;
   const size_t total = (size_t)n * half;
@@ -275,6 +315,20 @@ extern "C" int a3d_adaln_fwd(const float* x, const float* mod, float* y, int B, 
 extern "C" int a3d_adaln_bwd(const float* x, const float* mod, const float* dy, float* dx, float* dmod, int B, int L,
                              int E, void* stream) {
   if (!x || !mod || !dy || !dx || !dmod || B <= 0 || L <= 0 || E <= 0) { set_error("a3d_adaln_bwd: bad argument"); return A3D_ERR_ARG; }
+  if ((E & 3) == 0 && E <= 1024 && ((((uintptr_t)x) | ((uintptr_t)mod) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+    const int rpp = 256 / (E / 4);
+    // rows per workgroup: at least 4 passes each, at most ~2 workgroups per CU over the batch
+    int nsplit = std::max(1, std::min(cdiv(L, 4 * rpp), cdiv(512, B)));
+    const int rows_per_wg = cdiv(cdiv(L, nsplit), rpp) * rpp;
+    nsplit = cdiv(L, rows_per_wg);
+    if (nsplit > 1) {
+      hipError_t e = hipMemsetAsync(dmod, 0, (size_t)B * 2 * E * sizeof(float), (hipStream_t)stream);
+      if (e != hipSuccess) { set_error("a3d_adaln_bwd: memset: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(adaln_bwd_split_kernel, dim3(nsplit, B), dim3(256), (size_t)rpp * 2 * E * sizeof(float), (hipStream_t)stream, x, mod, dy,
+                       dx, dmod, L, E, rows_per_wg);
+    return check_launch("a3d_adaln_bwd");
+  }
   hipLaunchKernelGGL(adaln_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, mod, dy, dx, dmod, L, E);
   return check_launch("a3d_adaln_bwd");
 }

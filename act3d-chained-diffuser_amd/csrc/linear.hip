@@ -39,7 +39,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K, bool v
   return v;
 }
 
-// act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad]
+// act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad], 3 Y += result [a gradient accumulated in place]
 // One 64x64 output tile per workgroup; the next K-chunk is prefetched into registers while the current one is
 // multiplied, so a chunk costs one HBM round trip, not two barriers + a dependent load.
 template <bool WT>
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
       float v = acc[nt][r] + bv;
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = (mask[(size_t)m * ldm + n] > 0.f) ? v : 0.f;
+      else if (act == 3) v += Y[(size_t)m * ldy + n];
       Y[(size_t)m * ldy + n] = v;
     }
   }
@@ -352,6 +353,78 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
   }
 }
 
+// The same for E <= 128 (both models: 60 / 120) with LPR = 16 / 32 lanes per row and a float4 per lane: 4 / 2 rows per wave and
+// pass instead of one row per wave with 60 of 512 element slots used, 4- / 5-step reductions, a workgroup walks `rows_per_wg`
+// consecutive rows (one pass for the small maps) and issues its 2 E atomics once.  The one-row-per-wave kernel above took 33 us for
+// the 21 312 x 60 ghost-token rows (5 MB): a chain of dependent load -> 6-step reduce -> store rounds, ~5 rows deep per wave.
+template <int LPR>
+__global__ __launch_bounds__(256) void add_ln_bwd_rows_kernel(
+    const float* __restrict__ A, const float* __restrict__ R, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dY,
+    float* __restrict__ dS, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int E, int rows_per_wg) {
+  constexpr int RPW = 64 / LPR, SLOTS = 256 / LPR;
+  __shared__ float red_g[SLOTS][LPR * 4];
+  __shared__ float red_b[SLOTS][LPR * 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int e0 = l * 4;
+  const bool act = e0 < E;                                       // E % 4 == 0: a lane's four channels are all valid or all padding
+  float gm[4] = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gm[j] = gamma[e0 + j];           // parameters in a flat buffer are only 4-byte aligned
+  }
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+  const int m_beg = blockIdx.x * rows_per_wg, m_end = min(M, m_beg + rows_per_wg);
+  const float inv_e = 1.0f / (float)E;
+  for (int m0 = m_beg + wave * RPW; m0 < m_end; m0 += 4 * RPW) {
+    const int m = m0 + sub;
+    const bool ok = act && m < m_end;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f), dy = x;
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+      x = *reinterpret_cast<const float4*>(A + (size_t)m * E + e0);
+      if (R) {
+        const float4 r = *reinterpret_cast<const float4*>(R + (size_t)m * E + e0);
+        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+      }
+      dy = *reinterpret_cast<const float4*>(dY + (size_t)m * E + e0);
+      mean = mean_in[m];
+      rstd = rstd_in[m];
+    }
+    const float xv[4] = {x.x, x.y, x.z, x.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w};
+    float xh[4], gy[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = ok ? (xv[j] - mean) * rstd : 0.f;
+      gy[j] = dv[j] * gm[j];
+      pg[j] += dv[j] * xh[j];
+      pb[j] += dv[j];
+      s1 += gy[j];
+      s2 += gy[j] * xh[j];
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= inv_e;
+    s2 *= inv_e;
+    if (ok)
+      *reinterpret_cast<float4*>(dS + (size_t)m * E + e0) = make_float4(rstd * (gy[0] - s1 - xh[0] * s2), rstd * (gy[1] - s1 - xh[1] * s2),
+                                                                      rstd * (gy[2] - s1 - xh[2] * s2), rstd * (gy[3] - s1 - xh[3] * s2));
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red_g[wave * RPW + sub][e0 + j] = pg[j]; red_b[wave * RPW + sub][e0 + j] = pb[j]; }
+    __syncthreads();
+    for (int e = t; e < E; e += 256) {
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int u = 0; u < SLOTS; ++u) { sg += red_g[u][e]; sb += red_b[u][e]; }
+      atomicAdd(&dgamma[e], sg);
+      atomicAdd(&dbeta[e], sb);
+    }
+  }
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -473,6 +546,20 @@ extern "C" int a3d_add_layernorm_bwd(const float* A, const float* R, const float
     return A3D_ERR_ARG;
   }
   if (M == 0) return A3D_OK;
+  if (E <= 128 && (E & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)R) | ((uintptr_t)dY) | ((uintptr_t)dS)) & 15) == 0) {
+    // rows-per-workgroup: one pass (16 / 8 rows) while that still fills the chip, more rows per workgroup (fewer atomics) beyond
+    const int per_pass = E <= 64 ? 16 : 8;
+    int rpw = per_pass;
+    while (cdiv(M, rpw) > 2048 && rpw < 16 * per_pass) rpw *= 2;
+    const int grid = cdiv(M, rpw);
+    if (E <= 64)
+      hipLaunchKernelGGL(add_ln_bwd_rows_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS, dgamma,
+                         dbeta, M, E, rpw);
+    else
+      hipLaunchKernelGGL(add_ln_bwd_rows_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS, dgamma,
+                         dbeta, M, E, rpw);
+    return check_launch("a3d_add_layernorm_bwd");
+  }
   const int grid = min(cdiv(M, 16), 1024);
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean,
                      rstd, dY, dS, dgamma, dbeta, M, E);

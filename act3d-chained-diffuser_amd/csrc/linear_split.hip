@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(
       } else if (act == 2) {
         const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)m * ldm + n);
         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      } else if (act == 3) {                                     // accumulate into Y (a gradient summed in place)
+        const float4 old = *reinterpret_cast<const float4*>(Y + (size_t)m * ldy + n);
+        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
       }
       *reinterpret_cast<float4*>(Y + (size_t)m * ldy + n) = v;
     }

@@ -112,9 +112,28 @@ typedef __attribute__((ext_vector_type(2))) float rf32x2;
 __device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 __device__ __forceinline__ float h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 
+// two floats -> (hi, lo) packed fp16 pairs, x = hi + lo: hi = v_cvt_pk_f16_f32 (RNE), lo = fp16(x - hi) by v_fma_mixlo / mixhi_f16
+// (the fp16 half enters the fma directly; x * 1.0 - hi is exact in fp32, so the single rounding gives the bits of the
+// convert - subtract - convert sequence this replaces: 3 instructions per PAIR instead of ~6 per element; attn_ring.h's lo_f16)
+__device__ __forceinline__ void rp_split_f16(float a, float b, unsigned int& hi, unsigned int& lo) {
+  typedef __attribute__((ext_vector_type(2))) float rp_f32x2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 rp_h16x2;
+  hi = __builtin_bit_cast(unsigned int, __builtin_convertvector((rp_f32x2){a, b}, rp_h16x2));
+#ifdef A3D_NO_FMA_MIX
+  const rp_h16x2 hh = __builtin_bit_cast(rp_h16x2, hi);
+  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((rp_f32x2){a - (float)hh[0], b - (float)hh[1]}, rp_h16x2));
+#else
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo)
+      : "v"(a), "v"(b), "v"(hi));
+#endif
+}
+
 __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt, unsigned short* __restrict__ rows_out,
                                                         unsigned short* __restrict__ planes_out, int plane_parts, int b,
                                                         int n0, int Npad, int H) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int rp_u32x4;
   if (rows_out) {
     for (int idx = threadIdx.x; idx < RT_ROWS * H * 2; idx += blockDim.x) {
       const int half = idx & 1;
@@ -122,18 +141,17 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
       const int h = (idx >> 1) / RT_ROWS;
       const int n = n0 + r;
       if (n >= Npad) continue;
-      s16x8 ohi, olo;
+      unsigned int ohi[4], olo[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int d = half * 8 + j;
-        const float v = (d < HD) ? T[r * ldt + h * HD + d] : 0.f;
-        const unsigned short hi = f2h(v);
-        ohi[j] = (short)hi;
-        olo[j] = (short)f2h(v - h2f(hi));
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = half * 8 + 2 * j, d1 = d0 + 1;
+        const float v0 = (d0 < HD) ? T[r * ldt + h * HD + d0] : 0.f;
+        const float v1 = (d1 < HD) ? T[r * ldt + h * HD + d1] : 0.f;
+        rp_split_f16(v0, v1, ohi[j], olo[j]);
       }
       unsigned short* dst = rows_out + (((size_t)b * H + h) * Npad + n) * 32 + half * 8;
-      *reinterpret_cast<s16x8*>(dst) = ohi;
-      *reinterpret_cast<s16x8*>(dst + 16) = olo;
+      *reinterpret_cast<rp_u32x4*>(dst) = rp_u32x4{ohi[0], ohi[1], ohi[2], ohi[3]};
+      *reinterpret_cast<rp_u32x4*>(dst + 16) = rp_u32x4{olo[0], olo[1], olo[2], olo[3]};
     }
   }
   if (planes_out) {
@@ -145,17 +163,17 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
       const int seg = idx & 7;
       const int d = (idx >> 3) & 15;
       const int h = idx >> 7;
-      s16x8 o, o2;
+      const float pad = (ones && d == HD) ? 1.0f : 0.f;
+      unsigned int o[4], o2[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = (d < HD) ? T[(seg * 8 + j) * ldt + h * HD + d] : ((ones && d == HD) ? 1.0f : 0.f);
-        const unsigned short hi = f2h(v);
-        o[j] = (short)hi;
-        o2[j] = (short)f2h(v - h2f(hi));
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = (d < HD) ? T[(seg * 8 + 2 * j) * ldt + h * HD + d] : pad;
+        const float v1 = (d < HD) ? T[(seg * 8 + 2 * j + 1) * ldt + h * HD + d] : pad;
+        rp_split_f16(v0, v1, o[j], o2[j]);
       }
       unsigned short* dst = planes_out + ((((size_t)b * H + h) * parts) * 16 + d) * Npad + n0 + seg * 8;
-      *reinterpret_cast<s16x8*>(dst) = o;
-      if (parts == 2) *reinterpret_cast<s16x8*>(dst + (size_t)16 * Npad) = o2;
+      *reinterpret_cast<rp_u32x4*>(dst) = rp_u32x4{o[0], o[1], o[2], o[3]};
+      if (parts == 2) *reinterpret_cast<rp_u32x4*>(dst + (size_t)16 * Npad) = rp_u32x4{o2[0], o2[1], o2[2], o2[3]};
     }
   }
 }
@@ -190,10 +208,17 @@ struct ProjBlock {
 constexpr int PR_KC = 64;    // K chunk
 constexpr int PR_LD = 68;    // padded LDS row stride (floats)
 
-template <int NT>   // 16-column output tiles: 4 (E <= 64) or 8 (E <= 128)
+// EC: the channel count as a compile-time constant (60 / 120: the two models' widths; 0 = the run-time E).  The rotation loop
+// divides its item index by E / 2 and its channel by E / 3 -- with a run-time E that is two ~25-instruction integer divisions per
+// (row, pair) item, about half of this kernel's dynamic VALU instructions, and the kernel is issue-bound (four workgroups per CU,
+// ~1300 instructions per wave and tile): the specialisations turn them into multiply-shifts and give the loops constant bounds.
+// KEQ: the input width K equals E (every in-projection of the two models): one K chunk for E = 60, constant k-step counts.
+template <int NT, int EC, bool KEQ>   // 16-column output tiles: 4 (E <= 64) or 8 (E <= 128)
 __global__ __launch_bounds__(256) void proj_rope_split_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ bias, int K,
-    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E, int H, int fmt16) {
+    ProjBlock blk0, ProjBlock blk1, const float* __restrict__ freq, int B, int N, int Npad, int E_rt, int H_rt, int fmt16) {
+  const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
+  if (KEQ) K = EC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                          // [64][PR_LD]
   float* Ws = smem + RT_ROWS * PR_LD;        // [NT * 16][PR_LD]
@@ -316,6 +341,67 @@ __global__ __launch_bounds__(256) void rope_merge_bwd_kernel(
   }
 }
 
+// The same, one THREAD per row for the two models' widths (EC = 60 / 120 channels, H = EC / 15 heads).  The kernel above spends
+// its time on four 64-bit integer divisions per channel pair (item -> row / pair / sample) and reads each head's 15 channels of a
+// row as a separate 60-byte piece; here a thread sums its row's H x 16-float records over the splits with float4 loads
+// (consecutive threads = consecutive rows = consecutive 64-byte records of a head plane), rotates the EC / 2 pairs in registers
+// (no index arithmetic left: every channel index is a constant after unrolling) and writes the row as EC / 4 float4.
+template <int EC>
+__global__ __launch_bounds__(256) void rope_merge_bwd_rows_kernel(
+    const float* __restrict__ dR, int nsplit, const float* __restrict__ xyz, const float* __restrict__ freq,
+    float scale, float* __restrict__ dY, int ldy, int B, int N, int Npad) {
+  constexpr int H = EC / HD, third = EC / 3, NF = third / 2;
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const size_t split_stride = (size_t)B * H * Npad * HDP;
+  float g[EC];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* src = dR + (((size_t)b * H + h) * Npad + n) * HDP;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 4);
+    for (int s = 1; s < nsplit; ++s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(src + s * split_stride + q * 4);
+        v[q].x += w.x; v[q].y += w.y; v[q].z += w.z; v[q].w += w.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < HD) g[h * HD + q * 4 + j] = e[j];
+    }
+  }
+  const size_t m = (size_t)b * N + n;
+  if (xyz) {
+    float fr[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) fr[k] = freq[k];
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+      const float x = xyz[m * 3 + axis];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int c0 = axis * third + 2 * k;
+        float sn, cs;
+        fast_sincos(x * fr[k], &sn, &cs);
+        const float g0 = g[c0], g1 = g[c0 + 1];
+        g[c0] = cs * g0 + sn * g1;
+        g[c0 + 1] = cs * g1 - sn * g0;
+      }
+    }
+  }
+  float* dst = dY + m * ldy;
+#pragma unroll
+  for (int q = 0; q < EC / 4; ++q)
+    *reinterpret_cast<float4*>(dst + q * 4) = make_float4(g[q * 4] * scale, g[q * 4 + 1] * scale, g[q * 4 + 2] * scale, g[q * 4 + 3] * scale);
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -378,6 +464,18 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
               nsplit);
     return A3D_ERR_ARG;
   }
+  // the row-per-thread kernel serves the two models' widths when rows of dY can be written as float4 (dR is HDP = 16 floats per
+  // record, 16-byte aligned by construction of the attention backward's partial buffers)
+  const bool rows_ok = ((E == 60 && H == 4) || (E == 120 && H == 8)) && (ldy & 3) == 0 && ((((uintptr_t)dY) | ((uintptr_t)dR)) & 15) == 0 &&
+                       (Npad * HDP) % 4 == 0;
+  if (rows_ok) {
+    const dim3 grid(cdiv(N, 256), B);
+    if (E == 60)
+      hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<60>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    else
+      hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<120>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    return check_launch("a3d_rope_merge_bwd");
+  }
   const size_t total = (size_t)B * N * (E / 2);
   const int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(rope_merge_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz,
@@ -410,15 +508,21 @@ static int proj_rope_split_launch(const char* fn, const float* X, int ldx, const
   const size_t lds = std::max((size_t)(RT_ROWS + NT * 16) * PR_LD, (size_t)RT_ROWS * (E + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)proj_rope_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)proj_rope_split_kernel<8, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)proj_rope_split_kernel<8, 120, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)proj_rope_split_kernel<8, 120, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_set = true;
   }
-  if (NT == 4)
-    hipLaunchKernelGGL(proj_rope_split_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
-                       freq, B, N, Npad, E, H, fmt16);
-  else
-    hipLaunchKernelGGL(proj_rope_split_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1,
-                       freq, B, N, Npad, E, H, fmt16);
+#define A3D_PRS(NTV, ECV, KQ)                                                                                                   \
+  hipLaunchKernelGGL((proj_rope_split_kernel<NTV, ECV, KQ>), grid, dim3(256), lds, (hipStream_t)stream, X, ldx, W, ldw, bias, K, b0, b1, \
+                     freq, B, N, Npad, E, H, fmt16)
+  if (E == 60 && H == 4 && K == 60) A3D_PRS(4, 60, true);             // Act3D
+  else if (E == 60 && H == 4) A3D_PRS(4, 60, false);
+  else if (E == 120 && H == 8 && K == 120) A3D_PRS(8, 120, true);      // the trajectory diffusion model
+  else if (E == 120 && H == 8) A3D_PRS(8, 120, false);
+  else if (NT == 4) A3D_PRS(4, 0, false);
+  else A3D_PRS(8, 0, false);
+#undef A3D_PRS
   return check_launch(fn);
 }
 

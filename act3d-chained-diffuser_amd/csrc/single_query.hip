@@ -23,6 +23,18 @@ constexpr int SQ_T = 64;       // keys per tile
 constexpr int SQ_LD = 68;      // LDS row stride (floats) of the [64][<=64] tiles
 constexpr int SQ_NT = 4;       // 16-column tiles of a row (E <= 64)
 
+// round-5 candidates for the backward key pass, each an A/B switch at build time (A3D_HIPCC_FLAGS="-DSQ_DX_LDS=0 ..."):
+//   SQ_DX_LDS  the dX tile leaves through an LDS tile as coalesced float4 rows (a tile is ONE contiguous 64 E-float block of dX),
+//              with sum_h p_h dxbar_h as a fifth k-step of its GEMM instead of 128 LDS reads + 64 fma per lane; before: 16 guarded
+//              4-byte stores per lane
+//   SQ_DQ_PAR  the rotated-query gradient on all 64 lanes of the head's wave (key quarters) instead of a 64-step chain on 15 lanes
+#ifndef SQ_DX_LDS
+#define SQ_DX_LDS 1
+#endif
+#ifndef SQ_DQ_PAR
+#define SQ_DQ_PAR 1
+#endif
+
 // context rows n0 .. n0+63 of sample b (zero beyond S / E; column E := 1 for valid rows if `ones`): global -> registers
 // (issued one tile ahead, so the HBM round trip hides behind the previous tile's arithmetic) -> Xs[64][SQ_LD]
 struct SqRows { float4 v[4]; };
@@ -148,10 +160,14 @@ __device__ __forceinline__ void sq_rows_times_heads(const float* A, const float*
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (nsplit, B); partial [B][nsplit][H][E + 2] = {m, l, xbar[E]} per head
+// EC: E as a compile-time constant (60 = Act3D; 0 = run-time E): the rotation loops divide by E / 2 and E / 3 per item
+// (rope.hip's proj_rope_split_kernel has the numbers)
+template <int EC>
 __global__ __launch_bounds__(256) void sq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                      const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                      const float* __restrict__ qrot, const float* __restrict__ freq,
-                                                     float* __restrict__ part, int B, int S, int E, int H, int nsplit) {
+                                                     float* __restrict__ part, int B, int S, int E_rt, int H_rt, int nsplit) {
+  const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
   float* Ws = Xs + SQ_T * SQ_LD;
@@ -273,16 +289,26 @@ __global__ __launch_bounds__(64) void sq_vproj_bwd_kernel(const float* __restric
   }
 }
 
+// Phase timestamps (wall_clock64, 100 MHz) of workgroup (0, 0) of the last sq_bwd launch while a3d_dbg_sq_prof(1, ..) is armed:
+// development aid (profiles/sq_bwd_phases.py), no effect on results.  Marks: 0 entry, 1 weights / query / dxbar staged, then for
+// the workgroup's LAST tile 2 rows in LDS, 3 keys projected + rotated, 4 scores and dp, 5 p and ds, 6 rotated-query gradient,
+// 7 inverse rotation, 8 dX tile stored, 9 dW accumulated; 10 exit; 11 = tiles this workgroup walked.
+__device__ long long g_sq_prof[16];
+__device__ int g_sq_prof_on;
+#define SQ_MARK(i) do { if (prof_on && threadIdx.x == 0) g_sq_prof[i] = wall_clock64(); } while (0)
+
 // ------------------------------------------------------------------------------------------------ backward
 // grid (nsplit, B).  dX [B][S][E] (written, every row once); wpart [B * nsplit][E][E + 1] (dW_k | db_k partials);
 // dqp [nsplit][B][H][1][16] (rotated-query gradient partials, the layout a3d_rope_merge_bwd reads with Npad = 1)
-__global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
+template <int EC>
+__global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                      const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                      const float* __restrict__ qrot, const float* __restrict__ freq,
                                                      const float* __restrict__ lse, const float* __restrict__ dxbar,
                                                      const float* __restrict__ cD, float* __restrict__ dX,
-                                                     float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E,
-                                                     int H, int nsplit) {
+                                                     float* __restrict__ wpart, float* __restrict__ dqp, int B, int S, int E_rt,
+                                                     int H_rt, int nsplit, int acc_dx) {
+  const int E = EC > 0 ? EC : E_rt, H = EC > 0 ? EC / HD : H_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;
   float* Ws = Xs + SQ_T * SQ_LD;
@@ -291,9 +317,12 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   float* Dm = Qm + 16 * SQ_LD;             // [16][SQ_LD]: row h = dxbar[b][h]
   float* sS = Dm + 16 * SQ_LD;             // [4][64] scores -> p
   float* dS = sS + 4 * SQ_T;               // [4][64] dp -> ds
+  float* Ys = dS + 4 * SQ_T;               // [64][SQ_LD] the dX tile on its way out (SQ_DX_LDS)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, sp = blockIdx.x;
+  const bool prof_on = g_sq_prof_on != 0 && blockIdx.x == 0 && blockIdx.y == 0;
+  SQ_MARK(0);
   sq_stage_weight(Ws, Wk, ldw, E);
   for (int idx = t; idx < 16 * SQ_LD; idx += 256) {
     const int h = idx / SQ_LD, c = idx - h * SQ_LD;
@@ -313,16 +342,42 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
   SqRows rows;
   if (t_beg < t_end) rows = sq_load_rows(X, b, t_beg * SQ_T, S, E, true);     // column E = 1: the bias gradient rides in dW
   __syncthreads();
+  SQ_MARK(1);
+  int ys_n0 = -1;                            // first row of the dX tile waiting in Ys (-1: none)
+  auto flush_dx = [&]() {                    // Ys -> dX rows ys_n0 .. +63: one contiguous block of dX, float4 per thread and pass
+#if SQ_DX_LDS
+    if (ys_n0 >= 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = t + i * 256;
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        if (ys_n0 + r < S && c < E) {
+          float4* dst = reinterpret_cast<float4*>(dX + ((size_t)b * S + ys_n0 + r) * E + c);
+          float4 v = *reinterpret_cast<const float4*>(&Ys[r * SQ_LD + c]);
+          if (acc_dx) {                        // the context's gradient summed in place (several consumers, one buffer)
+            const float4 o = *dst;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *dst = v;
+        }
+      }
+    }
+#endif
+  };
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int n0 = tile * SQ_T;
+    flush_dx();                              // the previous tile's dX (its closing barrier made Ys complete)
     sq_store_rows(Xs, rows);
     if (tile + 1 < t_end) rows = sq_load_rows(X, b, n0 + SQ_T, S, E, true);
     __syncthreads();
+    SQ_MARK(2);
     float rot[SQ_ROT][2];                                    // (cos, sin) of this thread's items, reused by the inverse rotation
     sq_project_rope<true>(T, Xs, Ws, bk, xyz, freq, b, n0, S, E, rot);
+    SQ_MARK(3);
     sq_rows_times_heads(T, Qm, sS, E);                       // scores
     sq_rows_times_heads(Xs, Dm, dS, E);                      // dp = dxbar . x_k
     __syncthreads();
+    SQ_MARK(4);
     if (wave < H) {
       const bool ok = n0 + lane < S && lse_h != -INFINITY;
       const float p = ok ? __expf(sS[wave * SQ_T + lane] - lse_h) : 0.f;
@@ -330,14 +385,25 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       dS[wave * SQ_T + lane] = p * (dS[wave * SQ_T + lane] - cd_h);
     }
     __syncthreads();
+    SQ_MARK(5);
     // rotated-query gradient: dq_h[d] += sum_k ds_k,h k_k[h*15 + d]   (T still holds the rotated keys)
+#if SQ_DQ_PAR
+    if (wave < H && li < HD) {                  // lane = (key quarter g, channel li): partial sums, reduced over g after the loop
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < SQ_T / 4; ++k) a += dS[wave * SQ_T + g * (SQ_T / 4) + k] * T[(g * (SQ_T / 4) + k) * SQ_LD + wave * HD + li];
+      dqa += a;
+    }
+#else
     if (wave < H && lane < HD) {
       float a = 0.f;
 #pragma unroll 8
       for (int k = 0; k < SQ_T; ++k) a += dS[wave * SQ_T + k] * T[k * SQ_LD + wave * HD + lane];
       dqa += a;
     }
+#endif
     __syncthreads();
+    SQ_MARK(6);
     // T <- R_k^T (ds_k (x) q): gradient w.r.t. the projected (un-rotated) key rows
 #pragma unroll
     for (int it = 0; it < SQ_ROT; ++it) {
@@ -358,6 +424,7 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       T[r * SQ_LD + c1] = y1;
     }
     __syncthreads();
+    SQ_MARK(7);
     // dX tile = T W_k (dgrad, contraction over the projection's output channels) + sum_h p_h dxbar_h
     {
       f32x4 acc[SQ_NT];
@@ -369,6 +436,19 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
 #pragma unroll
         for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(a, Ws[(kk * 4 + g) * SQ_LD + ct * 16 + li], acc[ct]);
       }
+#if SQ_DX_LDS
+      {
+        // + sum_h p_h dxbar_h as one more k-step: A[row][k = head g] = p, B[k = head g][col] = dxbar (rows >= H of both are zero)
+        const float pa = sS[g * SQ_T + wave * 16 + li];
+#pragma unroll
+        for (int ct = 0; ct < SQ_NT; ++ct) acc[ct] = mfma_f32_16x16x4(pa, Dm[g * SQ_LD + ct * 16 + li], acc[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < SQ_NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ys[(wave * 16 + g * 4 + r) * SQ_LD + ct * 16 + li] = acc[ct][r];
+      ys_n0 = n0;                               // stored after the tile's closing barrier (top of the next iteration / after the loop)
+#else
 #pragma unroll
       for (int ct = 0; ct < SQ_NT; ++ct) {
         const int c = ct * 16 + li;
@@ -380,10 +460,13 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
           if (n >= S) continue;
           float v = acc[ct][r];
           for (int h = 0; h < H; ++h) v += sS[h * SQ_T + row] * Dm[h * SQ_LD + c];
+          if (acc_dx) v += dX[((size_t)b * S + n) * E + c];
           dX[((size_t)b * S + n) * E + c] = v;
         }
       }
+#endif
     }
+    SQ_MARK(8);
     // dW_k | db_k += T^T [Xs | 1]   (contraction over the tile's keys; wave -> output rows n = wave*16 .. +15)
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
@@ -397,7 +480,13 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
       }
     }
     __syncthreads();
+    SQ_MARK(9);
   }
+  flush_dx();                                // the last tile
+#if SQ_DQ_PAR
+  dqa += __shfl_xor(dqa, 16, 64);            // the four key quarters of a channel
+  dqa += __shfl_xor(dqa, 32, 64);
+#endif
   const int KE = E + 1;
   float* wp = wpart + ((size_t)b * nsplit + sp) * E * KE;
 #pragma unroll
@@ -411,6 +500,8 @@ __global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ X
     }
   }
   if (wave < H && lane < 16) dqp[(((size_t)sp * B + b) * H + wave) * 16 + lane] = lane < HD ? dqa : 0.f;
+  SQ_MARK(10);
+  if (prof_on && threadIdx.x == 0) g_sq_prof[11] = t_end - t_beg;
 }
 
 }  // namespace a3d
@@ -442,11 +533,14 @@ extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk
   const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 16 * SQ_LD + 4 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_fwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(sq_fwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
+  if (E == 60 && H == 4)
+    hipLaunchKernelGGL(sq_fwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
+  else
+    hipLaunchKernelGGL(sq_fwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
   rc = check_launch("a3d_sq_attn_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(sq_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, xbar, lse, B, H, E, nsplit);
@@ -460,15 +554,15 @@ extern "C" size_t a3d_sq_bwd_ws_floats(int B, int H, int E, int nsplit) {
   return (size_t)B * H * E + (size_t)B * H + (size_t)B * nsplit * E * (E + 1);      // dxbar | cD | weight-gradient partials
 }
 
-extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
-                               int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
-                               const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
-                               int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
+static int sq_attn_bwd_impl(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                            int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                            const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
+                            int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, int acc_dx, void* stream) {
   int rc = sq_check("a3d_sq_attn_bwd", B, S, E, H, nsplit);
   if (rc) return rc;
   // dO == NULL: ws already holds dxbar | cD (written by a3d_qs_post_bwd, which also owns the value projection's gradients)
   if (!X || !Wk || (dO && (!Wv || !dWv)) || !qrot || !xbar || !lse || !ws || !dX || !dqp || !dWk || !dbk || (xyz && !freq) ||
-      ((((uintptr_t)X) & 15) != 0)) {
+      ((((uintptr_t)X | (uintptr_t)dX) & 15) != 0)) {
     set_error("a3d_sq_attn_bwd: null / misaligned pointer");
     return A3D_ERR_ARG;
   }
@@ -481,15 +575,48 @@ extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk
     rc = check_launch("a3d_sq_attn_bwd(vproj)");
     if (rc) return rc;
   }
-  const size_t lds = (size_t)(3 * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
+  const size_t lds = (size_t)((3 + SQ_DX_LDS) * SQ_T * SQ_LD + 32 * SQ_LD + 8 * SQ_T) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)sq_bwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(sq_bwd_kernel, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX, wpart,
-                     dqp, B, S, E, H, nsplit);
+  if (E == 60 && H == 4)
+    hipLaunchKernelGGL(sq_bwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
+                       wpart, dqp, B, S, E, H, nsplit, acc_dx);
+  else
+    hipLaunchKernelGGL(sq_bwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
+                       wpart, dqp, B, S, E, H, nsplit, acc_dx);
   rc = check_launch("a3d_sq_attn_bwd");
   if (rc) return rc;
   return a3d_sq_wgrad_reduce(wpart, B * nsplit, dWk, lddwk, dbk, E, stream);
+}
+
+extern "C" int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                               int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                               const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv,
+                               int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, void* stream) {
+  return sq_attn_bwd_impl(X, xyz, Wk, ldw, bk, Wv, ldwv, qrot, freq, xbar, lse, dO, ws, dX, dqp, dWk, lddwk, dbk, dWv, lddwv, dbv, B, S,
+                          E, H, nsplit, 0, stream);
+}
+
+// the same with dX += (accumulate_dX != 0): the context's gradient summed in place by its consumers
+extern "C" int a3d_sq_attn_bwd_acc(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv,
+                                   int ldwv, const float* qrot, const float* freq, const float* xbar, const float* lse,
+                                   const float* dO, float* ws, float* dX, float* dqp, float* dWk, int lddwk, float* dbk,
+                                   float* dWv, int lddwv, float* dbv, int B, int S, int E, int H, int nsplit, int accumulate_dX,
+                                   void* stream) {
+  return sq_attn_bwd_impl(X, xyz, Wk, ldw, bk, Wv, ldwv, qrot, freq, xbar, lse, dO, ws, dX, dqp, dWk, lddwk, dbk, dWv, lddwv, dbv, B, S,
+                          E, H, nsplit, accumulate_dX ? 1 : 0, stream);
+}
+
+// development aid: arm (on != 0) / disarm the phase timestamps of sq_bwd_kernel's workgroup (0, 0) and read the 12 values of
+// the last armed launch back (out12 may be NULL when only arming)
+extern "C" int a3d_dbg_sq_prof(int on, long long* out12) {
+  const int v = on ? 1 : 0;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_sq_prof_on), &v, sizeof(int));
+  if (e == hipSuccess && out12) e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_sq_prof), 12 * sizeof(long long));
+  if (e != hipSuccess) { set_error("a3d_dbg_sq_prof: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  return A3D_OK;
 }

@@ -170,11 +170,18 @@ __global__ __launch_bounds__(256) void rgb_normalize_kernel(const float* __restr
 }
 
 // 8 channels (16 B) per thread
+// RBN: the residual is itself a raw convolution output with its own BatchNorm (the bottleneck's downsample branch,
+// clip.py:28-43: identity = downsample(x) = bn(conv(avgpool(x)))): y = relu?(x * scale + shift + (res * rscale + rshift)) -- the
+// branch's normalised map is never materialised (one read + one write of a 4 * planes map less per layer)
+template <bool RBN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__ x, const uint4* __restrict__ res,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                        uint4* __restrict__ y, size_t nvec, int C8, int relu) {
+  // C8 = C / 8 is a power of two for every BatchNorm of the ResNet (C = 32 .. 2048): mask instead of a 64-bit modulo per element
+  const bool pow2 = (C8 & (C8 - 1)) == 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8) * 8;
+    const int c = (pow2 ? (int)((unsigned int)i & (unsigned int)(C8 - 1)) : (int)(i % C8)) * 8;
     const uint4 v = x[i];
     uint4 rv = make_uint4(0, 0, 0, 0);
     if (res) rv = res[i];
@@ -186,8 +193,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
       float a = __uint_as_float(vw[j] << 16) * scale[c + 2 * j] + shift[c + 2 * j];
       float b = __uint_as_float(vw[j] & 0xFFFF0000u) * scale[c + 2 * j + 1] + shift[c + 2 * j + 1];
       if (res) {
-        a += __uint_as_float(rw[j] << 16);
-        b += __uint_as_float(rw[j] & 0xFFFF0000u);
+        float ra = __uint_as_float(rw[j] << 16), rb = __uint_as_float(rw[j] & 0xFFFF0000u);
+        if (RBN) {
+          ra = ra * rscale[c + 2 * j] + rshift[c + 2 * j];
+          rb = rb * rscale[c + 2 * j + 1] + rshift[c + 2 * j + 1];
+        }
+        a += ra;
+        b += rb;
       }
       if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
       ow[j] = pack2(a, b);
@@ -206,13 +218,26 @@ __global__ __launch_bounds__(256) void bn_apply_pool2_kernel(const uint4* __rest
                                                              int H, int W, int C8, int relu) {
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t nout = (size_t)N * Ho * Wo * C8;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    size_t pix = i / C8;
-    const int wo = (int)(pix % Wo);
-    pix /= Wo;
-    const int ho = (int)(pix % Ho);
-    const int n = (int)(pix / Ho);
+  // 32-bit index arithmetic (nout < 2^31: checked by the host), shifts / masks when C8 and Wo are powers of two (always, for the
+  // ResNet's maps): the five 64-bit divisions per element this replaces were ~500 instructions for 4 loads and <= 5 stores
+  const bool p2 = (C8 & (C8 - 1)) == 0 && (Wo & (Wo - 1)) == 0;
+  const int c8_sh = 31 - __clz(C8), wo_sh = 31 - __clz(Wo);
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned int)nout; i += gridDim.x * blockDim.x) {
+    int c8, wo;
+    unsigned int pix;
+    if (p2) {
+      c8 = (int)(i & (unsigned int)(C8 - 1));
+      pix = i >> c8_sh;
+      wo = (int)(pix & (unsigned int)(Wo - 1));
+      pix >>= wo_sh;
+    } else {
+      c8 = (int)(i % (unsigned int)C8);
+      pix = i / (unsigned int)C8;
+      wo = (int)(pix % (unsigned int)Wo);
+      pix /= (unsigned int)Wo;
+    }
+    const int ho = (int)(pix % (unsigned int)Ho);
+    const int n = (int)(pix / (unsigned int)Ho);
     const int c = c8 * 8;
     float sc[8], sh[8];
 #pragma unroll
@@ -269,13 +294,26 @@ __global__ __launch_bounds__(256) void upsample2_add_fwd_kernel(const uint2* __r
                                                                 uint2* __restrict__ y, int N, int H, int W, int C4) {
   const size_t total = (size_t)N * H * W * C4;
   const int Ht = H >> 1, Wt = W >> 1;
+  // shifts / masks when C4, W and H are powers of two (the policy's maps: 64 padded channels, 128 .. 8 pixels a side): the
+  // generic path's five 64-bit divisions per 8-byte element made this pass VALU-bound (~200 instructions per element)
+  const bool p2 = (C4 & (C4 - 1)) == 0 && (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
+  const int c_sh = 31 - __clz(C4), w_sh = 31 - __clz(W), h_sh = 31 - __clz(H);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    size_t pix = i / C4;
-    const int w = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int n = (int)(pix / H);
+    int c, w, h, n;
+    if (p2) {
+      c = (int)((unsigned int)i & (unsigned int)(C4 - 1));
+      const size_t pix = i >> c_sh;
+      w = (int)((unsigned int)pix & (unsigned int)(W - 1));
+      h = (int)((unsigned int)(pix >> w_sh) & (unsigned int)(H - 1));
+      n = (int)(pix >> (w_sh + h_sh));
+    } else {
+      c = (int)(i % C4);
+      size_t pix = i / C4;
+      w = (int)(pix % W);
+      pix /= W;
+      h = (int)(pix % H);
+      n = (int)(pix / H);
+    }
     float a[4], t[4] = {0.f, 0.f, 0.f, 0.f};
     bf16x4_to_f32(lat[i], a);
     if (top) bf16x4_to_f32(top[(((size_t)n * Ht + (h >> 1)) * Wt + (w >> 1)) * C4 + c], t);
@@ -294,13 +332,24 @@ __global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __r
   const int Ht = H >> 1, Wt = W >> 1;
   const size_t total = (size_t)N * Ht * Wt * C4;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool p2 = (C4 & (C4 - 1)) == 0 && (Wt & (Wt - 1)) == 0 && (Ht & (Ht - 1)) == 0;      // as in the forward kernel
+  const int c_sh = 31 - __clz(C4), w_sh = 31 - __clz(Wt), h_sh = 31 - __clz(Ht);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    size_t pix = i / C4;
-    const int wt = (int)(pix % Wt);
-    pix /= Wt;
-    const int ht = (int)(pix % Ht);
-    const int n = (int)(pix / Ht);
+    int c, wt, ht, n;
+    if (p2) {
+      c = (int)((unsigned int)i & (unsigned int)(C4 - 1));
+      const size_t pix = i >> c_sh;
+      wt = (int)((unsigned int)pix & (unsigned int)(Wt - 1));
+      ht = (int)((unsigned int)(pix >> w_sh) & (unsigned int)(Ht - 1));
+      n = (int)(pix >> (w_sh + h_sh));
+    } else {
+      c = (int)(i % C4);
+      size_t pix = i / C4;
+      wt = (int)(pix % Wt);
+      pix /= Wt;
+      ht = (int)(pix % Ht);
+      n = (int)(pix / Ht);
+    }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dyy = 0; dyy < 2; ++dyy)
@@ -419,17 +468,21 @@ extern "C" int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int
   return check_launch("a3d_bn_finalize");
 }
 
-extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y,
-                            size_t rows, int C, int relu, void* stream) {
-  if (!x || !scale || !shift || !y || rows == 0 || C <= 0 || (C % 8) != 0 ||
+extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,
+                            const float* shift, void* y, size_t rows, int C, int relu, void* stream) {
+  if (!x || !scale || !shift || !y || rows == 0 || C <= 0 || (C % 8) != 0 || (res_scale && (!res_shift || !residual)) ||
       ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)residual)) & 15)) {
-    set_error("a3d_bn_apply: bad argument (C=%d must be a multiple of 8, pointers 16-byte aligned)", C);
+    set_error("a3d_bn_apply: bad argument (C=%d must be a multiple of 8, pointers 16-byte aligned, res_scale needs res_shift and a residual)", C);
     return A3D_ERR_ARG;
   }
   const size_t nvec = rows * (size_t)(C / 8);
   const int grid = (int)std::min<size_t>((nvec + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
-                     scale, shift, (uint4*)y, nvec, C / 8, relu);
+  if (res_scale)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
+                       scale, shift, res_scale, res_shift, (uint4*)y, nvec, C / 8, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
+                       scale, shift, (const float*)nullptr, (const float*)nullptr, (uint4*)y, nvec, C / 8, relu);
   return check_launch("a3d_bn_apply");
 }
 
@@ -442,6 +495,7 @@ extern "C" int a3d_bn_apply_pool2(const void* x, const void* residual, const flo
     return A3D_ERR_ARG;
   }
   const size_t nout = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+  if (nout >= ((size_t)1 << 31)) { set_error("a3d_bn_apply_pool2: map too large (%zu 16-byte outputs)", nout); return A3D_ERR_ARG; }
   const int grid = (int)std::min<size_t>((nout + 255) / 256, 16384);
   hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
                      (const uint4*)residual, scale, shift, (uint4*)y_full, (uint4*)y_pool, N, H, W, C / 8, relu);

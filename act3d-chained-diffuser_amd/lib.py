@@ -60,6 +60,7 @@ SIGNATURES = {
     "a3d_attn16_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
     "a3d_attn16_bwd_pack_bytes": (_z, [_i, _i, _i]),
     "a3d_dbg_dn_prof": (_i, [_p]),
+    "a3d_dbg_sq_prof": (_i, [_i, _p]),
     "a3d_attn8_operand_bytes": (_z, [_i, _i, _i]),
     "a3d_attn8_fwd": (_i, [_p] * 8 + [_i] * 7 + [_p]),
     "a3d_attn16_bwd": (_i, [_p] * 16 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "a3d_sq_bwd_ws_floats": (_z, [_i, _i, _i, _i]),
     "a3d_sq_attn_bwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
                              _i, _p]),
+    "a3d_sq_attn_bwd_acc": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i,
+                                 _i, _i, _p]),
     "a3d_qs_pre_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
     "a3d_qs_pre_bwd": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "a3d_qs_save_floats": (_z, [_i, _i]),
@@ -128,7 +131,7 @@ SIGNATURES = {
     "a3d_conv3x3_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "a3d_bn_stats": (_i, [_p, _p, _z, _i, _i, _p]),
     "a3d_bn_finalize": (_i, [_p, _i, _z, _i, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
-    "a3d_bn_apply": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _p]),
+    "a3d_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_bn_apply_pool2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_rgb_normalize_nhwc_bf16": (_i, [_p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_upsample2_add_fwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),

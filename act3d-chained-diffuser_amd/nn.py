@@ -37,10 +37,11 @@ class RelativeCrossAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(embedding_dim)
         self.num_heads = num_heads
 
-    def forward(self, query, value, query_xyz=None, value_xyz=None, pad_mask=None):
-        """query (B, Lq, E), value (B, S, E) batch-first; xyz instead of materialised rotary codes."""
+    def forward(self, query, value, query_xyz=None, value_xyz=None, pad_mask=None, sink=None):
+        """query (B, Lq, E), value (B, S, E) batch-first; xyz instead of materialised rotary codes.  sink: the GradSink of
+        `value` when its consumers share one gradient buffer (ops.GradSink)."""
         return O.attn_block(query, value, value, query, query_xyz, value_xyz, pad_mask, self.multihead_attn, self.norm,
-                            self.num_heads)
+                            self.num_heads, sink=sink)
 
 
 class FeedforwardLayer(nn.Module):
@@ -67,6 +68,7 @@ class RelativeCrossAttentionModule(nn.Module):
     def forward(self, query, value, query_xyz=None, value_xyz=None):
         """Returns the list of per-layer outputs (layers.py:345-351), batch-first."""
         output = []
+        sink = getattr(value, "_a3d_sink", None)      # the context's shared gradient buffer (act3d.py attaches it), or None
         for attn, ffw in zip(self.attn_layers, self.ffw_layers):
             mha = attn.multihead_attn
             if O.query_layer_applicable(query, value, mha.embed_dim, attn.num_heads, ffw.linear1.out_features):
@@ -74,9 +76,9 @@ class RelativeCrossAttentionModule(nn.Module):
                 query = O.QueryLayerFn.apply(query, value, query_xyz, value_xyz, mha.in_proj_weight, mha.in_proj_bias,
                                              mha.out_proj.weight, mha.out_proj.bias, attn.norm.weight, attn.norm.bias,
                                              ffw.linear1.weight, ffw.linear1.bias, ffw.linear2.weight, ffw.linear2.bias,
-                                             ffw.norm.weight, ffw.norm.bias, attn.num_heads)
+                                             ffw.norm.weight, ffw.norm.bias, attn.num_heads, sink)
             else:
-                query = ffw(attn(query, value, query_xyz, value_xyz))
+                query = ffw(attn(query, value, query_xyz, value_xyz, sink=sink))
             output.append(query)
         return output
 
@@ -441,7 +443,7 @@ def conv3x3_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
     return y, partial
 
 
-def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None):
+def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None, residual_scale=None):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
     bf16 channels_last activation (vision.hip).  Three launches: stats (skipped when the producer left `partial` sums),
     finalize, apply.  pool=True also applies the nn.AvgPool2d(2) that follows in the CLIP ResNet inside the apply kernel and
@@ -461,8 +463,11 @@ def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=
     res_ptr = None if residual is None else residual.data_ptr()
     if not pool:
         y = torch.empty_like(x)
-        O.L.call("a3d_bn_apply", x.data_ptr(), res_ptr, sc_ptr, sh_ptr, y.data_ptr(), rows, C, 1 if relu else 0, st)
+        O.L.call("a3d_bn_apply", x.data_ptr(), res_ptr, None if residual_scale is None else residual_scale[0].data_ptr(),
+                 None if residual_scale is None else residual_scale[1].data_ptr(), sc_ptr, sh_ptr, y.data_ptr(), rows, C,
+                 1 if relu else 0, st)
         return y
+    assert residual_scale is None, "the pooled apply takes a materialised residual"
     y = torch.empty_like(x) if keep_full else None
     yp = torch.empty((N, C, H // 2, W // 2), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
     O.L.call("a3d_bn_apply_pool2", x.data_ptr(), res_ptr, sc_ptr, sh_ptr, None if y is None else y.data_ptr(), yp.data_ptr(),
@@ -541,16 +546,21 @@ def fused_frozen_backbone_forward(bb, x):
             else:
                 xin = dpool(x)
             cd, pd = conv1(blk.downsample[1], xin, want_stats=blk.downsample[2].training)
-            idn = bn_act(cd, blk.downsample[2], relu=False, partial=pd)
             bns.append(blk.downsample[2])
-        else:
-            idn = x
         nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
         want_pooled = nxt is not None and nxt.downsample is not None and _pool2_ok(nxt.downsample[0], o3)
+        idn_scale = None
+        if blk.downsample is None:
+            idn = x
+        elif FOLD_DOWNSAMPLE_BN and not want_pooled:
+            # the branch's BatchNorm rides in the block's final apply: bn_d(cd) is never materialised
+            idn, idn_scale = cd, bn_scale_shift(cd, blk.downsample[2], pd)
+        else:
+            idn = bn_act(cd, blk.downsample[2], relu=False, partial=pd)
         if want_pooled:
             x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True, partial=p3)
         else:
-            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, partial=p3), None
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, partial=p3, residual_scale=idn_scale), None
         bns += [blk.bn1, blk.bn2, blk.bn3]
         if id(blk) in last_of_layer:
             outs.append(x)
@@ -560,6 +570,9 @@ def fused_frozen_backbone_forward(bb, x):
 
 
 FUSED_BN = os.environ.get("A3D_FUSED_BN", "1") == "1"
+# BatchNorm of the bottleneck's downsample branch applied inside the block's final BatchNorm-apply + add + ReLU kernel (a second
+# scale / shift pair on the residual operand) instead of its own pass.  A3D_FOLD_DS_BN=0: the branch's map is materialised (A/B).
+FOLD_DOWNSAMPLE_BN = os.environ.get("A3D_FOLD_DS_BN", "1") not in ("0", "", "off")
 # The backbone's 1x1 convolutions of the HBM-bound layers (1 and 2: K <= 256, the shapes a3d_conv1x1_streams accepts) through
 # a3d_conv1x1_bn_fwd, with BatchNorm-apply of the producer and the statistics of the consumer folded into the GEMM; the deep,
 # compute-bound layers stay on MIOpen (profiles/r04_conv1x1_layers.json).  A3D_FUSED_CONV1X1=0: MIOpen everywhere (A/B).

@@ -395,6 +395,67 @@ def rope_merge(dR, nsplit, xyz, freq, scale, out_ptr, ldy, B, N, Npad, E, H):
 
 
 # ------------------------------------------------------------------------------------------------ fused blocks
+# One gradient buffer for a tensor that several kernels consume (Act3D's context tokens of a level: two ghost-attention layers and
+# two query-stream layers): each consumer's backward kernel writes (first) or accumulates (+=) into the same buffer and returns None
+# to autograd, the LAST registered consumer returns the total -- instead of four (B, S, E) tensors that autograd sums with three
+# 63 MB torch adds per level (9 of the step's 30 at::add launches, 0.3 ms).  Consumers may run on different streams (the query
+# stream's side stream): an event chain orders the writers.  A3D_CTX_SINK=0: every consumer returns its own tensor (A/B).
+CTX_GRAD_SINK = os.environ.get("A3D_CTX_SINK", "1") not in ("0", "", "off")
+
+
+class GradSink:
+    live = []                                     # the sinks of the last forward pass (for the partial-drain check)
+
+    def __init__(self, shape, device):
+        self.shape, self.device = tuple(shape), device
+        self.buf, self.event = None, None
+        self.pending, self.total = 0, 0
+
+    def register(self):
+        self.pending += 1
+        self.total += 1
+
+    def begin(self):
+        """-> (buffer, accumulate): this writer runs after the previous one, whatever stream that was on"""
+        cur = torch.cuda.current_stream(self.device)
+        if self.event is not None:
+            cur.wait_event(self.event)
+        acc = self.buf is not None
+        if not acc:
+            self.buf = torch.empty(self.shape, device=self.device, dtype=F32)
+        return self.buf, acc
+
+    def end(self):
+        """-> the summed gradient if this was the last registered consumer, else None"""
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(self.device))
+        self.pending -= 1
+        if self.pending > 0:
+            return None
+        out, self.buf, self.event, self.total = self.buf, None, None, 0
+        return out
+
+
+def begin_grad_sinks():
+    """Called once per forward pass of the owning model: a sink of the previous pass that SOME but not all of its consumers wrote
+    means a backward pass in which a registered consumer received no gradient -- the total was never handed to autograd."""
+    for sk in GradSink.live:
+        if sk.buf is not None and 0 < sk.pending:
+            raise RuntimeError("GradSink: %d of %d consumers of a context tensor never ran their backward; its gradient was dropped "
+                               "(set A3D_CTX_SINK=0)" % (sk.pending, sk.total))
+    GradSink.live = []
+
+
+def new_grad_sink(t):
+    """Attach a GradSink to the (B, S, E) fp32 tensor t (as t._a3d_sink) when its gradient is needed; the consumers pick it up."""
+    if not (CTX_GRAD_SINK and t.is_cuda and t.requires_grad and t.dtype == F32 and torch.is_grad_enabled()):
+        return None
+    sk = GradSink(t.shape, t.device)
+    GradSink.live.append(sk)
+    t._a3d_sink = sk
+    return sk
+
+
 class AttnBlockFn(torch.autograd.Function):
     """y = LayerNorm(resid + out_proj(MHA(q_in, k_in, v_in)))  with RoPE-3D on q/k from xyz.
 
@@ -406,7 +467,7 @@ class AttnBlockFn(torch.autograd.Function):
     """
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode,
-                drop=None, site=0, grad_mode=True):
+                drop=None, site=0, grad_mode=True, sink=None):
         """drop / site: DropCtx of the pass and this block's site id (attention weights: site, residual branch: site + 1;
         multihead_custom_attention.py:413, layers.py:146,181).  grad_mode: torch.is_grad_enabled() of the CALLER (grad mode is
         always off inside Function.forward, so it has to be handed in; attn_block does)."""
@@ -471,6 +532,11 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.extra = extra
         ctx.drop, ctx.site = drop, site
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
+        # the context's gradient goes into its shared buffer (packed k,v projection of ONE input only: a single dgrad GEMM)
+        ctx.sink = sink if (sink is not None and need_bwd and mode == "kv" and ctx.needs_input_grad[1] and
+                            tuple(k_in.shape) == sink.shape) else None
+        if ctx.sink is not None:
+            ctx.sink.register()
         return y.view(B, Lq, E)
 
     @staticmethod
@@ -528,7 +594,12 @@ class AttnBlockFn(torch.autograd.Function):
                 rope_merge(dV, 1, None, freq, 1.0, dkv.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
                 wgrad_raw(dkv.data_ptr(), 2 * E, k_in.data_ptr(), E, gW.data_ptr() + E * E * f4, E,
                        gb.data_ptr() + E * f4, B * S, 2 * E, E, dev, st)
-                if need_k or need_v:
+                if ctx.sink is not None:
+                    buf, acc = ctx.sink.begin()
+                    linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E, dev,
+                               act=3 if acc else 0, transposed=True, out=buf.view(B * S, E))
+                    d_k_in = ctx.sink.end()                  # the total from the last consumer, None from the others
+                elif need_k or need_v:
                     d_k_in = linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E,
                                         dev, transposed=True).view(B, S, E)
             else:
@@ -545,7 +616,7 @@ class AttnBlockFn(torch.autograd.Function):
                 if need_v:
                     d_v_in = dgrad2d(dv_pre, in_w[2 * E:]).view(B, S, E)
         d_resid = dS.view(B, Lq, E) if ctx.needs_input_grad[3] else None
-        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 14
+        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 15
 
 
 SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
@@ -633,7 +704,7 @@ class QueryLayerFn(torch.autograd.Function):
     Same arithmetic as SingleQueryAttnBlockFn followed by MLPFn (exact-f32 MFMA products; summation order differs)."""
 
     @staticmethod
-    def forward(ctx, x, kv_in, q_xyz, k_xyz, in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, H):
+    def forward(ctx, x, kv_in, q_xyz, k_xyz, in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2, H, sink=None):
         L.require_gpu(x, kv_in)
         x, kv_in = _c(x), _c(kv_in)
         B, _, E = x.shape
@@ -665,6 +736,9 @@ class QueryLayerFn(torch.autograd.Function):
                               k_xyz if k_xyz is not None else torch.empty(0, device=dev))
         ctx.params = (in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2)
         ctx.meta = (B, S, E, H, scale, nsplit, q_xyz is not None)
+        ctx.sink = sink if (sink is not None and ctx.needs_input_grad[1] and tuple(kv_in.shape) == sink.shape) else None
+        if ctx.sink is not None:
+            ctx.sink.register()
         return y
 
     @staticmethod
@@ -698,14 +772,18 @@ class QueryLayerFn(torch.autograd.Function):
         dx = torch.empty((B, 1, E), device=dev, dtype=F32)
         L.call("a3d_qs_post_bwd", _c(dy).data_ptr(), x.data_ptr(), xbar.data_ptr(), save.data_ptr(), C_byref(qp), C_byref(gr),
                ws.data_ptr(), ws.data_ptr() + B * H * E * f4, dx.data_ptr(), B, E, H, st)
-        dX = torch.empty((B, S, E), device=dev, dtype=F32)
         dqp = torch.empty((nsplit, B, H, 1, 16), device=dev, dtype=F32)
-        L.call("a3d_sq_attn_bwd", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, None, E, qrot.data_ptr(),
-               freq.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, ws.data_ptr(), dX.data_ptr(), dqp.data_ptr(),
-               gW.data_ptr() + E * E * f4, E, gb.data_ptr() + E * f4, None, E, None, B, S, E, H, nsplit, st)
+        if ctx.sink is not None:
+            dXb, acc = ctx.sink.begin()                      # the context's shared gradient buffer: written or summed into
+        else:
+            dXb, acc = torch.empty((B, S, E), device=dev, dtype=F32), False
+        L.call("a3d_sq_attn_bwd_acc", kv_in.data_ptr(), nz(k_xyz), wp + E * E * f4, E, bp + E * f4, None, E, qrot.data_ptr(),
+               freq.data_ptr(), xbar.data_ptr(), lse.data_ptr(), None, ws.data_ptr(), dXb.data_ptr(), dqp.data_ptr(),
+               gW.data_ptr() + E * E * f4, E, gb.data_ptr() + E * f4, None, E, None, B, S, E, H, nsplit, 1 if acc else 0, st)
+        dX = ctx.sink.end() if ctx.sink is not None else dXb
         L.call("a3d_qs_pre_bwd", dqp.data_ptr(), nsplit, nz(q_xyz), freq.data_ptr(), scale, x.data_ptr(), wp, gW.data_ptr(), gb.data_ptr(),
                dx.data_ptr(), B, E, H, st)
-        return (dx if ctx.needs_input_grad[0] else None, dX if ctx.needs_input_grad[1] else None) + (None,) * 15
+        return (dx if ctx.needs_input_grad[0] else None, dX if ctx.needs_input_grad[1] else None) + (None,) * 16
 
 
 def C_byref(struct):
@@ -718,7 +796,7 @@ def query_layer_applicable(query, value, E, H, hidden):
             H * 15 == E and hidden == E and value.dtype == F32 and query.dtype == F32)
 
 
-def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=None, site=0):
+def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=None, site=0, sink=None):
     """mha: module with in_proj_weight/in_proj_bias/out_proj; norm: LayerNorm-like with weight/bias.
 
     The projection path is chosen structurally (which inputs are the same tensor), replacing the reference's
@@ -736,7 +814,7 @@ def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=
         mode = "none"
     return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
                              mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site,
-                             torch.is_grad_enabled())
+                             torch.is_grad_enabled(), sink)
 
 
 class MLPFn(torch.autograd.Function):

@@ -37,7 +37,8 @@ const char* a3d_last_error_string(void);
 
 /* ---- dense layers ------------------------------------------------------------------------------------ */
 /* Y[m,n] = act(sum_k X[m,k] * W(n,k) + bias[n]);  W(n,k) = W[n*ldw+k], or W[k*ldw+n] if w_transposed (dgrad).
- * act: 0 none, 1 relu, 2 multiply by (mask[m*ldm+n] > 0) (ReLU backward fused into dgrad).
+ * act: 0 none, 1 relu, 2 multiply by (mask[m*ldm+n] > 0) (ReLU backward fused into dgrad), 3 Y += result (a gradient summed in place:
+ * the tensor's consumers accumulate into one buffer instead of autograd adding their outputs).
  * Replaces F.linear at multihead_custom_attention.py:246-303,447; layers.py:88-94,313-332; diffusion_head.py:41-49. */
 int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                    const float* mask, int ldm, int M, int N, int K, int act, int w_transposed, void* stream);
@@ -180,6 +181,11 @@ int a3d_sq_attn_bwd(const float* X, const float* xyz, const float* Wk, int ldw, 
                     const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
                     float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv, int lddwv, float* dbv, int B, int S,
                     int E, int H, int nsplit, void* stream);
+/* the same with dX += instead of dX = when accumulate_dX != 0 (the context's gradient summed in place by its consumers) */
+int a3d_sq_attn_bwd_acc(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* Wv, int ldwv,
+                        const float* qrot, const float* freq, const float* xbar, const float* lse, const float* dO, float* ws,
+                        float* dX, float* dqp, float* dWk, int lddwk, float* dbk, float* dWv, int lddwv, float* dbv, int B, int S,
+                        int E, int H, int nsplit, int accumulate_dX, void* stream);
 /* dW[n][k] += sum_z partial[z][n][k], db[n] += sum_z partial[z][n][E] for partial [nsplit][E][E + 1] (fixed order) */
 int a3d_sq_wgrad_reduce(const float* partial, int nsplit, float* dW, int lddw, float* db, int E, void* stream);
 
@@ -377,6 +383,9 @@ int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* tra
                 float* traj_out, int B, int L, int E, int t_step, void* stream);
 /* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dbg_dn_prof(long long* out18);
+/* development aid: arm / disarm the phase timestamps (100 MHz ticks) of workgroup (0, 0) of a3d_sq_attn_bwd's key pass and read the
+ * 12 values of the last armed launch (host buffer; NULL = only arm) */
+int a3d_dbg_sq_prof(int on, long long* out12);
 /* out[b][h][n][16] fp32 = rope3d(Y[b, n, :E] * scale, xyz) split into heads (column 15 and rows >= N zero): the K cache */
 int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B, int N,
                       int Npad, int E, int H, void* stream);
@@ -390,9 +399,10 @@ int a3d_bn_stats(const void* x, float* partial /* [nslab][2][C] */, size_t rows,
 int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int C, float eps, float momentum, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, float* scale, float* shift, int train,
                     void* stream);
-/* y = relu?(x * scale[c] + shift[c] (+ residual)) */
-int a3d_bn_apply(const void* x, const void* residual, const float* scale, const float* shift, void* y, size_t rows, int C,
-                 int relu, void* stream);
+/* y = relu?(x * scale[c] + shift[c] (+ residual)); res_scale / res_shift (or NULL): the residual is a raw convolution output with
+ * its own BatchNorm (the bottleneck's downsample branch, clip.py:28-43) and enters as residual * res_scale[c] + res_shift[c] */
+int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,
+                 const float* shift, void* y, size_t rows, int C, int relu, void* stream);
 /* Same, followed by the nn.AvgPool2d(2) that the CLIP bottleneck / stem applies to the activation (model/utils/clip.py
  * Bottleneck.avgpool, downsample[0], ModifiedResNet.avgpool): y_pool [N][H/2][W/2][C] = mean of the 2x2 bf16 activations;
  * y_full [N][H][W][C] is also written unless NULL.  scale == NULL: identity (plain average pool of x).  H, W even. */

@@ -58,7 +58,7 @@ for cin, cout, hw, count, pos in SHAPES:
 
     def unfused():
         if pos == "conv3":        # bn2 apply + relu of the 3x3 output, then the convolution, then the statistics of its output
-            L.call("a3d_bn_apply", x.data_ptr(), None, sc[0].data_ptr(), sc[1].data_ptr(), xn.data_ptr(), M, cin, 1, st)
+            L.call("a3d_bn_apply", x.data_ptr(), None, None, None, sc[0].data_ptr(), sc[1].data_ptr(), xn.data_ptr(), M, cin, 1, st)
             o = F.conv2d(xn, w)
         else:
             o = F.conv2d(x, w)

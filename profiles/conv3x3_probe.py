@@ -44,7 +44,7 @@ for (cin, cout, hw) in [(32, 32, 128), (32, 64, 128), (64, 64, 64)]:
 
         def unfused():
             y = torch.empty_like(x)
-            a3d.lib.call("a3d_bn_apply", x.data_ptr(), None, scale[0].data_ptr(), scale[1].data_ptr(), y.data_ptr(), N * hw * hw, cin, 1,
+            a3d.lib.call("a3d_bn_apply", x.data_ptr(), None, None, None, scale[0].data_ptr(), scale[1].data_ptr(), y.data_ptr(), N * hw * hw, cin, 1,
                          a3d.lib.stream())
             c = F.conv2d(y, conv.weight, None, 1, 1)
             nslab = a3d.lib.load().a3d_bn_nslab(N * hw * hw, cout)

@@ -345,6 +345,50 @@ def test_bf16_token_maps_gathered_in_place_equal_the_fp32_copy(a3d, dev):
         assert same > 0.9999, same                                 # same sparsity: only gathered rows receive a gradient
 
 
+def test_context_gradient_sink_equals_autograd_sum(a3d, dev):
+    """ops.GradSink: the four consumers of a level's context tokens (two ghost-attention layers, two query-stream layers) sum its
+    gradient in ONE buffer inside their kernels (first writes, the others += , the last hands the total to autograd) instead of
+    returning four tensors for autograd to add.  Same model, same inputs, A3D_CTX_SINK on / off: every parameter gradient and the
+    token-map gradients agree to fp32 re-association noise, and a second pass gives the same result (the sinks drain)."""
+    r, cfg, names = _act3d_case("train_L3_C1_N64")
+    P = act3d_params(cfg, r["seed"], r["gain"], names)
+    inp, _, _ = _golden_inputs(r, cfg, dev)
+    crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    sample = {"action": inp["action"].to(dev), "task": ["t"] * cfg["B"]}
+    keep = a3d.ops.CTX_GRAD_SINK
+    res = {}
+    try:
+        for tag, flag in (("sink", True), ("plain", False), ("sink2", True)):
+            a3d.ops.CTX_GRAD_SINK = flag
+            m = build_model(a3d, dev, cfg, P, cfg["Ng"], True)
+            maps = [f.to(dev).float().requires_grad_() for f in inp["feats"][:2]]
+            toks = [C.tokens_from_maps(f) for f in maps]
+            feats = [toks[0]] + [toks[1]] * (cfg["levels"] - 1)
+            out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
+                    ghost_points=[g.to(dev) for g in r["ghost"]], visual_features=feats)
+            loss = sum(crit.compute_loss(out, sample).values())
+            loss.backward()
+            if flag:
+                assert all(sk.buf is None and sk.pending == 0 for sk in a3d.ops.GradSink.live) and len(a3d.ops.GradSink.live) == cfg["levels"]
+            res[tag] = (loss.detach(), [f.grad.clone() for f in maps], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        a3d.ops.CTX_GRAD_SINK = keep
+    ls, ms, gs = res["sink"]
+    lp, mp_, gp = res["plain"]
+    assert torch.equal(ls, lp) and set(gs) == set(gp)
+    gmax = max(g_.abs().max().item() for g_ in gp.values())
+    worst = 0.0
+    for n in gp:
+        err = (gs[n] - gp[n]).abs().max().item()
+        worst = max(worst, err / max(1e-3 * gmax, gp[n].abs().max().item()))
+        assert err <= 1e-5 * max(1e-3 * gmax, gp[n].abs().max().item()), n
+    for a, b in zip(ms, mp_):
+        assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-12)
+    print(f"[parity] context gradient sink vs autograd sum: worst relative parameter-gradient difference {worst:.3e}")
+    for n in gs:                                   # the second pass with sinks reproduces the first
+        assert (res["sink2"][2][n] - gs[n]).abs().max().item() <= 1e-5 * max(1e-3 * gmax, gs[n].abs().max().item()), n
+
+
 def test_hot_path_forward_is_run_to_run_deterministic(a3d, dev):
     """Same visual tokens + same sampler state -> bit-identical free-running forward (ghost points, k-NN sets, mask logits,
     argmax cascade, action): no forward kernel depends on atomics or launch timing.  (The convolutions in front of the hot

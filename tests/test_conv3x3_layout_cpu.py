@@ -13,8 +13,8 @@ import torch.nn.functional as F
 HW_, HP = 34, 340                      # halo tile: 10 rows of 34 pixels
 
 
-def woff(row, seg):                   # c3_woff
-    return row * 32 + ((seg ^ ((row >> 1) & 3)) << 3)
+def woff(row, seg):                   # c3_woff (conv1x1.hip's c1_woff is the same function)
+    return row * 32 + ((seg ^ (((row >> 1) & 1) | (((row >> 4) & 1) << 1))) << 3)
 
 
 def xoff(hp, hx, seg):                # c3_xoff
@@ -195,18 +195,22 @@ def test_pixel_fragment_reads_are_bank_conflict_free_from_any_base():
     assert b128_cycles(lambda l: 64 * (5 + (l & 15)) + 16 * (l >> 4)) == 8
 
 
-def test_weight_fragment_reads_known_two_way_conflict_and_its_fix():
-    """Weight fragments read the PERMUTED rows (i >> 2) 4 NT + tn 4 + (i & 3) of a tile: with the shipped row swizzle
-    ((row >> 1) & 3) every such read is 2-way conflicted (8 LDS cycles instead of 4; NT of the 4 + NT fragment reads per tap --
-    the LDS array is ~20 % busy in this kernel, so this costs little; found by this enumeration after the last GPU run of round 4).
-    Keying the swizzle on row bits 1 and 4 makes them conflict-free for both tile counts: the change DESIGN.md section 8 lists."""
-    def cycles(swz, NT, tn):
+def test_weight_fragment_reads_are_bank_conflict_free():
+    """Weight fragments read the PERMUTED rows (i >> 2) 4 NT + tn 4 + (i & 3) of a tile (conv3x3.hip, NT = 2 / 4) or
+    (i >> 2) 16 + tn 4 + (i & 3) of a 64-row wave block (conv1x1.hip): conflict-free with the swizzle keyed on row bits 1 and 4;
+    the round-4 keyings ((row >> 1) & 3 / plane_off) were 2-way conflicted for this row order."""
+    def cycles(swz, rows_of_lane):
         def addr(l):
-            row = ((l & 15) >> 2) * (4 * NT) + tn * 4 + (l & 3)
+            row = rows_of_lane(l)
             return 2 * (row * 32 + (((l >> 4) ^ swz(row)) << 3))
         return b128_cycles(addr)
+    new = lambda r: ((r >> 1) & 1) | (((r >> 4) & 1) << 1)
     for NT in (2, 4):
         for tn in range(NT):
-            assert b128_cycles(lambda l: 2 * woff(((l & 15) >> 2) * (4 * NT) + tn * 4 + (l & 3), l >> 4)) == 8
-            assert cycles(lambda r: (r >> 1) & 3, NT, tn) == 8
-            assert cycles(lambda r: ((r >> 1) & 1) | (((r >> 4) & 1) << 1), NT, tn) == 4
+            rows = lambda l, NT=NT, tn=tn: ((l & 15) >> 2) * (4 * NT) + tn * 4 + (l & 3)
+            assert b128_cycles(lambda l: 2 * woff(rows(l), l >> 4)) == 4
+            assert cycles(new, rows) == 4 and cycles(lambda r: (r >> 1) & 3, rows) == 8
+    for wn in range(4):
+        for tn in range(4):
+            rows = lambda l, wn=wn, tn=tn: wn * 64 + ((l & 15) >> 2) * 16 + tn * 4 + (l & 3)
+            assert cycles(new, rows) == 4 and cycles(lambda r: (0 - (r >> 2)) & 3, rows) == 8

@@ -51,7 +51,8 @@ def test_c_abi_argument_validation_without_gpu():
     rc = lib.a3d_rope_split(dummy, 60, None, None, 1.0, dummy, 24, None, 1, 10, 64, 60, 4, None)      # rows width 24
     assert rc == -22 and b"rows_width" in lib.a3d_last_error_string()
     assert lib.a3d_bn_stats(dummy, dummy, 1024, 24, 4, None) == -22                                   # C/8 must divide 256
-    assert lib.a3d_bn_apply(dummy, None, dummy, dummy, dummy, 1024, 60, 1, None) == -22               # C % 8
+    assert lib.a3d_bn_apply(dummy, None, None, None, dummy, dummy, dummy, 1024, 60, 1, None) == -22   # C % 8
+    assert lib.a3d_bn_apply(dummy, None, dummy, dummy, dummy, dummy, dummy, 1024, 64, 1, None) == -22  # residual BatchNorm without a residual
     assert lib.a3d_bn_apply_pool2(dummy, None, None, None, None, dummy, 1, 7, 8, 64, 1, None) == -22  # odd H
     assert lib.a3d_upsample2_add_fwd(dummy, dummy, None, 0, dummy, 1, 8, 8, 62, None) == -22                   # C % 4
     assert lib.a3d_upsample2_add_bwd(dummy, dummy, None, 0, None, 1, 8, 9, 60, None) == -22                          # odd W

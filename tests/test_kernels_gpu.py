@@ -660,6 +660,20 @@ def test_fused_batchnorm_train_relu_residual(a3d, dev, N, C, H):
     assert torch.equal(yp2, yp)
     report("plain pool2", a3d.nn.bn_act(xd, None, relu=False, pool=True, keep_full=False)[1].float(),
            F.avg_pool2d(x.float(), 2), 1e-6, 8e-3)
+    # the residual as a raw convolution output with its own BatchNorm (the downsample branch folded into the final apply):
+    # relu(bn(x) + bn_r(res)) without materialising bn_r(res)
+    bn_r = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_r.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn_r.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    ref_r = torch.nn.BatchNorm2d(C)
+    ref_r.load_state_dict(bn_r.state_dict())
+    bnd.train(); ref_bn.train()
+    ref2 = torch.relu(ref_bn(x.float()) + ref_r(res.float()))
+    bn_rd = bn_r.to(dev).train()
+    y3 = a3d.nn.bn_act(xd, bnd, relu=True, residual=rd, residual_scale=a3d.nn.bn_scale_shift(rd, bn_rd))
+    report("bn_act with a normalised residual", y3.float(), ref2, 2e-2, 8e-3)
+    report("residual bn running_var", bn_rd.running_var, ref_r.running_var, 1e-5, 1e-4)
 
 
 def test_fused_frozen_backbone_matches_module(a3d, dev):
