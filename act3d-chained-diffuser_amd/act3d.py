@@ -168,11 +168,11 @@ class Act3D(nn.Module):
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):
                 # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row.
-                # The 3x3 output convolutions run bias-free: their bias rides on the token tensor (`row_bias`) and is added
+                # The 3x3 output convolutions run bias-free: their bias travels with the tokens (ops.TokenMap.row_bias) and is added
                 # to the rows a level gathers
                 E_ = self.curr_gripper_embed.weight.shape[1]
                 pyr, out_bias = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64,
-                                                     defer_output_bias=x.is_cuda)
+                                                     defer_output_bias=bool(x.is_cuda))
         else:
             pyr = self.feature_pyramid(feats, needed=self._needed_maps())
         tokens = {}
@@ -180,8 +180,7 @@ class Act3D(nn.Module):
             n, E, h, w = fm.shape                    # E: the map's channel count incl. padding (bf16 path)
             # (cam, h, w, E) rows of the channels-last map: a view, in the FPN's own dtype -- a bf16 map is gathered in place
             # by a3d_build_context_bf16 (no fp32 copy of the 128 x 128 map, of which a level reads 6 % of the rows)
-            tokens[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
-            tokens[name].row_bias = out_bias.get(name)
+            tokens[name] = O.TokenMap(fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E), out_bias.get(name))
         return [tokens[self.feature_map_pyramid[i]] for i in range(self.num_sampling_level)]
 
     # ------------------------------------------------------------------------------------------------ ghost points
@@ -233,7 +232,9 @@ class Act3D(nn.Module):
         gt_position = gt_action[:, :3].detach().float() if gt_action is not None else None
         grip_xyz = curr_gripper[:, :3].float().contiguous()
 
-        feats = visual_features if visual_features is not None else self.compute_visual_tokens(visible_rgb)
+        # plain tensors (complete feature rows) or ops.TokenMap pairs (tokens + the FPN output bias owed to gathered rows)
+        feats = [O.TokenMap.of(f) for f in (visual_features if visual_features is not None
+                                            else self.compute_visual_tokens(visible_rgb))]
         pcd_by_factor = {}
         pcd_pyramid = []
         for i in range(L):
@@ -255,7 +256,7 @@ class Act3D(nn.Module):
         O.begin_grad_sinks()
         accum = {}                                       # one gradient buffer per distinct token map (levels >= 1 share one)
         for f_ in feats:
-            accum.setdefault(id(f_), O.GradAccum())
+            accum.setdefault(id(f_.tokens), O.GradAccum())
         position_pyramid, ghost_pcd_pyramid, ghost_pcd_masks_pyramid, topk_pyramid = [], [], [], []
         ghost_features_pyramid = []
         query, prev_pos = None, None
@@ -270,7 +271,7 @@ class Act3D(nn.Module):
                 idx = None
             else:
                 idx = O.knn_topk(prev_pos, pcd_pyramid[i], 32 * 32 * ncam)
-            ctx = O.BuildContextFn.apply(feats[i], idx, grip_tok, accum[id(feats[i])], getattr(feats[i], "row_bias", None))
+            ctx = O.BuildContextFn.apply(feats[i].tokens, idx, grip_tok, accum[id(feats[i].tokens)], feats[i].row_bias)
             ctx_xyz = O.gather_rows(pcd_pyramid[i], idx, grip_xyz[:, None])
             topk_pyramid.append(idx)
             if self.use_instruction:
@@ -334,7 +335,10 @@ class Act3D(nn.Module):
             "ghost_pcd_masks_pyramid": ghost_pcd_masks_pyramid,
             "ghost_pcd_pyramid": ghost_pcd_pyramid,
             "fine_ghost_pcd_offsets": None if offsets is None else offsets.transpose(1, 2),
-            "visible_rgb_features_pyramid": feats,
+            # token-major (B, ncam*h*w, E) tensors.  On the bf16 FPN path the output convolution's bias is owed to the
+            # gathered rows only, so the entry is the ops.TokenMap pair: .with_bias() materialises the reference's map
+            # (act3d.py:352) on demand instead of a 63 MB pass per step nobody reads
+            "visible_rgb_features_pyramid": [f.tokens if f.row_bias is None else f for f in feats],
             "visible_pcd_pyramid": pcd_pyramid,
             "query_features": query.transpose(0, 1),            # (1, B, E) as the reference returns it
             "instruction_features": None if instr is None else instr.transpose(0, 1),

@@ -233,6 +233,9 @@ __global__ __launch_bounds__(TK_THREADS) void knn_dist_hist_kernel(const float* 
     unsigned int v = 0;
     if (ok) {
       v = __float_as_uint(nn_dist(qp, npos, squared, pts + (size_t)n * 3));
+      // a distance is >= +0 unless a NaN / inf point put a sign-bit NaN here: canonicalise so that v >> KN_SHIFT stays
+      // below KN_BINS (LDS histogram bound) and such points sort last
+      if (v & 0x80000000u) v = 0x7FC00000u;
       ws_dist[(size_t)b * N + n] = v;
     }
     hist_add_wave(hist, v >> KN_SHIFT, ok, lane);

@@ -368,11 +368,11 @@ __global__ __launch_bounds__(256) void upsample2_add_bwd_kernel(const uint2* __r
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = cs[j];
     __syncthreads();
-    if ((int)threadIdx.x < 4 * C4) {
-      const int c = threadIdx.x >> 2, j = threadIdx.x & 3;
+    for (int o = threadIdx.x; o < 4 * C4; o += 256) {          // C4 up to 256 (C = 1024): more outputs than threads
+      const int c = o >> 2, j = o & 3;
       float a = 0.f;
       for (int u = c; u < 256; u += C4) a += red[u * 4 + j];
-      bias_partial[(size_t)blockIdx.x * 4 * C4 + threadIdx.x] = a;
+      bias_partial[(size_t)blockIdx.x * 4 * C4 + o] = a;
     }
   }
 }
@@ -406,11 +406,13 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
   }
 }
 
-// column sums of the fp32 rows a gather's backward sees: rows (b, s), s < k, of src [B][S][ld] -> partial [gridDim.x][C]
+// column sums of the fp32 rows a gather's backward sees: rows (b, s), s < k, of src [B][S][ld] -> partial [gridDim.x][C];
+// blockIdx.y walks 64-column blocks (any C)
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ src, int B, int S, int k, int ld, int C,
                                                           float* __restrict__ partial) {
   __shared__ float red[256];
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;           // C <= 64 columns x 4 row groups
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;           // 64 columns x 4 row groups
+  const int c = blockIdx.y * 64 + cl;
   const size_t total = (size_t)B * k;
   float a = 0.f;
   if (c < C) {
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
   }
   red[threadIdx.x] = a;
   __syncthreads();
-  if (threadIdx.x < C) partial[(size_t)blockIdx.x * C + threadIdx.x] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+  if (threadIdx.x < 64 && c < C)
+    partial[(size_t)blockIdx.x * C + c] = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
 }
 
 }  // namespace a3d
@@ -557,12 +560,12 @@ extern "C" size_t a3d_colsum_rows_ws_floats(int B, int k, int C) {
 }
 
 extern "C" int a3d_colsum_rows(const float* src, int B, int S, int k, int ld, int C, float* out, int nout, float* ws, void* stream) {
-  if (!src || !out || !ws || B <= 0 || S <= 0 || k <= 0 || k > S || C <= 0 || C > 64 || ld < C || nout <= 0 || nout > C) {
-    set_error("a3d_colsum_rows: bad argument (B=%d S=%d k=%d ld=%d C=%d nout=%d; C <= 64, k <= S)", B, S, k, ld, C, nout);
+  if (!src || !out || !ws || B <= 0 || S <= 0 || k <= 0 || k > S || C <= 0 || ld < C || nout <= 0 || nout > C) {
+    set_error("a3d_colsum_rows: bad argument (B=%d S=%d k=%d ld=%d C=%d nout=%d; k <= S, nout <= C <= ld)", B, S, k, ld, C, nout);
     return A3D_ERR_ARG;
   }
   const int nblk = (int)(a3d_colsum_rows_ws_floats(B, k, C) / C);
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, src, B, S, k, ld, C, ws);
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, src, B, S, k, ld, C, ws);
   int rc = check_launch("a3d_colsum_rows");
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, ws, nblk, C, out, nout);

@@ -618,7 +618,7 @@ class DiffusionPlanner(nn.Module):
         trace = []
         # fused per-step kernels (csrc/denoise.hip) whenever the trajectory fits one 16-row tile; else the op-by-op path
         fused = FUSED_DENOISE if fused is None else fused
-        fused = fused and Ln <= 16 and E <= 128 and Ln * D <= 160 and not multi      # a3d_dn_rest stages L * D trajectory values in a 160-float area
+        fused = fused and Ln <= 16 and E <= 128 and D <= 16 and Ln * D <= 160 and not multi      # a3d_dn_rest stages L * D trajectory values in a 160-float area
         if multi:
             # multi-round / multi-scale heads: the fine-scale context follows the previous prediction, so nothing but the
             # image encoding is step-invariant -- every step evaluates the full head (no K/V cache, no fused kernels)

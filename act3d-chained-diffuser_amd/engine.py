@@ -314,18 +314,19 @@ def _split_backward(tokens, run_hot, on_hot_done):
     """Backward in two stages around the FPN's output tokens: the hot path runs on detached leaves, its backward fills
     every hot-path parameter gradient and the token gradients; `on_hot_done()` (the early all-reduce) is called; then the
     token gradients are pushed through the FPN (MIOpen convolution backward).  Same gradients as one backward() call."""
+    from .ops import TokenMap
     uniq, leaves = {}, []
     for t in tokens:
-        if id(t) not in uniq:
-            leaf = t.detach().requires_grad_(t.requires_grad)
-            leaf.row_bias = getattr(t, "row_bias", None)      # deferred FPN output bias (Act3D.compute_visual_tokens)
-            uniq[id(t)] = (t, leaf)
-        leaves.append(uniq[id(t)][1])
+        tm = TokenMap.of(t)                  # tokens + the FPN output bias owed to gathered rows (Act3D.compute_visual_tokens)
+        if id(tm.tokens) not in uniq:
+            uniq[id(tm.tokens)] = (tm.tokens, tm.leaf())
+        leaf = uniq[id(tm.tokens)][1]
+        leaves.append(leaf if isinstance(t, TokenMap) else leaf.tokens)      # plain tensors in, plain leaves out
     loss = run_hot(leaves)
     loss.backward()
     if on_hot_done is not None:
         on_hot_done()
-    pairs = [(t, l.grad) for t, l in uniq.values() if t.requires_grad and l.grad is not None]
+    pairs = [(t, l.tokens.grad) for t, l in uniq.values() if t.requires_grad and l.tokens.grad is not None]
     if pairs:
         torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
     return loss.detach()

@@ -237,7 +237,7 @@ class FeaturePyramidNetwork(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, feats, needed=None, pad_to=None, defer_output_bias=False):
+    def forward(self, feats, needed=None, pad_to=None, defer_output_bias=None):
         """pad_to: run every convolution with its output (and, for the 3x3 layer blocks, input) channel count zero-padded
         to this width and return the padded maps (pad channels are exact zeros).  MIOpen's bf16 NHWC kernels for C = 60
         are ~2x slower than for C = 64 (measured on MI355X, N = 256 at 128 x 128: forward + backward 5.2 ms vs 2.6 ms);
@@ -245,8 +245,9 @@ class FeaturePyramidNetwork(nn.Module):
 
         Biases (bf16 CUDA maps): the lateral 1x1 convolutions run bias-free and their bias is added by the top-down kernel
         that reads the lateral map anyway (forward) / reduced by the kernel that reads its gradient anyway (backward).
-        defer_output_bias=True also runs the 3x3 output convolutions bias-free and returns (maps, {name: bias Parameter}):
-        the consumer adds the bias to the token rows it gathers (ops.BuildContextFn) -- a level reads 6 % of the fine map."""
+        defer_output_bias=True also runs the 3x3 output convolutions bias-free: the consumer adds the bias to the token rows
+        it gathers (ops.BuildContextFn) -- a level reads 6 % of the fine map.  Whenever the keyword is passed (True OR False)
+        the return value is the pair (maps, {name: bias Parameter owed}); without it, the plain dict of maps."""
         names = list(feats.keys())
         xs = list(feats.values())
         C = self.inner_blocks[0][0].out_channels
@@ -289,7 +290,7 @@ class FeaturePyramidNetwork(nn.Module):
             last = inner(i, xs[i], last)
             if needed is None or names[i] in needed:
                 out[names[i]] = layer(i, last)
-        return (out, out_bias) if defer_output_bias else out
+        return out if defer_output_bias is None else (out, out_bias)
 
 
 class _Bottleneck(nn.Module):

@@ -986,6 +986,35 @@ class GradAccum:
         self.buf, self.pending = None, 0
 
 
+class TokenMap:
+    """One level's visual tokens (B, ncam*h*w, ld) plus the bias that is still OWED to the rows a level gathers: the FPN's 3x3
+    output convolution runs bias-free on the bf16 path (nn.FeaturePyramidNetwork.forward(defer_output_bias=True)) and
+    BuildContextFn adds `row_bias` to the gathered rows.  An explicit pair instead of an attribute on the tensor: any tensor
+    op (.float(), .detach(), slicing, save / load) would silently drop an attribute and run the model on bias-free features."""
+    __slots__ = ("tokens", "row_bias")
+
+    def __init__(self, tokens, row_bias=None):
+        self.tokens, self.row_bias = tokens, row_bias
+
+    @staticmethod
+    def of(x):
+        return x if isinstance(x, TokenMap) else TokenMap(x, None)
+
+    def detach(self):
+        return TokenMap(self.tokens.detach(), self.row_bias)
+
+    def leaf(self):
+        """detached leaf of the tokens that records a gradient (engine._split_backward); the bias keeps its own graph"""
+        return TokenMap(self.tokens.detach().requires_grad_(self.tokens.requires_grad), self.row_bias)
+
+    def with_bias(self):
+        """the tokens with the owed bias added (what the reference's feature map holds, act3d.py:352), fp32"""
+        if self.row_bias is None:
+            return self.tokens
+        E = self.row_bias.numel()
+        return self.tokens[..., :E].float() + self.row_bias.float()
+
+
 class BuildContextFn(torch.autograd.Function):
     """ctx tokens = [feat[b][idx[b]] | extra[b]]  (act3d.py:247-260).  feat (B, Npts, E) fp32, or bf16 (the FPN's
     channels-last output read in place: no fp32 copy of the map, the gradient goes back as one bf16 map); extra (B, X, E)."""

@@ -81,7 +81,7 @@ def cpu_baseline(a3d, B_cpu, steps):
 
     def step():
         opt.zero_grad()
-        feats = m.compute_visual_tokens(batch["rgbs"])
+        feats = [f.with_bias() for f in m.compute_visual_tokens(batch["rgbs"])]
         pcds = [torch.from_numpy(OS.pcd_downsample(batch["pcds"].numpy(), 8 if i == 0 else 2)) for i in range(3)]
         P = m.state_dict(keep_vars=True)
         out = OA.act3d_forward(P, cfg, feats, pcds, batch["curr_gripper"], None, gt_action=batch["action"], num_ghost_points=333)
@@ -580,9 +580,7 @@ def main():
         try:
             with torch.no_grad():
                 toks = model.compute_visual_tokens(batch["rgbs"])
-                feats = [f.detach() for f in toks]
-                for f, t in zip(feats, toks):
-                    f.row_bias = getattr(t, "row_bias", None)      # deferred FPN output bias rides on the token tensor
+                feats = [f.detach() for f in toks]                 # ops.TokenMap pairs: the owed FPN output bias travels along
 
             def hot_only():
                 opt.zero_grad()

@@ -413,3 +413,40 @@ def test_hot_path_forward_is_run_to_run_deterministic(a3d, dev):
             if i > 0:
                 assert torch.equal(o["topk_indices_pyramid"][i], outs[0]["topk_indices_pyramid"][i])
         assert torch.equal(o["rotation"], outs[0]["rotation"]) and torch.equal(o["gripper"], outs[0]["gripper"])
+
+
+def test_bf16_fpn_deferred_output_bias_width_120(a3d, dev):
+    """E = 120 / 8 heads with the bf16 FPN: the 3x3 output convolutions run bias-free and the bias is owed to the gathered rows
+    (ops.TokenMap.row_bias); its gradient is a column sum over the gathered rows (a3d_colsum_rows, any width).  Same step with the
+    bias materialised on the map (TokenMap.with_bias(), autograd sums the rows): same loss, same bias gradients."""
+    torch.manual_seed(0)
+    B, ncam, E, levels = 2, 1, 120, 2
+    m = a3d.Act3D(embedding_dim=E, num_attn_heads=8, gripper_loc_bounds=C.PERACT_BOUNDS, num_ghost_points=64 * levels,
+                  num_ghost_points_val=64 * levels, num_sampling_level=levels, sampler_seed=7).to(dev).train()
+    m.backbone_dtype = m.fpn_dtype = torch.bfloat16
+    inp = C.keypose_inputs(17, B, ncam, E, levels)
+    rgb = torch.rand((B, ncam, 3, 256, 256), generator=torch.Generator().manual_seed(3)).to(dev)
+    crit = a3d.losses.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+    sample = {"action": inp["action"].to(dev), "task": ["t"] * B}
+    teacher = [inp["action"][:, :3].to(dev).contiguous()] * levels
+    biases = {n: p for n, p in m.named_parameters() if "feature_pyramid.layer_blocks" in n and n.endswith("bias")}
+    res = {}
+    for tag in ("deferred", "materialised"):
+        m.zero_grad(set_to_none=True)
+        m._rng_state.copy_(torch.tensor([7, 0]))
+        toks = m.compute_visual_tokens(rgb)
+        assert all(isinstance(t, a3d.ops.TokenMap) and t.row_bias is not None and t.tokens.dtype == torch.bfloat16 for t in toks)
+        feats = toks if tag == "deferred" else [t.with_bias() for t in toks]
+        out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
+                visual_features=feats, teacher_positions=teacher)
+        loss = sum(crit.compute_loss(out, sample).values())
+        loss.backward()
+        res[tag] = (loss.detach().clone(), {n: p.grad.clone() for n, p in biases.items() if p.grad is not None})
+    (la, ga), (lb, gb) = res["deferred"], res["materialised"]
+    assert abs(la.item() - lb.item()) <= 1e-5 * max(1.0, abs(lb.item())), (la.item(), lb.item())
+    used = [n for n in gb if gb[n].abs().max().item() > 0]
+    assert used and set(used) <= set(ga), (sorted(ga), sorted(gb))
+    for n in used:
+        err, sc = (ga[n] - gb[n]).abs().max().item(), gb[n].abs().max().item()
+        print(f"[parity] deferred FPN output bias gradient {n}: err {err:.3e} of scale {sc:.3e}")
+        assert torch.isfinite(ga[n]).all() and err <= 1e-3 * sc, (n, err, sc)
