@@ -278,7 +278,7 @@ class Act3D(nn.Module):
                 ctx = self.vis_ins_attn_pyramid[i](ctx, instr)[-1]
                 ctx = O.BuildContextFn.apply(ctx, None, instr)
                 ctx_xyz = torch.cat([ctx_xyz, instr_xyz], dim=1)
-            O.new_grad_sink(ctx)                     # the level's four consumers of ctx sum its gradient in ONE buffer
+            ctx = O.attach_grad_sink(ctx)            # the level's four consumers of ctx sum its gradient in ONE buffer
             # ---- query cross-attends to the context (no positions at level 0).  The query stream (one row per sample:
             # ~100 launch-latency-bound kernels per step, forward + backward) is independent of the ghost stream, so it is
             # issued on a side stream (fork / join on events -- capturable, and autograd replays the same streams backward)

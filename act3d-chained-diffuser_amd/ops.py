@@ -397,23 +397,23 @@ def rope_merge(dR, nsplit, xyz, freq, scale, out_ptr, ldy, B, N, Npad, E, H):
 # ------------------------------------------------------------------------------------------------ fused blocks
 # One gradient buffer for a tensor that several kernels consume (Act3D's context tokens of a level: two ghost-attention layers and
 # two query-stream layers): each consumer's backward kernel writes (first) or accumulates (+=) into the same buffer and returns None
-# to autograd, the LAST registered consumer returns the total -- instead of four (B, S, E) tensors that autograd sums with three
-# 63 MB torch adds per level (9 of the step's 30 at::add launches, 0.3 ms).  Consumers may run on different streams (the query
-# stream's side stream): an event chain orders the writers.  A3D_CTX_SINK=0: every consumer returns its own tensor (A/B).
+# to autograd -- instead of four (B, S, E) tensors that autograd sums with three 63 MB torch adds per level (9 of the step's 30
+# at::add launches, 0.3 ms).  The total is handed over by a GATE node between the tensor and its consumers (attach_grad_sink):
+# autograd runs the gate's backward when every consumer THAT TAKES PART in this backward pass has run -- its own dependency
+# count decides, so a pass in which some consumers receive no gradient (a loss on the action only: the ghost layers of a level get
+# none) still delivers the others' sum.  (Round 5's first version let "the last REGISTERED consumer" return the total and dropped
+# the gradient in exactly that case; found by the 6D-head golden test.)  Consumers may run on different streams (the query
+# stream's side stream): an event chain orders the writers and the gate.  A3D_CTX_SINK=0: every consumer returns its own tensor (A/B).
 CTX_GRAD_SINK = os.environ.get("A3D_CTX_SINK", "1") not in ("0", "", "off")
 
 
 class GradSink:
-    live = []                                     # the sinks of the last forward pass (for the partial-drain check)
+    live = []                                     # the sinks of the last forward pass (tests look at them)
 
     def __init__(self, shape, device):
         self.shape, self.device = tuple(shape), device
         self.buf, self.event = None, None
-        self.pending, self.total = 0, 0
-
-    def register(self):
-        self.pending += 1
-        self.total += 1
+        self.writers = 0                          # consumers that wrote during the current backward pass
 
     def begin(self):
         """-> (buffer, accumulate): this writer runs after the previous one, whatever stream that was on"""
@@ -423,37 +423,63 @@ class GradSink:
         acc = self.buf is not None
         if not acc:
             self.buf = torch.empty(self.shape, device=self.device, dtype=F32)
+        else:
+            self.buf.record_stream(cur)
         return self.buf, acc
 
     def end(self):
-        """-> the summed gradient if this was the last registered consumer, else None"""
+        """the writer's kernels are enqueued: later writers / the gate wait for them.  Always returns None (the consumer's
+        gradient for the shared tensor as far as autograd is concerned)."""
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(self.device))
-        self.pending -= 1
-        if self.pending > 0:
-            return None
-        out, self.buf, self.event, self.total = self.buf, None, None, 0
+        self.writers += 1
+        return None
+
+    def drain(self):
+        """gate backward: the total of this pass (None when no consumer wrote), ordered after the last writer"""
+        out = self.buf
+        if out is not None:
+            cur = torch.cuda.current_stream(self.device)
+            if self.event is not None:
+                cur.wait_event(self.event)
+            out.record_stream(cur)
+        self.buf, self.event, self.writers = None, None, 0
         return out
 
 
+class _SinkGateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, sink):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)          # all consumers return None: no zero tensor is made up for them
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        total = ctx.sink.drain()
+        if total is None:
+            return g, None
+        return (total if g is None else total + g), None
+
+
 def begin_grad_sinks():
-    """Called once per forward pass of the owning model: a sink of the previous pass that SOME but not all of its consumers wrote
-    means a backward pass in which a registered consumer received no gradient -- the total was never handed to autograd."""
+    """Called once per forward pass of the owning model: forgets the sinks of the previous pass (a buffer a backward pass left
+    behind -- e.g. an exception between a writer and the gate -- is dropped with them)."""
     for sk in GradSink.live:
-        if sk.buf is not None and 0 < sk.pending:
-            raise RuntimeError("GradSink: %d of %d consumers of a context tensor never ran their backward; its gradient was dropped "
-                               "(set A3D_CTX_SINK=0)" % (sk.pending, sk.total))
+        sk.buf, sk.event, sk.writers = None, None, 0
     GradSink.live = []
 
 
-def new_grad_sink(t):
-    """Attach a GradSink to the (B, S, E) fp32 tensor t (as t._a3d_sink) when its gradient is needed; the consumers pick it up."""
+def attach_grad_sink(t):
+    """-> the tensor the consumers of the (B, S, E) fp32 tensor t should read: t itself, or -- when its gradient is needed -- a
+    view of it behind a gate node that owns a GradSink (as ._a3d_sink); the consumers pick the sink up from there."""
     if not (CTX_GRAD_SINK and t.is_cuda and t.requires_grad and t.dtype == F32 and torch.is_grad_enabled()):
-        return None
+        return t
     sk = GradSink(t.shape, t.device)
     GradSink.live.append(sk)
-    t._a3d_sink = sk
-    return sk
+    out = _SinkGateFn.apply(t, sk)
+    out._a3d_sink = sk
+    return out
 
 
 class AttnBlockFn(torch.autograd.Function):
@@ -535,8 +561,6 @@ class AttnBlockFn(torch.autograd.Function):
         # the context's gradient goes into its shared buffer (packed k,v projection of ONE input only: a single dgrad GEMM)
         ctx.sink = sink if (sink is not None and need_bwd and mode == "kv" and ctx.needs_input_grad[1] and
                             tuple(k_in.shape) == sink.shape) else None
-        if ctx.sink is not None:
-            ctx.sink.register()
         return y.view(B, Lq, E)
 
     @staticmethod
@@ -598,7 +622,7 @@ class AttnBlockFn(torch.autograd.Function):
                     buf, acc = ctx.sink.begin()
                     linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E, dev,
                                act=3 if acc else 0, transposed=True, out=buf.view(B * S, E))
-                    d_k_in = ctx.sink.end()                  # the total from the last consumer, None from the others
+                    d_k_in = ctx.sink.end()                  # None: the sink's gate node hands the total to autograd
                 elif need_k or need_v:
                     d_k_in = linear_raw(dkv.data_ptr(), 2 * E, in_w.data_ptr() + E * E * f4, E, None, B * S, E, 2 * E,
                                         dev, transposed=True).view(B, S, E)
@@ -737,8 +761,6 @@ class QueryLayerFn(torch.autograd.Function):
         ctx.params = (in_w, in_b, out_w, out_b, g1, b1, w1, c1, w2, c2, g2, b2)
         ctx.meta = (B, S, E, H, scale, nsplit, q_xyz is not None)
         ctx.sink = sink if (sink is not None and ctx.needs_input_grad[1] and tuple(kv_in.shape) == sink.shape) else None
-        if ctx.sink is not None:
-            ctx.sink.register()
         return y
 
     @staticmethod

@@ -201,3 +201,22 @@ def write_synthetic_dataset(root):
         pickle.dump(synthetic_episode(12, 3), f)
     rs = np.random.RandomState(13)
     return {"task_a": {0: rs_tensor(rs, (3, 53, 512))}, "task_b": {0: rs_tensor(rs, (2, 53, 512))}}
+
+
+def assert_topk_equal_up_to_exact_ties(got, ref, pos, xyz, what=""):
+    """k-NN indices `got` vs the reference's `ref` (B, k): bit-exact, except that torch.topk leaves the order AMONG EXACTLY TIED
+    distances unspecified (act3d.py:244-245) while the oracle / the HIP kernel order ties by index.  Every differing position must
+    therefore hold two points whose fp32 distances sqrt((dx^2 + dy^2) + dz^2) to the centre are the SAME BITS (0 ulp apart), and the
+    two index SETS must be equal.  Returns the number of tied positions that differ."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    pos, xyz = np.asarray(pos, dtype=np.float32).reshape(-1, 3), np.asarray(xyz, dtype=np.float32)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(np.sort(got, -1), np.sort(ref, -1)), f"{what}: k-NN index sets differ"
+    mis = np.argwhere(got != ref)
+    for b, j in mis:
+        def dist_bits(ix):
+            d = xyz[b, ix] - pos[b]
+            return np.sqrt(np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])).astype(np.float32).view(np.int32)
+        a, c = dist_bits(got[b, j]), dist_bits(ref[b, j])
+        assert a == c, f"{what}: position ({b}, {j}) differs and the two distances are {abs(int(a) - int(c))} ulp apart (not a tie)"
+    return len(mis)

@@ -257,7 +257,7 @@ def golden_act3d():
         "train_L3_C1_N64": run_act3d_case("train_L3_C1_N64", 60, 3, 1, 64, False, 2, True),
         "eval_L3_C1_N128": run_act3d_case("eval_L3_C1_N128", 60, 3, 1, 64, False, 2, False),
         "train_L2_C2_N64_instr": run_act3d_case("train_L2_C2_N64_instr", 60, 2, 2, 64, True, 2, True),
-        "train_L4_C1_N32": run_act3d_case("train_L4_C1_N32", 60, 4, 1, 32, False, 1, True, min_gap=2e-3),
+        "train_L4_C1_N32": run_act3d_case("train_L4_C1_N32", 60, 4, 1, 32, False, 1, True),      # default min_gap = 1e-2 (seed 175)
     }
     save("act3d.pt", out)
     # G12: parameter manifest of the default configuration

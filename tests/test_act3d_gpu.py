@@ -29,9 +29,10 @@ def rel_close(name, got, ref, atol, rtol):
     assert (err <= atol + rtol * ref.abs()).all(), f"{name}: max err {err.max().item():.3e}"
 
 
-def scale_close(name, got, ref, tol=1e-3, floor=1.0):
-    """|got - ref| <= tol * max(1, max|ref|): 1e-3 absolute for O(1) tensors (north_star), relative to the tensor's
-    scale for the deliberately large-logit fixtures (gain-3 weights, logits up to ~25)."""
+def scale_close(name, got, ref, tol=5e-4, floor=1.0):
+    """|got - ref| <= tol * max(1, max|ref|): north_star's bar is 1e-3 absolute for O(1) tensors; the assert is HALF of it
+    (2x the worst value observed on MI355X, 2.0e-4 -- profiles/r04_parity_report.txt -- so a regression cannot hide in the
+    slack), relative to the tensor's scale for the deliberately large-logit fixtures (gain-3 weights, logits up to ~25)."""
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs().max().item()
     scale = max(floor, ref.abs().max().item())
@@ -40,7 +41,7 @@ def scale_close(name, got, ref, tol=1e-3, floor=1.0):
     assert err <= tol * scale, f"{name}: max err {err:.3e} > {tol} * {scale:.3e}"
 
 
-GRAD_TOL = 1.5e-3      # of the tensor's scale; observed <= 1.1e-3 on MI355X (DESIGN.md "parity status")
+GRAD_TOL = 1e-3        # of the tensor's scale; 2x the worst keypose gradient observed on MI355X (4.9e-4, query_embed.weight)
 
 
 def build_model(a3d, dev, cfg, P, Ng, train, bounds=C.PERACT_BOUNDS, **kw):
@@ -70,21 +71,24 @@ def _golden_inputs(r, cfg, dev):
     return inp, fmaps, feats
 
 
-def _check_golden_forward(tag, r, cfg, out):
+def _check_golden_forward(tag, r, cfg, out, pcd):
     for i in range(cfg["levels"]):
         if i > 0:
-            got, ref = out["topk_indices_pyramid"][i].cpu(), r["topk"][i]
-            assert torch.equal(got.sort(-1).values, ref.sort(-1).values), f"top-k set level {i}"
-            assert (got == ref).float().mean() > 0.995, f"top-k order level {i}"
+            # ghost-point context indices: bit-exact vs the reference, up to torch.topk's unspecified order among EXACTLY
+            # tied distances (every differing position is proven to be a 0-ulp tie; all goldens together hold 2 of them)
+            pcd_i = OS.pcd_downsample(pcd.cpu().numpy(), pcd_factor(cfg, i))
+            nt = C.assert_topk_equal_up_to_exact_ties(out["topk_indices_pyramid"][i].cpu().numpy(), r["topk"][i].numpy(),
+                                                      r["positions"][i - 1].numpy(), pcd_i, f"{tag} level {i}")
+            assert nt <= 4, f"{tag} level {i}: {nt} tied positions differ"
         for l in range(2):
             scale_close(f"{tag} mask L{i} layer{l}", out["ghost_pcd_masks_pyramid"][i][l], r["masks"][i][l])
         assert torch.equal(out["position_pyramid"][i][:, 0].cpu(), r["positions"][i]), f"argmax position level {i}"
     rel_close("rotation", out["rotation"], r["rotation"], 1e-3, 0)
     rel_close("gripper", out["gripper"], r["gripper"], 1e-3, 0)
-    scale_close("query", out["query_features"][0], r["query_features"], 1e-3)
+    scale_close("query", out["query_features"][0], r["query_features"])
     rel_close("position", out["position"], r["position"], 1e-3, 0)
     if "offsets" in r:                                  # regress_position_offset (act3d.py:323-327)
-        scale_close("offsets", out["fine_ghost_pcd_offsets"], r["offsets"], 1e-3)
+        scale_close("offsets", out["fine_ghost_pcd_offsets"], r["offsets"])
 
 
 def _check_golden_grads(r, cfg, m, fmaps):
@@ -125,7 +129,7 @@ def test_act3d_vs_reference_golden(a3d, dev, tag):
     out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev),
             gt_action=inp["action"].to(dev) if cfg["train"] else None,
             ghost_points=[g.to(dev) for g in r["ghost"]], visual_features=feats)
-    _check_golden_forward(tag, r, cfg, out)
+    _check_golden_forward(tag, r, cfg, out, inp["pcd"])
     if not cfg["train"]:
         return
     sample = {"action": inp["action"].to(dev), "task": ["t"] * cfg["B"]}
@@ -180,7 +184,7 @@ def test_act3d_free_running_numpy_sampler(a3d, dev, tag):
         assert not torch.equal(before, flat.flat), "the optimizer step did not move the parameters"
     for i in range(cfg["levels"]):
         assert torch.equal(out["ghost_pcd_pyramid"][i].transpose(1, 2).cpu(), r["ghost"][i]), f"ghost points level {i}"
-    _check_golden_forward(tag, r, cfg, out)
+    _check_golden_forward(tag, r, cfg, out, inp["pcd"])
     if cfg["train"]:
         _check_golden_grads(r, cfg, m, fmaps)           # flat.grad still holds this step's gradients
 
@@ -347,7 +351,7 @@ def test_bf16_token_maps_gathered_in_place_equal_the_fp32_copy(a3d, dev):
 
 def test_context_gradient_sink_equals_autograd_sum(a3d, dev):
     """ops.GradSink: the four consumers of a level's context tokens (two ghost-attention layers, two query-stream layers) sum its
-    gradient in ONE buffer inside their kernels (first writes, the others += , the last hands the total to autograd) instead of
+    gradient in ONE buffer inside their kernels (first writes, the others += , a gate node hands the total to autograd) instead of
     returning four tensors for autograd to add.  Same model, same inputs, A3D_CTX_SINK on / off: every parameter gradient and the
     token-map gradients agree to fp32 re-association noise, and a second pass gives the same result (the sinks drain)."""
     r, cfg, names = _act3d_case("train_L3_C1_N64")
@@ -369,7 +373,7 @@ def test_context_gradient_sink_equals_autograd_sum(a3d, dev):
             loss = sum(crit.compute_loss(out, sample).values())
             loss.backward()
             if flag:
-                assert all(sk.buf is None and sk.pending == 0 for sk in a3d.ops.GradSink.live) and len(a3d.ops.GradSink.live) == cfg["levels"]
+                assert all(sk.buf is None and sk.writers == 0 for sk in a3d.ops.GradSink.live) and len(a3d.ops.GradSink.live) == cfg["levels"]
             res[tag] = (loss.detach(), [f.grad.clone() for f in maps], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
     finally:
         a3d.ops.CTX_GRAD_SINK = keep

@@ -123,7 +123,7 @@ def test_cfg3_full_shape_graph_vs_oracle(a3d, dev):
         outs.append(m.compute_trajectory(d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
                                          init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=tokens.to(dev),
                                          use_graph=True).cpu())
-    assert torch.equal(outs[0], outs[1]), "graph replay differs from the captured run"
+    assert torch.equal(outs[0], outs[1]), "graph replay differs from the captured run (max abs diff %.3e)" % (outs[0] - outs[1]).abs().max().item()
     eager = m.compute_trajectory(d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"],
                                  init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=tokens.to(dev)).cpu()
     assert torch.allclose(outs[0], eager, atol=1e-5), "graph differs from the eager loop"
