@@ -466,7 +466,11 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
   }
   // the row-per-thread kernel serves the two models' widths when rows of dY can be written as float4 (dR is HDP = 16 floats per
   // record, 16-byte aligned by construction of the attention backward's partial buffers)
-  const bool rows_ok = ((E == 60 && H == 4) || (E == 120 && H == 8)) && (ldy & 3) == 0 && ((((uintptr_t)dY) | ((uintptr_t)dR)) & 15) == 0 &&
+  // Measured on MI355X (round 5, gpurun r05a): 31.9 us vs 27.1 us per call for E = 60 and 16.4 vs 9.1 us for E = 120 -- the
+  // row-per-thread kernel keeps EC floats per thread live and runs at a fraction of the pair-per-thread kernel's occupancy.
+  // Kept behind A3D_ROPE_MERGE_ROWS=1 for the record; the pair kernel is the default again.
+  static const bool rows_on = getenv("A3D_ROPE_MERGE_ROWS") && atoi(getenv("A3D_ROPE_MERGE_ROWS")) != 0;
+  const bool rows_ok = rows_on && ((E == 60 && H == 4) || (E == 120 && H == 8)) && (ldy & 3) == 0 && ((((uintptr_t)dY) | ((uintptr_t)dR)) & 15) == 0 &&
                        (Npad * HDP) % 4 == 0;
   if (rows_ok) {
     const dim3 grid(cdiv(N, 256), B);
