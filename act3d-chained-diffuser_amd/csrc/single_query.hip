@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256, 2) void sq_bwd_kernel(const float* __restrict_
   if (prof_on && threadIdx.x == 0) g_sq_prof[11] = t_end - t_beg;
 }
 
+// wave-local kernels of single_query_wave.hip (round 5): the default; they return false when switched off (A3D_SQ_WAVE=0)
+bool sqw_launch_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
+                    float* part, int B, int S, int E, int H, int nsplit, hipStream_t s);
+bool sqw_launch_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
+                    const float* lse, const float* dxbar, const float* cD, float* dX, float* wpart, float* dqp, int B, int S, int E,
+                    int H, int nsplit, int acc_dx, hipStream_t s);
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -537,7 +544,8 @@ extern "C" int a3d_sq_attn_fwd(const float* X, const float* xyz, const float* Wk
     (void)hipFuncSetAttribute((const void*)sq_fwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  if (E == 60 && H == 4)
+  if (sqw_launch_fwd(X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit, s)) {
+  } else if (E == 60 && H == 4)
     hipLaunchKernelGGL(sq_fwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
   else
     hipLaunchKernelGGL(sq_fwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, ws, B, S, E, H, nsplit);
@@ -582,7 +590,8 @@ static int sq_attn_bwd_impl(const float* X, const float* xyz, const float* Wk, i
     (void)hipFuncSetAttribute((const void*)sq_bwd_kernel<60>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     attr_set = true;
   }
-  if (E == 60 && H == 4)
+  if (sqw_launch_bwd(X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX, wpart, dqp, B, S, E, H, nsplit, acc_dx, s)) {
+  } else if (E == 60 && H == 4)
     hipLaunchKernelGGL(sq_bwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX,
                        wpart, dqp, B, S, E, H, nsplit, acc_dx);
   else

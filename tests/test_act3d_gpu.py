@@ -435,11 +435,13 @@ def test_bf16_fpn_deferred_output_bias_width_120(a3d, dev):
     teacher = [inp["action"][:, :3].to(dev).contiguous()] * levels
     biases = {n: p for n, p in m.named_parameters() if "feature_pyramid.layer_blocks" in n and n.endswith("bias")}
     res = {}
+    # ONE pass through the backbone / FPN (MIOpen may pick another convolution algorithm on a second call, and the untrained
+    # model turns 1e-2 bf16 feature noise into a visibly different loss); the two runs differ only in where the bias is added
+    toks = [t.detach() for t in m.compute_visual_tokens(rgb)]
+    assert all(isinstance(t, a3d.ops.TokenMap) and t.row_bias is not None and t.tokens.dtype == torch.bfloat16 for t in toks)
     for tag in ("deferred", "materialised"):
         m.zero_grad(set_to_none=True)
         m._rng_state.copy_(torch.tensor([7, 0]))
-        toks = m.compute_visual_tokens(rgb)
-        assert all(isinstance(t, a3d.ops.TokenMap) and t.row_bias is not None and t.tokens.dtype == torch.bfloat16 for t in toks)
         feats = toks if tag == "deferred" else [t.with_bias() for t in toks]
         out = m(None, inp["pcd"].to(dev), inp["instr"].to(dev), inp["curr_gripper"].to(dev), gt_action=inp["action"].to(dev),
                 visual_features=feats, teacher_positions=teacher)
