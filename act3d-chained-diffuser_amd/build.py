@@ -8,7 +8,11 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "obj")
-LIB_PATH = os.path.join(PKG_DIR, "libact3d_hip.so")
+# A3D_LIB_OUT=libact3d_hip_<tag>.so (with A3D_HIPCC_FLAGS): an A/B build next to the default library, objects in obj_<tag>/
+_OUT = os.path.basename(os.environ.get("A3D_LIB_OUT", "libact3d_hip.so"))
+LIB_PATH = os.path.join(PKG_DIR, _OUT)
+if _OUT != "libact3d_hip.so":
+    OBJ_DIR = os.path.join(CSRC, "obj_" + _OUT[len("libact3d_hip_"):-3])
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 SOURCES = ["api.hip", "linear.hip", "linear_split.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "attention16.hip", "attention8.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip", "denoise.hip", "single_query.hip", "single_query_wave.hip", "query_stream.hip", "data.hip", "conv1x1.hip", "conv3x3.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

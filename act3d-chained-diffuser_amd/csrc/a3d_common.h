@@ -123,7 +123,7 @@ __device__ __forceinline__ float rope_freq(int k, int E) {
 // k = rint(x * 2/pi), r = x - k * pi/2 by two FMAs against a two-part pi/2 (the first product is exact inside the fma, so
 // r carries one rounding: |error| < 4e-8), then the Cephes single-precision minimax polynomials on [-pi/4, pi/4] (1 ulp)
 // and a quadrant swap -- 22 instructions, both results within 2 ulp of the correctly rounded values (tests/test_host_cpu.py
-// checks the host mirror a3d_sincos_host against float64 over the range).  Larger arguments take sincosf.
+// checks the host mirror a3d_sincos_host against float64 over the range).  Larger arguments: see fast_sincos below.
 __host__ __device__ __forceinline__ void sincos_poly(float x, float* sn, float* cs) {
   const float kf = rintf(x * 0.636619772367581343f);
   float r = fmaf(-kf, 1.57079637050628662109375f, x);
@@ -137,29 +137,24 @@ __host__ __device__ __forceinline__ void sincos_poly(float x, float* sn, float* 
   *sn = (q & 2) ? -s0 : s0;
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
-// out of line: ONE copy of libm's large-argument path per kernel, however often fast_sincos is unrolled (inlined, eight
-// unrolled calls in sq_bwd grew the kernel by 8 x Payne-Hanek and it ran 40 % slower on instruction fetch)
-// -- and returning BY VALUE: with pointer results the callers' result arrays had their address passed to a real call and were
-// kept in scratch memory (80 bytes per lane in sq_fwd / sq_bwd: a scratch store + load per item on the fast path too)
-__device__ __noinline__ static float2 sincos_libm(float x) {
-  float2 r;
-  sincosf(x, &r.x, &r.y);
-  return r;
-}
-__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
-#ifdef A3D_LIBM_SINCOS        // A/B build (A3D_HIPCC_FLAGS=-DA3D_LIBM_SINCOS): libm everywhere
+// Large arguments (|x| >= 200: never reached by real RoPE angles -- coordinates in metres times a frequency <= 1) are reduced
+// modulo 2 pi in DOUBLE precision (two-part 2 pi, |error| < 1e-13 for |x| < 1e8) and take the same polynomials: eight inline
+// instructions on a path that is never hot, NO function call in any rotating kernel.  History, kept because both earlier forms
+// cost a GPU lease each: round 4 called libm's sincosf out of line through pointer results (the callers' (cos, sin) arrays then
+// lived in scratch memory: 80 B per lane in sq_fwd / sq_bwd); round 5 first returned a float2 from a __noinline__ static
+// function instead -- with that build ONE fused denoise step was no longer run-to-run deterministic on MI355X (3e-4 .. 1e-3
+// differences between identical launches of dn_cross / dn_rest, profiles/r05_cfg3_probe_ab.txt: the round-4 tree and this tree
+// with round 4's helper are bit-stable, the float2-returning call is not), although the call is never taken.
+__host__ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+#if defined(A3D_LIBM_SINCOS) && defined(__HIP_DEVICE_COMPILE__)        // A/B build (A3D_HIPCC_FLAGS=-DA3D_LIBM_SINCOS): libm everywhere
   sincosf(x, sn, cs);
 #else
-  float s_, c_;
-  if (fabsf(x) < 200.0f) {
-    sincos_poly(x, &s_, &c_);
-  } else {
-    const float2 r = sincos_libm(x);
-    s_ = r.x;
-    c_ = r.y;
+  if (fabsf(x) >= 200.0f) {
+    const double t = (double)x;
+    const double k = rint(t * 0.15915494309189535);
+    x = (float)fma(-k, 2.4492935982947064e-16, fma(-k, 6.283185307179586, t));      // |x| <= pi now (inf / nan stay nan)
   }
-  *sn = s_;
-  *cs = c_;
+  sincos_poly(x, sn, cs);
 #endif
 }
 

@@ -568,7 +568,7 @@ extern "C" void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
 extern "C" void a3d_sincos_host(const float* x, float* sn, float* cs, size_t n) {
-  for (size_t i = 0; i < n; ++i) sincos_poly(x[i], sn + i, cs + i);
+  for (size_t i = 0; i < n; ++i) fast_sincos(x[i], sn + i, cs + i);
 }
 extern "C" int a3d_adamw_step(float* p, const float* g, float* m, float* v, float* step, const long long* seg_off,
                               float* seg_state, int nseg, size_t n, size_t n_nodecay, float lr, float beta1, float beta2, float eps,

@@ -24,8 +24,13 @@
 
 namespace a3d {
 
+// workgroups per CU the forward kernel is compiled for: 2 (<= 256 VGPRs, 175 used) or 3 (<= 170: one spill); A/B build flag
+#ifndef SQW_FWD_WGS_PER_CU
+#define SQW_FWD_WGS_PER_CU 2
+#endif
 constexpr int SQW_LD = 68;      // row stride (floats) of the LDS matrices W_k, W_k^T, Q, dxbar
-constexpr int SQW_XLD = 80;     // row stride of the wave-private key tiles: 80 = 16 (mod 32) banks per key row
+constexpr int SQW_XLD = 72;     // row stride of the wave-private key tiles: 72 = 8 (mod 32): the (4 s + g, li) scalar reads hit every
+                                // bank exactly twice, and the backward's LDS stays under 80 KB (two workgroups per CU)
 
 __device__ __forceinline__ float sqw_pick(int ax, float x, float y, float z) { return ax == 0 ? x : (ax == 1 ? y : z); }
 __device__ __forceinline__ float sqw_pick4(int i, float a, float b, float c, float d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
@@ -173,7 +178,7 @@ __device__ __forceinline__ unsigned int sqw_rope_consts(const float* __restrict_
 // ------------------------------------------------------------------------------------------------ forward
 // grid (nsplit, B); partial [B][nsplit][H][E + 2] = {m, l, xbar[E]} per head (as sq_fwd_kernel: sq_combine_kernel reads it)
 template <int EC>
-__global__ __launch_bounds__(256, 2) void sqw_fwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
+__global__ __launch_bounds__(256, SQW_FWD_WGS_PER_CU) void sqw_fwd_kernel(const float* __restrict__ X, const float* __restrict__ xyz,
                                                          const float* __restrict__ Wk, int ldw, const float* __restrict__ bk,
                                                          const float* __restrict__ qrot, const float* __restrict__ freq,
                                                          float* __restrict__ part, int B, int S, int E_rt, int H_rt, int nsplit) {

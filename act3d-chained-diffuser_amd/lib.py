@@ -8,7 +8,9 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libact3d_hip.so")
+# development aid: A3D_LIB names another build of the same library inside the package directory (A/B builds made with
+# A3D_HIPCC_FLAGS and A3D_LIB_OUT, e.g. libact3d_hip_occ3.so); the default library is the one build() makes
+LIB_PATH = os.path.join(_PKG_DIR, os.path.basename(os.environ.get("A3D_LIB", "libact3d_hip.so")))
 
 _p = C.c_void_p
 _i = C.c_int

@@ -644,6 +644,14 @@ class AttnBlockFn(torch.autograd.Function):
 
 
 SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
+# key splits of the single-query kernels = workgroups per sample.  The wave-local kernels (single_query_wave.hip) hold two
+# workgroups per CU and pay a fixed prologue (W_k and its transpose into LDS) + epilogue (merge of the per-lane / per-wave
+# partials) per workgroup: ONE resident round of 512 workgroups with 8 tiles each instead of 1024 with 4 (A3D_SQ_WGS to A/B)
+SQ_TARGET_WGS = int(os.environ.get("A3D_SQ_WGS", "512" if os.environ.get("A3D_SQ_WAVE", "1") != "0" else "1024"))
+
+
+def sq_nsplit(B, S):
+    return max(1, min((S + 63) // 64, SQ_TARGET_WGS // B))
 
 
 class SingleQueryAttnBlockFn(torch.autograd.Function):
@@ -668,7 +676,7 @@ class SingleQueryAttnBlockFn(torch.autograd.Function):
         q_pre = linear_raw(q_in.data_ptr(), E, wp, E, bp, B, E, E, dev)
         qrot = torch.empty((B, H, 1, 16), device=dev, dtype=F32)
         L.call("a3d_rope_rows_f32", q_pre.data_ptr(), E, nz(q_xyz), freq.data_ptr(), scale, qrot.data_ptr(), B, 1, 1, E, H, L.stream())
-        nsplit = max(1, min((S + 63) // 64, 1024 // B))
+        nsplit = sq_nsplit(B, S)
         lib = L.load()
         ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)
         xbar = torch.empty((B, H, E), device=dev, dtype=F32)
@@ -745,7 +753,7 @@ class QueryLayerFn(torch.autograd.Function):
         lib = L.load()
         qrot = torch.empty((B, H, 1, 16), device=dev, dtype=F32)
         L.call("a3d_qs_pre_fwd", x.data_ptr(), wp, bp, nz(q_xyz), freq.data_ptr(), scale, qrot.data_ptr(), B, E, H, st)
-        nsplit = max(1, min((S + 63) // 64, 1024 // B))
+        nsplit = sq_nsplit(B, S)
         ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=dev, dtype=F32)
         xbar = torch.empty((B, H, E), device=dev, dtype=F32)
         lse = torch.empty((B, H), device=dev, dtype=F32)

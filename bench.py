@@ -205,7 +205,7 @@ def other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq):
     f4 = 4
     out = {}
     qrot = torch.randn(B, H, 1, 16, device=device)
-    nsplit = max(1, min((S + 63) // 64, 1024 // B))
+    nsplit = O.sq_nsplit(B, S)
     ws = torch.empty((lib.a3d_sq_fwd_ws_floats(B, H, E, nsplit),), device=device)
     xbar, lse = torch.empty((B, H, E), device=device), torch.empty((B, H), device=device)
     wp, bp = w.data_ptr(), bb.data_ptr()

@@ -252,7 +252,7 @@ int a3d_sample_ghost_points(const unsigned long long* state, const float* bounds
                             float* out, int B, int Ng, int level, int max_attempts, void* stream);
 int a3d_rng_advance(unsigned long long* state, unsigned long long n, void* stream);
 void a3d_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-/* Host mirror of the device RoPE sin / cos (a3d_common.h sincos_poly, used for |x| < 200; the rotary code of
+/* Host mirror of the device RoPE sin / cos (a3d_common.h fast_sincos: sincos_poly, behind a double-precision reduction for |x| >= 200; the rotary code of
  * position_encodings.py:64-97 evaluated in-kernel): the same fp32 operations, so a CPU test can bound it against float64. */
 void a3d_sincos_host(const float* x, float* sn, float* cs, size_t n);
 /* torch.optim.AdamW semantics (engine.py:89-102) on a flat buffer; elements [0, n_nodecay) use wd_nodecay.  The decision

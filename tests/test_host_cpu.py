@@ -631,3 +631,10 @@ def test_rope_sincos_host_mirror_within_1e7_of_float64():
     assert np.abs(sn * sn + cs * cs - 1.0).max() <= 3e-7
     small = np.abs(xd) < 0.5                       # relative accuracy of sin near 0 (the polynomial is odd in r)
     assert np.abs(sn[small] - np.sin(xd[small])).max() <= 6e-8 and not sn[x == 0].any()
+    # large arguments (never reached by real RoPE angles): double-precision reduction modulo 2 pi + the same polynomials,
+    # inline -- no libm call in any kernel (a3d_common.h fast_sincos)
+    big = np.concatenate([rng.uniform(200, 1e6, 100000), -rng.uniform(200, 1e6, 100000), [200.0, -200.0, 1e7, 12345678.0]]).astype(np.float32)
+    sb, cb = np.empty_like(big), np.empty_like(big)
+    lib.a3d_sincos_host(big.ctypes.data, sb.ctypes.data, cb.ctypes.data, big.size)
+    bd = big.astype(np.float64)
+    assert np.abs(sb - np.sin(bd)).max() <= 2e-7 and np.abs(cb - np.cos(bd)).max() <= 2e-7
