@@ -514,6 +514,37 @@ struct DnOp {
 };
 struct DnOpTable { int n; DnOp op[13]; };
 
+// operation table of one layer remainder (dn_rest_loop_kernel / the persistent sampler): LDS offsets in floats from the start
+// of the dynamic LDS.  One definition for the host (a3d_dn_rest passes the table by value) and the device (the persistent
+// sampler builds it per layer in LDS).
+__host__ __device__ inline void dn_build_ops(DnOpTable& tab, const a3d_dn_rest_params& p, int E) {
+  const int oX = 0, oA = DR * LDX, oB = 2 * DR * LDX, oT = 3 * DR * LDX, oQK = 4 * DR * LDX, oH = oQK + DR * LDQK, oP = oH + DR * LDH;
+  const int oMisc = oP + 2560 + DR * 128;
+  int n = 0;
+  auto lin = [&](int x, int ldx, int K, const float* W, int bias, int N, int y, int ldy, int act) {
+    tab.op[n++] = DnOp{DN_OP_LINEAR, x, ldx, K, bias, N, y, ldy | (act << 16), W};
+  };
+  auto other = [&](int type, int a, int b, int c, int d, int e) { tab.op[n++] = DnOp{type, a, b, c, d, e, 0, 0, nullptr}; };
+  lin(oA, LDX, E, p.c_out_w, p.c_out_b ? oP : -1, E, oT, LDX, 0);
+  other(DN_OP_ADDLN, oX, oT, oP + 128, oP + 256, oX);
+  if (p.s_in_w) {
+    other(DN_OP_ADALN, oX, p.sem ? oP + 2560 : -1, p.s_mod ? oP + 384 : -1, oA, oB);
+    lin(oA, LDX, E, p.s_in_w, p.s_in_b ? oP + 640 : -1, 2 * E, oQK, LDQK, 0);
+    lin(oB, LDX, E, p.s_in_w + (size_t)2 * E * E, p.s_in_b ? oP + 640 + 2 * E : -1, E, oH, LDH, 0);
+    other(DN_OP_ROPE, oQK, oMisc, p.freq ? oMisc + 160 : -1, 0, 0);
+    other(DN_OP_ATTN, oQK, oQK + E, oH, oMisc + 192, oA);
+    lin(oA, LDX, E, p.s_out_w, p.s_out_b ? oP + 1024 : -1, E, oT, LDX, 0);
+    other(DN_OP_ADDLN, oX, oT, oP + 1152, oP + 1280, oX);
+  }
+  if (p.f_w1) {
+    other(DN_OP_ADALN, oX, -1, p.f_mod ? oP + 1408 : -1, oA, -1);
+    lin(oA, LDX, E, p.f_w1, p.f_b1 ? oP + 1664 : -1, p.F, oH, LDH, 1);
+    lin(oH, LDH, p.F, p.f_w2, p.f_b2 ? oP + 2176 : -1, E, oT, LDX, 0);
+    other(DN_OP_ADDLN, oA, oT, oP + 2304, oP + 2432, oX);
+  }
+  tab.n = n;
+}
+
 // Round 4 measured a deeper weight fetch here -- a wave's rounds fetched four at a time (32 float4 per lane in flight) before
 // their MFMAs, on the hypothesis that every round exposes an L2 round trip: 0.913 ms per denoise step with guarded loads, 1.10 ms
 // with unconditional ones (redundant re-fetches for waves with fewer than four rounds), against 0.86 ms for the one-round-ahead
@@ -782,6 +813,444 @@ __global__ __launch_bounds__(256) void rope_rows_f32_kernel(const float* __restr
   }
 }
 
+
+// ================================================================================================ persistent sampler (round 5)
+// The whole 100-step sampling loop of one trajectory batch as ONE launch with two workgroup roles (north_star: "trajectory-noise
+// add + eps-prediction loop fused per denoise step"; diffusion_model.py:86-119 over diffusion_head.py:200-363):
+//   sample role  (workgroups 0 .. B-1, one per trajectory): the per-sample chain of a step -- traj_encoder [+ instruction
+//                attention] -> per layer {q = rope(W_q AdaLN(x + index embedding)) published for the streamers | wait for the
+//                layer's cross-attention partials | combine -> out-proj -> LayerNorm -> self-attention block -> FFN block} ->
+//                regressors -> DDPM reverse step -- looping over layers AND denoise steps without leaving the kernel;
+//   stream role  (the remaining CUs): serve (sample, layer, key split) items from a ready queue: every wave streams one head's
+//                slice of the cached context K / V against the sample's 16 published queries (the arithmetic of dn_cross_kernel)
+//                and writes the partial (o, m); a counter per sample tells the sample workgroup when its layer is complete.
+// Why: with one launch per phase the 64 sample workgroups of a3d_dn_rest sit on 64 of 256 CUs for 61 us per layer (a latency chain:
+// MfmaUtil 2.5 %) while the HBM-bound cross-attention launch waits behind them, and vice versa; the samples never interact, so
+// nothing but the launch boundaries forces them into lockstep.  Here each sample advances at its own pace, the streamers stay busy
+// with whichever samples are ready, and the step-invariant staging of a layer's vectors / weights overlaps the sample's own wait.
+// Synchronisation: agent-scope release / acquire on a ready queue (sample -> streamers) and a per-sample completion counter
+// (streamers -> sample); all workgroups are co-resident (grid <= CU count, one workgroup per CU by LDS size), every spin loop is
+// bounded and raises an abort flag instead of hanging.
+struct DnLayerDev { a3d_dn_cross_params c; a3d_dn_rest_params r; };      // c.mod, r.s_mod, r.f_mod: BASES of the [T][2E] tables
+struct DnPersist {
+  const DnLayerDev* layers;       // device array [n_traj + n_pos + n_rot]
+  a3d_dn_head_params head;
+  a3d_dn_tail_params tail;        // tail.noise: BASE of the [T][B][L][D] step noise (row t is used at step t > 0), or NULL
+  float* traj;                    // [B][L][D] in / out
+  float* qbuf;                    // [B][16][128] published queries of the sample's current layer
+  float* part;                    // Op [nse][B][H][16][16] | Mp [nse][B][H][16]   (nse = nsplit * nsub)
+  int* sync;                      // [0] ticket  [1] queue tail  [2] abort  | [16 + 16 b] completion counter of sample b | queue
+  int B, L, D, E, H, S, Sp, nsplit, nsub, n_traj, n_pos, n_rot, t_first, nsteps, spin_limit;
+};
+constexpr int DNP_XDONE0 = 16;
+__device__ __forceinline__ int dnp_queue0(int B) { return DNP_XDONE0 + 16 * B; }
+
+// thread 0 of the workgroup spins until *flag >= target (acquire, agent scope); returns false when the kernel is aborting
+// (the polls are RELAXED loads -- an acquire per poll would invalidate the XCD's L2 under the streamers' feet -- and ONE acquire
+// fence follows the successful poll)
+__device__ __forceinline__ bool dnp_wait_ge(int* flag, int target, int* abort_flag, int spin_limit) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 127) == 0) {
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      if (spins > spin_limit) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+// The argument block is re-read through an opaque copy of its pointer at every phase: otherwise the compiler hoists ALL its (loop-
+// invariant) pointer loads to the top of the role function and keeps ~150 SGPRs live across the step / layer loops (755 SGPR spills).
+__device__ __forceinline__ const DnPersist& dnp_args(const DnPersist* p) {
+  asm volatile("" : "+s"(p));
+  return *p;
+}
+
+// ---- stream role
+__device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem) {
+  const DnPersist& a = dnp_args(ap);
+  int* sh = reinterpret_cast<int*>(smem);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int NL = a.n_traj + a.n_pos + a.n_rot;
+  const long long total = (long long)a.nsteps * NL * a.B * a.nsplit;
+  const int nse = a.nsplit * a.nsub;
+  float* Op = a.part;
+  float* Mp = a.part + (size_t)nse * a.B * a.H * 256;
+  int* abort_flag = a.sync + 2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  for (;;) {
+    __syncthreads();                                     // everybody has read the previous item's sh[]
+    if (t == 0) {
+      const long long i = (long long)atomicAdd(&a.sync[0], 1);
+      int code = 0;
+      if (i < total) {
+        int* slot = a.sync + dnp_queue0(a.B) + (int)(i / a.nsplit);
+        if (dnp_wait_ge(slot, 1, abort_flag, a.spin_limit)) code = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh[0] = i < total ? (int)(i % a.nsplit) : -1;
+      sh[1] = code;
+    }
+    __syncthreads();
+    const int sp = sh[0], code = sh[1];
+    if (sp < 0 || code == 0) break;
+    const int gl = (code - 1) / a.B, b = (code - 1) - gl * a.B;
+    const a3d_dn_cross_params& c = dnp_args(ap).layers[gl % NL].c;
+    if (wave < a.H * a.nsub) {
+      const int h = wave % a.H, sub = wave / a.H;
+      const int se = sp * a.nsub + sub;
+      const size_t bh = (size_t)b * a.H + h;
+      const float* qrow = a.qbuf + ((size_t)b * 16 + li) * 128 + h * HD;       // rows >= L and columns >= E are published as zeros
+      float4 qb;                                         // B operand: channel 4 g + j of query li (channel 15 = pad)
+      qb.x = qrow[4 * g + 0];
+      qb.y = qrow[4 * g + 1];
+      qb.z = qrow[4 * g + 2];
+      qb.w = (4 * g + 3 < HD) ? qrow[4 * g + 3] : 0.f;
+      const int NH = a.Sp >> 5;
+      const int h_beg = (int)((long long)NH * se / nse), h_end = (int)((long long)NH * (se + 1) / nse);
+      const float* Kb = c.Kf + bh * (size_t)a.Sp * 16;
+      const unsigned short* Vhi = c.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)a.Sp;
+      const unsigned short* Vlo = c.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)a.Sp;
+      const int krow_off[2] = {(li >> 2) * 8 + (li & 3), (li >> 2) * 8 + (li & 3) + 4};
+      struct Frag { float4 k0, k1; s16x8 vh, vl; };
+      auto load = [&](int hf) {
+        Frag f;
+        const int key0 = hf * 32;
+        f.k0 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g);
+        f.k1 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g);
+        f.vh = *reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8);
+        f.vl = *reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8);
+        return f;
+      };
+      float m_run = -INFINITY;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // three fragments in flight per wave (an item is ~6 - 12 halves of 32 keys: the first round trips are the item's latency)
+      Frag f0, f1, f2;
+      if (h_beg < h_end) f0 = load(h_beg);
+      f1 = f0;
+      if (h_beg + 1 < h_end) f1 = load(h_beg + 1);
+      f2 = f1;
+      if (h_beg + 2 < h_end) f2 = load(h_beg + 2);
+      for (int hf = h_beg; hf < h_end; ++hf) {
+        const Frag cur = f0;
+        f0 = f1;
+        f1 = f2;
+        if (hf + 3 < h_end) f2 = load(hf + 3);
+        const int key0 = hf * 32;
+        f32x4 s[2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < a.S) ? 0.f : -INFINITY;
+          const float4 kf = T ? cur.k1 : cur.k0;
+          s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.z, qb.z, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.w, qb.w, s[T]);
+        }
+        const float mt = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        const float m_new = fmaxf(m_run, colmax4(mt));
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float nm = -m_use * LOG2E_F;
+        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));
+        unsigned int hw[4], lw[4];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr], LOG2E_F, nm)),
+                              __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr + 1], LOG2E_F, nm))};
+            const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
+            const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
+            hw[T * 2 + pr] = h2;
+            lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
+          }
+        }
+        const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+        const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+        const s16x8 vh = (li == 15) ? ones : cur.vh;        // pad channel 15 := 1: acc[15] = sum_k p on the MFMA pipe
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+        acc = mfma_bf16_16x16x32(vh, phi, acc);
+        acc = mfma_bf16_16x16x32(vh, plo, acc);
+        acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
+      }
+      // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
+      const size_t row0 = (((size_t)se * a.B + b) * a.H + h) * 16;
+      *reinterpret_cast<float4*>(&Op[(row0 + li) * 16 + 4 * g]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (g == 0) Mp[row0 + li] = m_run;
+    }
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// the layer remainder's operation loop (the body of dn_rest_loop_kernel's table walk, without the phase probe)
+__device__ __forceinline__ void dnp_run_ops(float* smem, const DnOpTable& tab, int L, int D, int E, int H) {
+#pragma nounroll
+  for (int i = 0; i < tab.n; ++i) {
+    const DnOp& op = tab.op[i];
+    switch (op.type) {
+      case DN_OP_LINEAR: {
+        const bool vec = ((op.c & 3) == 0) && ((((uintptr_t)op.W) & 15) == 0);
+        const int act = op.g >> 16, ldy = op.g & 0xFFFF;
+        if (vec) wg_linear_rt<true>(smem + op.a, op.b, op.c, op.W, op.c, op.d >= 0 ? smem + op.d : nullptr, op.e, smem + op.f, ldy, act);
+        else wg_linear_rt<false>(smem + op.a, op.b, op.c, op.W, op.c, op.d >= 0 ? smem + op.d : nullptr, op.e, smem + op.f, ldy, act);
+        break;
+      }
+      case DN_OP_ADDLN:
+        wg_add_layernorm(smem + op.a, LDX, smem + op.b, LDX, smem + op.c, smem + op.d, smem + op.e, LDX, E);
+        break;
+      case DN_OP_ADALN:
+        wg_adaln(smem + op.a, LDX, op.b >= 0 ? smem + op.b : nullptr, op.c >= 0 ? smem + op.c : nullptr, smem + op.d, LDX, L, E,
+                 op.e >= 0 ? smem + op.e : nullptr, LDX);
+        break;
+      case DN_OP_ROPE:
+        wg_rope(smem + op.a, LDQK, 0, 2, smem + op.b, D, op.c >= 0 ? smem + op.c : nullptr, L, E, 1.0f / sqrtf((float)HD));
+        break;
+      default: {               // DN_OP_ATTN   a: Q, b: K, c: V, d: mask (floats), e: O
+        const float* mk = smem + op.d;
+        const float* Q = smem + op.a;
+        const float* Kk = smem + op.b;
+        const float* V = smem + op.c;
+        float* O = smem + op.e;
+        const int r = (threadIdx.x >> 4) & 15, h = threadIdx.x & 15;
+        if (threadIdx.x < 256 && h < H) {
+          float q[HD], acc[HD];
+#pragma unroll
+          for (int d = 0; d < HD; ++d) { q[d] = Q[r * LDQK + h * HD + d]; acc[d] = 0.f; }
+          float m = -INFINITY, l = 0.f;
+          for (int s2 = 0; s2 < L; ++s2) {
+            if (mk[s2] != 0.f) continue;
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc += q[d] * Kk[s2 * LDQK + h * HD + d];
+            const float mn = fmaxf(m, sc);
+            const float al = __expf(m - mn), pw = __expf(sc - mn);
+            l = l * al + pw;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * al + pw * V[s2 * LDH + h * HD + d];
+            m = mn;
+          }
+          const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) O[r * LDX + h * HD + d] = acc[d] * inv;
+        }
+        __syncthreads();
+        break;
+      }
+    }
+  }
+}
+
+constexpr int DNP_LDS_FLOATS = DR * (4 * LDX + LDQK + LDH) + DN_PS + 2 * DR * LDX + 256 + 16 + 160;
+
+// ---- sample role
+__device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem) {
+  const DnPersist& a = dnp_args(ap);
+  float* Xs = smem;
+  float* As = Xs + DR * LDX;
+  float* Bs = As + DR * LDX;
+  float* Ts = Bs + DR * LDX;
+  float* QK = smem + 4 * DR * LDX;
+  float* Hs = QK + DR * LDQK;
+  float* Ps = Hs + DR * LDH;
+  float* Xt = Ps + DN_PS;                    // x after the trajectory stack (start of the position and the rotation stack)
+  float* Pf = Xt + DR * LDX;                 // position features
+  float* Tr = Pf + DR * LDX;                 // [16][16] the sample's trajectory rows (D <= 16 channels)
+  int* shi = reinterpret_cast<int*>(Tr + 256);
+  DnOpTable* tab = reinterpret_cast<DnOpTable*>(Tr + 256 + 16);
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int L = a.L, D = a.D, E = a.E, H = a.H;
+  const int Epad = (E + 15) & ~15;
+  const int NL = a.n_traj + a.n_pos + a.n_rot;
+  const int nse = a.nsplit * a.nsub;
+  const float* Op = a.part;
+  const float* Mp = a.part + (size_t)nse * a.B * a.H * 256;
+  int* abort_flag = a.sync + 2;
+  for (int i = t; i < 256; i += blockDim.x) {
+    const int r = i >> 4, c = i & 15;
+    Tr[i] = (r < L && c < D) ? a.traj[((size_t)b * L + r) * D + c] : 0.f;
+  }
+  for (int i = t; i < 4 * DR * LDX; i += blockDim.x) smem[i] = 0.f;          // pads of the four row tiles
+  __syncthreads();
+  for (int step = 0; step < a.nsteps; ++step) {
+    const int t_step = a.t_first - step;
+    // ================= head: trajectory encoder [+ attention over the instruction tokens]   (dn_head_kernel)
+    {
+      const a3d_dn_head_params& p = dnp_args(ap).head;
+      float* Qs = Bs;
+      float* kvS = QK;                       // [S_lang][2E] over the idle QK | Hs | Ps area
+      for (int i = t; i < DR * 16; i += blockDim.x) As[(i >> 4) * LDX + (i & 15)] = Tr[i];
+      wg_zero_pad(Ts, LDX, E, Epad);
+      wg_zero_pad(Xs, LDX, E, Epad);
+      wg_zero_pad(Qs, LDX, E, Epad);
+      __syncthreads();
+      wg_linear<1>(As, LDX, D, p.enc_w0, D, p.enc_b0, E, Ts, LDX);
+      wg_linear<0>(Ts, LDX, E, p.enc_w1, E, p.enc_b1, E, Xs, LDX);
+      if (p.lang_kv) {
+        wg_zero_pad(As, LDX, E, Epad);
+        wg_adaln(Xs, LDX, p.sem, nullptr, As, LDX, L, E);
+        wg_linear<0>(As, LDX, E, p.q_w, E, p.q_b, E, Qs, LDX);
+        const float scale = 1.0f / sqrtf((float)HD);
+        for (int i = t; i < DR * E; i += blockDim.x) Qs[(i / E) * LDX + i % E] *= scale;
+        __syncthreads();
+        const float* kv = p.lang_kv + (size_t)b * p.S_lang * 2 * E;
+        for (int i = t; i < p.S_lang * 2 * E; i += blockDim.x) kvS[i] = kv[i];
+        __syncthreads();
+        wg_small_attention(Qs, LDX, kvS, 2 * E, kvS + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
+        wg_linear<0>(As, LDX, E, p.out_w, E, p.out_b, E, Ts, LDX);
+        wg_add_layernorm(Xs, LDX, Ts, LDX, p.ln_g, p.ln_b, Xs, LDX, E);
+      }
+    }
+    // ================= layers
+    for (int l = 0; l < NL; ++l) {
+      const int gl = step * NL + l;
+      const DnLayerDev& lay = dnp_args(ap).layers[l];
+      if (l == a.n_traj) {                                        // start of the position stack: keep x for the rotation stack
+        for (int i = t; i < DR * LDX; i += blockDim.x) Xt[i] = Xs[i];
+        __syncthreads();
+      } else if (l == a.n_traj + a.n_pos) {                       // start of the rotation stack
+        for (int i = t; i < DR * LDX; i += blockDim.x) { Pf[i] = Xs[i]; Xs[i] = Xt[i]; }
+        __syncthreads();
+      }
+      // ---- (1) publish the layer's queries: rope(W_q AdaLN(x + index embedding) + b_q) * d^-1/2, all heads
+      {
+        const a3d_dn_cross_params& c = dnp_args(ap).layers[l].c;
+        wg_zero_pad(As, LDX, E, Epad);
+        wg_zero_pad(Ts, LDX, E, Epad);
+        wg_adaln(Xs, LDX, c.sem, c.mod ? c.mod + (size_t)t_step * 2 * E : nullptr, As, LDX, L, E);
+        wg_linear<0>(As, LDX, E, c.q_w, E, c.q_b, E, Ts, LDX);
+        wg_rope(Ts, LDX, 0, 1, Tr, 16, c.freq, L, E, 1.0f / sqrtf((float)HD));
+        float* qrow = a.qbuf + (size_t)b * 16 * 128;
+        for (int i = t; i < 16 * 128; i += blockDim.x) {
+          const int r = i >> 7, cc = i & 127;
+          qrow[i] = (r < L && cc < E) ? Ts[r * LDX + cc] : 0.f;
+        }
+        __syncthreads();
+        if (t == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          const int slot = atomicAdd(&a.sync[1], 1);
+          __hip_atomic_store(&a.sync[dnp_queue0(a.B) + slot], 1 + gl * a.B + b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // ---- (2) while the streamers work: this layer's vectors -> LDS, weights touched in L2, pads, operation table
+      {
+        const a3d_dn_rest_params& p = dnp_args(ap).layers[l].r;
+        const float* s_mod = p.s_mod ? p.s_mod + (size_t)t_step * 2 * E : nullptr;
+        const float* f_mod = p.f_mod ? p.f_mod + (size_t)t_step * 2 * E : nullptr;
+        float* const vd[12] = {Ps, Ps + 128, Ps + 256, Ps + 384, Ps + 640, Ps + 1024, Ps + 1152, Ps + 1280, Ps + 1408, Ps + 1664, Ps + 2176,
+                               Ps + 2304};
+        const VecList vl = {{p.c_out_b, p.c_ln_g, p.c_ln_b, p.s_in_w ? s_mod : nullptr, p.s_in_w ? p.s_in_b : nullptr,
+                             p.s_in_w ? p.s_out_b : nullptr, p.s_in_w ? p.s_ln_g : nullptr, p.s_in_w ? p.s_ln_b : nullptr,
+                             p.f_w1 ? f_mod : nullptr, p.f_w1 ? p.f_b1 : nullptr, p.f_w1 ? p.f_b2 : nullptr, p.f_w1 ? p.f_ln_g : nullptr},
+                            {E, E, E, 2 * E, 3 * E, E, E, E, 2 * E, p.F, E, E}};
+        wg_stage_vectors(vl, vd, (p.sem && p.s_in_w) ? p.sem : nullptr, L * E, Ps + 2560);
+        float* const misc = Ps + 2560 + DR * 128;
+        if (p.f_w1 && t < E) Ps[2432 + t] = p.f_ln_b[t];
+        if (p.s_in_w) {
+          if (t < L * D) misc[t] = Tr[(t / D) * 16 + t % D];
+          if (p.freq && t < E / 6) misc[160 + t] = p.freq[t];
+          if (t < DR) misc[192 + t] = (p.kmask && t < L && p.kmask[(size_t)b * L + t]) ? 1.f : 0.f;
+        }
+        const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
+                             {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
+        wg_warm_l2(wl, a.B);
+        if (t == 0) {
+          a3d_dn_rest_params pl = p;
+          pl.s_mod = s_mod;
+          pl.f_mod = f_mod;
+          dn_build_ops(*tab, pl, E);
+        }
+        wg_zero_pad(Bs, LDX, E, Epad);
+        if (p.f_w1) {
+          const int padw = ((p.F + 15) & ~15) - p.F;
+          for (int i = t; i < DR * padw; i += blockDim.x) Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
+        }
+      }
+      // ---- (3) wait for the layer's nsplit items of this sample
+      if (t == 0) shi[0] = dnp_wait_ge(&a.sync[DNP_XDONE0 + 16 * b], (gl + 1) * a.nsplit, abort_flag, a.spin_limit) ? 1 : 0;
+      __syncthreads();
+      if (shi[0] == 0) return;
+      // ---- (4) combine the key splits -> As
+      wg_zero_pad(As, LDX, E, Epad);
+      wg_zero_pad(Ts, LDX, E, Epad);
+      for (int i = t; i < DR * E; i += blockDim.x) {
+        const int r = i / E, c = i - r * E;
+        const int h = c / HD, d = c - h * HD;
+        float m = -INFINITY;
+        for (int s = 0; s < nse; ++s) m = fmaxf(m, Mp[(((size_t)s * a.B + b) * H + h) * 16 + r]);
+        const float m_use = (m == -INFINITY) ? 0.f : m;
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < nse; ++s) {
+          const size_t row = (((size_t)s * a.B + b) * H + h) * 16 + r;
+          const float w = __expf(Mp[row] - m_use);
+          num += w * Op[row * 16 + d];
+          den += w * Op[row * 16 + 15];
+        }
+        As[r * LDX + c] = den > 0.f ? num / den : 0.f;
+      }
+      __syncthreads();
+      // ---- (5) out-proj + LayerNorm, self-attention block, FFN block
+      dnp_run_ops(smem, *tab, L, D, E, H);
+    }
+    // ================= tail: regressors, trajectory update, DDPM reverse step   (dn_tail_kernel; Pf = position, Xs = rotation features)
+    {
+      const a3d_dn_tail_params& p = dnp_args(ap).tail;
+      float* Us = QK;                        // [16][16]
+      wg_zero_pad(Ts, LDX, E, Epad);
+      __syncthreads();
+      wg_linear<1>(Pf, LDX, E, p.pos_w0, E, p.pos_b0, E, Ts, LDX);
+      wg_linear<0>(Ts, LDX, E, p.pos_w1, E, p.pos_b1, 3, Us, 16);
+      wg_linear<1>(Xs, LDX, E, p.rot_w0, E, p.rot_b0, E, Ts, LDX);
+      wg_linear<0>(Ts, LDX, E, p.rot_w1, E, p.rot_b1, D - 3, Us + 3, 16);
+      for (int i = t; i < L * D; i += blockDim.x) {
+        const int r = i / D, c = i - r * D;
+        const size_t gi = ((size_t)b * L + r) * D + c;
+        const float old = Tr[r * 16 + c];
+        float mo = Us[r * 16 + c] + (c < 3 ? old : 0.f);
+        if (p.cond_mask && p.cond_mask[gi]) mo = p.cond_data[gi];
+        float out = mo;
+        if (t_step > 0) {
+          const float* cf = ((c < 3) ? p.coef_pos : p.coef_rot) + (size_t)t_step * 3;
+          const float x0 = fminf(fmaxf(mo, -1.0f), 1.0f);
+          out = cf[0] * x0 + cf[1] * old;
+          if (p.noise) out += cf[2] * p.noise[(size_t)t_step * a.B * L * D + gi];
+        }
+        Tr[r * 16 + c] = out;
+        a.traj[gi] = out;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// The argument block lives in device memory (behind the sync words) and is read field by field with scalar loads: passed by value
+// its ~120 SGPRs of pointers stay live across both roles and the register allocator spills hundreds of them through VGPR lanes
+// (measured at compile time: 884 SGPR + 974 VGPR spills, 3.5 KB of scratch per lane).  A one-wave kernel writes the block first.
+__global__ void dn_persist_args_kernel(DnPersist a, DnPersist* dst) {
+  const int n = (int)(sizeof(DnPersist) / sizeof(int));
+  const int* src = reinterpret_cast<const int*>(&a);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<int*>(dst)[i] = src[i];
+}
+__global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < B) dnp_sample_role(ap, smem);
+  else dnp_stream_role(ap, smem);
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -872,32 +1341,8 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
   }
   const float* Op = ws;
   const float* Mp = ws + (size_t)nsplit * B * H * 16 * 16;
-  // operation table of dn_rest_loop_kernel: LDS offsets in floats from the start of the dynamic LDS
-  const int oX = 0, oA = DR * LDX, oB = 2 * DR * LDX, oT = 3 * DR * LDX, oQK = 4 * DR * LDX, oH = oQK + DR * LDQK, oP = oH + DR * LDH;
-  const int oMisc = oP + 2560 + DR * 128;
   DnOpTable tab;
-  tab.n = 0;
-  auto lin = [&](int x, int ldx, int K, const float* W, int bias, int N, int y, int ldy, int act) {
-    tab.op[tab.n++] = DnOp{DN_OP_LINEAR, x, ldx, K, bias, N, y, ldy | (act << 16), W};
-  };
-  auto other = [&](int type, int a, int b, int c, int d, int e) { tab.op[tab.n++] = DnOp{type, a, b, c, d, e, 0, 0, nullptr}; };
-  lin(oA, LDX, E, p->c_out_w, p->c_out_b ? oP : -1, E, oT, LDX, 0);
-  other(DN_OP_ADDLN, oX, oT, oP + 128, oP + 256, oX);
-  if (p->s_in_w) {
-    other(DN_OP_ADALN, oX, p->sem ? oP + 2560 : -1, p->s_mod ? oP + 384 : -1, oA, oB);
-    lin(oA, LDX, E, p->s_in_w, p->s_in_b ? oP + 640 : -1, 2 * E, oQK, LDQK, 0);
-    lin(oB, LDX, E, p->s_in_w + (size_t)2 * E * E, p->s_in_b ? oP + 640 + 2 * E : -1, E, oH, LDH, 0);
-    other(DN_OP_ROPE, oQK, oMisc, p->freq ? oMisc + 160 : -1, 0, 0);
-    other(DN_OP_ATTN, oQK, oQK + E, oH, oMisc + 192, oA);
-    lin(oA, LDX, E, p->s_out_w, p->s_out_b ? oP + 1024 : -1, E, oT, LDX, 0);
-    other(DN_OP_ADDLN, oX, oT, oP + 1152, oP + 1280, oX);
-  }
-  if (p->f_w1) {
-    other(DN_OP_ADALN, oX, -1, p->f_mod ? oP + 1408 : -1, oA, -1);
-    lin(oA, LDX, E, p->f_w1, p->f_b1 ? oP + 1664 : -1, p->F, oH, LDH, 1);
-    lin(oH, LDH, p->F, p->f_w2, p->f_b2 ? oP + 2176 : -1, E, oT, LDX, 0);
-    other(DN_OP_ADDLN, oA, oT, oP + 2304, oP + 2432, oX);
-  }
+  dn_build_ops(tab, *p, E);
   const size_t lds2 = ((size_t)DR * (4 * LDX + LDQK + LDH) + DN_PS) * sizeof(float);
   static bool attr2 = false;
   if (!attr2) {
@@ -907,6 +1352,70 @@ extern "C" int a3d_dn_rest(const float* x_in, const float* traj, int D, const fl
   hipLaunchKernelGGL(dn_rest_loop_kernel, dim3(B), dim3(dn_threads()), lds2, (hipStream_t)stream, x_in, traj, D, Op, Mp, *p, tab, x_out, B,
                      L, E, H, nsplit, dn_warm());
   return check_launch("a3d_dn_rest");
+}
+
+// ---- persistent sampler: host side
+static int dnp_nsub(int H) { return (H <= 8 && 8 % H == 0) ? 8 / H : 1; }
+
+extern "C" int a3d_dn_persist_splits(int H, int nsplit) { return nsplit * dnp_nsub(H); }
+
+extern "C" size_t a3d_dn_persist_sync_ints(int B, int n_layers, int nsteps) {
+  if (B <= 0 || n_layers <= 0 || nsteps <= 0) return 0;
+  const size_t words = (size_t)DNP_XDONE0 + (size_t)16 * B + (size_t)nsteps * n_layers * B;
+  return ((words + 3) & ~(size_t)3) + (sizeof(DnPersist) + sizeof(int) - 1) / sizeof(int);      // + the kernels' argument block
+}
+
+extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos, int n_rot, const a3d_dn_head_params* head,
+                              const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, int* sync, int B, int L, int D,
+                              int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream) {
+  int rc = dn_check("a3d_dn_persist", B, L, E, H);
+  if (rc) return rc;
+  static_assert(sizeof(a3d_dn_layer_params) == sizeof(DnLayerDev), "layer table layout");
+  if (!layers_dev || !head || !tail || !traj || !qbuf || !part || !sync || n_traj < 0 || n_pos < 1 || n_rot < 1 || D < 4 || D > 16 ||
+      L * D > DN_MISC_XYZ || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 || nsplit > 64 || H > 8 || nsteps < 1 || t_first < nsteps - 1 ||
+      !head->enc_w0 || !head->enc_w1 || (head->lang_kv && (!head->q_w || !head->out_w || !head->ln_g || !head->sem || head->S_lang <= 0)) ||
+      !tail->pos_w0 || !tail->rot_w0 || !tail->coef_pos || !tail->coef_rot || (tail->cond_mask && !tail->cond_data)) {
+    set_error("a3d_dn_persist: bad argument (B=%d L=%d D=%d E=%d H=%d S=%d Sp=%d nsplit=%d stacks %d/%d/%d steps %d from t=%d)", B, L, D, E, H,
+              S, Sp, nsplit, n_traj, n_pos, n_rot, nsteps, t_first);
+    return A3D_ERR_ARG;
+  }
+  if (head->lang_kv && (size_t)head->S_lang * 2 * E > (size_t)DR * (LDQK + LDH) + DN_PS) {
+    set_error("a3d_dn_persist: %d instruction tokens do not fit the LDS staging", head->S_lang);
+    return A3D_ERR_ARG;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1;
+  }
+  // every workgroup must be resident at once (the roles wait for each other): one workgroup per CU (121 KB of LDS each)
+  const int nworkers = n_cu - B;
+  if (n_cu <= 0 || nworkers < 16) {
+    set_error("a3d_dn_persist: %d trajectories leave %d of %d CUs for the streaming role (>= 16 needed); use the per-phase launches", B,
+              nworkers, n_cu);
+    return A3D_ERR_ARG;
+  }
+  DnPersist a;
+  a.layers = reinterpret_cast<const DnLayerDev*>(layers_dev);
+  a.head = *head;
+  a.tail = *tail;
+  a.traj = traj; a.qbuf = qbuf; a.part = part; a.sync = sync;
+  a.B = B; a.L = L; a.D = D; a.E = E; a.H = H; a.S = S; a.Sp = Sp; a.nsplit = nsplit; a.nsub = dnp_nsub(H);
+  a.n_traj = n_traj; a.n_pos = n_pos; a.n_rot = n_rot; a.t_first = t_first; a.nsteps = nsteps;
+  a.spin_limit = 1 << 21;                     // ~2 s of polling: a wait is at most a few milliseconds; beyond it the launch aborts
+  hipStream_t s = (hipStream_t)stream;
+  const size_t words = (((size_t)DNP_XDONE0 + (size_t)16 * B + (size_t)nsteps * (n_traj + n_pos + n_rot) * B) + 3) & ~(size_t)3;
+  hipError_t e = hipMemsetAsync(sync, 0, words * sizeof(int), s);
+  if (e != hipSuccess) { set_error("a3d_dn_persist: memset: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  DnPersist* a_dev = reinterpret_cast<DnPersist*>(sync + words);
+  hipLaunchKernelGGL(dn_persist_args_kernel, dim3(1), dim3(64), 0, s, a, a_dev);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dn_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dn_persist_kernel, dim3(B + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, B);
+  return check_launch("a3d_dn_persist");
 }
 
 extern "C" int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D,

@@ -31,6 +31,7 @@ DnCrossParams = _struct("DnCrossParams", [(n, _p) for n in ("sem", "mod", "q_w",
 DnRestParams = _struct("DnRestParams", [(n, _p) for n in (
     "c_out_w", "c_out_b", "c_ln_g", "c_ln_b", "sem", "s_mod", "s_in_w", "s_in_b", "s_out_w", "s_out_b", "s_ln_g", "s_ln_b", "freq",
     "kmask", "f_mod", "f_w1", "f_b1", "f_w2", "f_b2", "f_ln_g", "f_ln_b")] + [("F", _i)])
+DnLayerParams = _struct("DnLayerParams", [("cross", DnCrossParams), ("rest", DnRestParams)])
 DnTailParams = _struct("DnTailParams", [(n, _p) for n in (
     "pos_w0", "pos_b0", "pos_w1", "pos_b1", "rot_w0", "rot_b0", "rot_w1", "rot_b1", "noise", "cond_data", "cond_mask", "coef_pos",
     "coef_rot")])
@@ -89,6 +90,9 @@ SIGNATURES = {
     "a3d_dn_cross": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_dn_rest": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_dn_tail": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "a3d_dn_persist_splits": (_i, [_i, _i]),
+    "a3d_dn_persist_sync_ints": (_z, [_i, _i, _i]),
+    "a3d_dn_persist": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "a3d_rope_rows_f32": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
     "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),

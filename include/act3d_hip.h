@@ -381,6 +381,25 @@ int a3d_dn_rest(const float* x_in, const float* traj, int D, const float* ws, co
 /* regressors + trajectory update + DDPM reverse step t_step: traj ([B][L][D]) -> traj_out */
 int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D, const a3d_dn_tail_params* p,
                 float* traj_out, int B, int L, int E, int t_step, void* stream);
+/* ---- persistent sampler: nsteps consecutive denoise steps t_first, t_first - 1, ... of one trajectory batch in ONE launch
+ *      (diffusion_model.py:86-119: the loop body `out = prediction_head(...); trajectory = scheduler.step(...)`).  Two workgroup
+ *      roles: one workgroup per trajectory runs that sample's chain (head, per layer q-projection / combine / layer remainder, tail,
+ *      DDPM step) across layers AND steps; the remaining CUs stream the cached context K / V for whichever (sample, layer) is ready.
+ *      layers_dev: DEVICE array of n_traj + n_pos + n_rot entries in stack order (trajectory, position, rotation; diffusion_head.py:
+ *      343-357), whose cross.mod / rest.s_mod / rest.f_mod are the BASES of the [T][2E] AdaLN tables (row t is used at step t), and
+ *      tail->noise is the BASE of the [T][B][L][D] step noise.  traj is updated in place.  qbuf: B * 16 * 128 floats; part:
+ *      a3d_dn_cross_ws_floats(B, H, a3d_dn_persist_splits(H, nsplit)) floats; sync: a3d_dn_persist_sync_ints(..) ints (zeroed by the
+ *      call; sync[2] != 0 afterwards = a wait exceeded its bound and the launch gave up: the trajectory is then invalid).
+ *      Needs B + 16 <= the device's CU count (all workgroups are co-resident); otherwise A3D_ERR_ARG -> use the per-phase entry points. */
+typedef struct {
+  a3d_dn_cross_params cross;
+  a3d_dn_rest_params rest;
+} a3d_dn_layer_params;
+int a3d_dn_persist_splits(int H, int nsplit);
+size_t a3d_dn_persist_sync_ints(int B, int n_layers, int nsteps);
+int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos, int n_rot, const a3d_dn_head_params* head,
+                   const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, int* sync, int B, int L, int D, int E, int H,
+                   int S, int Sp, int nsplit, int t_first, int nsteps, void* stream);
 /* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dbg_dn_prof(long long* out18);
 /* development aid: arm / disarm the phase timestamps (100 MHz ticks) of workgroup (0, 0) of a3d_sq_attn_bwd's key pass and read the
