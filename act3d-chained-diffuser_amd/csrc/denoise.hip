@@ -871,6 +871,13 @@ __device__ __forceinline__ const DnPersist& dnp_args(const DnPersist* p) {
   return *p;
 }
 
+// the same for the shape scalars: every per-thread index expression (i / E, i % E, row / column offsets ...) of the inlined phase
+// helpers is invariant across the step / layer loops, and hoisted to the role's prologue they are hundreds of live VGPRs (398 spills)
+__device__ __forceinline__ int dnp_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return __builtin_amdgcn_readfirstlane(v);          // uniform again (a scalar register) as far as the compiler is concerned
+}
+
 // ---- stream role
 __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem) {
   const DnPersist& a = dnp_args(ap);
@@ -1060,21 +1067,27 @@ constexpr int DNP_LDS_FLOATS = DR * (4 * LDX + LDQK + LDH) + DN_PS + 2 * DR * LD
 // ---- sample role
 __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem) {
   const DnPersist& a = dnp_args(ap);
-  float* Xs = smem;
-  float* As = Xs + DR * LDX;
-  float* Bs = As + DR * LDX;
-  float* Ts = Bs + DR * LDX;
-  float* QK = smem + 4 * DR * LDX;
-  float* Hs = QK + DR * LDQK;
-  float* Ps = Hs + DR * LDH;
-  float* Xt = Ps + DN_PS;                    // x after the trajectory stack (start of the position and the rotation stack)
-  float* Pf = Xt + DR * LDX;                 // position features
-  float* Tr = Pf + DR * LDX;                 // [16][16] the sample's trajectory rows (D <= 16 channels)
-  int* shi = reinterpret_cast<int*>(Tr + 256);
-  DnOpTable* tab = reinterpret_cast<DnOpTable*>(Tr + 256 + 16);
+  float* smem0 = smem;
+  float *Xs, *As, *Bs, *Ts, *QK, *Hs, *Ps, *Xt, *Pf, *Tr;
+  int* shi;
+  DnOpTable* tab;
   const int b = blockIdx.x, t = threadIdx.x;
-  const int L = a.L, D = a.D, E = a.E, H = a.H;
-  const int Epad = (E + 15) & ~15;
+  const int L0 = a.L, D0 = a.D, E0 = a.E, H0 = a.H;
+  int L, D, E, H, Epad;
+  // LDS map + shape scalars, re-derived from opaque values at every phase (see dnp_opaque)
+#define DNP_REFRESH()                                                                                                        \
+  do {                                                                                                                       \
+    smem = smem0 + dnp_opaque(0);                                                                                            \
+    Xs = smem; As = Xs + DR * LDX; Bs = As + DR * LDX; Ts = Bs + DR * LDX;                                                   \
+    QK = smem + 4 * DR * LDX; Hs = QK + DR * LDQK; Ps = Hs + DR * LDH;                                                       \
+    Xt = Ps + DN_PS;              /* x after the trajectory stack (start of the position and the rotation stack) */        \
+    Pf = Xt + DR * LDX;           /* position features */                                                                   \
+    Tr = Pf + DR * LDX;           /* [16][16] the sample's trajectory rows (D <= 16 channels) */                            \
+    shi = reinterpret_cast<int*>(Tr + 256);                                                                                  \
+    tab = reinterpret_cast<DnOpTable*>(Tr + 256 + 16);                                                                       \
+    L = dnp_opaque(L0); D = dnp_opaque(D0); E = dnp_opaque(E0); H = dnp_opaque(H0); Epad = (E + 15) & ~15;                   \
+  } while (0)
+  DNP_REFRESH();
   const int NL = a.n_traj + a.n_pos + a.n_rot;
   const int nse = a.nsplit * a.nsub;
   const float* Op = a.part;
@@ -1088,6 +1101,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   __syncthreads();
   for (int step = 0; step < a.nsteps; ++step) {
     const int t_step = a.t_first - step;
+    DNP_REFRESH();
     // ================= head: trajectory encoder [+ attention over the instruction tokens]   (dn_head_kernel)
     {
       const a3d_dn_head_params& p = dnp_args(ap).head;
@@ -1118,7 +1132,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
     // ================= layers
     for (int l = 0; l < NL; ++l) {
       const int gl = step * NL + l;
-      const DnLayerDev& lay = dnp_args(ap).layers[l];
+      DNP_REFRESH();
       if (l == a.n_traj) {                                        // start of the position stack: keep x for the rotation stack
         for (int i = t; i < DR * LDX; i += blockDim.x) Xt[i] = Xs[i];
         __syncthreads();
@@ -1146,6 +1160,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
           __hip_atomic_store(&a.sync[dnp_queue0(a.B) + slot], 1 + gl * a.B + b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      DNP_REFRESH();
       // ---- (2) while the streamers work: this layer's vectors -> LDS, weights touched in L2, pads, operation table
       {
         const a3d_dn_rest_params& p = dnp_args(ap).layers[l].r;
@@ -1180,6 +1195,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
           for (int i = t; i < DR * padw; i += blockDim.x) Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
         }
       }
+      DNP_REFRESH();
       // ---- (3) wait for the layer's nsplit items of this sample
       if (t == 0) shi[0] = dnp_wait_ge(&a.sync[DNP_XDONE0 + 16 * b], (gl + 1) * a.nsplit, abort_flag, a.spin_limit) ? 1 : 0;
       __syncthreads();
@@ -1203,9 +1219,11 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         As[r * LDX + c] = den > 0.f ? num / den : 0.f;
       }
       __syncthreads();
+      DNP_REFRESH();
       // ---- (5) out-proj + LayerNorm, self-attention block, FFN block
       dnp_run_ops(smem, *tab, L, D, E, H);
     }
+    DNP_REFRESH();
     // ================= tail: regressors, trajectory update, DDPM reverse step   (dn_tail_kernel; Pf = position, Xs = rotation features)
     {
       const a3d_dn_tail_params& p = dnp_args(ap).tail;

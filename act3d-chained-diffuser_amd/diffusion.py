@@ -380,7 +380,81 @@ class DiffusionHead(nn.Module):
         nws = O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"])
         st["ws"] = torch.empty((nws,), device=dev, dtype=torch.float32)
         st["ws_side"] = torch.empty((nws,), device=dev, dtype=torch.float32)      # rotation branch, concurrent
+        st["persist"] = self._build_persist(st, B, H, E, Sp, time_sin.shape[0], dev) if DN_PERSIST else None
         return st
+
+    def _build_persist(self, st, B, H, E, Sp, T, dev):
+        """State of the persistent sampler (a3d_dn_persist: the whole denoise loop as one launch, csrc/denoise.hip): the device
+        table of per-layer parameter blocks (AdaLN tables by their base: the kernel indexes them with the step), the query /
+        partial exchange buffers and the synchronisation words.  None when the batch leaves too few CUs for the streaming role."""
+        import ctypes
+        Lb = O.L
+        lib = Lb.load()
+        if B + 16 > torch.cuda.get_device_properties(dev).multi_processor_count or H > 8:
+            return None
+        recs = st["layers"]
+        table = (Lb.DnLayerParams * len(recs))()
+        for i, rec in enumerate(recs):
+            lay, mods, ff = rec["lay"], rec["mods"], rec["lay"].ffn_12
+            table[i].cross = Lb.DnCrossParams(
+                sem=st["sem"].data_ptr(), mod=mods[0].data_ptr(), q_w=lay.cross_12.in_proj_weight.data_ptr(),
+                q_b=lay.cross_12.in_proj_bias.data_ptr(), freq=st["freq"].data_ptr(), Kf=rec["Kf"].data_ptr(), Vt=rec["Vt"].data_ptr())
+            table[i].rest = Lb.DnRestParams(
+                c_out_w=lay.cross_12.out_proj.weight.data_ptr(), c_out_b=lay.cross_12.out_proj.bias.data_ptr(),
+                c_ln_g=lay.norm_12.weight.data_ptr(), c_ln_b=lay.norm_12.bias.data_ptr(), sem=st["sem"].data_ptr(),
+                s_mod=mods[1].data_ptr(), s_in_w=lay.sa1.in_proj_weight.data_ptr(), s_in_b=lay.sa1.in_proj_bias.data_ptr(),
+                s_out_w=lay.sa1.out_proj.weight.data_ptr(), s_out_b=lay.sa1.out_proj.bias.data_ptr(),
+                s_ln_g=lay.norm_1.weight.data_ptr(), s_ln_b=lay.norm_1.bias.data_ptr(), freq=st["freq"].data_ptr(),
+                kmask=None if st["kmask"] is None else st["kmask"].data_ptr(), f_mod=mods[2].data_ptr(), f_w1=ff[0].weight.data_ptr(),
+                f_b1=ff[0].bias.data_ptr(), f_w2=ff[3].weight.data_ptr(), f_b2=ff[3].bias.data_ptr(),
+                f_ln_g=lay.norm_122.weight.data_ptr(), f_ln_b=lay.norm_122.bias.data_ptr(), F=ff[0].weight.shape[0])
+        raw = bytes(memoryview(table))
+        nsplit = max(1, min(DN_PERSIST_SPLIT, Sp // 64))
+        nse = lib.a3d_dn_persist_splits(H, nsplit)
+        n_layers = len(recs)
+        return {
+            "table": torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev),
+            "nsplit": nsplit,
+            "qbuf": torch.zeros((B * 16 * 128,), device=dev, dtype=torch.float32),
+            "part": torch.empty((lib.a3d_dn_cross_ws_floats(B, H, nse),), device=dev, dtype=torch.float32),
+            "sync": torch.zeros((lib.a3d_dn_persist_sync_ints(B, n_layers, T),), device=dev, dtype=torch.int32),
+            "stacks": (len(self.traj_attention[0].layers), len(self.pos_attention[0].layers), len(self.rot_attention[0].layers)),
+        }
+
+    @torch.no_grad()
+    def fused_persist(self, st, traj, t_first, nsteps, step_noise, cond_data, cond_mask_u8, tb):
+        """nsteps consecutive denoise steps t_first, t_first - 1, ... (network evaluation + DDPM reverse step each) as ONE launch of
+        the persistent sampler; returns the trajectory after the last of them (a new tensor).  step_noise: the (T, B, L, D) table."""
+        Lb = O.L
+        ps = st["persist"]
+        B, Ln, D = traj.shape
+        H = self.num_attn_heads
+        E = self.curr_gripper_embed.weight.shape[1]
+        hp = Lb.DnHeadParams(enc_w0=self.traj_encoder[0].weight.data_ptr(), enc_b0=self.traj_encoder[0].bias.data_ptr(),
+                             enc_w1=self.traj_encoder[3].weight.data_ptr(), enc_b1=self.traj_encoder[3].bias.data_ptr(),
+                             sem=st["sem"].data_ptr(), lang_kv=None if st["lang_kv"] is None else st["lang_kv"].data_ptr(),
+                             S_lang=st.get("S_lang", 0))
+        if st["lang_kv"] is not None:
+            ll = self.traj_lang_attention[0].layers[0]
+            hp.q_w, hp.q_b = ll.cross_12.in_proj_weight.data_ptr(), ll.cross_12.in_proj_bias.data_ptr()
+            hp.out_w, hp.out_b = ll.cross_12.out_proj.weight.data_ptr(), ll.cross_12.out_proj.bias.data_ptr()
+            hp.ln_g, hp.ln_b = ll.norm_12.weight.data_ptr(), ll.norm_12.bias.data_ptr()
+        pr, rr = self.pos_regressor[0], self.rot_regressor[0]
+        tp = Lb.DnTailParams(pos_w0=pr[0].weight.data_ptr(), pos_b0=pr[0].bias.data_ptr(), pos_w1=pr[3].weight.data_ptr(),
+                             pos_b1=pr[3].bias.data_ptr(), rot_w0=rr[0].weight.data_ptr(), rot_b0=rr[0].bias.data_ptr(),
+                             rot_w1=rr[3].weight.data_ptr(), rot_b1=rr[3].bias.data_ptr(), noise=step_noise.data_ptr(),
+                             cond_data=cond_data.data_ptr(), cond_mask=cond_mask_u8.data_ptr(), coef_pos=tb.coef_pos.data_ptr(),
+                             coef_rot=tb.coef_rot.data_ptr())
+        out = traj.clone()
+        self._last_persist = ps                      # tests read the abort word (sync[2]) after synchronising
+        nt, npos, nrot = ps["stacks"]
+        Lb.call("a3d_dn_persist", ps["table"].data_ptr(), nt, npos, nrot, C_byref(hp), C_byref(tp), out.data_ptr(), ps["qbuf"].data_ptr(),
+                ps["part"].data_ptr(), ps["sync"].data_ptr(), B, Ln, D, E, H, st["S"], st["Sp"], ps["nsplit"], int(t_first), int(nsteps),
+                Lb.stream())
+        if DN_PERSIST_CHECK:
+            if int(ps["sync"][2].item()) != 0:
+                raise RuntimeError("a3d_dn_persist gave up waiting (sync[2] != 0): the trajectory is invalid")
+        return out
 
     @torch.no_grad()
     def fused_step(self, st, traj, t, noise, cond_data, cond_mask_u8, tb):
@@ -467,6 +541,11 @@ class DiffusionHead(nn.Module):
 # (B x H = 512) 1 split 0.924 ms per denoise step, 2 splits 0.955, 4 splits 1.04, 8 splits 1.20
 DN_TARGET_WGS = int(os.environ.get("A3D_DN_TARGET_WGS", "512"))
 FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
+# the sampling loop as ONE launch of the persistent two-role kernel (a3d_dn_persist); A3D_DN_PERSIST=0: one launch per phase
+# (head, per layer cross + rest, tail: 18 per step).  A3D_DN_PERSIST_SPLIT: key splits per (sample, layer) = items of the ready queue.
+DN_PERSIST = os.environ.get("A3D_DN_PERSIST", "1") == "1"
+DN_PERSIST_SPLIT = int(os.environ.get("A3D_DN_PERSIST_SPLIT", "8"))
+DN_PERSIST_CHECK = os.environ.get("A3D_DN_PERSIST_CHECK", "0") == "1"      # synchronise and check the abort word after every launch
 _DN_SIDE = {}
 
 
@@ -628,20 +707,26 @@ class DiffusionPlanner(nn.Module):
             tmask = trajectory_mask.bool()
         elif fused:
             state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln)
-            static = state["tensors"]
+            static = list(state["tensors"])
         else:
             state = head.build_kv_cache(ctx, ctx_xyz, instr)
             static = [c[k] for c in state["ctx"] for k in ("Ks", "Vt")] + \
                 ([state["lang"]["Ks"], state["lang"]["Vt"]] if "lang" in state else [])
         static = static + [step_noise, cond_data, cond_mask_u8, kmask]
 
+        persist = fused and state.get("persist") is not None and all(a_ - b_ == 1 for a_, b_ in zip(steps, steps[1:]))
+
         def run_loop(x):
+            if persist and not return_trace:                # the whole loop: one launch
+                return head.fused_persist(state, x, steps[0], len(steps), step_noise, cond_data, cond_mask_u8, tb)
             for t in steps:
                 nz = step_noise[t] if t > 0 else None
                 if multi:
                     tt = torch.full((B,), t, device=dev, dtype=torch.long)
                     out = head.forward_multi(x, tmask, tt, toks, xyzs, instruction, cg, gg)[-1]
                     x = O.ddpm_step(out, x, nz, cond_data, cond_mask_u8, tb.coef_pos, tb.coef_rot, t)
+                elif persist:                              # traced: the same kernel, one step per launch
+                    x = head.fused_persist(state, x, t, 1, step_noise, cond_data, cond_mask_u8, tb)
                 elif fused:
                     x = head.fused_step(state, x, t, nz, cond_data, cond_mask_u8, tb)
                 else:
@@ -661,7 +746,8 @@ class DiffusionPlanner(nn.Module):
                     run_loop(static_in)                     # warm-up (allocator, lazy module state) outside capture
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                self._graph = {"key": key, "in": static_in, "static": static}
+                # "state" keeps every buffer the captured launches address alive (workspaces, the persistent sampler's tables)
+                self._graph = {"key": key, "in": static_in, "static": static, "state": state}
                 with torch.cuda.graph(g):
                     self._graph["out"] = run_loop(static_in)
                 self._graph["g"] = g

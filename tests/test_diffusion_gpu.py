@@ -157,6 +157,49 @@ def test_fused_denoise_step_equals_op_by_op_path(setup, dev):
     scale_close("fused vs op-by-op final pose", fa, fb, 2e-5)
 
 
+@pytest.mark.parametrize("B,Ln,n_steps", [(3, 16, 100), (64, 16, 12), (5, 7, 9)])
+def test_persistent_sampler_equals_per_phase_launches(a3d, dev, B, Ln, n_steps):
+    """a3d_dn_persist (the whole denoise loop as ONE launch: one workgroup per trajectory walks head / layers / tail across the
+    steps, the other CUs stream the cached context for whichever (sample, layer) is ready) against the per-phase launches
+    (a3d_dn_head / a3d_dn_cross / a3d_dn_rest / a3d_dn_tail, 18 per step): same arithmetic up to the summation order of the
+    query projection and of the key-split combine.  Full loop in one launch, the traced variant (one step per launch) state by
+    state, the abort word stays zero, and a second launch reproduces the first bit for bit."""
+    r = load("diffusion.pt")
+    E, ncam = 120, 3
+    m = a3d.DiffusionPlanner(embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+    m.load_state_dict(_diffusion_params(r), strict=False)
+    m.to(dev).eval()
+    inp = C.trajectory_inputs(91, B, Ln, ncam, E, pad_last=3 if Ln > 8 else 1)
+    tokens = C.tokens_from_maps(inp["fmap"]).to(dev)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    D = a3d.diffusion
+
+    def run(persist, **kw):
+        keep = D.DN_PERSIST
+        D.DN_PERSIST = persist
+        try:
+            out = m.compute_trajectory(d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"], init_noise=d["init_noise"],
+                                       step_noise=d["step_noise"], visual_tokens=tokens, n_steps=n_steps, **kw)
+            torch.cuda.synchronize()
+            if persist:
+                ps = m.prediction_head._last_persist
+                assert ps is not None and int(ps["sync"][2].item()) == 0, "the persistent sampler gave up waiting"
+            return out
+        finally:
+            D.DN_PERSIST = keep
+
+    ref, ref_trace = run(False, return_trace=True)
+    got = run(True)
+    scale_close(f"persistent vs per-phase, {n_steps} steps in one launch", got, ref, 5e-5)
+    assert torch.equal(run(True), got), "the persistent sampler is not run-to-run deterministic"
+    got_t, trace = run(True, return_trace=True)
+    for i in sorted(set([0, 1, n_steps // 2, n_steps - 1])):
+        scale_close(f"persistent (traced) vs per-phase state after step {i}", trace[i], ref_trace[i], 5e-5)
+    scale_close("persistent traced vs one launch", got_t, got, 1e-6)
+
+
 def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
     """attn_rounds = 2 x feat_scales_to_use = 2, untied module sets, goal-conditioned (diffusion_head.py:249-275) against
     tests/golden/diffusion_multi.pt: the four chained predictions, the find_traj_nn neighbourhoods (a3d_traj_nn_topk), the
