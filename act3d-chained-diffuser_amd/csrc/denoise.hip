@@ -839,15 +839,23 @@ struct DnPersist {
   float* traj;                    // [B][L][D] in / out
   float* qbuf;                    // [B][16][128] published queries of the sample's current layer
   float* part;                    // Op [nse][B][H][16][16] | Mp [nse][B][H][16]   (nse = nsplit * nsub)
-  int* sync;                      // [0] ticket  [1] queue tail  [2] abort  | [16 + 16 b] completion counter of sample b | queue
-  int B, L, D, E, H, S, Sp, nsplit, nsub, n_traj, n_pos, n_rot, t_first, nsteps, spin_limit;
+  int* sync;                      // [0] ticket  [1] queue tail  [2] abort  | [16 + 16 u] completion counter of unit u |
+                                  // [.. + 16 b] self-attention exchange counter of sample b | ready queue
+  float* kvx;                     // [B][2][NT * 16][2E] rotated keys | values of the self-attention, exchanged between a sample's row tiles
+                                  // (NT > 1 only; two buffers alternate from layer to layer)
+  int B, L, NT, D, E, H, S, Sp, nsplit, nsub, n_traj, n_pos, n_rot, t_first, nsteps, spin_limit;
+  long long* prof;                // development aid (A3D_DN_PROF=1): phase timestamps, see a3d_dn_persist_prof; else NULL
 };
+constexpr int DNP_PROF_WORDS = 256;      // long longs: [0, 96) 32 items x {ticket, ready, done} of streamer 0; [96, 96 + 7 * 16) layer marks of sample 0; [250..] head / tail
+// A trajectory of L <= 64 steps is NT = ceil(L / 16) row tiles; a UNIT = (sample b, tile) = one sample-role workgroup, u = b NT + tile.
+// Every row-wise operation (encoder, cross-attention queries / partials, projections, LayerNorm, FFN, regressors, DDPM step) is the
+// unit's own; only the self-attention couples the tiles of a sample: they exchange their rotated keys / values through kvx.
 constexpr int DNP_XDONE0 = 16;
-__device__ __forceinline__ int dnp_queue0(int B) { return DNP_XDONE0 + 16 * B; }
+__host__ __device__ __forceinline__ int dnp_kvdone0(int B, int NT) { return DNP_XDONE0 + 16 * B * NT; }
+__host__ __device__ __forceinline__ int dnp_queue0(int B, int NT) { return DNP_XDONE0 + 16 * B * NT + 16 * B; }
 
 // thread 0 of the workgroup spins until *flag >= target (acquire, agent scope); returns false when the kernel is aborting
-// (the polls are RELAXED loads -- an acquire per poll would invalidate the XCD's L2 under the streamers' feet -- and ONE acquire
-// fence follows the successful poll)
+// (the polls are RELAXED agent-scope loads; no acquire fence follows: see dnp_ld)
 __device__ __forceinline__ bool dnp_wait_ge(int* flag, int target, int* abort_flag, int spin_limit) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -860,8 +868,16 @@ __device__ __forceinline__ bool dnp_wait_ge(int* flag, int target, int* abort_fl
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return true;
+}
+// Exchange data (published queries, attention partials) is READ with agent-scope relaxed atomic word loads: they are served from the
+// coherence point whatever stale copy the reader's XCD L2 may hold (the flag polls above are the same kind of load and do observe
+// the other role's stores), so the reader needs NO acquire fence.  An agent-scope acquire invalidates the XCD's L2: with one per
+// queue item (512 per layer round) the layer weights the sample role streams from L2 were evicted continuously and the layer
+// remainder ran at Infinity-Cache latency (measured: 1.01 ms per denoise step with the fences vs 0.86 ms for the per-phase launches).
+// Writers publish with plain stores + workgroup barrier + agent-scope RELEASE (L2 write-back of a few KB) + the flag store.
+__device__ __forceinline__ float dnp_ld(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // The argument block is re-read through an opaque copy of its pointer at every phase: otherwise the compiler hoists ALL its (loop-
@@ -885,42 +901,47 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int NL = a.n_traj + a.n_pos + a.n_rot;
-  const long long total = (long long)a.nsteps * NL * a.B * a.nsplit;
+  const int U = a.B * a.NT;
+  const long long total = (long long)a.nsteps * NL * U * a.nsplit;
   const int nse = a.nsplit * a.nsub;
   float* Op = a.part;
-  float* Mp = a.part + (size_t)nse * a.B * a.H * 256;
+  float* Mp = a.part + (size_t)nse * U * a.H * 256;
   int* abort_flag = a.sync + 2;
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  int nprof = 0;
   for (;;) {
     __syncthreads();                                     // everybody has read the previous item's sh[]
+    long long tk0 = 0;
     if (t == 0) {
+      if (a.prof) tk0 = wall_clock64();
       const long long i = (long long)atomicAdd(&a.sync[0], 1);
       int code = 0;
       if (i < total) {
-        int* slot = a.sync + dnp_queue0(a.B) + (int)(i / a.nsplit);
+        int* slot = a.sync + dnp_queue0(a.B, a.NT) + (int)(i / a.nsplit);
         if (dnp_wait_ge(slot, 1, abort_flag, a.spin_limit)) code = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       sh[0] = i < total ? (int)(i % a.nsplit) : -1;
       sh[1] = code;
+      if (a.prof && (int)blockIdx.x == U && nprof < 32) { a.prof[nprof * 3] = tk0; a.prof[nprof * 3 + 1] = wall_clock64(); }
     }
     __syncthreads();
     const int sp = sh[0], code = sh[1];
     if (sp < 0 || code == 0) break;
-    const int gl = (code - 1) / a.B, b = (code - 1) - gl * a.B;
+    const int gl = (code - 1) / U, b = (code - 1) - gl * U;          // b: the UNIT; its sample = b / NT
     const a3d_dn_cross_params& c = dnp_args(ap).layers[gl % NL].c;
     if (wave < a.H * a.nsub) {
       const int h = wave % a.H, sub = wave / a.H;
       const int se = sp * a.nsub + sub;
-      const size_t bh = (size_t)b * a.H + h;
+      const size_t bh = (size_t)(b / a.NT) * a.H + h;
       const float* qrow = a.qbuf + ((size_t)b * 16 + li) * 128 + h * HD;       // rows >= L and columns >= E are published as zeros
       float4 qb;                                         // B operand: channel 4 g + j of query li (channel 15 = pad)
-      qb.x = qrow[4 * g + 0];
-      qb.y = qrow[4 * g + 1];
-      qb.z = qrow[4 * g + 2];
-      qb.w = (4 * g + 3 < HD) ? qrow[4 * g + 3] : 0.f;
+      qb.x = dnp_ld(qrow + 4 * g + 0);
+      qb.y = dnp_ld(qrow + 4 * g + 1);
+      qb.z = dnp_ld(qrow + 4 * g + 2);
+      qb.w = (4 * g + 3 < HD) ? dnp_ld(qrow + 4 * g + 3) : 0.f;
       const int NH = a.Sp >> 5;
       const int h_beg = (int)((long long)NH * se / nse), h_end = (int)((long long)NH * (se + 1) / nse);
       const float* Kb = c.Kf + bh * (size_t)a.Sp * 16;
@@ -931,10 +952,15 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       auto load = [&](int hf) {
         Frag f;
         const int key0 = hf * 32;
-        f.k0 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g);
-        f.k1 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g);
-        f.vh = *reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8);
-        f.vl = *reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8);
+        // non-temporal: the K / V stream (205 MB per layer round) is read once -- it must not push the layer weights the sample
+        // role re-reads every layer out of the 4 MB L2s
+        typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
+        const nt_f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g));
+        const nt_f32x4 a1 = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g));
+        f.k0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        f.k1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        f.vh = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8));
+        f.vl = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8));
         return f;
       };
       float m_run = -INFINITY;
@@ -992,7 +1018,7 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
         acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
       }
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
-      const size_t row0 = (((size_t)se * a.B + b) * a.H + h) * 16;
+      const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
       *reinterpret_cast<float4*>(&Op[(row0 + li) * 16 + 4 * g]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       if (g == 0) Mp[row0 + li] = m_run;
     }
@@ -1000,12 +1026,22 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
     if (t == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.prof && (int)blockIdx.x == U && nprof < 32) { a.prof[nprof * 3 + 2] = wall_clock64(); ++nprof; }
     }
   }
 }
 
+// what the self-attention of a multi-tile trajectory needs beyond the unit's own LDS tiles
+struct DnpTiles {
+  float* kvx;                    // this sample's [2][NT * 16][2E] exchange buffers
+  int* kvdone;                   // this sample's counter
+  int* abort_flag;
+  const unsigned char* kmask;    // this sample's [Lfull] key-padding mask or NULL
+  int NT, tile, Lfull, target, parity, spin_limit;
+};
+
 // the layer remainder's operation loop (the body of dn_rest_loop_kernel's table walk, without the phase probe)
-__device__ __forceinline__ void dnp_run_ops(float* smem, const DnOpTable& tab, int L, int D, int E, int H) {
+__device__ __forceinline__ bool dnp_run_ops(float* smem, const DnOpTable& tab, int L, int D, int E, int H, const DnpTiles& tl) {
 #pragma nounroll
   for (int i = 0; i < tab.n; ++i) {
     const DnOp& op = tab.op[i];
@@ -1034,23 +1070,75 @@ __device__ __forceinline__ void dnp_run_ops(float* smem, const DnOpTable& tab, i
         const float* V = smem + op.c;
         float* O = smem + op.e;
         const int r = (threadIdx.x >> 4) & 15, h = threadIdx.x & 15;
-        if (threadIdx.x < 256 && h < H) {
-          float q[HD], acc[HD];
+        const bool worker = threadIdx.x < 256 && h < H;
+        float q[HD], acc[HD];
 #pragma unroll
-          for (int d = 0; d < HD; ++d) { q[d] = Q[r * LDQK + h * HD + d]; acc[d] = 0.f; }
-          float m = -INFINITY, l = 0.f;
-          for (int s2 = 0; s2 < L; ++s2) {
-            if (mk[s2] != 0.f) continue;
-            float sc = 0.f;
+        for (int d = 0; d < HD; ++d) { q[d] = worker ? Q[r * LDQK + h * HD + d] : 0.f; acc[d] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+        if (tl.NT == 1) {
+          if (worker) {
+            for (int s2 = 0; s2 < L; ++s2) {
+              if (mk[s2] != 0.f) continue;
+              float sc = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) sc += q[d] * Kk[s2 * LDQK + h * HD + d];
-            const float mn = fmaxf(m, sc);
-            const float al = __expf(m - mn), pw = __expf(sc - mn);
-            l = l * al + pw;
+              for (int d = 0; d < HD; ++d) sc += q[d] * Kk[s2 * LDQK + h * HD + d];
+              const float mn = fmaxf(m, sc);
+              const float al = __expf(m - mn), pw = __expf(sc - mn);
+              l = l * al + pw;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * al + pw * V[s2 * LDH + h * HD + d];
-            m = mn;
+              for (int d = 0; d < HD; ++d) acc[d] = acc[d] * al + pw * V[s2 * LDH + h * HD + d];
+              m = mn;
+            }
           }
+        } else {
+          // ---- multi-tile trajectory: the keys are all L rows of the SAMPLE.  Publish this tile's rotated keys / values, wait for
+          // the sample's other tiles, then walk the tiles (staged through two idle row tiles) with one running softmax state
+          float* Kc = smem + 2 * DR * LDX;                 // Bs: the value stream's AdaLN output, consumed by the v projection
+          float* Vc = smem + 3 * DR * LDX;                 // Ts: written next by the out projection
+          const int ldkv = 2 * E;
+          float* mine = tl.kvx + ((size_t)tl.parity * tl.NT * 16 + (size_t)tl.tile * 16) * ldkv;
+          for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
+            const int rr = i / E, c = i - rr * E;
+            mine[rr * ldkv + c] = Kk[rr * LDQK + c];
+            mine[rr * ldkv + E + c] = V[rr * LDH + c];
+          }
+          __syncthreads();
+          int* ok = reinterpret_cast<int*>(smem + 4 * DR * LDX);       // q | k tile's first word: q is in registers, k is published
+          if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(tl.kvdone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            *ok = dnp_wait_ge(tl.kvdone, tl.target, tl.abort_flag, tl.spin_limit) ? 1 : 0;
+          }
+          __syncthreads();
+          if (*ok == 0) return false;
+          __syncthreads();
+          for (int tt = 0; tt < tl.NT; ++tt) {
+            const float* src = tl.kvx + ((size_t)tl.parity * tl.NT * 16 + (size_t)tt * 16) * ldkv;
+            for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
+              const int rr = i / E, c = i - rr * E;
+              Kc[rr * LDX + c] = dnp_ld(src + rr * ldkv + c);
+              Vc[rr * LDX + c] = dnp_ld(src + rr * ldkv + E + c);
+            }
+            __syncthreads();
+            const int nk = min(16, tl.Lfull - tt * 16);
+            if (worker) {
+              for (int s2 = 0; s2 < nk; ++s2) {
+                if (tl.kmask && tl.kmask[tt * 16 + s2]) continue;
+                float sc = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) sc += q[d] * Kc[s2 * LDX + h * HD + d];
+                const float mn = fmaxf(m, sc);
+                const float al = __expf(m - mn), pw = __expf(sc - mn);
+                l = l * al + pw;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) acc[d] = acc[d] * al + pw * Vc[s2 * LDX + h * HD + d];
+                m = mn;
+              }
+            }
+            __syncthreads();
+          }
+        }
+        if (worker) {
           const float inv = l > 0.f ? 1.0f / l : 0.f;
 #pragma unroll
           for (int d = 0; d < HD; ++d) O[r * LDX + h * HD + d] = acc[d] * inv;
@@ -1060,6 +1148,7 @@ __device__ __forceinline__ void dnp_run_ops(float* smem, const DnOpTable& tab, i
       }
     }
   }
+  return true;
 }
 
 constexpr int DNP_LDS_FLOATS = DR * (4 * LDX + LDQK + LDH) + DN_PS + 2 * DR * LDX + 256 + 16 + 160;
@@ -1071,8 +1160,10 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   float *Xs, *As, *Bs, *Ts, *QK, *Hs, *Ps, *Xt, *Pf, *Tr;
   int* shi;
   DnOpTable* tab;
-  const int b = blockIdx.x, t = threadIdx.x;
-  const int L0 = a.L, D0 = a.D, E0 = a.E, H0 = a.H;
+  const int b = blockIdx.x, t = threadIdx.x;                  // b: the UNIT (sample bs, row tile)
+  const int NT = a.NT, U = a.B * NT;
+  const int bs = b / NT, tile = b - bs * NT, r0 = tile * 16, Lf = a.L;
+  const int L0 = min(16, Lf - r0), D0 = a.D, E0 = a.E, H0 = a.H;      // L (below): the unit's own rows
   int L, D, E, H, Epad;
   // LDS map + shape scalars, re-derived from opaque values at every phase (see dnp_opaque)
 #define DNP_REFRESH()                                                                                                        \
@@ -1091,17 +1182,21 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   const int NL = a.n_traj + a.n_pos + a.n_rot;
   const int nse = a.nsplit * a.nsub;
   const float* Op = a.part;
-  const float* Mp = a.part + (size_t)nse * a.B * a.H * 256;
+  const float* Mp = a.part + (size_t)nse * U * a.H * 256;
   int* abort_flag = a.sync + 2;
+  int sa_count = 0;                                           // self-attention blocks this unit has been through (all steps)
+  long long* const prof = a.prof;
+#define DNP_MARK(slot) do { if (prof && b == 0 && t == 0 && step == 1) prof[slot] = wall_clock64(); } while (0)
   for (int i = t; i < 256; i += blockDim.x) {
     const int r = i >> 4, c = i & 15;
-    Tr[i] = (r < L && c < D) ? a.traj[((size_t)b * L + r) * D + c] : 0.f;
+    Tr[i] = (r < L && c < D) ? a.traj[((size_t)bs * Lf + r0 + r) * D + c] : 0.f;
   }
   for (int i = t; i < 4 * DR * LDX; i += blockDim.x) smem[i] = 0.f;          // pads of the four row tiles
   __syncthreads();
   for (int step = 0; step < a.nsteps; ++step) {
     const int t_step = a.t_first - step;
     DNP_REFRESH();
+    DNP_MARK(250);
     // ================= head: trajectory encoder [+ attention over the instruction tokens]   (dn_head_kernel)
     {
       const a3d_dn_head_params& p = dnp_args(ap).head;
@@ -1116,12 +1211,12 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
       wg_linear<0>(Ts, LDX, E, p.enc_w1, E, p.enc_b1, E, Xs, LDX);
       if (p.lang_kv) {
         wg_zero_pad(As, LDX, E, Epad);
-        wg_adaln(Xs, LDX, p.sem, nullptr, As, LDX, L, E);
+        wg_adaln(Xs, LDX, p.sem + (size_t)r0 * E, nullptr, As, LDX, L, E);
         wg_linear<0>(As, LDX, E, p.q_w, E, p.q_b, E, Qs, LDX);
         const float scale = 1.0f / sqrtf((float)HD);
         for (int i = t; i < DR * E; i += blockDim.x) Qs[(i / E) * LDX + i % E] *= scale;
         __syncthreads();
-        const float* kv = p.lang_kv + (size_t)b * p.S_lang * 2 * E;
+        const float* kv = p.lang_kv + (size_t)bs * p.S_lang * 2 * E;
         for (int i = t; i < p.S_lang * 2 * E; i += blockDim.x) kvS[i] = kv[i];
         __syncthreads();
         wg_small_attention(Qs, LDX, kvS, 2 * E, kvS + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
@@ -1133,6 +1228,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
     for (int l = 0; l < NL; ++l) {
       const int gl = step * NL + l;
       DNP_REFRESH();
+      DNP_MARK(96 + 7 * l + 0);
       if (l == a.n_traj) {                                        // start of the position stack: keep x for the rotation stack
         for (int i = t; i < DR * LDX; i += blockDim.x) Xt[i] = Xs[i];
         __syncthreads();
@@ -1145,9 +1241,10 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         const a3d_dn_cross_params& c = dnp_args(ap).layers[l].c;
         wg_zero_pad(As, LDX, E, Epad);
         wg_zero_pad(Ts, LDX, E, Epad);
-        wg_adaln(Xs, LDX, c.sem, c.mod ? c.mod + (size_t)t_step * 2 * E : nullptr, As, LDX, L, E);
+        wg_adaln(Xs, LDX, c.sem ? c.sem + (size_t)r0 * E : nullptr, c.mod ? c.mod + (size_t)t_step * 2 * E : nullptr, As, LDX, L, E);
         wg_linear<0>(As, LDX, E, c.q_w, E, c.q_b, E, Ts, LDX);
         wg_rope(Ts, LDX, 0, 1, Tr, 16, c.freq, L, E, 1.0f / sqrtf((float)HD));
+        DNP_MARK(96 + 7 * l + 1);
         float* qrow = a.qbuf + (size_t)b * 16 * 128;
         for (int i = t; i < 16 * 128; i += blockDim.x) {
           const int r = i >> 7, cc = i & 127;
@@ -1157,9 +1254,10 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         if (t == 0) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           const int slot = atomicAdd(&a.sync[1], 1);
-          __hip_atomic_store(&a.sync[dnp_queue0(a.B) + slot], 1 + gl * a.B + b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&a.sync[dnp_queue0(a.B, NT) + slot], 1 + gl * U + b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      DNP_MARK(96 + 7 * l + 2);
       DNP_REFRESH();
       // ---- (2) while the streamers work: this layer's vectors -> LDS, weights touched in L2, pads, operation table
       {
@@ -1172,17 +1270,17 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
                              p.s_in_w ? p.s_out_b : nullptr, p.s_in_w ? p.s_ln_g : nullptr, p.s_in_w ? p.s_ln_b : nullptr,
                              p.f_w1 ? f_mod : nullptr, p.f_w1 ? p.f_b1 : nullptr, p.f_w1 ? p.f_b2 : nullptr, p.f_w1 ? p.f_ln_g : nullptr},
                             {E, E, E, 2 * E, 3 * E, E, E, E, 2 * E, p.F, E, E}};
-        wg_stage_vectors(vl, vd, (p.sem && p.s_in_w) ? p.sem : nullptr, L * E, Ps + 2560);
+        wg_stage_vectors(vl, vd, (p.sem && p.s_in_w) ? p.sem + (size_t)r0 * E : nullptr, L * E, Ps + 2560);
         float* const misc = Ps + 2560 + DR * 128;
         if (p.f_w1 && t < E) Ps[2432 + t] = p.f_ln_b[t];
         if (p.s_in_w) {
           if (t < L * D) misc[t] = Tr[(t / D) * 16 + t % D];
           if (p.freq && t < E / 6) misc[160 + t] = p.freq[t];
-          if (t < DR) misc[192 + t] = (p.kmask && t < L && p.kmask[(size_t)b * L + t]) ? 1.f : 0.f;
+          if (t < DR) misc[192 + t] = (p.kmask && t < L && p.kmask[(size_t)bs * Lf + r0 + t]) ? 1.f : 0.f;
         }
         const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
                              {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
-        wg_warm_l2(wl, a.B);
+        wg_warm_l2(wl, U);
         if (t == 0) {
           a3d_dn_rest_params pl = p;
           pl.s_mod = s_mod;
@@ -1195,35 +1293,82 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
           for (int i = t; i < DR * padw; i += blockDim.x) Hs[(i / padw) * LDH + p.F + i % padw] = 0.f;
         }
       }
+      DNP_MARK(96 + 7 * l + 3);
       DNP_REFRESH();
       // ---- (3) wait for the layer's nsplit items of this sample
       if (t == 0) shi[0] = dnp_wait_ge(&a.sync[DNP_XDONE0 + 16 * b], (gl + 1) * a.nsplit, abort_flag, a.spin_limit) ? 1 : 0;
       __syncthreads();
       if (shi[0] == 0) return;
+      DNP_MARK(96 + 7 * l + 4);
       // ---- (4) combine the key splits -> As
       wg_zero_pad(As, LDX, E, Epad);
       wg_zero_pad(Ts, LDX, E, Epad);
-      for (int i = t; i < DR * E; i += blockDim.x) {
-        const int r = i / E, c = i - r * E;
-        const int h = c / HD, d = c - h * HD;
+      // one thread per (query row, head, channel quad): 16 x 8 x 4 = the workgroup's 512 threads.  The partials of all key splits
+      // are fetched with INDEPENDENT loads (fixed trip count, predicated, eight splits per batch) -- a loop over a run-time split
+      // count issues them one L2 round trip after the other, and this sits on the sample's critical path (measured: 8 splits cost
+      // 0.15 ms per denoise step more than 4 with the serial loop)
+      {
+        constexpr int NSE_MAX = 16;
+        const int r = t >> 5, h = (t >> 2) & 7, q = t & 3;
+        const bool on = h < H;
+        const size_t stride = (size_t)U * H * 16;                   // rows per split
+        const size_t row0 = ((size_t)b * H + (on ? h : 0)) * 16 + r;
+        float ms[NSE_MAX];
+#pragma unroll
+        for (int s = 0; s < NSE_MAX; ++s) ms[s] = (on && s < nse) ? dnp_ld(&Mp[row0 + s * stride]) : -INFINITY;
         float m = -INFINITY;
-        for (int s = 0; s < nse; ++s) m = fmaxf(m, Mp[(((size_t)s * a.B + b) * H + h) * 16 + r]);
+#pragma unroll
+        for (int s = 0; s < NSE_MAX; ++s) m = fmaxf(m, ms[s]);
         const float m_use = (m == -INFINITY) ? 0.f : m;
-        float num = 0.f, den = 0.f;
-        for (int s = 0; s < nse; ++s) {
-          const size_t row = (((size_t)s * a.B + b) * H + h) * 16 + r;
-          const float w = __expf(Mp[row] - m_use);
-          num += w * Op[row * 16 + d];
-          den += w * Op[row * 16 + 15];
+        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s0 = 0; s0 < NSE_MAX; s0 += 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (on && s0 + u < nse) {
+              const float* src = &Op[(row0 + (s0 + u) * stride) * 16 + 4 * q];
+              v[u] = make_float4(dnp_ld(src), dnp_ld(src + 1), dnp_ld(src + 2), dnp_ld(src + 3));
+            } else {
+              v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float w = (on && s0 + u < nse) ? __expf(ms[s0 + u] - m_use) : 0.f;
+            acc4.x += w * v[u].x; acc4.y += w * v[u].y; acc4.z += w * v[u].z; acc4.w += w * v[u].w;
+          }
         }
-        As[r * LDX + c] = den > 0.f ? num / den : 0.f;
+        const float den = __shfl(acc4.w, (t & 63) | 3, 64);          // channel 15 = sum_k p lives in the quad's last thread
+        const float inv = den > 0.f ? 1.0f / den : 0.f;
+        if (on) {
+          float* dst = &As[r * LDX + h * HD + 4 * q];
+          dst[0] = acc4.x * inv;
+          dst[1] = acc4.y * inv;
+          dst[2] = acc4.z * inv;
+          if (q < 3) dst[3] = acc4.w * inv;
+        }
       }
       __syncthreads();
+      DNP_MARK(96 + 7 * l + 5);
       DNP_REFRESH();
       // ---- (5) out-proj + LayerNorm, self-attention block, FFN block
-      dnp_run_ops(smem, *tab, L, D, E, H);
+      {
+        const a3d_dn_rest_params& p = dnp_args(ap).layers[l].r;
+        const bool has_sa = p.s_in_w != nullptr;
+        DnpTiles tl;
+        tl.kvx = a.kvx ? a.kvx + (size_t)bs * 2 * NT * 16 * 2 * E : nullptr;
+        tl.kvdone = a.sync + dnp_kvdone0(a.B, NT) + 16 * bs;
+        tl.abort_flag = abort_flag;
+        tl.kmask = p.kmask ? p.kmask + (size_t)bs * Lf : nullptr;
+        tl.NT = NT; tl.tile = tile; tl.Lfull = Lf; tl.target = NT * (sa_count + 1); tl.parity = sa_count & 1;
+        tl.spin_limit = a.spin_limit;
+        if (!dnp_run_ops(smem, *tab, L, D, E, H, tl)) return;
+        if (has_sa) ++sa_count;
+      }
+      DNP_MARK(96 + 7 * l + 6);
     }
     DNP_REFRESH();
+    DNP_MARK(251);
     // ================= tail: regressors, trajectory update, DDPM reverse step   (dn_tail_kernel; Pf = position, Xs = rotation features)
     {
       const a3d_dn_tail_params& p = dnp_args(ap).tail;
@@ -1236,7 +1381,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
       wg_linear<0>(Ts, LDX, E, p.rot_w1, E, p.rot_b1, D - 3, Us + 3, 16);
       for (int i = t; i < L * D; i += blockDim.x) {
         const int r = i / D, c = i - r * D;
-        const size_t gi = ((size_t)b * L + r) * D + c;
+        const size_t gi = ((size_t)bs * Lf + r0 + r) * D + c;
         const float old = Tr[r * 16 + c];
         float mo = Us[r * 16 + c] + (c < 3 ? old : 0.f);
         if (p.cond_mask && p.cond_mask[gi]) mo = p.cond_data[gi];
@@ -1245,12 +1390,13 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
           const float* cf = ((c < 3) ? p.coef_pos : p.coef_rot) + (size_t)t_step * 3;
           const float x0 = fminf(fmaxf(mo, -1.0f), 1.0f);
           out = cf[0] * x0 + cf[1] * old;
-          if (p.noise) out += cf[2] * p.noise[(size_t)t_step * a.B * L * D + gi];
+          if (p.noise) out += cf[2] * p.noise[(size_t)t_step * a.B * Lf * D + gi];
         }
         Tr[r * 16 + c] = out;
         a.traj[gi] = out;
       }
       __syncthreads();
+      DNP_MARK(252);
     }
   }
 }
@@ -1258,14 +1404,21 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
 // The argument block lives in device memory (behind the sync words) and is read field by field with scalar loads: passed by value
 // its ~120 SGPRs of pointers stay live across both roles and the register allocator spills hundreds of them through VGPR lanes
 // (measured at compile time: 884 SGPR + 974 VGPR spills, 3.5 KB of scratch per lane).  A one-wave kernel writes the block first.
-__global__ void dn_persist_args_kernel(DnPersist a, DnPersist* dst) {
-  const int n = (int)(sizeof(DnPersist) / sizeof(int));
-  const int* src = reinterpret_cast<const int*>(&a);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<int*>(dst)[i] = src[i];
+// It also zeroes the synchronisation words (ticket, queue tail, abort word, completion counters, ready queue).  A captured
+// hipMemsetAsync did that first: eager launches and the FIRST replay of a captured graph were right, every later replay ran on
+// stale counters (wrong trajectories, then a memory fault at 100 steps; profiles/r05_persist_graph_probe.txt) -- a kernel node
+// replays like every other launch of this library.
+__global__ __launch_bounds__(256) void dn_persist_args_kernel(DnPersist a, DnPersist* dst, int* sync, int words) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) sync[i] = 0;
+  if (blockIdx.x == 0) {
+    const int n = (int)(sizeof(DnPersist) / sizeof(int));
+    const int* src = reinterpret_cast<const int*>(&a);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<int*>(dst)[i] = src[i];
+  }
 }
-__global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int B) {
+__global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int U) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < B) dnp_sample_role(ap, smem);
+  if ((int)blockIdx.x < U) dnp_sample_role(ap, smem);
   else dnp_stream_role(ap, smem);
 }
 
@@ -1377,20 +1530,45 @@ static int dnp_nsub(int H) { return (H <= 8 && 8 % H == 0) ? 8 / H : 1; }
 
 extern "C" int a3d_dn_persist_splits(int H, int nsplit) { return nsplit * dnp_nsub(H); }
 
-extern "C" size_t a3d_dn_persist_sync_ints(int B, int n_layers, int nsteps) {
-  if (B <= 0 || n_layers <= 0 || nsteps <= 0) return 0;
-  const size_t words = (size_t)DNP_XDONE0 + (size_t)16 * B + (size_t)nsteps * n_layers * B;
-  return ((words + 3) & ~(size_t)3) + (sizeof(DnPersist) + sizeof(int) - 1) / sizeof(int);      // + the kernels' argument block
+static size_t dnp_words(int B, int L, int n_layers, int nsteps) {
+  const int NT = (L + DR - 1) / DR;
+  return (((size_t)dnp_queue0(B, NT) + (size_t)nsteps * n_layers * B * NT) + 3) & ~(size_t)3;
+}
+
+extern "C" size_t a3d_dn_persist_kvx_floats(int B, int L, int E) {
+  const int NT = (L + DR - 1) / DR;
+  return NT > 1 ? (size_t)B * 2 * NT * 16 * 2 * E : 0;
+}
+
+extern "C" size_t a3d_dn_persist_sync_ints(int B, int L, int n_layers, int nsteps) {
+  if (B <= 0 || L <= 0 || n_layers <= 0 || nsteps <= 0) return 0;
+  const size_t words = dnp_words(B, L, n_layers, nsteps);
+  return ((words + 3) & ~(size_t)3) + ((sizeof(DnPersist) + 15) / 16) * 4 + 2 * DNP_PROF_WORDS;      // + the argument block + phase probe
+}
+
+// development aid: the DNP_PROF_WORDS phase timestamps (100 MHz ticks) of the last a3d_dn_persist launch made with A3D_DN_PROF=1
+// (sync / B / n_layers / nsteps as passed to that launch); host buffer
+extern "C" int a3d_dn_persist_prof(const int* sync, int B, int L, int n_layers, int nsteps, long long* out256) {
+  if (!sync || !out256) { set_error("a3d_dn_persist_prof: null pointer"); return A3D_ERR_ARG; }
+  const size_t words = dnp_words(B, L, n_layers, nsteps);
+  const int* src = sync + words + ((sizeof(DnPersist) + 15) / 16) * 4;
+  hipError_t e = hipMemcpy(out256, src, DNP_PROF_WORDS * sizeof(long long), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { set_error("a3d_dn_persist_prof: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  return A3D_OK;
 }
 
 extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos, int n_rot, const a3d_dn_head_params* head,
-                              const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, int* sync, int B, int L, int D,
-                              int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream) {
-  int rc = dn_check("a3d_dn_persist", B, L, E, H);
-  if (rc) return rc;
+                              const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, float* kvx, int* sync, int B, int L,
+                              int D, int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream) {
+  int rc = A3D_OK;
+  if (B <= 0 || L <= 0 || L > 4 * DR || E <= 0 || E > 128 || (E % 6) != 0 || H * HD != E) {
+    set_error("a3d_dn_persist: bad shape (B=%d L=%d E=%d H=%d; L <= 64, E = 15 H <= 128)", B, L, E, H);
+    return A3D_ERR_ARG;
+  }
+  const int NT = (L + DR - 1) / DR, U = B * NT;
   static_assert(sizeof(a3d_dn_layer_params) == sizeof(DnLayerDev), "layer table layout");
-  if (!layers_dev || !head || !tail || !traj || !qbuf || !part || !sync || n_traj < 0 || n_pos < 1 || n_rot < 1 || D < 4 || D > 16 ||
-      L * D > DN_MISC_XYZ || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 || nsplit > 64 || H > 8 || nsteps < 1 || t_first < nsteps - 1 ||
+  if (!layers_dev || !head || !tail || !traj || !qbuf || !part || !sync || (NT > 1 && !kvx) || n_traj < 0 || n_pos < 1 || n_rot < 1 || D < 4 ||
+      D > 16 || std::min(L, DR) * D > DN_MISC_XYZ || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 || nsplit * dnp_nsub(H) > 16 || H > 8 || nsteps < 1 || t_first < nsteps - 1 ||
       !head->enc_w0 || !head->enc_w1 || (head->lang_kv && (!head->q_w || !head->out_w || !head->ln_g || !head->sem || head->S_lang <= 0)) ||
       !tail->pos_w0 || !tail->rot_w0 || !tail->coef_pos || !tail->coef_rot || (tail->cond_mask && !tail->cond_data)) {
     set_error("a3d_dn_persist: bad argument (B=%d L=%d D=%d E=%d H=%d S=%d Sp=%d nsplit=%d stacks %d/%d/%d steps %d from t=%d)", B, L, D, E, H,
@@ -1407,32 +1585,34 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1;
   }
   // every workgroup must be resident at once (the roles wait for each other): one workgroup per CU (121 KB of LDS each)
-  const int nworkers = n_cu - B;
+  const int nworkers = n_cu - U;
   if (n_cu <= 0 || nworkers < 16) {
-    set_error("a3d_dn_persist: %d trajectories leave %d of %d CUs for the streaming role (>= 16 needed); use the per-phase launches", B,
+    set_error("a3d_dn_persist: %d trajectories x %d row tiles leave %d of %d CUs for the streaming role (>= 16 needed)", B, NT,
               nworkers, n_cu);
     return A3D_ERR_ARG;
   }
+  const size_t words = dnp_words(B, L, n_traj + n_pos + n_rot, nsteps);
   DnPersist a;
   a.layers = reinterpret_cast<const DnLayerDev*>(layers_dev);
   a.head = *head;
   a.tail = *tail;
-  a.traj = traj; a.qbuf = qbuf; a.part = part; a.sync = sync;
-  a.B = B; a.L = L; a.D = D; a.E = E; a.H = H; a.S = S; a.Sp = Sp; a.nsplit = nsplit; a.nsub = dnp_nsub(H);
+  a.traj = traj; a.qbuf = qbuf; a.part = part; a.sync = sync; a.kvx = kvx;
+  a.B = B; a.L = L; a.NT = NT; a.D = D; a.E = E; a.H = H; a.S = S; a.Sp = Sp; a.nsplit = nsplit; a.nsub = dnp_nsub(H);
   a.n_traj = n_traj; a.n_pos = n_pos; a.n_rot = n_rot; a.t_first = t_first; a.nsteps = nsteps;
+  a.prof = (dn_warm() & 2) ? reinterpret_cast<long long*>(sync + words + ((sizeof(DnPersist) + 15) / 16) * 4) : nullptr;
   a.spin_limit = 1 << 21;                     // ~2 s of polling: a wait is at most a few milliseconds; beyond it the launch aborts
   hipStream_t s = (hipStream_t)stream;
-  const size_t words = (((size_t)DNP_XDONE0 + (size_t)16 * B + (size_t)nsteps * (n_traj + n_pos + n_rot) * B) + 3) & ~(size_t)3;
-  hipError_t e = hipMemsetAsync(sync, 0, words * sizeof(int), s);
-  if (e != hipSuccess) { set_error("a3d_dn_persist: memset: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
   DnPersist* a_dev = reinterpret_cast<DnPersist*>(sync + words);
-  hipLaunchKernelGGL(dn_persist_args_kernel, dim3(1), dim3(64), 0, s, a, a_dev);
+  hipLaunchKernelGGL(dn_persist_args_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 256)), dim3(256), 0, s, a, a_dev, sync,
+                     (int)words);
+  rc = check_launch("a3d_dn_persist(args)");
+  if (rc) return rc;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dn_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(dn_persist_kernel, dim3(B + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, B);
+  hipLaunchKernelGGL(dn_persist_kernel, dim3(U + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, U);
   return check_launch("a3d_dn_persist");
 }
 

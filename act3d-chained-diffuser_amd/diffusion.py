@@ -380,17 +380,18 @@ class DiffusionHead(nn.Module):
         nws = O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"])
         st["ws"] = torch.empty((nws,), device=dev, dtype=torch.float32)
         st["ws_side"] = torch.empty((nws,), device=dev, dtype=torch.float32)      # rotation branch, concurrent
-        st["persist"] = self._build_persist(st, B, H, E, Sp, time_sin.shape[0], dev) if DN_PERSIST else None
+        st["persist"] = self._build_persist(st, B, Ln, H, E, Sp, time_sin.shape[0], dev) if DN_PERSIST else None
         return st
 
-    def _build_persist(self, st, B, H, E, Sp, T, dev):
+    def _build_persist(self, st, B, Ln, H, E, Sp, T, dev):
         """State of the persistent sampler (a3d_dn_persist: the whole denoise loop as one launch, csrc/denoise.hip): the device
         table of per-layer parameter blocks (AdaLN tables by their base: the kernel indexes them with the step), the query /
         partial exchange buffers and the synchronisation words.  None when the batch leaves too few CUs for the streaming role."""
         import ctypes
         Lb = O.L
         lib = Lb.load()
-        if B + 16 > torch.cuda.get_device_properties(dev).multi_processor_count or H > 8:
+        NT = -(-Ln // 16)                                   # 16-step row tiles per trajectory: one sample-role workgroup each
+        if B * NT + 16 > torch.cuda.get_device_properties(dev).multi_processor_count or H > 8 or NT > 4:
             return None
         recs = st["layers"]
         table = (Lb.DnLayerParams * len(recs))()
@@ -409,15 +410,16 @@ class DiffusionHead(nn.Module):
                 f_b1=ff[0].bias.data_ptr(), f_w2=ff[3].weight.data_ptr(), f_b2=ff[3].bias.data_ptr(),
                 f_ln_g=lay.norm_122.weight.data_ptr(), f_ln_b=lay.norm_122.bias.data_ptr(), F=ff[0].weight.shape[0])
         raw = bytes(memoryview(table))
-        nsplit = max(1, min(DN_PERSIST_SPLIT, Sp // 64))
+        nsplit = max(1, min(DN_PERSIST_SPLIT, Sp // 64, 16 // lib.a3d_dn_persist_splits(H, 1)))      # at most 16 partials per (sample, head)
         nse = lib.a3d_dn_persist_splits(H, nsplit)
         n_layers = len(recs)
         return {
             "table": torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev),
             "nsplit": nsplit,
-            "qbuf": torch.zeros((B * 16 * 128,), device=dev, dtype=torch.float32),
-            "part": torch.empty((lib.a3d_dn_cross_ws_floats(B, H, nse),), device=dev, dtype=torch.float32),
-            "sync": torch.zeros((lib.a3d_dn_persist_sync_ints(B, n_layers, T),), device=dev, dtype=torch.int32),
+            "qbuf": torch.zeros((B * NT * 16 * 128,), device=dev, dtype=torch.float32),
+            "part": torch.empty((lib.a3d_dn_cross_ws_floats(B * NT, H, nse),), device=dev, dtype=torch.float32),
+            "kvx": torch.empty((lib.a3d_dn_persist_kvx_floats(B, Ln, E),), device=dev, dtype=torch.float32) if NT > 1 else None,
+            "sync": torch.zeros((lib.a3d_dn_persist_sync_ints(B, Ln, n_layers, T),), device=dev, dtype=torch.int32),
             "stacks": (len(self.traj_attention[0].layers), len(self.pos_attention[0].layers), len(self.rot_attention[0].layers)),
         }
 
@@ -449,7 +451,7 @@ class DiffusionHead(nn.Module):
         self._last_persist = ps                      # tests read the abort word (sync[2]) after synchronising
         nt, npos, nrot = ps["stacks"]
         Lb.call("a3d_dn_persist", ps["table"].data_ptr(), nt, npos, nrot, C_byref(hp), C_byref(tp), out.data_ptr(), ps["qbuf"].data_ptr(),
-                ps["part"].data_ptr(), ps["sync"].data_ptr(), B, Ln, D, E, H, st["S"], st["Sp"], ps["nsplit"], int(t_first), int(nsteps),
+                ps["part"].data_ptr(), None if ps["kvx"] is None else ps["kvx"].data_ptr(), ps["sync"].data_ptr(), B, Ln, D, E, H, st["S"], st["Sp"], ps["nsplit"], int(t_first), int(nsteps),
                 Lb.stream())
         if DN_PERSIST_CHECK:
             if int(ps["sync"][2].item()) != 0:
@@ -697,7 +699,9 @@ class DiffusionPlanner(nn.Module):
         trace = []
         # fused per-step kernels (csrc/denoise.hip) whenever the trajectory fits one 16-row tile; else the op-by-op path
         fused = FUSED_DENOISE if fused is None else fused
-        fused = fused and Ln <= 16 and E <= 128 and D <= 16 and Ln * D <= 160 and not multi      # a3d_dn_rest stages L * D trajectory values in a 160-float area
+        # fused kernels (csrc/denoise.hip): per-phase launches serve one 16-row tile; the persistent sampler up to four (L <= 64: the
+        # reference's interpolation_length = 50, scripts/train_trajectory.sh:7-8, online_evaluation/eval.sh:17)
+        fused = fused and E <= 128 and D <= 16 and min(Ln, 16) * D <= 160 and not multi and (Ln <= 16 or (DN_PERSIST and Ln <= 64))
         if multi:
             # multi-round / multi-scale heads: the fine-scale context follows the previous prediction, so nothing but the
             # image encoding is step-invariant -- every step evaluates the full head (no K/V cache, no fused kernels)
@@ -708,6 +712,11 @@ class DiffusionPlanner(nn.Module):
         elif fused:
             state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln)
             static = list(state["tensors"])
+            if Ln > 16 and state.get("persist") is None:           # too many units for the CU count: the op-by-op path serves it
+                fused = False
+                state = head.build_kv_cache(ctx, ctx_xyz, instr)
+                static = [c[k] for c in state["ctx"] for k in ("Ks", "Vt")] + \
+                    ([state["lang"]["Ks"], state["lang"]["Vt"]] if "lang" in state else [])
         else:
             state = head.build_kv_cache(ctx, ctx_xyz, instr)
             static = [c[k] for c in state["ctx"] for k in ("Ks", "Vt")] + \

@@ -8,6 +8,8 @@ TrainTester.train_one_step (main_keypose.py:207-234, main_trajectory.py:177-204)
   save/load_checkpoint -> {"weight" (module.-prefixed), "optimizer", "iter", "best_loss"}
 The reference's CLI, data loaders, tensorboard and evaluation loop are out of scope.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -202,6 +204,9 @@ def get_optimizer(model, lr=1e-4, active_names=None):
     return flat, FlatAdamW(flat, lr=lr)
 
 
+DP_ONESHOT = os.environ.get("A3D_DP_ONESHOT", "0") == "1"
+
+
 class FlatDataParallel:
     """Data parallelism over one flat gradient buffer (replaces DistributedDataParallel, engine.py:121-124).
 
@@ -219,7 +224,9 @@ class FlatDataParallel:
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.overlap = overlap and flat.flat.is_cuda
+        # A3D_DP_ONESHOT=1: ONE all-reduce of the whole flat buffer after the backward instead of the three overlapped messages
+        # (hot no-decay | hot decay early on the side stream, FPN segment late) -- the A/B switch for the first multi-GPU run
+        self.overlap = overlap and flat.flat.is_cuda and not DP_ONESHOT
         self._pending = []
         self._side = torch.cuda.Stream() if self.overlap else None
         self._early_done = False

@@ -172,6 +172,16 @@ def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     assert torch.isfinite(out).all()
+    # the timed path (captured graph, replayed) must reproduce the eager loop on the same noise: a replay that runs on stale
+    # synchronisation state would be fast and wrong
+    g = torch.Generator(device=dev).manual_seed(5)
+    n0, n1 = torch.randn(B, Ln, 9, device=dev, generator=g), torch.randn(100, B, Ln, 9, device=dev, generator=g)
+    args = (s["trajectory_mask"], None, s["pcds"], s["instr"], s["curr_gripper"], s["action"])
+    ref = m.compute_trajectory(*args, init_noise=n0, step_noise=n1, visual_tokens=tokens, use_graph=False)
+    got = m.compute_trajectory(*args, init_noise=n0, step_noise=n1, visual_tokens=tokens, use_graph=graph)
+    torch.cuda.synchronize()
+    replay_err = (got - ref).abs().max().item()
+    assert replay_err <= 1e-4, "the timed (graph) path differs from the eager loop by %.3e" % replay_err
     S = C * 1024 + 2
     rl = cached_attention_roofline(a3d, B, Ln, S, dev)
     return {
@@ -181,7 +191,7 @@ def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
         "config": {"workload": f"ChainedDiffuser compute_trajectory (BASELINE configs[2]): B={B}, horizon={Ln}, {C} cameras "
                                f"(S={S} context tokens), E=120, H=8, 100 steps, context + K/V cache built once, "
                                "18 fused launches per step (csrc/denoise.hip)",
-                   "hipgraph": graph},
+                   "hipgraph": graph, "graph_vs_eager_max_abs_diff": replay_err},
         "roofline": rl,
     }
 

@@ -50,9 +50,20 @@ with torch.no_grad():
     for i in (1, 2):
         print("context run", i, "vs 0: ctx", diff(ctxs[i][0], ctxs[0][0]), "instr", diff(ctxs[i][1], ctxs[0][1]),
               "fused tensors", max(diff(a.float(), b.float()) for a, b in zip(ctxs[i][2], ctxs[0][2])))
-for n in (1, 5, 100):
-    e1, e2 = run(n_steps=n), run(n_steps=n)
+def abort_word():
+    ps = getattr(m.prediction_head, "_last_persist", None)
+    return None if ps is None else int(ps["sync"][2].item())
+
+
+for n in (1, 5, 30, 100):
+    print(f"-- n_steps={n}: eager", flush=True)
+    e1 = run(n_steps=n)
+    print("   abort word", abort_word(), flush=True)
+    e2 = run(n_steps=n)
     m._graph = None
-    g1, g2, g3 = run(n_steps=n, use_graph=True), run(n_steps=n, use_graph=True), run(n_steps=n, use_graph=True)
+    print(f"-- n_steps={n}: graph", flush=True)
+    g1 = run(n_steps=n, use_graph=True)
+    print("   captured + replayed once; abort word", abort_word(), flush=True)
+    g2, g3 = run(n_steps=n, use_graph=True), run(n_steps=n, use_graph=True)
     print(f"n_steps={n}: eager-eager {diff(e1, e2):.3e}  graph1-eager {diff(g1, e1):.3e}  graph2-eager {diff(g2, e1):.3e}  graph3-eager {diff(g3, e1):.3e}  "
           f"graph1-graph2 {diff(g1, g2):.3e}")

@@ -200,6 +200,50 @@ def test_persistent_sampler_equals_per_phase_launches(a3d, dev, B, Ln, n_steps):
     scale_close("persistent traced vs one launch", got_t, got, 1e-6)
 
 
+def test_persistent_sampler_script_horizon_50_vs_oracle(a3d, dev):
+    """The horizon the reference deploys (interpolation_length = 50: scripts/train_trajectory.sh:7-8, online_evaluation/eval.sh:17)
+    on the fused path: four 16-step row tiles per trajectory, one sample-role workgroup each, self-attention keys / values exchanged
+    between the tiles of a trajectory.  100 steps in one launch with a padded trajectory, against (a) the op-by-op path (separate
+    kernels, three-part bf16 K cache) on the whole batch and (b) the CPU oracle's loop on two of the samples."""
+    from oracle import diffusion as OD
+    from oracle import sampling as OS
+    r = load("diffusion.pt")
+    E, B, Ln, ncam, H = 120, 6, 50, 3, 8
+    m = a3d.DiffusionPlanner(embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+    P = _diffusion_params(r)
+    m.load_state_dict(P, strict=False)
+    m.to(dev).eval()
+    inp = C.trajectory_inputs(93, B, Ln, ncam, E, pad_last=7)
+    tokens = C.tokens_from_maps(inp["fmap"])
+    d = {k: v.to(dev) for k, v in inp.items()}
+    args = (d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"])
+    kw = dict(init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=tokens.to(dev))
+    got = m.compute_trajectory(*args, **kw)
+    torch.cuda.synchronize()
+    ps = m.prediction_head._last_persist
+    assert ps is not None and ps["kvx"] is not None and int(ps["sync"][2].item()) == 0, "not on the persistent sampler / it gave up waiting"
+    assert torch.isfinite(got).all()
+    ref = m.compute_trajectory(*args, fused=False, **kw)
+    scale_close("L = 50 persistent sampler vs op-by-op path (100 steps)", got, ref, 1e-4)
+    g2 = m.compute_trajectory(*args, use_graph=True, **kw)
+    g3 = m.compute_trajectory(*args, use_graph=True, **kw)
+    assert torch.equal(g2, got) and torch.equal(g3, got), "graph capture / replay of the L = 50 sampler differs from the eager launch"
+    sub = [1, 4]                                           # one unpadded and one padded trajectory (pad_last pads the second half)
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    pcdn = OD.normalize_pos(inp["pcd"][sub].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
+    with torch.no_grad():
+        ofinal, _ = OD.compute_trajectory(P, OD.DDPMSchedules(100), inp["mask"][sub], tokens[sub], None, inp["instr"][sub],
+                                          inp["curr_gripper"][sub], inp["goal_gripper"][sub], bounds, inp["init_noise"][sub],
+                                          inp["step_noise"][:, sub], H, ctx_xyz_norm=cxyz_n)
+    o = got[sub].cpu()
+    scale_close("L = 50 sampled xyz vs oracle", o[..., :3], ofinal[..., :3], 3e-4)
+    sign = torch.sign((o[..., 3:] * ofinal[..., 3:]).sum(-1, keepdim=True))
+    scale_close("L = 50 sampled quaternion vs oracle", o[..., 3:] * sign, ofinal[..., 3:], 3e-4)
+
+
 def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
     """attn_rounds = 2 x feat_scales_to_use = 2, untied module sets, goal-conditioned (diffusion_head.py:249-275) against
     tests/golden/diffusion_multi.pt: the four chained predictions, the find_traj_nn neighbourhoods (a3d_traj_nn_topk), the

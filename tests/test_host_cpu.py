@@ -638,3 +638,124 @@ def test_rope_sincos_host_mirror_within_1e7_of_float64():
     lib.a3d_sincos_host(big.ctypes.data, sb.ctypes.data, cb.ctypes.data, big.size)
     bd = big.astype(np.float64)
     assert np.abs(sb - np.sin(bd)).max() <= 2e-7 and np.abs(cb - np.cos(bd)).max() <= 2e-7
+
+
+# ------------------------------------------------------------------------------------------------ N-rank schedule with a mocked dist
+class _Rec:
+    """call log shared by the mocks below"""
+    def __init__(self):
+        self.log = []
+
+
+def _mock_cuda(monkeypatch, rec):
+    """torch.cuda's stream / event surface as recording objects, so that the device-side schedule of FlatDataParallel /
+    GraphedStep can be driven on a CPU-only machine."""
+    import contextlib
+    import torch
+
+    class Stream:
+        def __init__(self, name="side"):
+            self.name = name
+
+        def wait_event(self, ev):
+            rec.log.append(("wait_event", self.name))
+
+        def wait_stream(self, other):
+            rec.log.append(("wait_stream", self.name, other.name))
+
+    main = Stream("main")
+
+    class Event:
+        def record(self, stream=None):
+            rec.log.append(("record", (stream or main).name))
+
+    @contextlib.contextmanager
+    def stream_ctx(s):
+        rec.log.append(("enter", s.name))
+        yield
+        rec.log.append(("exit", s.name))
+
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: Stream("side"))
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: Event())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: main)
+    monkeypatch.setattr(torch.cuda, "stream", stream_ctx)
+    return main
+
+
+def _mock_dist(monkeypatch, E, rec, world=8):
+    class Work:
+        def wait(self):
+            rec.log.append(("work.wait",))
+
+    class Dist:
+        class ReduceOp:
+            SUM = "sum"
+
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_world_size(group=None):
+            return world
+
+        @staticmethod
+        def all_reduce(t, op=None, group=None, async_op=False):
+            rec.log.append(("all_reduce", int(t.storage_offset()), int(t.numel()), bool(async_op)))
+            return Work() if async_op else None
+
+    monkeypatch.setattr(E, "dist", Dist)
+
+
+class _FakeFlat:
+    def __init__(self, n=1000, late=(400, 700)):
+        import torch
+        self.flat = torch.zeros(n)
+        self.grad = torch.zeros(n)
+        self.n, self.late_range = n, late
+
+
+def test_data_parallel_schedule_three_messages_and_one_shot(monkeypatch):
+    """The N-rank gradient exchange as an 8-GPU node will execute it, with torch.distributed and the stream surface mocked (no
+    multi-GPU box is available inside a session): overlapped mode = hot segments [0, a) and [b, n) all-reduced asynchronously on the
+    side stream after the hot-path backward, the FPN segment [a, b) after the whole backward, then joined; A3D_DP_ONESHOT = ONE
+    blocking all-reduce of the whole buffer.  Also GraphedStep's replay order around them (three graphs)."""
+    a3d = load_pkg()
+    E = a3d.engine
+    import torch
+    for oneshot in (False, True):
+        rec = _Rec()
+        _mock_cuda(monkeypatch, rec)
+        _mock_dist(monkeypatch, E, rec)
+        monkeypatch.setattr(E, "DP_ONESHOT", oneshot)
+        flat = _FakeFlat()
+        monkeypatch.setattr(type(flat.flat), "is_cuda", property(lambda self: True), raising=False)
+        ddp = E.FlatDataParallel(flat, overlap=True)
+        assert ddp.world == 8 and ddp.overlap == (not oneshot)
+
+        class G:
+            def __init__(self, name):
+                self.name = name
+
+            def replay(self):
+                rec.log.append(("replay", self.name))
+        gs = object.__new__(E.GraphedStep)
+        gs.static_inputs, gs.optimizer, gs.ddp, gs.world = {}, None, ddp, ddp.world
+        gs.g_fb, gs.g_late, gs.g_opt, gs.loss = G("fwd+hot-bwd"), G("fpn-bwd"), G("adamw"), "loss"
+        rec.log.clear()
+        assert gs() == "loss"
+        calls = [c for c in rec.log if c[0] in ("replay", "all_reduce", "work.wait")]
+        if not oneshot:
+            assert calls == [("replay", "fwd+hot-bwd"),
+                             ("all_reduce", 0, 400, True), ("all_reduce", 700, 300, True),       # hot segments, side stream
+                             ("replay", "fpn-bwd"),
+                             ("all_reduce", 400, 300, True),                                        # FPN segment
+                             ("work.wait",), ("work.wait",), ("work.wait",),
+                             ("replay", "adamw")], calls
+            # the early reductions are issued inside the side stream's context, after it waited for the main stream's event
+            i0 = rec.log.index(("all_reduce", 0, 400, True))
+            assert rec.log[i0 - 1] == ("enter", "side") and ("wait_event", "side") in rec.log[:i0] and ("record", "main") in rec.log[:i0]
+            assert rec.log.index(("wait_stream", "main", "side")) > rec.log.index(("all_reduce", 400, 300, True))
+        else:
+            assert calls == [("replay", "fwd+hot-bwd"), ("replay", "fpn-bwd"), ("all_reduce", 0, 1000, False), ("replay", "adamw")], calls
+        assert ddp.finish_sync() == 1.0 / 8
