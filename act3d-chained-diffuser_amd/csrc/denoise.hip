@@ -841,8 +841,9 @@ struct DnPersist {
   float* part;                    // Op [nse][B][H][16][16] | Mp [nse][B][H][16]   (nse = nsplit * nsub)
   int* sync;                      // [0] ticket  [1] queue tail  [2] abort  | [16 + 16 u] completion counter of unit u |
                                   // [.. + 16 b] self-attention exchange counter of sample b | ready queue
-  float* kvx;                     // [B][2][NT * 16][2E] rotated keys | values of the self-attention, exchanged between a sample's row tiles
-                                  // (NT > 1 only; two buffers alternate from layer to layer)
+  float* kvx;                     // [2 roles][B][2][NT * 16][2E] rotated keys | values of the self-attention, exchanged between a
+                                  // sample's row tiles (NT > 1 only; two buffers alternate from layer to layer)
+  float* xbuf;                    // [U][2][16][128]: x after the trajectory stack (primary -> helper) | rotation features (helper -> primary)
   int B, L, NT, D, E, H, S, Sp, nsplit, nsub, n_traj, n_pos, n_rot, t_first, nsteps, spin_limit;
   long long* prof;                // development aid (A3D_DN_PROF=1): phase timestamps, see a3d_dn_persist_prof; else NULL
 };
@@ -850,16 +851,23 @@ constexpr int DNP_PROF_WORDS = 256;      // long longs: [0, 96) 32 items x {tick
 // A trajectory of L <= 64 steps is NT = ceil(L / 16) row tiles; a UNIT = (sample b, tile) = one sample-role workgroup, u = b NT + tile.
 // Every row-wise operation (encoder, cross-attention queries / partials, projections, LayerNorm, FFN, regressors, DDPM step) is the
 // unit's own; only the self-attention couples the tiles of a sample: they exchange their rotated keys / values through kvx.
-constexpr int DNP_XDONE0 = 16;
-__host__ __device__ __forceinline__ int dnp_kvdone0(int B, int NT) { return DNP_XDONE0 + 16 * B * NT; }
-__host__ __device__ __forceinline__ int dnp_queue0(int B, int NT) { return DNP_XDONE0 + 16 * B * NT + 16 * B; }
+// Two sample-role workgroups per unit: the PRIMARY runs head, trajectory stack, position stack and tail; the HELPER runs the
+// rotation stack (diffusion_head.py:343-357: the position and the rotation stack both start from the trajectory stack's output and
+// are independent), so a step's chain is n_traj + max(n_pos, n_rot) layers deep instead of n_traj + n_pos + n_rot.  They hand
+// x over through xbuf (primary -> helper after the trajectory stack, helper -> primary after the rotation stack) with one flag each.
+// For the streamers a helper is just another unit: streaming unit id v = role * U + u (qbuf / partial / completion-counter slot).
+constexpr int DNP_XDONE0 = 16;                      // sync words: [16 + 16 v] completion counter of streaming unit v < 2U
+__host__ __device__ __forceinline__ int dnp_kvdone0(int B, int NT) { return DNP_XDONE0 + 16 * 2 * B * NT; }          // [+ 16 (role B + b)]
+__host__ __device__ __forceinline__ int dnp_xtready0(int B, int NT) { return dnp_kvdone0(B, NT) + 16 * 2 * B; }      // [+ 16 u]
+__host__ __device__ __forceinline__ int dnp_rdone0(int B, int NT) { return dnp_xtready0(B, NT) + 16 * B * NT; }       // [+ 16 u]
+__host__ __device__ __forceinline__ int dnp_queue0(int B, int NT) { return dnp_rdone0(B, NT) + 16 * B * NT; }
 
 // thread 0 of the workgroup spins until *flag >= target (acquire, agent scope); returns false when the kernel is aborting
 // (the polls are RELAXED agent-scope loads; no acquire fence follows: see dnp_ld)
 __device__ __forceinline__ bool dnp_wait_ge(int* flag, int target, int* abort_flag, int spin_limit) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(16);                      // ~0.4 us between polls: 200 pollers must not hammer one memory channel
     if ((++spins & 127) == 0) {
       if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
       if (spins > spin_limit) {
@@ -878,6 +886,13 @@ __device__ __forceinline__ bool dnp_wait_ge(int* flag, int target, int* abort_fl
 // Writers publish with plain stores + workgroup barrier + agent-scope RELEASE (L2 write-back of a few KB) + the flag store.
 __device__ __forceinline__ float dnp_ld(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// ... and WRITTEN with agent-scope relaxed atomic word stores (write-through to the coherence point), followed by the workgroup
+// barrier (which waits for every wave's outstanding stores) and a relaxed flag update by thread 0.  No agent-scope RELEASE fence
+// either: a release writes back the XCD's whole L2, and with one per queue item the phase probe showed every memory-latency-bound
+// phase of the sample role slowing down as the items got finer (layer remainder 53 -> 84 us from 4 to 16 key splits).
+__device__ __forceinline__ void dnp_st(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The argument block is re-read through an opaque copy of its pointer at every phase: otherwise the compiler hoists ALL its (loop-
@@ -901,8 +916,8 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int NL = a.n_traj + a.n_pos + a.n_rot;
-  const int U = a.B * a.NT;
-  const long long total = (long long)a.nsteps * NL * U * a.nsplit;
+  const int U0 = a.B * a.NT, U = 2 * U0;            // U: streaming units (primaries + helpers)
+  const long long total = (long long)a.nsteps * NL * U0 * a.nsplit;
   const int nse = a.nsplit * a.nsub;
   float* Op = a.part;
   float* Mp = a.part + (size_t)nse * U * a.H * 256;
@@ -930,12 +945,12 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
     __syncthreads();
     const int sp = sh[0], code = sh[1];
     if (sp < 0 || code == 0) break;
-    const int gl = (code - 1) / U, b = (code - 1) - gl * U;          // b: the UNIT; its sample = b / NT
-    const a3d_dn_cross_params& c = dnp_args(ap).layers[gl % NL].c;
+    const int gl = (code - 1) / U, b = (code - 1) - gl * U;          // gl: the layer; b: the streaming unit, its sample = (b mod U0) / NT
+    const a3d_dn_cross_params& c = dnp_args(ap).layers[gl].c;
     if (wave < a.H * a.nsub) {
       const int h = wave % a.H, sub = wave / a.H;
       const int se = sp * a.nsub + sub;
-      const size_t bh = (size_t)(b / a.NT) * a.H + h;
+      const size_t bh = (size_t)((b % U0) / a.NT) * a.H + h;
       const float* qrow = a.qbuf + ((size_t)b * 16 + li) * 128 + h * HD;       // rows >= L and columns >= E are published as zeros
       float4 qb;                                         // B operand: channel 4 g + j of query li (channel 15 = pad)
       qb.x = dnp_ld(qrow + 4 * g + 0);
@@ -954,13 +969,17 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
         const int key0 = hf * 32;
         // non-temporal: the K / V stream (205 MB per layer round) is read once -- it must not push the layer weights the sample
         // role re-reads every layer out of the 4 MB L2s
+        // (global address space stated explicitly: the cache pointers come out of a device-memory table, which leaves the compiler
+        // with generic pointers and FLAT loads)
         typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
-        const nt_f32x4 a0 = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g));
-        const nt_f32x4 a1 = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g));
+        typedef const __attribute__((address_space(1))) nt_f32x4* g_f32x4_p;
+        typedef const __attribute__((address_space(1))) s16x8* g_s16x8_p;
+        const nt_f32x4 a0 = __builtin_nontemporal_load((g_f32x4_p)(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g));
+        const nt_f32x4 a1 = __builtin_nontemporal_load((g_f32x4_p)(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g));
         f.k0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
         f.k1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
-        f.vh = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8));
-        f.vl = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8));
+        f.vh = __builtin_nontemporal_load((g_s16x8_p)(Vhi + key0 + g * 8));
+        f.vl = __builtin_nontemporal_load((g_s16x8_p)(Vlo + key0 + g * 8));
         return f;
       };
       float m_run = -INFINITY;
@@ -1019,13 +1038,13 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       }
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
       const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
-      *reinterpret_cast<float4*>(&Op[(row0 + li) * 16 + 4 * g]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      if (g == 0) Mp[row0 + li] = m_run;
+      float* od = &Op[(row0 + li) * 16 + 4 * g];
+      dnp_st(od, acc[0]); dnp_st(od + 1, acc[1]); dnp_st(od + 2, acc[2]); dnp_st(od + 3, acc[3]);
+      if (g == 0) dnp_st(&Mp[row0 + li], m_run);
     }
     __syncthreads();
     if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.prof && (int)blockIdx.x == U && nprof < 32) { a.prof[nprof * 3 + 2] = wall_clock64(); ++nprof; }
     }
   }
@@ -1099,14 +1118,13 @@ __device__ __forceinline__ bool dnp_run_ops(float* smem, const DnOpTable& tab, i
           float* mine = tl.kvx + ((size_t)tl.parity * tl.NT * 16 + (size_t)tl.tile * 16) * ldkv;
           for (int i = threadIdx.x; i < DR * E; i += blockDim.x) {
             const int rr = i / E, c = i - rr * E;
-            mine[rr * ldkv + c] = Kk[rr * LDQK + c];
-            mine[rr * ldkv + E + c] = V[rr * LDH + c];
+            dnp_st(&mine[rr * ldkv + c], Kk[rr * LDQK + c]);
+            dnp_st(&mine[rr * ldkv + E + c], V[rr * LDH + c]);
           }
           __syncthreads();
           int* ok = reinterpret_cast<int*>(smem + 4 * DR * LDX);       // q | k tile's first word: q is in registers, k is published
           if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(tl.kvdone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(tl.kvdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *ok = dnp_wait_ge(tl.kvdone, tl.target, tl.abort_flag, tl.spin_limit) ? 1 : 0;
           }
           __syncthreads();
@@ -1160,9 +1178,10 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   float *Xs, *As, *Bs, *Ts, *QK, *Hs, *Ps, *Xt, *Pf, *Tr;
   int* shi;
   DnOpTable* tab;
-  const int b = blockIdx.x, t = threadIdx.x;                  // b: the UNIT (sample bs, row tile)
-  const int NT = a.NT, U = a.B * NT;
-  const int bs = b / NT, tile = b - bs * NT, r0 = tile * 16, Lf = a.L;
+  const int b = blockIdx.x, t = threadIdx.x;                  // b: the STREAMING UNIT id v = role * U0 + u
+  const int NT = a.NT, U0 = a.B * NT, U = 2 * U0;
+  const int role = b >= U0 ? 1 : 0, u = b - role * U0;        // role 0: primary (head, trajectory + position stack, tail); 1: helper (rotation stack)
+  const int bs = u / NT, tile = u - bs * NT, r0 = tile * 16, Lf = a.L;
   const int L0 = min(16, Lf - r0), D0 = a.D, E0 = a.E, H0 = a.H;      // L (below): the unit's own rows
   int L, D, E, H, Epad;
   // LDS map + shape scalars, re-derived from opaque values at every phase (see dnp_opaque)
@@ -1184,9 +1203,15 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   const float* Op = a.part;
   const float* Mp = a.part + (size_t)nse * U * a.H * 256;
   int* abort_flag = a.sync + 2;
-  int sa_count = 0;                                           // self-attention blocks this unit has been through (all steps)
+  int sa_count = 0;                                           // self-attention blocks this workgroup has been through (all steps)
+  int my_layers = 0;                                          // layers this workgroup has published (all steps)
+  const int l_beg = role ? a.n_traj + a.n_pos : 0, l_end = role ? NL : a.n_traj + a.n_pos;
+  float* xb_traj = a.xbuf + ((size_t)u * 2 + 0) * 16 * 128;   // x after the trajectory stack
+  float* xb_rot = a.xbuf + ((size_t)u * 2 + 1) * 16 * 128;    // rotation features
+  int* xt_flag = a.sync + dnp_xtready0(a.B, NT) + 16 * u;
+  int* rd_flag = a.sync + dnp_rdone0(a.B, NT) + 16 * u;
   long long* const prof = a.prof;
-#define DNP_MARK(slot) do { if (prof && b == 0 && t == 0 && step == 1) prof[slot] = wall_clock64(); } while (0)
+#define DNP_MARK(slot) do { if (prof && u == 0 && t == 0 && step == 1) prof[slot] = wall_clock64(); } while (0)
   for (int i = t; i < 256; i += blockDim.x) {
     const int r = i >> 4, c = i & 15;
     Tr[i] = (r < L && c < D) ? a.traj[((size_t)bs * Lf + r0 + r) * D + c] : 0.f;
@@ -1196,7 +1221,22 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
   for (int step = 0; step < a.nsteps; ++step) {
     const int t_step = a.t_first - step;
     DNP_REFRESH();
-    DNP_MARK(250);
+    if (role == 0) DNP_MARK(250);
+    if (role == 1) {
+      // ================= helper: take x (after the trajectory stack) and the step's trajectory rows over from the primary
+      if (t == 0) shi[0] = dnp_wait_ge(xt_flag, step + 1, abort_flag, a.spin_limit) ? 1 : 0;
+      __syncthreads();
+      if (shi[0] == 0) return;
+      for (int i = t; i < DR * 128; i += blockDim.x) {
+        const int r = i >> 7, c = i & 127;
+        Xs[r * LDX + c] = dnp_ld(xb_traj + i);
+      }
+      for (int i = t; i < 256; i += blockDim.x) {
+        const int r = i >> 4, c = i & 15;
+        Tr[i] = (r < L && c < D) ? dnp_ld(&a.traj[((size_t)bs * Lf + r0 + r) * D + c]) : 0.f;
+      }
+      __syncthreads();
+    } else
     // ================= head: trajectory encoder [+ attention over the instruction tokens]   (dn_head_kernel)
     {
       const a3d_dn_head_params& p = dnp_args(ap).head;
@@ -1216,8 +1256,25 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         const float scale = 1.0f / sqrtf((float)HD);
         for (int i = t; i < DR * E; i += blockDim.x) Qs[(i / E) * LDX + i % E] *= scale;
         __syncthreads();
-        const float* kv = p.lang_kv + (size_t)bs * p.S_lang * 2 * E;
-        for (int i = t; i < p.S_lang * 2 * E; i += blockDim.x) kvS[i] = kv[i];
+        // instruction k | v rows -> LDS: float4 loads, eight in flight per thread (the plain element loop issued one dependent
+        // global load per iteration: 25 round trips, most of the 56 us the phase probe showed for the head)
+        {
+          const float4* kv4 = reinterpret_cast<const float4*>(p.lang_kv + (size_t)bs * p.S_lang * 2 * E);      // rows of 2E floats: 16-byte aligned
+          const int n4 = (p.S_lang * 2 * E) >> 2;
+          for (int i0 = 0; i0 < n4; i0 += 8 * (int)blockDim.x) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + u * (int)blockDim.x + t;
+              v[u] = i < n4 ? kv4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + u * (int)blockDim.x + t;
+              if (i < n4) reinterpret_cast<float4*>(kvS)[i] = v[u];
+            }
+          }
+        }
         __syncthreads();
         wg_small_attention(Qs, LDX, kvS, 2 * E, kvS + E, 2 * E, nullptr, p.S_lang, H, As, LDX);
         wg_linear<0>(As, LDX, E, p.out_w, E, p.out_b, E, Ts, LDX);
@@ -1225,16 +1282,16 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
       }
     }
     // ================= layers
-    for (int l = 0; l < NL; ++l) {
-      const int gl = step * NL + l;
+    for (int l = l_beg; l < l_end; ++l) {
       DNP_REFRESH();
       DNP_MARK(96 + 7 * l + 0);
-      if (l == a.n_traj) {                                        // start of the position stack: keep x for the rotation stack
-        for (int i = t; i < DR * LDX; i += blockDim.x) Xt[i] = Xs[i];
+      if (role == 0 && l == a.n_traj) {                           // end of the trajectory stack: hand x to the helper (rotation stack)
+        for (int i = t; i < DR * 128; i += blockDim.x) {
+          const int r = i >> 7, c = i & 127;
+          dnp_st(&xb_traj[i], c < E ? Xs[r * LDX + c] : 0.f);
+        }
         __syncthreads();
-      } else if (l == a.n_traj + a.n_pos) {                       // start of the rotation stack
-        for (int i = t; i < DR * LDX; i += blockDim.x) { Pf[i] = Xs[i]; Xs[i] = Xt[i]; }
-        __syncthreads();
+        if (t == 0) __hip_atomic_store(xt_flag, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // ---- (1) publish the layer's queries: rope(W_q AdaLN(x + index embedding) + b_q) * d^-1/2, all heads
       {
@@ -1248,13 +1305,12 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         float* qrow = a.qbuf + (size_t)b * 16 * 128;
         for (int i = t; i < 16 * 128; i += blockDim.x) {
           const int r = i >> 7, cc = i & 127;
-          qrow[i] = (r < L && cc < E) ? Ts[r * LDX + cc] : 0.f;
+          dnp_st(&qrow[i], (r < L && cc < E) ? Ts[r * LDX + cc] : 0.f);
         }
         __syncthreads();
         if (t == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           const int slot = atomicAdd(&a.sync[1], 1);
-          __hip_atomic_store(&a.sync[dnp_queue0(a.B, NT) + slot], 1 + gl * U + b, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&a.sync[dnp_queue0(a.B, NT) + slot], 1 + l * U + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       DNP_MARK(96 + 7 * l + 2);
@@ -1280,7 +1336,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         }
         const WarmList wl = {{p.c_out_w, p.s_in_w, p.s_in_w ? p.s_out_w : nullptr, p.f_w1, p.f_w1 ? p.f_w2 : nullptr, nullptr},
                              {E * E, 3 * E * E, E * E, p.F * E, p.F * E, 0}};
-        wg_warm_l2(wl, U);
+        wg_warm_l2(wl, U0);
         if (t == 0) {
           a3d_dn_rest_params pl = p;
           pl.s_mod = s_mod;
@@ -1296,7 +1352,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
       DNP_MARK(96 + 7 * l + 3);
       DNP_REFRESH();
       // ---- (3) wait for the layer's nsplit items of this sample
-      if (t == 0) shi[0] = dnp_wait_ge(&a.sync[DNP_XDONE0 + 16 * b], (gl + 1) * a.nsplit, abort_flag, a.spin_limit) ? 1 : 0;
+      if (t == 0) shi[0] = dnp_wait_ge(&a.sync[DNP_XDONE0 + 16 * b], (my_layers + 1) * a.nsplit, abort_flag, a.spin_limit) ? 1 : 0;
       __syncthreads();
       if (shi[0] == 0) return;
       DNP_MARK(96 + 7 * l + 4);
@@ -1356,28 +1412,49 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         const a3d_dn_rest_params& p = dnp_args(ap).layers[l].r;
         const bool has_sa = p.s_in_w != nullptr;
         DnpTiles tl;
-        tl.kvx = a.kvx ? a.kvx + (size_t)bs * 2 * NT * 16 * 2 * E : nullptr;
-        tl.kvdone = a.sync + dnp_kvdone0(a.B, NT) + 16 * bs;
+        tl.kvx = a.kvx ? a.kvx + ((size_t)role * a.B + bs) * 2 * NT * 16 * 2 * E : nullptr;
+        tl.kvdone = a.sync + dnp_kvdone0(a.B, NT) + 16 * (role * a.B + bs);
         tl.abort_flag = abort_flag;
         tl.kmask = p.kmask ? p.kmask + (size_t)bs * Lf : nullptr;
         tl.NT = NT; tl.tile = tile; tl.Lfull = Lf; tl.target = NT * (sa_count + 1); tl.parity = sa_count & 1;
         tl.spin_limit = a.spin_limit;
         if (!dnp_run_ops(smem, *tab, L, D, E, H, tl)) return;
         if (has_sa) ++sa_count;
+        ++my_layers;
       }
       DNP_MARK(96 + 7 * l + 6);
     }
     DNP_REFRESH();
+    if (role == 1) {
+      // ================= helper: the rotation features back to the primary
+      for (int i = t; i < DR * 128; i += blockDim.x) {
+        const int r = i >> 7, c = i & 127;
+        dnp_st(&xb_rot[i], c < E ? Xs[r * LDX + c] : 0.f);
+      }
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(rd_flag, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
     DNP_MARK(251);
-    // ================= tail: regressors, trajectory update, DDPM reverse step   (dn_tail_kernel; Pf = position, Xs = rotation features)
+    // the rotation features (helper) -> Xt; the position features stay in Xs
+    if (t == 0) shi[0] = dnp_wait_ge(rd_flag, step + 1, abort_flag, a.spin_limit) ? 1 : 0;
+    __syncthreads();
+    if (shi[0] == 0) return;
+    for (int i = t; i < DR * 128; i += blockDim.x) {
+      const int r = i >> 7, c = i & 127;
+      Xt[r * LDX + c] = dnp_ld(xb_rot + i);
+    }
+    __syncthreads();
+    DNP_MARK(253);
+    // ================= tail: regressors, trajectory update, DDPM reverse step   (dn_tail_kernel; Xs = position, Xt = rotation features)
     {
       const a3d_dn_tail_params& p = dnp_args(ap).tail;
       float* Us = QK;                        // [16][16]
       wg_zero_pad(Ts, LDX, E, Epad);
       __syncthreads();
-      wg_linear<1>(Pf, LDX, E, p.pos_w0, E, p.pos_b0, E, Ts, LDX);
+      wg_linear<1>(Xs, LDX, E, p.pos_w0, E, p.pos_b0, E, Ts, LDX);
       wg_linear<0>(Ts, LDX, E, p.pos_w1, E, p.pos_b1, 3, Us, 16);
-      wg_linear<1>(Xs, LDX, E, p.rot_w0, E, p.rot_b0, E, Ts, LDX);
+      wg_linear<1>(Xt, LDX, E, p.rot_w0, E, p.rot_b0, E, Ts, LDX);
       wg_linear<0>(Ts, LDX, E, p.rot_w1, E, p.rot_b1, D - 3, Us + 3, 16);
       for (int i = t; i < L * D; i += blockDim.x) {
         const int r = i / D, c = i - r * D;
@@ -1393,7 +1470,7 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
           if (p.noise) out += cf[2] * p.noise[(size_t)t_step * a.B * Lf * D + gi];
         }
         Tr[r * 16 + c] = out;
-        a.traj[gi] = out;
+        dnp_st(&a.traj[gi], out);                    // the helper workgroup reads the rows next step
       }
       __syncthreads();
       DNP_MARK(252);
@@ -1416,7 +1493,7 @@ __global__ __launch_bounds__(256) void dn_persist_args_kernel(DnPersist a, DnPer
     for (int i = threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<int*>(dst)[i] = src[i];
   }
 }
-__global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int U) {
+__global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int U) {      // U: sample-role workgroups (2 per unit)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < U) dnp_sample_role(ap, smem);
   else dnp_stream_role(ap, smem);
@@ -1537,8 +1614,10 @@ static size_t dnp_words(int B, int L, int n_layers, int nsteps) {
 
 extern "C" size_t a3d_dn_persist_kvx_floats(int B, int L, int E) {
   const int NT = (L + DR - 1) / DR;
-  return NT > 1 ? (size_t)B * 2 * NT * 16 * 2 * E : 0;
+  return NT > 1 ? (size_t)2 * B * 2 * NT * 16 * 2 * E : 0;            // two roles (primary / helper workgroups) x two alternating buffers
 }
+
+extern "C" size_t a3d_dn_persist_xbuf_floats(int B, int L) { return (size_t)B * ((L + DR - 1) / DR) * 2 * 16 * 128; }
 
 extern "C" size_t a3d_dn_persist_sync_ints(int B, int L, int n_layers, int nsteps) {
   if (B <= 0 || L <= 0 || n_layers <= 0 || nsteps <= 0) return 0;
@@ -1558,8 +1637,8 @@ extern "C" int a3d_dn_persist_prof(const int* sync, int B, int L, int n_layers, 
 }
 
 extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos, int n_rot, const a3d_dn_head_params* head,
-                              const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, float* kvx, int* sync, int B, int L,
-                              int D, int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream) {
+                              const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, float* kvx, float* xbuf, int* sync,
+                              int B, int L, int D, int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream) {
   int rc = A3D_OK;
   if (B <= 0 || L <= 0 || L > 4 * DR || E <= 0 || E > 128 || (E % 6) != 0 || H * HD != E) {
     set_error("a3d_dn_persist: bad shape (B=%d L=%d E=%d H=%d; L <= 64, E = 15 H <= 128)", B, L, E, H);
@@ -1567,7 +1646,7 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
   }
   const int NT = (L + DR - 1) / DR, U = B * NT;
   static_assert(sizeof(a3d_dn_layer_params) == sizeof(DnLayerDev), "layer table layout");
-  if (!layers_dev || !head || !tail || !traj || !qbuf || !part || !sync || (NT > 1 && !kvx) || n_traj < 0 || n_pos < 1 || n_rot < 1 || D < 4 ||
+  if (!layers_dev || !head || !tail || !traj || !qbuf || !part || !xbuf || !sync || (NT > 1 && !kvx) || n_traj < 0 || n_pos < 1 || n_rot < 1 || D < 4 ||
       D > 16 || std::min(L, DR) * D > DN_MISC_XYZ || S <= 0 || Sp < S || (Sp % 64) != 0 || nsplit < 1 || nsplit * dnp_nsub(H) > 16 || H > 8 || nsteps < 1 || t_first < nsteps - 1 ||
       !head->enc_w0 || !head->enc_w1 || (head->lang_kv && (!head->q_w || !head->out_w || !head->ln_g || !head->sem || head->S_lang <= 0)) ||
       !tail->pos_w0 || !tail->rot_w0 || !tail->coef_pos || !tail->coef_rot || (tail->cond_mask && !tail->cond_data)) {
@@ -1585,9 +1664,9 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1;
   }
   // every workgroup must be resident at once (the roles wait for each other): one workgroup per CU (121 KB of LDS each)
-  const int nworkers = n_cu - U;
+  const int nworkers = n_cu - 2 * U;                  // two sample-role workgroups per unit (primary + rotation-stack helper)
   if (n_cu <= 0 || nworkers < 16) {
-    set_error("a3d_dn_persist: %d trajectories x %d row tiles leave %d of %d CUs for the streaming role (>= 16 needed)", B, NT,
+    set_error("a3d_dn_persist: %d trajectories x %d row tiles x 2 roles leave %d of %d CUs for the streaming role (>= 16 needed)", B, NT,
               nworkers, n_cu);
     return A3D_ERR_ARG;
   }
@@ -1596,7 +1675,7 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
   a.layers = reinterpret_cast<const DnLayerDev*>(layers_dev);
   a.head = *head;
   a.tail = *tail;
-  a.traj = traj; a.qbuf = qbuf; a.part = part; a.sync = sync; a.kvx = kvx;
+  a.traj = traj; a.qbuf = qbuf; a.part = part; a.sync = sync; a.kvx = kvx; a.xbuf = xbuf;
   a.B = B; a.L = L; a.NT = NT; a.D = D; a.E = E; a.H = H; a.S = S; a.Sp = Sp; a.nsplit = nsplit; a.nsub = dnp_nsub(H);
   a.n_traj = n_traj; a.n_pos = n_pos; a.n_rot = n_rot; a.t_first = t_first; a.nsteps = nsteps;
   a.prof = (dn_warm() & 2) ? reinterpret_cast<long long*>(sync + words + ((sizeof(DnPersist) + 15) / 16) * 4) : nullptr;
@@ -1612,7 +1691,7 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
     (void)hipFuncSetAttribute((const void*)dn_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(dn_persist_kernel, dim3(U + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, U);
+  hipLaunchKernelGGL(dn_persist_kernel, dim3(2 * U + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, 2 * U);
   return check_launch("a3d_dn_persist");
 }
 

@@ -391,7 +391,8 @@ class DiffusionHead(nn.Module):
         Lb = O.L
         lib = Lb.load()
         NT = -(-Ln // 16)                                   # 16-step row tiles per trajectory: one sample-role workgroup each
-        if B * NT + 16 > torch.cuda.get_device_properties(dev).multi_processor_count or H > 8 or NT > 4:
+        # two sample-role workgroups per (trajectory, tile) -- primary + rotation-stack helper -- and >= 16 streamers, all co-resident
+        if 2 * B * NT + 16 > torch.cuda.get_device_properties(dev).multi_processor_count or H > 8 or NT > 4:
             return None
         recs = st["layers"]
         table = (Lb.DnLayerParams * len(recs))()
@@ -416,8 +417,9 @@ class DiffusionHead(nn.Module):
         return {
             "table": torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev),
             "nsplit": nsplit,
-            "qbuf": torch.zeros((B * NT * 16 * 128,), device=dev, dtype=torch.float32),
-            "part": torch.empty((lib.a3d_dn_cross_ws_floats(B * NT, H, nse),), device=dev, dtype=torch.float32),
+            "qbuf": torch.zeros((2 * B * NT * 16 * 128,), device=dev, dtype=torch.float32),
+            "part": torch.empty((lib.a3d_dn_cross_ws_floats(2 * B * NT, H, nse),), device=dev, dtype=torch.float32),
+            "xbuf": torch.zeros((lib.a3d_dn_persist_xbuf_floats(B, Ln),), device=dev, dtype=torch.float32),
             "kvx": torch.empty((lib.a3d_dn_persist_kvx_floats(B, Ln, E),), device=dev, dtype=torch.float32) if NT > 1 else None,
             "sync": torch.zeros((lib.a3d_dn_persist_sync_ints(B, Ln, n_layers, T),), device=dev, dtype=torch.int32),
             "stacks": (len(self.traj_attention[0].layers), len(self.pos_attention[0].layers), len(self.rot_attention[0].layers)),
@@ -451,7 +453,8 @@ class DiffusionHead(nn.Module):
         self._last_persist = ps                      # tests read the abort word (sync[2]) after synchronising
         nt, npos, nrot = ps["stacks"]
         Lb.call("a3d_dn_persist", ps["table"].data_ptr(), nt, npos, nrot, C_byref(hp), C_byref(tp), out.data_ptr(), ps["qbuf"].data_ptr(),
-                ps["part"].data_ptr(), None if ps["kvx"] is None else ps["kvx"].data_ptr(), ps["sync"].data_ptr(), B, Ln, D, E, H, st["S"], st["Sp"], ps["nsplit"], int(t_first), int(nsteps),
+                ps["part"].data_ptr(), None if ps["kvx"] is None else ps["kvx"].data_ptr(), ps["xbuf"].data_ptr(), ps["sync"].data_ptr(),
+                B, Ln, D, E, H, st["S"], st["Sp"], ps["nsplit"], int(t_first), int(nsteps),
                 Lb.stream())
         if DN_PERSIST_CHECK:
             if int(ps["sync"][2].item()) != 0:

@@ -94,7 +94,8 @@ SIGNATURES = {
     "a3d_dn_persist_sync_ints": (_z, [_i, _i, _i, _i]),
     "a3d_dn_persist_kvx_floats": (_z, [_i, _i, _i]),
     "a3d_dn_persist_prof": (_i, [_p, _i, _i, _i, _i, _p]),
-    "a3d_dn_persist": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
+    "a3d_dn_persist_xbuf_floats": (_z, [_i, _i]),
+    "a3d_dn_persist": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "a3d_rope_rows_f32": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
     "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),

@@ -186,7 +186,12 @@ def kernel_rooflines(a3d, device, B):
         "attn_bwd": {"bound": "mfma", "achieved": f_bwd / (t_bwd * 1e-3) / 1e12, "peak": 2500.0,
                      "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6, "dtype": dt, "family": O.ATTN_MODE,
                      "executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12, "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15},
-        "kv_proj_rope": {"bound": "hbm", "achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        # achieved / frac: SURVEY 8(d)'s ALGORITHMIC bytes -- the fp32 context rows in + ONE 16-bit K and ONE 16-bit V out
+        # (B S (4 E + 2 * 2 E)); stored_*: what the kernel really writes (four two-part operand tensors), the figure rounds 1 - 4
+        # reported as "achieved" (flattering: the review's recomputation gave 0.11 where the bench line said 0.30)
+        "kv_proj_rope": {"bound": "hbm", "achieved": B * S * E * 8.0 / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "algorithmic_bytes": B * S * E * 8.0, "stored_bytes": bytes_proj,
+                         "stored_achieved": bytes_proj / (t_proj * 1e-3) / 1e9, "stored_frac": bytes_proj / (t_proj * 1e-3) / 1e9 / 8000.0,
                          "ms": t_proj, "launches_per_step": 6},
     }}
 

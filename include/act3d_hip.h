@@ -383,29 +383,32 @@ int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* tra
                 float* traj_out, int B, int L, int E, int t_step, void* stream);
 /* ---- persistent sampler: nsteps consecutive denoise steps t_first, t_first - 1, ... of one trajectory batch in ONE launch
  *      (diffusion_model.py:86-119: the loop body `out = prediction_head(...); trajectory = scheduler.step(...)`).  Two workgroup
- *      roles: one workgroup per (trajectory, 16-step row tile) runs that unit's chain (head, per layer q-projection / combine / layer
- *      remainder, tail, DDPM step) across layers AND steps -- the row tiles of a trajectory exchange their self-attention keys /
- *      values through kvx --; the remaining CUs stream the cached context K / V for whichever (unit, layer) is ready.
+ *      roles: TWO workgroups per (trajectory, 16-step row tile) run that unit's chain across layers AND steps -- the primary: head,
+ *      trajectory stack, position stack, tail + DDPM step; the helper: the rotation stack, concurrently with the position stack (x
+ *      handed over through xbuf); the row tiles of a trajectory exchange their self-attention keys / values through kvx --; the
+ *      remaining CUs stream the cached context K / V for whichever (unit, layer) is ready.
  *      L <= 64 trajectory steps (scripts/train_trajectory.sh:7-8 and online_evaluation/eval.sh:17 use interpolation_length 50).
  *      layers_dev: DEVICE array of n_traj + n_pos + n_rot entries in stack order (trajectory, position, rotation; diffusion_head.py:
  *      343-357), whose cross.mod / rest.s_mod / rest.f_mod are the BASES of the [T][2E] AdaLN tables (row t is used at step t), and
- *      tail->noise is the BASE of the [T][B][L][D] step noise.  traj is updated in place.  With NT = ceil(L / 16): qbuf: B * NT * 16 *
- *      128 floats; part: a3d_dn_cross_ws_floats(B * NT, H, a3d_dn_persist_splits(H, nsplit)) floats; kvx: a3d_dn_persist_kvx_floats
- *      floats (NULL when L <= 16); sync: a3d_dn_persist_sync_ints(..) ints (zeroed by the call; sync[2] != 0 afterwards = a wait
- *      exceeded its bound and the launch gave up: the trajectory is then invalid).  Needs B * NT + 16 <= the device's CU count (all
- *      workgroups are co-resident); otherwise A3D_ERR_ARG -> per-phase entry points (L <= 16) or a smaller batch per call. */
+ *      tail->noise is the BASE of the [T][B][L][D] step noise.  traj is updated in place.  With NT = ceil(L / 16): qbuf: 2 * B * NT *
+ *      16 * 128 floats; part: a3d_dn_cross_ws_floats(2 * B * NT, H, a3d_dn_persist_splits(H, nsplit)) floats; kvx:
+ *      a3d_dn_persist_kvx_floats floats (NULL when L <= 16); xbuf: a3d_dn_persist_xbuf_floats floats; sync: a3d_dn_persist_sync_ints(..)
+ *      ints (zeroed by the call; sync[2] != 0 afterwards = a wait exceeded its bound and the launch gave up: the trajectory is then
+ *      invalid).  Needs 2 * B * NT + 16 <= the device's CU count (all workgroups are co-resident); otherwise A3D_ERR_ARG -> per-phase
+ *      entry points (L <= 16) or a smaller batch per call. */
 typedef struct {
   a3d_dn_cross_params cross;
   a3d_dn_rest_params rest;
 } a3d_dn_layer_params;
 int a3d_dn_persist_splits(int H, int nsplit);
 size_t a3d_dn_persist_kvx_floats(int B, int L, int E);
+size_t a3d_dn_persist_xbuf_floats(int B, int L);
 /* development aid: 256 phase timestamps (100 MHz ticks) of the last a3d_dn_persist launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dn_persist_prof(const int* sync, int B, int L, int n_layers, int nsteps, long long* out256);
 size_t a3d_dn_persist_sync_ints(int B, int L, int n_layers, int nsteps);
 int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos, int n_rot, const a3d_dn_head_params* head,
-                   const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, float* kvx, int* sync, int B, int L, int D,
-                   int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream);
+                   const a3d_dn_tail_params* tail, float* traj, float* qbuf, float* part, float* kvx, float* xbuf, int* sync, int B,
+                   int L, int D, int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream);
 /* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dbg_dn_prof(long long* out18);
 /* development aid: arm / disarm the phase timestamps (100 MHz ticks) of workgroup (0, 0) of a3d_sq_attn_bwd's key pass and read the

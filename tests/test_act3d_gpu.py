@@ -194,6 +194,9 @@ def test_act3d_free_running_numpy_sampler(a3d, dev, tag):
     ("cfg2", 2, 4, 3, 333, C.PERACT_BOUNDS, 5),
     # configs[4] shapes: 74-task workspace, 4 levels at 10000 ghost points (2500 / level), 3 cameras, S = 3073
     ("cfg5", 2, 3, 4, 2500, C.HIVEFORMER_BOUNDS, 6),
+    # configs[3] (joint keypose + trajectory training, DP batch 128 over 8 GPUs): the keypose half at its PER-GPU shape, 16 keyframes;
+    # the trajectory half is tests/test_diffusion_gpu.py::test_cfg4_trajectory_half_per_gpu_shape_vs_oracle
+    ("cfg4-keypose", 16, 4, 3, 333, C.PERACT_BOUNDS, 7),
 ])
 def test_act3d_full_shapes_vs_oracle_teacher_forced(a3d, dev, name, B, ncam, levels, Ng, bounds, seed):
     """Full token counts of the training configurations -- HIP vs CPU oracle, per-level teacher forcing."""

@@ -200,6 +200,56 @@ def test_persistent_sampler_equals_per_phase_launches(a3d, dev, B, Ln, n_steps):
     scale_close("persistent traced vs one launch", got_t, got, 1e-6)
 
 
+def test_cfg4_trajectory_half_per_gpu_shape_vs_oracle(a3d, dev):
+    """BASELINE.json configs[3] (joint keypose + trajectory-diffusion training, DP batch 128 over 8 GPUs), trajectory half at its
+    PER-GPU shape: 16 trajectories of horizon 50 (scripts/train_trajectory.sh), 3 cameras (S = 3074), E = 120 -- training loss and
+    gradients of the HIP step against the CPU oracle's planner loss (diffusion_model.py:253-324) on the same noise / timesteps,
+    dropout off (the Philox dropout has its own parity tests).  The keypose half: test_act3d_gpu.py [cfg4-keypose]."""
+    from oracle import diffusion as OD
+    from oracle import sampling as OS
+    r = load("diffusion.pt")
+    E, B, Ln, ncam, H = 120, 16, 50, 3, 8
+    m = a3d.DiffusionPlanner(embedding_dim=E, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100, dropout=0.0)
+    P = _diffusion_params(r)
+    m.load_state_dict(P, strict=False)
+    m.to(dev).train()
+    inp = C.trajectory_inputs(95, B, Ln, ncam, E, pad_last=6)
+    tokens = C.tokens_from_maps(inp["fmap"])
+    g = torch.Generator().manual_seed(95)
+    noise = torch.randn(B, Ln, 9, generator=g)
+    timesteps = torch.randint(0, 100, (B,), generator=g)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    for p in m.parameters():
+        p.grad = None
+    loss = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"], noise=noise.to(dev),
+             timesteps=timesteps.to(dev), visual_tokens=tokens.to(dev))
+    loss.backward()
+    # oracle on leaf copies of the same parameters
+    leaf, Po = {}, {}
+    for n, t in P.items():
+        if id(t) not in leaf:
+            leaf[id(t)] = t.clone().requires_grad_(t.dtype.is_floating_point)
+        Po[n] = leaf[id(t)]
+    bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
+    pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
+    cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
+    oloss, _, _ = OD.planner_loss(Po, OD.DDPMSchedules(100), inp["trajectory"], inp["mask"], tokens, None, inp["instr"], inp["curr_gripper"],
+                                  inp["goal_gripper"], bounds, noise, timesteps, H, ctx_xyz_norm=cxyz_n)
+    oloss.backward()
+    scale_close("cfg4 trajectory-half loss", loss, oloss.detach(), 1e-3)
+    named = dict(m.named_parameters())
+    checked = 0
+    for n in ("prediction_head.traj_encoder.0.weight", "prediction_head.traj_attention.0.layers.0.cross_12.in_proj_weight",
+              "prediction_head.traj_attention.0.layers.0.sa1.in_proj_weight", "prediction_head.traj_attention.0.layers.0.ffn_12.0.weight",
+              "prediction_head.pos_regressor.0.3.weight", "prediction_head.vl_attention.0.layers.0.cross_12.in_proj_weight"):
+        if n in named and n in Po and Po[n].grad is not None and named[n].grad is not None:
+            scale_close("cfg4 grad " + n, named[n].grad, Po[n].grad, 1.5e-3, floor=1e-3)
+            checked += 1
+    assert checked >= 4, "too few gradient tensors were comparable (parameter names changed?)"
+
+
 def test_persistent_sampler_script_horizon_50_vs_oracle(a3d, dev):
     """The horizon the reference deploys (interpolation_length = 50: scripts/train_trajectory.sh:7-8, online_evaluation/eval.sh:17)
     on the fused path: four 16-step row tiles per trajectory, one sample-role workgroup each, self-attention keys / values exchanged
