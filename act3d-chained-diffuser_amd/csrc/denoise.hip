@@ -404,17 +404,18 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
   const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   float m_run = -INFINITY;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  Frag cur;
-  if (h_beg < h_end) cur = load(h_beg);
-  for (int hf = h_beg; hf < h_end; ++hf) {
-    Frag nxt = cur;
-    if (hf + 1 < h_end) nxt = load(hf + 1);
+  // Three fragments in flight per wave in three FIXED register sets, the loop unrolled by three, unconditional clamped refills and
+  // masked consumption (see the persistent sampler's stream role below for the why: with rotating sets -- cur = nxt -- the register
+  // moves wait for loads in flight and the effective depth was one: 2 us per 32-key half, the bare memory latency)
+  const int NHc = Sp >> 5;
+  auto consume = [&](const Frag& cur, int hf, bool live) {
+    const int s_lim = live ? S : 0;
     const int key0 = hf * 32;
     f32x4 s[2];
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < S) ? 0.f : -INFINITY;
+      for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
       const float4 kf = T ? cur.k1 : cur.k0;
       s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
       s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
@@ -448,7 +449,28 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
     acc = mfma_bf16_16x16x32(vh, phi, acc);
     acc = mfma_bf16_16x16x32(vh, plo, acc);
     acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
-    cur = nxt;
+  };
+  Frag f0, f1, f2;
+  __builtin_amdgcn_sched_barrier(0);
+  f0 = load(min(h_beg, NHc - 1));
+  __builtin_amdgcn_sched_barrier(0);
+  f1 = load(min(h_beg + 1, NHc - 1));
+  __builtin_amdgcn_sched_barrier(0);
+  f2 = load(min(h_beg + 2, NHc - 1));
+  __builtin_amdgcn_sched_barrier(0);
+  for (int hf = h_beg; hf < h_end; hf += 3) {
+    consume(f0, hf, true);
+    __builtin_amdgcn_sched_barrier(0);
+    f0 = load(min(hf + 3, NHc - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    consume(f1, hf + 1, hf + 1 < h_end);
+    __builtin_amdgcn_sched_barrier(0);
+    f1 = load(min(hf + 4, NHc - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    consume(f2, hf + 2, hf + 2 < h_end);
+    __builtin_amdgcn_sched_barrier(0);
+    f2 = load(min(hf + 5, NHc - 1));
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- combine the four waves (disjoint key ranges) and write this split's partial
 #pragma unroll
@@ -984,24 +1006,19 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       };
       float m_run = -INFINITY;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      // three fragments in flight per wave (an item is ~6 - 12 halves of 32 keys: the first round trips are the item's latency)
-      Frag f0, f1, f2;
-      if (h_beg < h_end) f0 = load(h_beg);
-      f1 = f0;
-      if (h_beg + 1 < h_end) f1 = load(h_beg + 1);
-      f2 = f1;
-      if (h_beg + 2 < h_end) f2 = load(h_beg + 2);
-      for (int hf = h_beg; hf < h_end; ++hf) {
-        const Frag cur = f0;
-        f0 = f1;
-        f1 = f2;
-        if (hf + 3 < h_end) f2 = load(hf + 3);
+      // Three fragments in flight per wave, in THREE FIXED register sets: the loop is unrolled by three and each set is refilled in
+      // place right after its use.  (Rotating the sets -- cur = f0; f0 = f1; f1 = f2; f2 = load() -- compiles to register moves of
+      // fragments whose loads are still in flight, i.e. a full s_waitcnt per iteration and an effective depth of ONE: the phase
+      // probe showed 1.75 us per 32-key half, the bare memory latency, in this loop and in dn_cross_kernel's two-set version.)
+      const int S_keys = a.S;               // read ONCE: a load of the argument block inside the loop is the newest load there and forces vmcnt(0)
+      auto consume = [&](const Frag& cur, int hf, bool live) {      // live == false: a half past the range, every key masked
         const int key0 = hf * 32;
+        const int s_lim = live ? S_keys : 0;
         f32x4 s[2];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < a.S) ? 0.f : -INFINITY;
+          for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
           const float4 kf = T ? cur.k1 : cur.k0;
           s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
           s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
@@ -1035,6 +1052,32 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
         acc = mfma_bf16_16x16x32(vh, phi, acc);
         acc = mfma_bf16_16x16x32(vh, plo, acc);
         acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
+      };
+      Frag f0, f1, f2;
+      __builtin_amdgcn_sched_barrier(0);
+      f0 = load(min(h_beg, NH - 1));                          // (an empty range -- more splits than halves -- loads one fragment it never uses)
+      __builtin_amdgcn_sched_barrier(0);
+      f1 = load(min(h_beg + 1, NH - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      f2 = load(min(h_beg + 2, NH - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      // straight-line body: UNCONDITIONAL refills (clamped addresses) and masked consumption, so that the number of loads in
+      // flight at every use is a compile-time constant and the compiler waits with vmcnt(8), not vmcnt(0)
+      // (the scheduling barriers pin the order consume | refill | consume ...: left alone, the machine scheduler sinks all twelve
+      // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
+      for (int hf = h_beg; hf < h_end; hf += 3) {
+        consume(f0, hf, true);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = load(min(hf + 3, NH - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(f1, hf + 1, hf + 1 < h_end);
+        __builtin_amdgcn_sched_barrier(0);
+        f1 = load(min(hf + 4, NH - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(f2, hf + 2, hf + 2 < h_end);
+        __builtin_amdgcn_sched_barrier(0);
+        f2 = load(min(hf + 5, NH - 1));
+        __builtin_amdgcn_sched_barrier(0);
       }
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
       const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
