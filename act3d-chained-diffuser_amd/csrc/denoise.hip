@@ -458,20 +458,23 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
   __builtin_amdgcn_sched_barrier(0);
   f2 = load(min(h_beg + 2, NHc - 1));
   __builtin_amdgcn_sched_barrier(0);
-  for (int hf = h_beg; hf < h_end; hf += 3) {
+  int hf = h_beg;
+  for (; hf + 3 <= h_end; hf += 3) {
     consume(f0, hf, true);
     __builtin_amdgcn_sched_barrier(0);
     f0 = load(min(hf + 3, NHc - 1));
     __builtin_amdgcn_sched_barrier(0);
-    consume(f1, hf + 1, hf + 1 < h_end);
+    consume(f1, hf + 1, true);
     __builtin_amdgcn_sched_barrier(0);
     f1 = load(min(hf + 4, NHc - 1));
     __builtin_amdgcn_sched_barrier(0);
-    consume(f2, hf + 2, hf + 2 < h_end);
+    consume(f2, hf + 2, true);
     __builtin_amdgcn_sched_barrier(0);
     f2 = load(min(hf + 5, NHc - 1));
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (hf < h_end) consume(f0, hf, true);                      // the last one or two halves of the range (wave-uniform branches)
+  if (hf + 1 < h_end) consume(f1, hf + 1, true);
   // ---- combine the four waves (disjoint key ranges) and write this split's partial
 #pragma unroll
   for (int r = 0; r < 4; ++r) Cacc[wave][li][g * 4 + r] = acc[r];
@@ -1065,20 +1068,23 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       // flight at every use is a compile-time constant and the compiler waits with vmcnt(8), not vmcnt(0)
       // (the scheduling barriers pin the order consume | refill | consume ...: left alone, the machine scheduler sinks all twelve
       // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
-      for (int hf = h_beg; hf < h_end; hf += 3) {
+      int hf = h_beg;
+      for (; hf + 3 <= h_end; hf += 3) {
         consume(f0, hf, true);
         __builtin_amdgcn_sched_barrier(0);
         f0 = load(min(hf + 3, NH - 1));
         __builtin_amdgcn_sched_barrier(0);
-        consume(f1, hf + 1, hf + 1 < h_end);
+        consume(f1, hf + 1, true);
         __builtin_amdgcn_sched_barrier(0);
         f1 = load(min(hf + 4, NH - 1));
         __builtin_amdgcn_sched_barrier(0);
-        consume(f2, hf + 2, hf + 2 < h_end);
+        consume(f2, hf + 2, true);
         __builtin_amdgcn_sched_barrier(0);
         f2 = load(min(hf + 5, NH - 1));
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (hf < h_end) consume(f0, hf, true);                  // the last one or two halves of the range (wave-uniform branches)
+      if (hf + 1 < h_end) consume(f1, hf + 1, true);
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
       const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
       float* od = &Op[(row0 + li) * 16 + 4 * g];

@@ -727,6 +727,9 @@ class DiffusionPlanner(nn.Module):
         static = static + [step_noise, cond_data, cond_mask_u8, kmask]
 
         persist = fused and state.get("persist") is not None and all(a_ - b_ == 1 for a_, b_ in zip(steps, steps[1:]))
+        # which sampler serves this call (read by the bench line and the tests)
+        self.last_sampler_path = "multi-round" if multi else ("persistent (a3d_dn_persist)" if persist else
+                                                               ("per-phase fused launches" if fused else "op-by-op"))
 
         def run_loop(x):
             if persist and not return_trace:                # the whole loop: one launch

@@ -16,8 +16,11 @@ GROUPS = {
     "attn_bwd": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel", "attn16_bwd_prep_kernel",
                  "attn16_bwd_dq_kernel", "attn16_bwd_dkv_kernel"],
     "kv_proj_rope": ["proj_rope_split_kernel"],
-    "sq_fwd": ["sq_fwd_kernel", "sq_combine_kernel"],
-    "sq_bwd": ["sq_bwd_kernel"],
+    "sq_fwd": ["sq_fwd_kernel", "sqw_fwd_kernel", "sq_combine_kernel"],
+    "sq_bwd": ["sq_bwd_kernel", "sqw_bwd_kernel"],
+    "dn_cross": ["dn_cross_kernel"],
+    "dn_rest": ["dn_rest_loop_kernel"],
+    "dn_persist": ["dn_persist_kernel"],
     "knn_topk": ["knn_dist_hist_kernel", "knn_select_sort_kernel"],
     "bn_stats": ["bn_stats_kernel"],
 }

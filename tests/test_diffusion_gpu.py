@@ -245,7 +245,14 @@ def test_cfg4_trajectory_half_per_gpu_shape_vs_oracle(a3d, dev):
               "prediction_head.traj_attention.0.layers.0.sa1.in_proj_weight", "prediction_head.traj_attention.0.layers.0.ffn_12.0.weight",
               "prediction_head.pos_regressor.0.3.weight", "prediction_head.vl_attention.0.layers.0.cross_12.in_proj_weight"):
         if n in named and n in Po and Po[n].grad is not None and named[n].grad is not None:
-            scale_close("cfg4 grad " + n, named[n].grad, Po[n].grad, 1.5e-3, floor=1e-3)
+            # 16 x 50 x 9 = 7200 L1 terms: a residual within rounding of zero flips its sign(pred - gt) between the two runs and moves
+            # every upstream gradient by a discrete 100 / N or 10 / N step (the golden fixtures are chosen away from such kinks, a
+            # full-shape random batch cannot be) -- so the tensors are held in aggregate (relative L2) and loosely element-wise
+            gd, go = named[n].grad.detach().float().cpu(), Po[n].grad.float()
+            rel = ((gd - go).norm() / go.norm()).item()
+            print(f"[parity] cfg4 grad {n}: relative L2 {rel:.3e}, max abs err {(gd - go).abs().max().item():.3e} of scale {go.abs().max().item():.3e}")
+            assert rel <= 3e-3, (n, rel)
+            scale_close("cfg4 grad " + n, named[n].grad, Po[n].grad, 5e-3, floor=1e-3)
             checked += 1
     assert checked >= 4, "too few gradient tensors were comparable (parameter names changed?)"
 
