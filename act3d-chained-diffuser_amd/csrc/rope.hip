@@ -341,6 +341,43 @@ __global__ __launch_bounds__(256) void rope_merge_bwd_kernel(
   }
 }
 
+// The same per (row, pair) item with 32-bit indices and the channel count as a compile-time constant (grid.y = sample): the generic
+// kernel above spends most of its instructions on four 64-bit integer divisions per item (idx -> pair / row / sample) and two
+// run-time divisions by E / 3 and 15; here idx % (EC / 2), / 15 and / (EC / 3) are multiply-shifts.  Same loads, same arithmetic.
+template <int EC>
+__global__ __launch_bounds__(256) void rope_merge_bwd_pairs_kernel(
+    const float* __restrict__ dR, int nsplit, const float* __restrict__ xyz, const float* __restrict__ freq,
+    float scale, float* __restrict__ dY, int ldy, int B, int N, int Npad) {
+  constexpr int H = EC / HD, half = EC / 2, third = EC / 3;
+  const int b = blockIdx.y;
+  const unsigned int idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (unsigned int)N * half) return;
+  const int n = (int)(idx / half), p = (int)(idx - (unsigned int)n * half);
+  const int c0 = 2 * p, c1 = c0 + 1;
+  const int h0 = c0 / HD, d0 = c0 - h0 * HD;
+  const int h1 = c1 / HD, d1 = c1 - h1 * HD;
+  const size_t split_stride = (size_t)B * H * Npad * HDP;
+  const size_t o0 = (((size_t)b * H + h0) * Npad + n) * HDP + d0;
+  const size_t o1 = (((size_t)b * H + h1) * Npad + n) * HDP + d1;
+  float g0 = 0.f, g1 = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    g0 += dR[s * split_stride + o0];
+    g1 += dR[s * split_stride + o1];
+  }
+  const size_t m = (size_t)b * N + n;
+  float y0 = g0, y1 = g1;
+  if (xyz) {
+    const int axis = c0 / third;
+    const int k = (c0 - axis * third) >> 1;
+    float sn, cs;
+    fast_sincos(xyz[m * 3 + axis] * freq[k], &sn, &cs);
+    y0 = cs * g0 + sn * g1;
+    y1 = cs * g1 - sn * g0;
+  }
+  dY[m * ldy + c0] = y0 * scale;
+  dY[m * ldy + c1] = y1 * scale;
+}
+
 // The same, one THREAD per row for the two models' widths (EC = 60 / 120 channels, H = EC / 15 heads).  The kernel above spends
 // its time on four 64-bit integer divisions per channel pair (item -> row / pair / sample) and reads each head's 15 channels of a
 // row as a separate 60-byte piece; here a thread sums its row's H x 16-float records over the splits with float4 loads
@@ -478,6 +515,15 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
       hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<60>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
     else
       hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<120>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    return check_launch("a3d_rope_merge_bwd");
+  }
+  static const bool pairs_on = !(getenv("A3D_ROPE_MERGE_PAIRS") && atoi(getenv("A3D_ROPE_MERGE_PAIRS")) == 0);      // A/B: the generic kernel
+  if (pairs_on && ((E == 60 && H == 4) || (E == 120 && H == 8)) && (size_t)N * (E / 2) < (1u << 31) && B <= 65535) {
+    const dim3 grid2((unsigned)(((size_t)N * (E / 2) + 255) / 256), B);
+    if (E == 60)
+      hipLaunchKernelGGL(rope_merge_bwd_pairs_kernel<60>, grid2, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
+    else
+      hipLaunchKernelGGL(rope_merge_bwd_pairs_kernel<120>, grid2, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
     return check_launch("a3d_rope_merge_bwd");
   }
   const size_t total = (size_t)B * N * (E / 2);

@@ -75,7 +75,17 @@ def _time(fn, iters):
 
 # HBM bytes per a3d_dn_cross launch at cfg-3 from the committed counter passes: FETCH_SIZE 111215.5 KiB x 2 (gfx950 wide-read
 # correction) + WRITE_SIZE 1088 KiB
-PMC_DN_CROSS_BYTES = (111215.5 * 2 + 1088.0) * 1024
+PMC_DN_CROSS_BYTES = (111215.5 * 2 + 1088.0) * 1024      # round 2 (superseded by the committed round-5 records read below)
+
+
+def _pmc_bytes(fname, key):
+    """HBM bytes per launch of `key` from a committed counter record (profiles/pmc_json_cmd.sh), or None"""
+    import json
+    try:
+        with open(os.path.join(ROOT, "profiles", fname)) as fh:
+            return json.load(fh)["kernels"][key]["hbm_bytes"]
+    except Exception:
+        return None
 
 
 def cached_attention_roofline(a3d, B, Ln, S, dev, nlayers=8):
@@ -111,8 +121,8 @@ def cached_attention_roofline(a3d, B, Ln, S, dev, nlayers=8):
     return {"bound": "hbm", "kernel": "dn_cross (trajectory -> context cross-attention against the fp32-K / bf16-V cache)",
             "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0, "ms": t * 1e3,
             "timing": f"mean over launches rotating through {nlayers} distinct caches ({nlayers * stored / 1e9:.2f} GB working set)",
-            "traffic": PMC_DN_CROSS_BYTES if (B, Ln, S) == (64, 16, 3074) else None,
-            "traffic_source": "profiles/r02_pmc_denoise_summary.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, same "
+            "traffic": _pmc_bytes("r05_pmc_denoise_perphase.json", "dn_cross") if (B, Ln, S) == (64, 16, 3074) else None,
+            "traffic_source": "profiles/r05_pmc_denoise_perphase.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, same "
                               f"kernel and shapes, nsplit {ns})",
             "algorithmic_bytes_per_launch": alg, "stored_bytes_per_launch": stored,
             "stored_bytes_rate_GBps": stored / t / 1e9, "launches_per_denoise_step": 8, "nsplit": ns}
@@ -193,7 +203,10 @@ def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
     loop = {"bound": "hbm", "kernel": "sampling loop (a3d_dn_persist: one launch)" if "persistent" in str(getattr(m, "last_sampler_path", "")) else "sampling loop",
             "achieved": alg_step / step_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg_step / step_s / 1e9 / 8000.0,
             "algorithmic_bytes_per_step": alg_step, "stored_bytes_per_step": stored_step, "stored_frac": stored_step / step_s / 1e9 / 8000.0,
-            "traffic": None, "note": "whole denoise step incl. the per-sample chain (head, 8 layer remainders, tail) and the per-call context build "
+            "traffic": (lambda v: None if v is None else v / 100.0)(_pmc_bytes("r05_pmc_denoise_persist.json", "dn_persist"))
+            if (B, Ln, S) == (64, 16, 3074) and "persistent" in str(getattr(m, "last_sampler_path", "")) else None,
+            "traffic_source": "profiles/r05_pmc_denoise_persist.json: dn_persist_kernel, one launch = 100 steps (FETCH_SIZE x2 + WRITE_SIZE) / 100",
+            "note": "whole denoise step incl. the per-sample chain (head, 8 layer remainders, tail) and the per-call context build "
                                      "amortised over 100 steps; the streaming itself is VALU / MFMA-issue bound (exp2, bf16 split, fp32 QK^T), see DESIGN 4"}
     return {
         "metric": "DDPM trajectory sampling, 100 denoise steps (trajectories/s)", "value": B / dt, "unit": "trajectories/s",
