@@ -1055,94 +1055,81 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       // place right after its use.  (Rotating the sets -- cur = f0; f0 = f1; f1 = f2; f2 = load() -- compiles to register moves of
       // fragments whose loads are still in flight, i.e. a full s_waitcnt per iteration and an effective depth of ONE: the phase
       // probe showed 1.75 us per 32-key half, the bare memory latency, in this loop and in dn_cross_kernel's two-set version.)
+      // (Measured and reverted in round 5: THREE halves per softmax update with ping-pong fragment groups -- 24 independent score
+      // MFMAs, one rescale per 96 keys, three value accumulators, graded vmcnt(21 .. 12) waits -- made an item SLOWER, 20 -> 23.5 us
+      // for 12 halves, 0.768 -> 0.86 ms per denoise step: gpurun r05q.  The single-half body below stays.)
       const int S_keys = a.S;               // read ONCE: a load of the argument block inside the loop is the newest load there and forces vmcnt(0)
-      // THREE halves (96 keys) per softmax update: their 24 score MFMAs and 24 exponentials are independent of each other, one running
-      // maximum / rescale serves all three, and the value products go into three accumulators -- the single-half body was a dependent
-      // chain (4 + 4 score MFMAs -> max -> cross-lane max -> exp -> convert -> 3 chained value MFMAs) that two waves per SIMD cannot
-      // hide: ~3800 cycles per half measured against ~900 of issue.  nlive < 3: the range's tail, the missing halves fully masked.
-      auto consume3 = [&](const Frag& fa, const Frag& fb, const Frag& fc, int hf, int nlive) {
-        const Frag* fr[3] = {&fa, &fb, &fc};
-        f32x4 s[3][2];
+      auto consume = [&](const Frag& cur, int hf, bool live) {      // live == false: a half past the range, every key masked
+        const int key0 = hf * 32;
+        const int s_lim = live ? S_keys : 0;
+        f32x4 s[2];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int key0 = (hf + j) * 32;
-          const int s_lim = j < nlive ? S_keys : 0;
+        for (int T = 0; T < 2; ++T) {
 #pragma unroll
-          for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[j][T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
-          }
+          for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
+          const float4 kf = T ? cur.k1 : cur.k0;
+          s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.z, qb.z, s[T]);
+          s[T] = mfma_f32_16x16x4(kf.w, qb.w, s[T]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                         // k-step e of all six score tiles back to back: six independent chains
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float4 k0 = fr[j]->k0, k1 = fr[j]->k1;
-            const float a0 = e == 0 ? k0.x : (e == 1 ? k0.y : (e == 2 ? k0.z : k0.w));
-            const float a1 = e == 0 ? k1.x : (e == 1 ? k1.y : (e == 2 ? k1.z : k1.w));
-            const float qe = e == 0 ? qb.x : (e == 1 ? qb.y : (e == 2 ? qb.z : qb.w));
-            s[j][0] = mfma_f32_16x16x4(a0, qe, s[j][0]);
-            s[j][1] = mfma_f32_16x16x4(a1, qe, s[j][1]);
-          }
-        }
-        float mt = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int T = 0; T < 2; ++T)
-            mt = fmaxf(mt, fmaxf(fmaxf(s[j][T][0], s[j][T][1]), fmaxf(s[j][T][2], s[j][T][3])));
+        const float mt = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
         const float m_new = fmaxf(m_run, colmax4(mt));
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float nm = -m_use * LOG2E_F;
         const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));
-        m_run = m_new;
-        f32x4 part[3];
+        unsigned int hw[4], lw[4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          unsigned int hw[4], lw[4];
+        for (int T = 0; T < 2; ++T) {
 #pragma unroll
-          for (int T = 0; T < 2; ++T) {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-              const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[j][T][2 * pr], LOG2E_F, nm)),
-                                __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][T][2 * pr + 1], LOG2E_F, nm))};
-              const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
-              const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
-              hw[T * 2 + pr] = h2;
-              lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
-            }
+          for (int pr = 0; pr < 2; ++pr) {
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr], LOG2E_F, nm)),
+                              __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr + 1], LOG2E_F, nm))};
+            const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
+            const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
+            hw[T * 2 + pr] = h2;
+            lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
           }
-          const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-          const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-          const s16x8 vh = (li == 15) ? ones : fr[j]->vh;     // pad channel 15 := 1: the denominator on the MFMA pipe
-          f32x4 pj = {0.f, 0.f, 0.f, 0.f};
-          pj = mfma_bf16_16x16x32(vh, phi, pj);
-          pj = mfma_bf16_16x16x32(vh, plo, pj);
-          pj = mfma_bf16_16x16x32(fr[j]->vl, phi, pj);
-          part[j] = pj;
         }
+        const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+        const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+        const s16x8 vh = (li == 15) ? ones : cur.vh;        // pad channel 15 := 1: acc[15] = sum_k p on the MFMA pipe
+        m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = acc[r] * alpha + ((part[0][r] + part[1][r]) + part[2][r]);
+        for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+        acc = mfma_bf16_16x16x32(vh, phi, acc);
+        acc = mfma_bf16_16x16x32(vh, plo, acc);
+        acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
       };
-      // Two groups of three fragments in FIXED register sets, ping-pong: while one group is consumed the other's loads are in flight;
-      // refills are unconditional (clamped addresses) and pinned behind scheduling barriers, so every wait is a vmcnt(12)-class wait on
-      // the OLDER group (rotating sets / conditional refills / any other load in the loop degrade to vmcnt(0): see the notes in DESIGN 4.2)
-      Frag a0, a1, a2, b0, b1, b2;
+      Frag f0, f1, f2;
       __builtin_amdgcn_sched_barrier(0);
-      a0 = load(min(h_beg, NH - 1)); a1 = load(min(h_beg + 1, NH - 1)); a2 = load(min(h_beg + 2, NH - 1));
+      f0 = load(min(h_beg, NH - 1));                          // (an empty range -- more splits than halves -- loads one fragment it never uses)
       __builtin_amdgcn_sched_barrier(0);
-      b0 = load(min(h_beg + 3, NH - 1)); b1 = load(min(h_beg + 4, NH - 1)); b2 = load(min(h_beg + 5, NH - 1));
+      f1 = load(min(h_beg + 1, NH - 1));
       __builtin_amdgcn_sched_barrier(0);
-      for (int hf = h_beg; hf < h_end; hf += 6) {
-        consume3(a0, a1, a2, hf, min(3, h_end - hf));
+      f2 = load(min(h_beg + 2, NH - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      // straight-line body: UNCONDITIONAL refills (clamped addresses) and masked consumption, so that the number of loads in
+      // flight at every use is a compile-time constant and the compiler waits with vmcnt(8), not vmcnt(0)
+      // (the scheduling barriers pin the order consume | refill | consume ...: left alone, the machine scheduler sinks all twelve
+      // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
+      int hf = h_beg;
+      for (; hf + 3 <= h_end; hf += 3) {
+        consume(f0, hf, true);
         __builtin_amdgcn_sched_barrier(0);
-        a0 = load(min(hf + 6, NH - 1)); a1 = load(min(hf + 7, NH - 1)); a2 = load(min(hf + 8, NH - 1));
+        f0 = load(min(hf + 3, NH - 1));
         __builtin_amdgcn_sched_barrier(0);
-        consume3(b0, b1, b2, hf + 3, max(0, min(3, h_end - hf - 3)));      // nlive = 0: every key masked (p = 0, alpha = 1)
+        consume(f1, hf + 1, true);
         __builtin_amdgcn_sched_barrier(0);
-        b0 = load(min(hf + 9, NH - 1)); b1 = load(min(hf + 10, NH - 1)); b2 = load(min(hf + 11, NH - 1));
+        f1 = load(min(hf + 4, NH - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(f2, hf + 2, true);
+        __builtin_amdgcn_sched_barrier(0);
+        f2 = load(min(hf + 5, NH - 1));
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (hf < h_end) consume(f0, hf, true);                  // the last one or two halves of the range (wave-uniform branches)
+      if (hf + 1 < h_end) consume(f1, hf + 1, true);
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
       const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
       float* od = &Op[(row0 + li) * 16 + 4 * g];

@@ -7,7 +7,9 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (PyTorch's allocator); the library never allocates
- *     or frees device memory and keeps no state besides a thread-local error string;
+ *     or frees device memory and keeps no state besides a thread-local error string.  There is no workspace object
+ *     (SURVEY 8b sketched a3d_workspace_create / _destroy): workspaces are caller-owned pointers whose sizes the
+ *     `*_ws_bytes` / `*_ws_floats` / `*_sync_ints` / `*_floats` queries return, which keeps every entry capturable;
  *   - every call only enqueues work on `stream` (a hipStream_t passed as void*): no host synchronisation, no
  *     default-stream use, so a sequence of calls is capturable with hipStreamBeginCapture / torch.cuda.graph;
  *   - return value 0 = ok, negative errno-style code otherwise (-22 bad argument, -5 launch failure);
