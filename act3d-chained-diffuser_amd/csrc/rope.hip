@@ -517,8 +517,9 @@ extern "C" int a3d_rope_merge_bwd(const float* dR, int nsplit, const float* xyz,
       hipLaunchKernelGGL(rope_merge_bwd_rows_kernel<120>, grid, dim3(256), 0, (hipStream_t)stream, dR, nsplit, xyz, freq, scale, dY, ldy, B, N, Npad);
     return check_launch("a3d_rope_merge_bwd");
   }
-  // opt-in (A3D_ROPE_MERGE_PAIRS=1): written at the end of round 5, parity-tested on MI355X but not timed kernel by kernel (the one
-  // bench run with it on was 2.6 % slower than the evidence run, inside box-to-box noise but not a measured gain)
+  // opt-in (A3D_ROPE_MERGE_PAIRS=1).  Measured in the eager keypose step (gpurun r05r, same box, kernel trace): 26.2 vs 27.1 us on
+  // average over the step's 18 calls, 36.3 vs 37.3 us for the 12 context-row calls -- the integer divisions were NOT this kernel's
+  // cost; it moves 131 MB per context-row call in 37 us = 3.5 TB/s (64-byte head records in, 240-byte rows out).  Not worth a default.
   static const bool pairs_on = getenv("A3D_ROPE_MERGE_PAIRS") && atoi(getenv("A3D_ROPE_MERGE_PAIRS")) != 0;
   if (pairs_on && ((E == 60 && H == 4) || (E == 120 && H == 8)) && (size_t)N * (E / 2) < (1u << 31) && B <= 65535) {
     const dim3 grid2((unsigned)(((size_t)N * (E / 2) + 255) / 256), B);

@@ -125,3 +125,9 @@ try:
 except Exception as e: print("persist=$1 split=$2 failed", e, open("$O/s.err").read()[-400:])
 P
 done
+
+# ======================================================================== later calls (seventh .. last): see the scripts kept beside this file
+#   r05_seventh.sh .. r05_sixteenth.sh  persistent sampler bring-up (fault isolation, fences, prefetch depth, helper workgroups, splits)
+#   r05_final.sh                        the evidence run (parity suite, bench line, traces)
+#   r05_pmc.sh                          counter passes
+#   r05_last.sh, r05_rope_ab.sh         final tree check, rope_merge_bwd A/B
