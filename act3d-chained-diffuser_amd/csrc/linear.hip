@@ -42,11 +42,14 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K, bool v
 // act: 0 none, 1 relu, 2 multiply by (mask > 0) [relu backward fused into dgrad], 3 Y += result [a gradient accumulated in place]
 // One 64x64 output tile per workgroup; the next K-chunk is prefetched into registers while the current one is
 // multiplied, so a chunk costs one HBM round trip, not two barriers + a dependent load.
-template <bool WT>
+// DROP: the nn.Dropout that follows the layer (dropout.hip's mask: element index m * N + n of the contiguous output, N % 8 == 0)
+// applied in the epilogue -- bit-identical to a3d_linear_fwd followed by a3d_dropout in place, one launch instead of two.
+template <bool WT, bool DROP>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
     const float* __restrict__ bias, float* __restrict__ Y, int ldy,
-    const float* __restrict__ mask, int ldm, int M, int N, int K, int act) {
+    const float* __restrict__ mask, int ldm, int M, int N, int K, int act,
+    const unsigned long long* __restrict__ drop_state, uint32_t drop_site, uint32_t drop_thr16, float drop_scale) {
   __shared__ __attribute__((aligned(16))) float Xs[LT_BM * LT_LD];
   __shared__ __attribute__((aligned(16))) float Ws[LT_BN * LT_LD];
   const int t = threadIdx.x;
@@ -118,9 +121,21 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     __syncthreads();
   }
   // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+  DropKey dkey{0u, 0u};
+  if (DROP) dkey = drop_key(drop_state);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int n = n0 + nt * 16 + li;
+    // A 16 x 16 tile holds 32 eight-element mask blocks (16 rows x 2 halves): lane (g, li) generates the block of row
+    // g*4 + (li & 3), half (li >> 2) & 1 (every block twice), and the four rows of a lane's column fetch theirs by shuffle --
+    // one Philox call per lane and tile instead of one per element.  All lanes take part (before the bounds guards).
+    uint32_t kbits[4] = {0u, 0u, 0u, 0u};
+    if (DROP) {
+      const size_t blk = ((size_t)(m0 + wave * 16 + g * 4 + (li & 3)) * N + (n0 + nt * 16 + ((li >> 2) & 1) * 8)) >> 3;
+      const uint32_t mine = drop_keep8(dkey, (uint32_t)blk, (uint32_t)(blk >> 32), 0xFFFFFFFFu, drop_site, drop_thr16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbits[r] = (uint32_t)__shfl((int)mine, (lane & 48) + r + 4 * (li >> 3), 64);
+    }
     if (n >= N) continue;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = (mask[(size_t)m * ldm + n] > 0.f) ? v : 0.f;
       else if (act == 3) v += Y[(size_t)m * ldy + n];
+      if (DROP) v = ((kbits[r] >> (li & 7)) & 1u) ? v * drop_scale : 0.f;
       Y[(size_t)m * ldy + n] = v;
     }
   }
@@ -357,11 +373,15 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
 // pass instead of one row per wave with 60 of 512 element slots used, 4- / 5-step reductions, a workgroup walks `rows_per_wg`
 // consecutive rows (one pass for the small maps) and issues its 2 E atomics once.  The one-row-per-wave kernel above took 33 us for
 // the 21 312 x 60 ghost-token rows (5 MB): a chain of dependent load -> 6-step reduce -> store rounds, ~5 rows deep per wave.
-template <int LPR>
+// DROP: second output dSd = dropout(dS) (the gradient through the nn.Dropout on the residual branch, dropout.hip's mask over the
+// flat index m * E + e, E % 8 == 0) -- bit-identical to a3d_dropout(dS -> dSd) afterwards, without the launch and the re-read.
+template <int LPR, bool DROP>
 __global__ __launch_bounds__(256) void add_ln_bwd_rows_kernel(
     const float* __restrict__ A, const float* __restrict__ R, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dY,
-    float* __restrict__ dS, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int E, int rows_per_wg) {
+    float* __restrict__ dS, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int E, int rows_per_wg,
+    float* __restrict__ dSd, const unsigned long long* __restrict__ drop_state, uint32_t drop_site, uint32_t drop_thr16,
+    float drop_scale) {
   constexpr int RPW = 64 / LPR, SLOTS = 256 / LPR;
   __shared__ float red_g[SLOTS][LPR * 4];
   __shared__ float red_b[SLOTS][LPR * 4];
@@ -407,9 +427,18 @@ __global__ __launch_bounds__(256) void add_ln_bwd_rows_kernel(
     for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     s1 *= inv_e;
     s2 *= inv_e;
-    if (ok)
-      *reinterpret_cast<float4*>(dS + (size_t)m * E + e0) = make_float4(rstd * (gy[0] - s1 - xh[0] * s2), rstd * (gy[1] - s1 - xh[1] * s2),
-                                                                      rstd * (gy[2] - s1 - xh[2] * s2), rstd * (gy[3] - s1 - xh[3] * s2));
+    if (ok) {
+      const float4 o = make_float4(rstd * (gy[0] - s1 - xh[0] * s2), rstd * (gy[1] - s1 - xh[1] * s2),
+                                   rstd * (gy[2] - s1 - xh[2] * s2), rstd * (gy[3] - s1 - xh[3] * s2));
+      *reinterpret_cast<float4*>(dS + (size_t)m * E + e0) = o;
+      if (DROP) {
+        const size_t idx = (size_t)m * E + e0;                     // a lane's four channels are one half of a mask block
+        const uint32_t keep = drop_keep8(drop_key(drop_state), (uint32_t)(idx >> 3), (uint32_t)(idx >> 35), 0xFFFFFFFFu, drop_site,
+                                         drop_thr16) >> (idx & 4);
+        *reinterpret_cast<float4*>(dSd + idx) = make_float4((keep & 1u) ? o.x * drop_scale : 0.f, (keep & 2u) ? o.y * drop_scale : 0.f,
+                                                            (keep & 4u) ? o.z * drop_scale : 0.f, (keep & 8u) ? o.w * drop_scale : 0.f);
+      }
+    }
   }
   if (dgamma) {
 #pragma unroll
@@ -444,20 +473,67 @@ extern "C" int a3d_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
   if (linear_split_applicable(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act))
     return linear_split_launch(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act, w_transposed, s);
   if (w_transposed)
-    hipLaunchKernelGGL(linear_fwd_kernel<true>, grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act);
+    hipLaunchKernelGGL((linear_fwd_kernel<true, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act,
+                       (const unsigned long long*)nullptr, 0u, 0u, 0.f);
   else
-    hipLaunchKernelGGL(linear_fwd_kernel<false>, grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act);
+    hipLaunchKernelGGL((linear_fwd_kernel<false, false>), grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act,
+                       (const unsigned long long*)nullptr, 0u, 0u, 0.f);
   return check_launch("a3d_linear_fwd");
+}
+
+static int linear_drop_params(const char* fn, float p, uint32_t* thr16, float* scale) {     // as dropout.hip's drop_params
+  if (!(p >= 0.f) || !(p < 1.f)) {
+    set_error("%s: dropout probability %g outside [0, 1)", fn, (double)p);
+    return A3D_ERR_ARG;
+  }
+  *thr16 = (uint32_t)lrintf(p * 65536.0f);
+  *scale = 1.0f / (1.0f - p);
+  return A3D_OK;
+}
+
+// Y = dropout(act(X W^T + b)): the layer and the nn.Dropout behind it (layers.py:82-84,146,181, diffusion_head.py:46,183,193) in
+// one launch.  Same bits as a3d_linear_fwd + a3d_dropout(Y -> Y) -- which is also what runs when the epilogue does not apply
+// (N % 8 != 0, or a row count that the bf16x3 kernel of linear_split.hip serves).
+extern "C" int a3d_linear_fwd_drop(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                                   const float* mask, int ldm, int M, int N, int K, int act, int w_transposed,
+                                   const unsigned long long* state, unsigned int site, float p, void* stream) {
+  if (!X || !W || !Y || !state || M < 0 || N <= 0 || K <= 0 || ldx < K || ldy != N || act == 3) {
+    set_error("a3d_linear_fwd_drop: bad argument (M=%d N=%d K=%d ldx=%d ldy=%d act=%d; the output must be contiguous, ldy == N, and "
+              "act 3 has no dropout form)", M, N, K, ldx, ldy, act);
+    return A3D_ERR_ARG;
+  }
+  if (act == 2 && !mask) { set_error("a3d_linear_fwd_drop: act=2 needs a mask"); return A3D_ERR_ARG; }
+  uint32_t thr; float scale;
+  int rc = linear_drop_params("a3d_linear_fwd_drop", p, &thr, &scale);
+  if (rc) return rc;
+  if (M == 0) return A3D_OK;
+  if ((N & 7) || linear_split_applicable(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act)) {
+    rc = a3d_linear_fwd(X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act, w_transposed, stream);
+    return rc ? rc : a3d_dropout(Y, Y, (size_t)M * N, state, site, p, stream);
+  }
+  dim3 grid(cdiv(M, LT_BM), cdiv(N, LT_BN));
+  hipStream_t s = (hipStream_t)stream;
+  if (w_transposed)
+    hipLaunchKernelGGL((linear_fwd_kernel<true, true>), grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act,
+                       state, (uint32_t)site, thr, scale);
+  else
+    hipLaunchKernelGGL((linear_fwd_kernel<false, true>), grid, dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, mask, ldm, M, N, K, act,
+                       state, (uint32_t)site, thr, scale);
+  return check_launch("a3d_linear_fwd_drop");
 }
 
 // With a workspace the M reduction is split into single-stage (64-row) .. 256-row chunks whose partial tiles a second
 // kernel adds in order; without one (or for M < 1024) the one-stage kernel accumulates with float atomics.
-constexpr int WG_TWO_STAGE_MIN_ROWS = 1024;
+// (A3D_WGRAD_TWO_STAGE_MIN_ROWS to A/B the threshold: the trajectory stream's M = B * L = 1100 rows sit just above it.)
+static int wg_two_stage_min_rows() {
+  static const int v = getenv("A3D_WGRAD_TWO_STAGE_MIN_ROWS") ? atoi(getenv("A3D_WGRAD_TWO_STAGE_MIN_ROWS")) : 1024;
+  return v;
+}
 
 static void wgrad_plan(int M, int N, int KE, bool have_ws, int* nsplit_out, int* rows_out, bool* two_stage) {
   const int tiles = cdiv(N, 64) * cdiv(KE, 64);
   int nsplit;
-  *two_stage = have_ws && M >= WG_TWO_STAGE_MIN_ROWS;
+  *two_stage = have_ws && M >= wg_two_stage_min_rows();
   if (*two_stage) {
     // no atomics: oversubscribe (up to ~4 workgroups per CU hide the stage latency); short chunks for mid-size M
     static int target2 = getenv("A3D_WGRAD_WGS2") ? atoi(getenv("A3D_WGRAD_WGS2")) : 1024;
@@ -555,15 +631,42 @@ extern "C" int a3d_add_layernorm_bwd(const float* A, const float* R, const float
     while (cdiv(M, rpw) > 2048 && rpw < 16 * per_pass) rpw *= 2;
     const int grid = cdiv(M, rpw);
     if (E <= 64)
-      hipLaunchKernelGGL(add_ln_bwd_rows_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS, dgamma,
-                         dbeta, M, E, rpw);
+      hipLaunchKernelGGL((add_ln_bwd_rows_kernel<16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS,
+                         dgamma, dbeta, M, E, rpw, (float*)nullptr, (const unsigned long long*)nullptr, 0u, 0u, 0.f);
     else
-      hipLaunchKernelGGL(add_ln_bwd_rows_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS, dgamma,
-                         dbeta, M, E, rpw);
+      hipLaunchKernelGGL((add_ln_bwd_rows_kernel<32, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd, dY, dS,
+                         dgamma, dbeta, M, E, rpw, (float*)nullptr, (const unsigned long long*)nullptr, 0u, 0u, 0.f);
     return check_launch("a3d_add_layernorm_bwd");
   }
   const int grid = min(cdiv(M, 16), 1024);
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean,
                      rstd, dY, dS, dgamma, dbeta, M, E);
   return check_launch("a3d_add_layernorm_bwd");
+}
+
+// a3d_add_layernorm_bwd with a second output dS_drop = dropout(dS): the gradient of the residual branch behind its nn.Dropout
+// (layers.py:146,181: x + dropout(branch) -> LayerNorm).  Same bits as a3d_add_layernorm_bwd + a3d_dropout(dS -> dS_drop), which is
+// what runs outside the rows kernel's range (64 < E <= 128, E % 8 == 0).
+extern "C" int a3d_add_layernorm_bwd_drop(const float* A, const float* R, const float* gamma, const float* mean, const float* rstd,
+                                          const float* dY, float* dS, float* dS_drop, float* dgamma, float* dbeta, int M, int E,
+                                          const unsigned long long* state, unsigned int site, float p, void* stream) {
+  if (!A || !gamma || !mean || !rstd || !dY || !dS || !dS_drop || !state || dS_drop == dS || E <= 0 || E > 512 || M < 0 ||
+      (!dgamma != !dbeta)) {
+    set_error("a3d_add_layernorm_bwd_drop: bad argument (M=%d E=%d; dS_drop must be a second buffer)", M, E);
+    return A3D_ERR_ARG;
+  }
+  uint32_t thr; float scale;
+  int rc = linear_drop_params("a3d_add_layernorm_bwd_drop", p, &thr, &scale);
+  if (rc) return rc;
+  if (M == 0) return A3D_OK;
+  if (E > 64 && E <= 128 && (E & 7) == 0 &&
+      ((((uintptr_t)A) | ((uintptr_t)R) | ((uintptr_t)dY) | ((uintptr_t)dS) | ((uintptr_t)dS_drop)) & 15) == 0) {
+    int rpw = 8;                                                   // as a3d_add_layernorm_bwd for this width
+    while (cdiv(M, rpw) > 2048 && rpw < 128) rpw *= 2;
+    hipLaunchKernelGGL((add_ln_bwd_rows_kernel<32, true>), dim3(cdiv(M, rpw)), dim3(256), 0, (hipStream_t)stream, A, R, gamma, mean, rstd,
+                       dY, dS, dgamma, dbeta, M, E, rpw, dS_drop, state, (uint32_t)site, thr, scale);
+    return check_launch("a3d_add_layernorm_bwd_drop");
+  }
+  rc = a3d_add_layernorm_bwd(A, R, gamma, mean, rstd, dY, dS, dgamma, dbeta, M, E, stream);
+  return rc ? rc : a3d_dropout(dS, dS_drop, (size_t)M * E, state, site, p, stream);
 }

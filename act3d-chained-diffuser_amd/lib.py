@@ -99,6 +99,8 @@ SIGNATURES = {
     "a3d_rope_rows_f32": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_dropout": (_i, [_p, _p, _z, _p, C.c_uint, _f, _p]),
     "a3d_dropout_mask": (_i, [_p, _z, _p, C.c_uint, C.c_uint, C.c_uint, _f, _p]),
+    "a3d_linear_fwd_drop": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, C.c_uint, _f, _p]),
+    "a3d_add_layernorm_bwd_drop": (_i, [_p] * 10 + [_i, _i, _p, C.c_uint, _f, _p]),
     "a3d_attn_fwd_dropout": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_uint, _f, _p]),
     "a3d_attn_bwd_bf16_dropout": (_i, [_p] * 15 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
     "a3d_pcd_downsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

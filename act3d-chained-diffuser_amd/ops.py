@@ -43,32 +43,49 @@ def rope_freq(E, device):
 
 
 # ------------------------------------------------------------------------------------------------ raw launchers
+# the nn.Dropout behind a Linear / in front of a post-norm applied by the producing kernel (same bits as the separate a3d_dropout
+# launch, 84 launches fewer per ChainedDiffuser training step); A3D_DROPOUT_FOLD=0: separate launches (the A/B and test switch)
+DROP_FOLD = os.environ.get("A3D_DROPOUT_FOLD", "1") != "0"
+
+
 def linear_raw(x_ptr, ldx, W_ptr, ldw, b_ptr, M, N, K, device, act=0, mask_ptr=None, ldm=0, transposed=False,
-               out=None):
+               out=None, drop=None, site=0):
+    """drop / site: DropCtx and site of an nn.Dropout applied to the result (None: none)."""
     y = out if out is not None else torch.empty((M, N), device=device, dtype=F32)
+    if drop is not None and DROP_FOLD:
+        L.call("a3d_linear_fwd_drop", x_ptr, ldx, W_ptr, ldw, b_ptr, y.data_ptr(), N, mask_ptr, ldm, M, N, K, act,
+               1 if transposed else 0, drop.state.data_ptr(), int(site), drop.p, L.stream())
+        return y
     L.call("a3d_linear_fwd", x_ptr, ldx, W_ptr, ldw, b_ptr, y.data_ptr(), N, mask_ptr, ldm, M, N, K, act,
            1 if transposed else 0, L.stream())
+    if drop is not None:
+        L.call("a3d_dropout", y.data_ptr(), y.data_ptr(), y.numel(), drop.state.data_ptr(), int(site), drop.p, L.stream())
     return y
 
 
-def linear2d(x2d, W, b, act=0):
-    """y = act(x W^T + b) for contiguous x2d [M,K], W [N,K]."""
+def linear2d(x2d, W, b, act=0, drop=None, site=0):
+    """y = dropout?(act(x W^T + b)) for contiguous x2d [M,K], W [N,K]."""
     M, K = x2d.shape
     N = W.shape[0]
     if W.shape[1] != K or (b is not None and b.numel() != N):
         raise ValueError("linear: activation rows of %d features against a weight of shape %s / bias of %s" %
                          (K, tuple(W.shape), None if b is None else tuple(b.shape)))
     return linear_raw(x2d.data_ptr(), K, W.data_ptr(), W.shape[1], None if b is None else b.data_ptr(), M, N, K,
-                      x2d.device, act=act)
+                      x2d.device, act=act, drop=drop, site=site)
 
 
-def dgrad2d(dy2d, W, mask=None):
-    """dx = dy W (optionally masked by mask > 0) for dy [M,N], W [N,K] -> [M,K]."""
+def dgrad2d(dy2d, W, mask=None, drop=None, site=0, accum_into=None):
+    """dx = dropout?(dy W (optionally masked by mask > 0)) for dy [M,N], W [N,K] -> [M,K]; accum_into: a contiguous [M,K] gradient
+    that the product is ADDED to in place (and returned) instead."""
     M, N = dy2d.shape
     K = W.shape[1]
+    if accum_into is not None:
+        if mask is not None or drop is not None or tuple(accum_into.shape) != (M, K) or not accum_into.is_contiguous():
+            raise ValueError("dgrad2d: accum_into takes a contiguous [M, K] buffer and neither mask nor dropout")
+        return linear_raw(dy2d.data_ptr(), N, W.data_ptr(), K, None, M, K, N, dy2d.device, act=3, transposed=True, out=accum_into)
     return linear_raw(dy2d.data_ptr(), N, W.data_ptr(), K, None, M, K, N, dy2d.device,
                       act=2 if mask is not None else 0, mask_ptr=None if mask is None else mask.data_ptr(),
-                      ldm=K, transposed=True)
+                      ldm=K, transposed=True, drop=drop, site=site)
 
 
 def wgrad_raw(dy_ptr, lddy, x_ptr, ldx, gw_ptr, lddw, gb_ptr, M, N, K, device, st=None):
@@ -100,13 +117,23 @@ def add_layernorm(a2d, r2d, g, b, eps=1e-5):
     return y, mean, rstd
 
 
-def add_layernorm_bwd(a2d, r2d, g, b, mean, rstd, dy2d):
+def add_layernorm_bwd(a2d, r2d, g, b, mean, rstd, dy2d, drop=None, site=0):
+    """dS = d (a + r).  With `drop`: returns (dS, dropout(dS, site)) -- the gradients of LayerNorm(x + dropout(branch)) with respect
+    to x and to the branch."""
     M, E = a2d.shape
     ds = torch.empty_like(a2d)
     gg, gb = grad_buf(g), grad_buf(b)
+    if drop is not None and DROP_FOLD:
+        dsd = torch.empty_like(a2d)
+        L.call("a3d_add_layernorm_bwd_drop", a2d.data_ptr(), None if r2d is None else r2d.data_ptr(), g.data_ptr(),
+               mean.data_ptr(), rstd.data_ptr(), dy2d.data_ptr(), ds.data_ptr(), dsd.data_ptr(), gg.data_ptr(), gb.data_ptr(),
+               M, E, drop.state.data_ptr(), int(site), drop.p, L.stream())
+        return ds, dsd
     L.call("a3d_add_layernorm_bwd", a2d.data_ptr(), None if r2d is None else r2d.data_ptr(), g.data_ptr(),
            mean.data_ptr(), rstd.data_ptr(), dy2d.data_ptr(), ds.data_ptr(), gg.data_ptr(), gb.data_ptr(), M, E,
            L.stream())
+    if drop is not None:
+        return ds, dropout_raw(ds, drop, site)
     return ds
 
 
@@ -546,9 +573,7 @@ class AttnBlockFn(torch.autograd.Function):
             del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
         O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site, need_bwd=need_bwd)
-        Y = linear2d(O.view(B * Lq, E), out_w, out_b)
-        if drop is not None:
-            dropout_raw(Y, drop, site + 1, out=Y)          # seq1 + dropout(attn_out): Y now holds the dropped branch
+        Y = linear2d(O.view(B * Lq, E), out_w, out_b, drop=drop, site=site + 1)   # seq1 + dropout(attn_out): Y is the dropped branch
         y, mean, rstd = add_layernorm(resid.view(B * Lq, E), Y, ln_g, ln_b)
         ctx.save_for_backward(q_in, k_in, v_in, resid, Y, mean, rstd, Qs, Ks, Vt, O, LSE,
                               q_xyz if q_xyz is not None else torch.empty(0, device=dev),
@@ -558,6 +583,9 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.extra = extra
         ctx.drop, ctx.site = drop, site
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
+        # the usual post-norm layer: the query IS the residual stream -- its two gradients are summed by the dgrad kernel (in place, into
+        # the LayerNorm's input gradient) instead of by an autograd add
+        ctx.q_is_resid = q_in.data_ptr() == resid.data_ptr() and q_in.shape == resid.shape
         # the context's gradient goes into its shared buffer (packed k,v projection of ONE input only: a single dgrad GEMM)
         ctx.sink = sink if (sink is not None and need_bwd and mode == "kv" and ctx.needs_input_grad[1] and
                             tuple(k_in.shape) == sink.shape) else None
@@ -579,8 +607,10 @@ class AttnBlockFn(torch.autograd.Function):
         freq = rope_freq(E, dev)
         dy = _c(dy).view(B * Lq, E)
         f4 = 4
-        dS = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)      # = d resid = d (dropped) Y
-        dYo = dS if ctx.drop is None else dropout_raw(dS, ctx.drop, ctx.site + 1)         # through the residual dropout
+        if ctx.drop is None:
+            dS = dYo = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy)     # = d resid = d Y
+        else:                                                                                     # dYo: through the residual dropout
+            dS, dYo = add_layernorm_bwd(resid.view(B * Lq, E), Y, ln_g, ln_b, mean, rstd, dy, drop=ctx.drop, site=ctx.site + 1)
         dO = dgrad2d(dYo, out_w)
         wgrad2d(dYo, O.view(B * Lq, E), out_w, out_b)
         dQp, dK, dV = attn_core_bwd(Qs, Ks, Vt, kmask, O, dO.view(B, Lq, E), LSE, B, H, Lq, Lqp, S, Sp, nsplit,
@@ -589,6 +619,7 @@ class AttnBlockFn(torch.autograd.Function):
         st = L.stream()
         need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         d_q_in = d_k_in = d_v_in = None
+        fold_q = ctx.q_is_resid and ctx.needs_input_grad[3]      # d_q_in is added into dS (no reader of dS / dYo is left by then)
         if mode == "qk":
             dqk = torch.empty((B * Lq, 2 * E), device=dev, dtype=F32)
             rope_merge(dQp, nsplit, q_xyz, freq, scale, dqk.data_ptr(), 2 * E, B, Lq, Lqp, E, H)
@@ -599,7 +630,9 @@ class AttnBlockFn(torch.autograd.Function):
                    B * Lq, 2 * E, E, dev, st)
             wgrad_raw(dv_pre.data_ptr(), E, v_in.data_ptr(), E, gW.data_ptr() + 2 * E * E * f4, E,
                    gb.data_ptr() + 2 * E * f4, B * S, E, E, dev, st)
-            if need_q or need_k:
+            if (need_q or need_k) and fold_q:
+                linear_raw(dqk.data_ptr(), 2 * E, in_w.data_ptr(), E, None, B * Lq, E, 2 * E, dev, act=3, transposed=True, out=dS)
+            elif need_q or need_k:
                 d_q_in = linear_raw(dqk.data_ptr(), 2 * E, in_w.data_ptr(), E, None, B * Lq, E, 2 * E, dev,
                                     transposed=True).view(B, Lq, E)
             if need_v:
@@ -610,7 +643,9 @@ class AttnBlockFn(torch.autograd.Function):
             rope_merge(dQp, nsplit, q_xyz, freq, scale, dq_pre.data_ptr(), E, B, Lq, Lqp, E, H)
             wgrad_raw(dq_pre.data_ptr(), E, q_in.data_ptr(), E, gW.data_ptr(), E, gb.data_ptr(),
                    B * Lq, E, E, dev, st)
-            if need_q:
+            if need_q and fold_q:
+                dgrad2d(dq_pre, in_w[:E], accum_into=dS)
+            elif need_q:
                 d_q_in = dgrad2d(dq_pre, in_w[:E]).view(B, Lq, E)
             if mode == "kv":
                 dkv = torch.empty((B * S, 2 * E), device=dev, dtype=F32)
@@ -862,12 +897,8 @@ class MLPFn(torch.autograd.Function):
         x2 = x.view(-1, K)
         if drop is not None and drop.p <= 0:
             drop = None
-        h = linear2d(x2, w1, b1, act=1)
-        if drop is not None:
-            dropout_raw(h, drop, site_hidden, out=h)       # h > 0 <=> relu active AND kept: still the ReLU mask of dgrad
-        o = linear2d(h, w2, b2)
-        if drop is not None and site_out is not None:
-            dropout_raw(o, drop, site_out, out=o)
+        h = linear2d(x2, w1, b1, act=1, drop=drop, site=site_hidden)   # h > 0 <=> relu active AND kept: still the ReLU mask of dgrad
+        o = linear2d(h, w2, b2, drop=drop if site_out is not None else None, site=site_out or 0)
         ctx.drop, ctx.sites = drop, (site_hidden, site_out)
         if ln_g is not None:
             y, mean, rstd = add_layernorm(x2, o, ln_g, ln_b)
@@ -882,27 +913,28 @@ class MLPFn(torch.autograd.Function):
     def backward(ctx, dy):
         w1, b1, w2, b2, ln_g, ln_b = ctx.params
         dy = _c(dy)
+        drop, (site_hidden, site_out) = ctx.drop, ctx.sites
+        out_drop = drop if site_out is not None else None
         if ln_g is not None:
             x2, h, o, mean, rstd = ctx.saved_tensors
-            dS = add_layernorm_bwd(x2, o, ln_g, ln_b, mean, rstd, dy.view(-1, dy.shape[-1]))
-            do = dS
+            if out_drop is None:
+                dS = do = add_layernorm_bwd(x2, o, ln_g, ln_b, mean, rstd, dy.view(-1, dy.shape[-1]))
+            else:
+                dS, do = add_layernorm_bwd(x2, o, ln_g, ln_b, mean, rstd, dy.view(-1, dy.shape[-1]), drop=out_drop, site=site_out)
         else:
             x2, h = ctx.saved_tensors
             dS = None
             do = dy.view(-1, dy.shape[-1])
-        drop, (site_hidden, site_out) = ctx.drop, ctx.sites
-        if drop is not None and site_out is not None:
-            do = dropout_raw(do, drop, site_out)
+            if out_drop is not None:
+                do = dropout_raw(do, drop, site_out)
         wgrad2d(do, h, w2, b2)
-        dpre = dgrad2d(do, w2, mask=h)          # relu backward fused: (do W2) * (h > 0)
-        if drop is not None:
-            dropout_raw(dpre, drop, site_hidden, out=dpre)     # the 1 / (1 - p) of the kept (h > 0) elements
+        # relu backward fused: (do W2) * (h > 0), then the 1 / (1 - p) of the kept (h > 0) elements
+        dpre = dgrad2d(do, w2, mask=h, drop=drop, site=site_hidden)
         wgrad2d(dpre, x2, w1, b1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dgrad2d(dpre, w1)
-            if dS is not None:
-                dx = dx + dS
+            # dS (and `do`, which may be the same buffer) has no reader left: the input gradient is summed into it in place
+            dx = dgrad2d(dpre, w1) if dS is None else dgrad2d(dpre, w1, accum_into=dS)
             dx = dx.view(*dy.shape[:-1], x2.shape[1])
         return dx, None, None, None, None, None, None, None, None, None
 

@@ -110,6 +110,19 @@ int a3d_attn_bwd_bf16(const void* Qs, const void* Qt, const void* Ks, const void
  * y = x o keep / (1 - p) over a flat fp32 array; the same call is its own backward (dx from dy).  y may alias x. */
 int a3d_dropout(const float* x, float* y, size_t n, const unsigned long long* drop_state, unsigned int site, float p,
                 void* stream);
+/* The layer and the nn.Dropout behind it in one launch: Y = dropout(act(X W^T + b)) with a3d_dropout's mask over the flat index
+ * m * N + n of the contiguous output (ldy == N required; act 3 is not accepted).  Bit-identical to a3d_linear_fwd followed by
+ * a3d_dropout(Y -> Y), which is also what it runs when the epilogue does not apply (N % 8 != 0, row counts served by the bf16x3
+ * kernel).  Replaces `dropout(relu(linear1(x)))`, `dropout(linear2(...))` layers.py:82-84, `dropout(attn_output)` layers.py:146,181,
+ * and with act 2 / w_transposed their backward (dgrad, ReLU mask, dropout of the hidden gradient). */
+int a3d_linear_fwd_drop(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                        const float* mask, int ldm, int M, int N, int K, int act, int w_transposed,
+                        const unsigned long long* drop_state, unsigned int site, float p, void* stream);
+/* a3d_add_layernorm_bwd with a second output dS_drop = dropout(dS) (a separate buffer): the gradient of LayerNorm(x + dropout(branch))
+ * with respect to x (dS) and to the branch (dS_drop).  Bit-identical to a3d_add_layernorm_bwd + a3d_dropout(dS -> dS_drop). */
+int a3d_add_layernorm_bwd_drop(const float* A, const float* R, const float* gamma, const float* mean, const float* rstd,
+                               const float* dY, float* dS, float* dS_drop, float* dgamma, float* dbeta, int M, int E,
+                               const unsigned long long* drop_state, unsigned int site, float p, void* stream);
 /* out[i] = keep flag (0 / 1) of element i of a block row: c2 == 0xFFFFFFFF selects the flat elementwise indexing of
  * a3d_dropout (c1 ignored); otherwise (c2 = b * H + h, c1 = query) the attention-weight indexing, i = key.  Test hook. */
 int a3d_dropout_mask(unsigned char* out, size_t n, const unsigned long long* drop_state, unsigned int c2, unsigned int c1,

@@ -264,3 +264,85 @@ def test_planner_training_step_script_shape_vs_oracle(a3d, dev):
     print(f"[parity] dropout train gradients (script shape): median relative L2 {l2[len(l2) // 2]:.3e}, worst {l2[-1]:.3e}, "
           f"{100 * strict:.0f} % of {len(errs)} parameters within 1.5e-3")
     assert len(errs) > 200 and strict >= 0.6 and l2[-1] <= 0.2
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (1100, 120, 120, "plain"),        # out-projection of the trajectory stream (B = 22, L = 50)
+    (1100, 480, 120, "relu"),         # FFN hidden
+    (1100, 120, 480, "plain"),        # FFN output
+    (1100, 480, 120, "dgrad"),        # its backward: transposed weight, ReLU mask, dropout of the hidden gradient
+    (37, 120, 120, "relu"),           # ragged last row tile
+    (1100, 3, 120, "plain"),          # N % 8 != 0: the two-launch form inside the entry point
+    (5000, 120, 120, "plain"),        # row count of the bf16x3 kernel: two launches as well
+])
+def test_linear_dropout_epilogue_is_the_separate_launch_bit_for_bit(a3d, dev, M, N, K, kind):
+    """a3d_linear_fwd_drop (the layer + the nn.Dropout behind it in one launch) against a3d_linear_fwd + a3d_dropout in place."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(M + N + K)
+    drop, _ = _ctx(a3d, dev, 11, 2, 0.1)
+    site = O.site_id("layers.3", 4)
+    x = torch.randn(M, K, generator=g).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    outs = []
+    for fold in (True, False):
+        old, O.DROP_FOLD = O.DROP_FOLD, fold
+        try:
+            if kind == "dgrad":
+                W = (torch.randn(K, N, generator=torch.Generator().manual_seed(1)) / 11).to(dev)      # [N_out_of_fwd, K_of_fwd]: dy [M, K] W
+                msk = torch.randn(M, N, generator=torch.Generator().manual_seed(2)).to(dev)
+                outs.append(O.dgrad2d(x, W, mask=msk, drop=drop, site=site))
+            else:
+                W = (torch.randn(N, K, generator=torch.Generator().manual_seed(1)) / 11).to(dev)
+                outs.append(O.linear2d(x, W, b, act=1 if kind == "relu" else 0, drop=drop, site=site))
+        finally:
+            O.DROP_FOLD = old
+    assert tuple(outs[0].shape) == (M, N)
+    assert torch.equal(outs[0], outs[1])
+    kept = (outs[0] != 0).float().mean().item()
+    assert kept > (0.35 if kind != "plain" else 0.85)          # it IS a dropped tensor (relu / mask halve it), not zeros
+    assert (outs[0] == 0).float().mean().item() > 0.05
+
+
+@pytest.mark.parametrize("M,E", [(1100, 120), (352, 120), (7, 120), (1100, 60), (300, 256)])
+def test_add_layernorm_backward_dropout_output_is_the_separate_launch_bit_for_bit(a3d, dev, M, E):
+    O = a3d.ops
+    g = torch.Generator().manual_seed(M + E)
+    drop, _ = _ctx(a3d, dev, 7, 5, 0.1)
+    site = O.site_id("layers.1", 1)
+    a, r, dy = (torch.randn(M, E, generator=g).to(dev) for _ in range(3))
+    gam = torch.nn.Parameter((torch.rand(E, generator=g) + 0.5).to(dev))
+    bet = torch.nn.Parameter(torch.zeros(E, device=dev))
+    _, mean, rstd = O.add_layernorm(a, r, gam, bet)
+    res = []
+    for fold in (True, False):
+        old, O.DROP_FOLD = O.DROP_FOLD, fold
+        gam.grad = bet.grad = None
+        try:
+            ds, dsd = O.add_layernorm_bwd(a, r, gam, bet, mean, rstd, dy, drop=drop, site=site)
+        finally:
+            O.DROP_FOLD = old
+        res.append((ds, dsd, gam.grad.clone(), bet.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][1], O.dropout_raw(res[0][0], drop, site))
+    report("add_ln_bwd_drop d gamma (atomic order)", res[0][2], res[1][2], 1e-4, 1e-5)
+    report("add_ln_bwd_drop d beta (atomic order)", res[0][3], res[1][3], 1e-4, 1e-5)
+
+
+def test_planner_step_with_folded_dropout_equals_separate_launches(a3d, dev):
+    """The whole training step with the dropout launches folded into their producers (ops.DROP_FOLD) against the separate launches:
+    same loss to the last bit (the forward pass has no atomics), gradients to the atomics' summation order."""
+    O = a3d.ops
+    r, case = load("diffusion.pt"), load("dropout_case.pt")
+    out = []
+    for fold in (True, False):
+        old, O.DROP_FOLD = O.DROP_FOLD, fold
+        try:
+            m, _, _, loss, _, _, _ = _planner_dropout_draw(a3d, dev, r, case["drop_seed"], cfg=case["cfg"], input_seed=case["input_seed"])
+        finally:
+            O.DROP_FOLD = old
+        out.append((loss, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert out[0][1].keys() == out[1][1].keys()
+    for n, gref in out[1][1].items():
+        got = out[0][1][n]
+        assert (got - gref).norm().item() <= 1e-4 * max(1e-6, gref.norm().item()), n
