@@ -14,6 +14,10 @@ namespace a3d {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Zeroes `bytes` (a multiple of 4, 4-byte aligned) with a KERNEL node.  hipMemsetAsync is not used anywhere in this library: a
+// captured memset node replayed wrong on this stack (right on eager launches and on the first replay, stale on every later
+// one -- profiles/r05_persist_graph_probe.txt), and every entry point here must be capturable.
+int zero_words(void* p, size_t bytes, hipStream_t s, const char* what);
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;

@@ -25,6 +25,18 @@ int check_launch(const char* what) {
   return A3D_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int zero_words(void* p, size_t bytes, hipStream_t s, const char* what) {
+  if (!bytes) return A3D_OK;
+  if ((bytes & 3) || (((size_t)p) & 3)) { set_error("%s: zero_words needs 4-byte granularity", what); return A3D_ERR_ARG; }
+  const size_t n = bytes / 4;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, s, (unsigned int*)p, n);
+  return check_launch(what);
+}
+
 // D[16][16] = A[16][32] * B[32][16] with the bf16 16x16x32 MFMA; A,B given as bf16 bit patterns, row-major.
 __global__ void dbg_mfma_bf16_kernel(const unsigned short* A, const unsigned short* Bm, float* D) {
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;

@@ -379,8 +379,8 @@ extern "C" int a3d_attn8_fwd(const void* Qr, const void* Kr, const void* Vp, voi
   unsigned char* K8 = (unsigned char*)ops8;
   unsigned char* V8 = K8 + kv;
   unsigned int* amax = (unsigned int*)(V8 + kv);
-  hipError_t e = hipMemsetAsync(amax, 0, (size_t)B * H * 16, s);
-  if (e != hipSuccess) { set_error("a3d_attn8_fwd: hipMemsetAsync: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+  rc = zero_words(amax, (size_t)B * H * 16, s, "a3d_attn8_fwd(zero)");
+  if (rc) return rc;
   const int gx = std::max(1, std::min(cdiv(Sp, 256), 16));
   hipLaunchKernelGGL(attn8_amax_kernel, dim3(gx, B * H), dim3(256), 0, s, (const unsigned short*)Qr, (const unsigned short*)Kr,
                      (const unsigned short*)Vp, amax, B, H, Lq, Lqp, S, Sp);

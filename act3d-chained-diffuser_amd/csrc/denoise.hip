@@ -1587,6 +1587,13 @@ __global__ __launch_bounds__(256) void dn_persist_args_kernel(DnPersist a, DnPer
     for (int i = threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<int*>(dst)[i] = src[i];
   }
 }
+// An aborted launch (a co-resident workgroup never arrived: fewer free CUs than the grid assumes -- CU masking, another process on
+// the device) must not hand back a plausible-looking trajectory: this node follows the persistent launch and turns the whole batch
+// into NaN when the abort word is set.  In-band, no host synchronisation, replays with the graph.
+__global__ __launch_bounds__(256) void dn_persist_poison_kernel(float* __restrict__ traj, int n, const int* __restrict__ sync) {
+  if (sync[2] == 0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) traj[i] = __builtin_nanf("");
+}
 __global__ __launch_bounds__(512) void dn_persist_kernel(const DnPersist* __restrict__ ap, int U) {      // U: sample-role workgroups (2 per unit)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < U) dnp_sample_role(ap, smem);
@@ -1774,6 +1781,7 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
   a.n_traj = n_traj; a.n_pos = n_pos; a.n_rot = n_rot; a.t_first = t_first; a.nsteps = nsteps;
   a.prof = (dn_warm() & 2) ? reinterpret_cast<long long*>(sync + words + ((sizeof(DnPersist) + 15) / 16) * 4) : nullptr;
   a.spin_limit = 1 << 21;                     // ~2 s of polling: a wait is at most a few milliseconds; beyond it the launch aborts
+  if (const char* sl = getenv("A3D_DN_SPIN_LIMIT")) a.spin_limit = atoi(sl);      // test hook: 0 forces the abort path (tests/test_diffusion_gpu.py)
   hipStream_t s = (hipStream_t)stream;
   DnPersist* a_dev = reinterpret_cast<DnPersist*>(sync + words);
   hipLaunchKernelGGL(dn_persist_args_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 256)), dim3(256), 0, s, a, a_dev, sync,
@@ -1786,7 +1794,10 @@ extern "C" int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj,
     attr_set = true;
   }
   hipLaunchKernelGGL(dn_persist_kernel, dim3(2 * U + nworkers), dim3(512), (size_t)DNP_LDS_FLOATS * sizeof(float), s, a_dev, 2 * U);
-  return check_launch("a3d_dn_persist");
+  rc = check_launch("a3d_dn_persist");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dn_persist_poison_kernel, dim3(std::min(cdiv(B * L * D, 256), 64)), dim3(256), 0, s, traj, B * L * D, sync);
+  return check_launch("a3d_dn_persist(poison)");
 }
 
 extern "C" int a3d_dn_tail(const float* pos_feats, const float* rot_feats, const float* traj, int D,

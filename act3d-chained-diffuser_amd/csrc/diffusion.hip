@@ -322,8 +322,9 @@ extern "C" int a3d_adaln_bwd(const float* x, const float* mod, const float* dy, 
     const int rows_per_wg = cdiv(cdiv(L, nsplit), rpp) * rpp;
     nsplit = cdiv(L, rows_per_wg);
     if (nsplit > 1) {
-      hipError_t e = hipMemsetAsync(dmod, 0, (size_t)B * 2 * E * sizeof(float), (hipStream_t)stream);
-      if (e != hipSuccess) { set_error("a3d_adaln_bwd: memset: %s", hipGetErrorString(e)); return A3D_ERR_LAUNCH; }
+      // a kernel node, not a memset node: this call sits inside the captured diffusion training step (engine.GraphedStep)
+      const int zrc = zero_words(dmod, (size_t)B * 2 * E * sizeof(float), (hipStream_t)stream, "a3d_adaln_bwd(zero)");
+      if (zrc) return zrc;
     }
     hipLaunchKernelGGL(adaln_bwd_split_kernel, dim3(nsplit, B), dim3(256), (size_t)rpp * 2 * E * sizeof(float), (hipStream_t)stream, x, mod, dy,
                        dx, dmod, L, E, rows_per_wg);

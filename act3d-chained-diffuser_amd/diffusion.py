@@ -550,7 +550,10 @@ FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
 # (head, per layer cross + rest, tail: 18 per step).  A3D_DN_PERSIST_SPLIT: key splits per (sample, layer) = items of the ready queue.
 DN_PERSIST = os.environ.get("A3D_DN_PERSIST", "1") == "1"
 DN_PERSIST_SPLIT = int(os.environ.get("A3D_DN_PERSIST_SPLIT", "8"))
-DN_PERSIST_CHECK = os.environ.get("A3D_DN_PERSIST_CHECK", "0") == "1"      # synchronise and check the abort word after every launch
+# An aborted persistent launch (a co-resident workgroup never arrived) poisons the whole trajectory batch with NaN inside the launch
+# sequence itself (dn_persist_poison_kernel), so the failure is visible in the result without a host synchronisation, eager or
+# replayed.  A3D_DN_PERSIST_CHECK=1 additionally synchronises after every launch and raises on the abort word.
+DN_PERSIST_CHECK = os.environ.get("A3D_DN_PERSIST_CHECK", "0") == "1"
 _DN_SIDE = {}
 
 

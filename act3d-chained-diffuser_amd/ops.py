@@ -520,8 +520,10 @@ class AttnBlockFn(torch.autograd.Function):
     """
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, in_w, in_b, out_w, out_b, ln_g, ln_b, H, mode,
-                drop=None, site=0, grad_mode=True, sink=None):
-        """drop / site: DropCtx of the pass and this block's site id (attention weights: site, residual branch: site + 1;
+                drop=None, site=0, grad_mode=True, sink=None, q_is_resid=False):
+        """q_is_resid: the caller passed the SAME tensor object as query and residual (decided at the call site, `q_in is resid`:
+        two distinct autograd tensors that merely share storage -- a detached leaf, a view alias -- keep separate gradients).
+        drop / site: DropCtx of the pass and this block's site id (attention weights: site, residual branch: site + 1;
         multihead_custom_attention.py:413, layers.py:146,181).  grad_mode: torch.is_grad_enabled() of the CALLER (grad mode is
         always off inside Function.forward, so it has to be handed in; attn_block does)."""
         L.require_gpu(q_in, k_in, v_in, resid)
@@ -585,7 +587,7 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
         # the usual post-norm layer: the query IS the residual stream -- its two gradients are summed by the dgrad kernel (in place, into
         # the LayerNorm's input gradient) instead of by an autograd add
-        ctx.q_is_resid = q_in.data_ptr() == resid.data_ptr() and q_in.shape == resid.shape
+        ctx.q_is_resid = bool(q_is_resid)
         # the context's gradient goes into its shared buffer (packed k,v projection of ONE input only: a single dgrad GEMM)
         ctx.sink = sink if (sink is not None and need_bwd and mode == "kv" and ctx.needs_input_grad[1] and
                             tuple(k_in.shape) == sink.shape) else None
@@ -675,7 +677,7 @@ class AttnBlockFn(torch.autograd.Function):
                 if need_v:
                     d_v_in = dgrad2d(dv_pre, in_w[2 * E:]).view(B, S, E)
         d_resid = dS.view(B, Lq, E) if ctx.needs_input_grad[3] else None
-        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 15
+        return (d_q_in, d_k_in, d_v_in, d_resid) + (None,) * 16
 
 
 SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
@@ -879,7 +881,7 @@ def attn_block(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha, norm, H, drop=
         mode = "none"
     return AttnBlockFn.apply(q_in, k_in, v_in, resid, q_xyz, k_xyz, kmask, mha.in_proj_weight, mha.in_proj_bias,
                              mha.out_proj.weight, mha.out_proj.bias, norm.weight, norm.bias, H, mode, drop, site,
-                             torch.is_grad_enabled(), sink)
+                             torch.is_grad_enabled(), sink, q_in is resid)
 
 
 class MLPFn(torch.autograd.Function):

@@ -358,3 +358,79 @@ def test_multi_round_multi_scale_head_vs_reference(a3d, dev):
                                     init_noise=inp["init_noise"], step_noise=inp["step_noise"], visual_tokens=toks, n_steps=5,
                                     return_trace=True)
     scale_close("state after 5 steps", trace[-1], r["sample_state_after_5_steps"], 1e-3)      # observed 2.4e-7 of scale
+
+
+def _script_planner(a3d, dev):
+    r = load("diffusion.pt")
+    m = a3d.DiffusionPlanner(embedding_dim=120, output_dim=7, num_vis_ins_attn_layers=2, num_query_cross_attn_layers=6,
+                             use_instruction=True, use_goal=True, use_goal_at_test=True, weight_tying=True,
+                             gripper_loc_bounds=C.DIFFUSION_BOUNDS, rotation_parametrization="6D", diffusion_timesteps=100)
+    m.load_state_dict(_diffusion_params(r), strict=False)
+    return m.to(dev).eval()
+
+
+def test_persistent_sampler_abort_is_visible_in_the_result(a3d, dev):
+    """A persistent launch whose workgroups give up waiting (here forced with the A3D_DN_SPIN_LIMIT=0 test hook: any wait longer
+    than 128 polls aborts; in the field: fewer free CUs than the grid assumes) must not return a plausible trajectory: the abort
+    word is set AND the whole batch comes back NaN (dn_persist_poison_kernel, part of the launch sequence), without the caller
+    having asked for a check.  The next launch, with the hook removed, is healthy again."""
+    m = _script_planner(a3d, dev)
+    B, Ln, ncam, E = 4, 16, 3, 120
+    inp = C.trajectory_inputs(95, B, Ln, ncam, E, pad_last=2)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    args = (d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"])
+    kw = dict(init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=C.tokens_from_maps(inp["fmap"]).to(dev), n_steps=10)
+    good = m.compute_trajectory(*args, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all() and int(m.prediction_head._last_persist["sync"][2].item()) == 0
+    os.environ["A3D_DN_SPIN_LIMIT"] = "0"
+    try:
+        bad = m.compute_trajectory(*args, **kw)
+        torch.cuda.synchronize()
+        aborted = int(m.prediction_head._last_persist["sync"][2].item())
+    finally:
+        del os.environ["A3D_DN_SPIN_LIMIT"]
+    print(f"[parity] forced abort: abort word {aborted}, NaN entries {int(torch.isnan(bad).sum())} of {bad.numel()}")
+    assert aborted != 0, "the test hook did not force an abort (no wait exceeded 128 polls?)"
+    assert torch.isnan(bad).all(), "an aborted persistent launch returned finite numbers"
+    again = m.compute_trajectory(*args, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
+
+
+def test_persistent_sampler_stress_every_cu_200_replays(a3d, dev):
+    """The occupancy limit of the persistent sampler under repetition: B = 30 trajectories of horizon 50 = 4 row tiles x 2 roles
+    = 240 sample-role workgroups + 16 streamers = every CU of the device, replayed 200 times from a captured graph (20 denoise
+    steps each = 4000 steps, ~10^6 exchange hand-offs).  Every replay must reproduce the first eager result bit for bit and
+    leave the abort word at zero.  (The exchange protocol is relaxed sc1 word stores / loads ordered by workgroup barriers --
+    outside what the HIP memory model promises, see denoise.hip: this is the test that stands behind it.)"""
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    Ln, ncam, E = 50, 3, 120
+    B = (cus - 16) // 8
+    if B < 2:
+        pytest.skip("device too small")
+    m = _script_planner(a3d, dev)
+    inp = C.trajectory_inputs(97, B, Ln, ncam, E, pad_last=5)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    args = (d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"])
+    kw = dict(init_noise=d["init_noise"], step_noise=d["step_noise"], visual_tokens=C.tokens_from_maps(inp["fmap"]).to(dev), n_steps=20)
+    first = m.compute_trajectory(*args, **kw)
+    torch.cuda.synchronize()
+    ps = m.prediction_head._last_persist
+    assert ps is not None and ps["kvx"] is not None, "not on the persistent sampler"
+    assert int(ps["sync"][2].item()) == 0 and torch.isfinite(first).all()
+    bad = 0
+    for rep in range(200):
+        out = m.compute_trajectory(*args, use_graph=True, **kw)
+        if rep % 20 == 19 or rep < 2:
+            torch.cuda.synchronize()
+            if not torch.equal(out, first):
+                bad += 1
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
+    gsync = m._graph["state"]["persist"]["sync"] if isinstance(m._graph, dict) and "state" in m._graph and "persist" in m._graph["state"] else None
+    if gsync is not None:
+        assert int(gsync[2].item()) == 0
+    print(f"[parity] persistent sampler stress: B = {B}, L = {Ln}, {2 * B * 4 + 16} workgroups on {cus} CUs, 200 replays x 20 steps, "
+          f"{bad} mismatching checkpoints of 12")
+    assert bad == 0

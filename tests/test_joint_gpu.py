@@ -304,3 +304,43 @@ def _joint_vs_separate(E, joint, ks, ts, kcrit, tcrit, kA, kB, tA, tB, kfA, kfB,
         assert pd[solid].max().item() <= 1e-6 and pd.max().item() <= 2.01e-4
     assert torch.equal(koA.step_count, koB.step_count) and torch.equal(toA.step_count, toB.step_count)
     assert torch.equal(tA.prediction_head._drop_state, tB.prediction_head._drop_state)
+
+
+# ------------------------------------------------------------------------------------------------ graph replays of the trajectory step
+def test_graphed_trajectory_step_gradients_equal_eager_on_every_replay(a3d, dev):
+    """The captured diffusion training step (engine.GraphedStep over fwd_bwd_trajectory, what bench.py replays) against the eager
+    step, over FOUR replays from the same weights / batch / dropout state (learning rate 0, so every replay must reproduce the
+    same gradients).  Horizon 40 puts a3d_adaln_bwd on its split path (per-split partial sums accumulated into a zeroed dmod):
+    that zeroing was a captured hipMemsetAsync, which this stack replays right once and stale afterwards (round-5 advisor
+    finding) -- it is a kernel node now, and this test is what would have caught it."""
+    E = a3d.engine
+    tcrit = a3d.TrajectoryCriterion()
+    ts = _tr_sample(3, 40, 1, dev, 91)
+    tr = _make_planner(a3d, dev, 5, 321)
+    flat, opt = E.get_optimizer(tr, lr=0.0)
+
+    def eager():
+        _set_drop(tr, 321, 0)
+        opt.zero_grad()
+        loss = E.fwd_bwd_trajectory(tr, tcrit, ts)
+        torch.cuda.synchronize()
+        return loss.item(), flat.grad.clone()
+
+    l_ref, g_ref = eager()
+    l_again, g_again = eager()                                       # run-to-run noise of the eager step itself (float atomics)
+    gs = g_ref.abs().max().item()
+    noise = (g_again - g_ref).abs().max().item()
+    graphed = E.GraphedStep(lambda s: E.fwd_bwd_trajectory(tr, tcrit, s), opt, ts, warmup=2)
+    mods = [n for n in flat.slices if "adaln" in n and "modulation" in n]
+    assert mods
+    for rep in range(4):
+        _set_drop(tr, 321, 0)
+        loss = graphed(ts).clone()
+        torch.cuda.synchronize()
+        g = flat.grad
+        gd = (g - g_ref).abs().max().item()
+        md = max((g[a:b] - g_ref[a:b]).abs().max().item() for a, b in (flat.slices[n] for n in mods))
+        print(f"[parity] graphed trajectory step, replay {rep}: loss {loss.item():.7f} vs eager {l_ref:.7f}; gradient diff {gd:.3e} "
+              f"(AdaLN modulation weights {md:.3e}; scale {gs:.3e}; eager run-to-run {noise:.3e})")
+        assert abs(loss.item() - l_ref) <= 1e-5 * max(1.0, abs(l_ref))
+        assert gd <= max(2e-4 * gs, 4 * noise), (rep, gd, gs)

@@ -316,6 +316,35 @@ def test_attn_block_fwd_bwd_split_bf16_family(a3d, dev, B, Lq, S, E, H, rope, ma
         a3d.ops.ATTN_MODE = old
 
 
+def test_attn_block_query_gradient_with_aliased_residual(a3d, dev):
+    """The query / residual gradient fold is decided by OBJECT identity at the call site (`q_in is resid`), not by storage: a
+    detached requires-grad leaf that shares the residual's storage is a different autograd tensor and keeps its own gradient
+    (round-5 advisor finding: data_ptr equality routed it into the residual's graph and left q_in.grad None)."""
+    O = a3d.ops
+    B, Lq, S, E, H = 2, 19, 70, 60, 4
+    g = torch.Generator().manual_seed(11)
+    in_w, in_b, out_w, out_b = _mha_params(E, g, scale=1.0)
+    mha, norm = _mk_modules(dev, in_w, in_b, out_w, out_b, torch.ones(E), torch.zeros(E))
+    x = torch.randn(B, Lq, E, generator=g).to(dev)
+    ctxt = torch.randn(B, S, E, generator=g).to(dev)
+    dy = torch.randn(B, Lq, E, generator=g).to(dev)
+    # (a) the same object: one gradient, the sum of both roles
+    xa = x.clone().requires_grad_()
+    O.attn_block(xa, ctxt, ctxt, xa, None, None, None, mha, norm, H).backward(dy)
+    # (b) separate tensors: the two roles' gradients
+    xq, xr = x.clone().requires_grad_(), x.clone().requires_grad_()
+    O.attn_block(xq, ctxt, ctxt, xr, None, None, None, mha, norm, H).backward(dy)
+    # (c) an alias: same storage, distinct autograd leaves
+    base = x.clone()
+    aq, ar = base.detach().requires_grad_(), base.detach().requires_grad_()
+    assert aq.data_ptr() == ar.data_ptr() and aq is not ar
+    O.attn_block(aq, ctxt, ctxt, ar, None, None, None, mha, norm, H).backward(dy)
+    assert aq.grad is not None and ar.grad is not None
+    report("aliased query gradient", aq.grad, xq.grad.cpu(), 1e-4, 1e-5)
+    report("aliased residual gradient", ar.grad, xr.grad.cpu(), 1e-4, 1e-5)
+    report("folded gradient = sum of the roles", xa.grad, (xq.grad + xr.grad).cpu(), 1e-4, 1e-5)
+
+
 def test_attn_softmax_rescale_spike(a3d, dev):
     """Online-softmax rescale path: one key with a huge score in a late chunk (cdna guide rule 26)."""
     O = a3d.ops
