@@ -96,6 +96,29 @@ __device__ __forceinline__ void dma_plane_subtile(const unsigned short* plane, s
   glds16(plane + (size_t)ch * ld + r0 + seg * 8, sub);
 }
 
+// ---- transposed fragments from a ROWS tile (round 6).  ds_read_b64_tr_b16: within each 16-lane group, lane i passes the address of 4
+// consecutive halfs and receives R[i][j] = D[lane 4 j + (i >> 2)][i & 3] (profiles/ubench/tr_read.hip confirms it on gfx950): with
+// lane i pointing at (row r0 + (i >> 2), columns 4 (i & 3) .. + 3) of a row-major [4 rows][16 columns] block, lane i receives COLUMN i
+// of the four rows.  Two reads (rows + 0..3, + 4..7) give lane (li, g) the MFMA A fragment [channel li][keys g*8 .. g*8+7] of a
+// [64 keys][hi16 | lo16] rows tile -- what used to need a second, transposed copy of K (dQ) and V (forward) in HBM and in LDS.
+// Bank behaviour with the tile_off swizzle: a 16-lane group touches 4 rows x 32 B at a 64-byte row stride (banks 16 r + 0..7 or
+// + 8..15), the two groups of a 32-lane service half differ in (row >> 3) & 3, i.e. in the swizzle -> disjoint banks.
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+__device__ __forceinline__ s16x4_ lds_tr16(const unsigned short* p) {
+  typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+}
+// offset (halfs) lane (li, g) passes for: part (0: hi, 1: lo), 32-key half hf, row block rr (keys g*8 + rr*4 ..+3)
+__device__ __forceinline__ int tr_off(int li, int g, int part, int hf, int rr) {
+  const int row = hf * 32 + g * 8 + rr * 4 + (li >> 2);
+  const int c = part * 16 + (li & 3) * 4;
+  return tile_off(row, c >> 3) + (c & 7);
+}
+__device__ __forceinline__ s16x8 tr_frag(const unsigned short* tile, int off0, int off1) {
+  const s16x4_ a = lds_tr16(tile + off0), b = lds_tr16(tile + off1);
+  return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 // Pins a register-resident operand loaded before the main loop: the (empty) asm is a use, so hipcc retires the load HERE and
 // not at its first use inside the loop, where its vmcnt wait would also drain the LDS-DMA ring.
 #define A3D_PIN(x) asm volatile("" ::"v"(x))

@@ -135,6 +135,11 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
                                                         int n0, int Npad, int H) {
   typedef __attribute__((ext_vector_type(4))) unsigned int rp_u32x4;
   if (rows_out) {
+    // plane_parts & 8: the padded channel 15 of the hi part of every ROW is written as 1.0 -- the value rows of the rows-only operand
+    // set (round 6): the forward forms its V^T fragments from these rows with transposed LDS reads, and its PV MFMA then accumulates
+    // the softmax denominator in output channel 15 exactly as with the value planes; the backward kernels contract that channel
+    // against the zero-padded channel 15 of dO
+    const float row_pad = (plane_parts & 8) ? 1.0f : 0.f;
     for (int idx = threadIdx.x; idx < RT_ROWS * H * 2; idx += blockDim.x) {
       const int half = idx & 1;
       const int r = (idx >> 1) % RT_ROWS;
@@ -146,7 +151,7 @@ __device__ __forceinline__ void write_operand_formats16(const float* T, int ldt,
       for (int j = 0; j < 4; ++j) {
         const int d0 = half * 8 + 2 * j, d1 = d0 + 1;
         const float v0 = (d0 < HD) ? T[r * ldt + h * HD + d0] : 0.f;
-        const float v1 = (d1 < HD) ? T[r * ldt + h * HD + d1] : 0.f;
+        const float v1 = (d1 < HD) ? T[r * ldt + h * HD + d1] : row_pad;       // d1 = 15 is the only padded channel
         rp_split_f16(v0, v1, ohi[j], olo[j]);
       }
       unsigned short* dst = rows_out + (((size_t)b * H + h) * Npad + n) * 32 + half * 8;
@@ -457,8 +462,8 @@ static int rope_split_launch(const char* fn, const float* Y, int ldy, const floa
                              int fmt16, void* stream) {
   int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
-  if (fmt16 ? ((rows_width & 3) != 1 && (rows_width & 3) != 2) || (rows_width & ~7) : (rows_out && rows_width != VRW && rows_width != QKW)) {
-    set_error(fmt16 ? "%s: plane parts must be 1 or 2 (+ 4: ones channel), got %d" : "%s: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", fn,
+  if (fmt16 ? ((rows_width & 3) != 1 && (rows_width & 3) != 2) || (rows_width & ~15) : (rows_out && rows_width != VRW && rows_width != QKW)) {
+    set_error(fmt16 ? "%s: plane parts must be 1 or 2 (+ 4: ones channel in the hi plane, + 8: in the rows), got %d" : "%s: rows_width must be 32 (hi|lo) or 48 (hi|lo|lo2), got %d", fn,
               rows_width);
     return A3D_ERR_ARG;
   }
@@ -543,7 +548,7 @@ static int proj_rope_split_launch(const char* fn, const float* X, int ldx, const
   int rc = check_rope_args(fn, B, N, Npad, E, H);
   if (rc) return rc;
   const bool two = rows1 || planes1;
-  auto parts_ok = [](int p) { return ((p & 3) == 1 || (p & 3) == 2) && !(p & ~7); };
+  auto parts_ok = [](int p) { return ((p & 3) == 1 || (p & 3) == 2) && !(p & ~15); };      // | 4: ones channel in the hi plane, | 8: in the rows
   const bool w0_ok = fmt16 ? parts_ok(rows0_width) : (!rows0 || rows0_width == VRW || rows0_width == QKW);
   const bool w1_ok = fmt16 ? (!two || parts_ok(rows1_width)) : (!rows1 || rows1_width == VRW || rows1_width == QKW);
   if (!X || !W || K <= 0 || (K & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || E > 128 ||

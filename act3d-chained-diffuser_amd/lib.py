@@ -61,6 +61,7 @@ SIGNATURES = {
     "a3d_rope_split16": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_proj_rope_split16": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _p, _p, _i, _p, _f, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_attn16_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
+    "a3d_attn16_fwd_rows": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _i, _p]),
     "a3d_attn16_bwd_pack_bytes": (_z, [_i, _i, _i]),
     "a3d_dbg_dn_prof": (_i, [_p]),
     "a3d_dbg_sq_prof": (_i, [_i, _p]),

@@ -173,19 +173,30 @@ PLANE_PARTS = 2       # q / k planes of the backward: hi and lo parts
 
 
 V_PLANES = 2 | 4      # value planes: hi and lo parts, padded channel 15 of the hi plane = 1.0 (the softmax-denominator channel)
+V_ROWS = 2 | 8        # value rows of the rows-only operand set: the same 1.0 in channel 15 of the hi part of every row
+
+# Rows-only operand set (round 6, default): the projection kernels write ONE layout of q, k and v (rows16); the forward forms V^T and
+# the dQ kernel K^T with transposed LDS reads (ds_read_b64_tr_b16) of the rows tiles.  Per key and head 128 B of operands instead of
+# 256 B (k rows + k planes + v rows + v planes), and forward and backward read the same tensors.  A3D_ATTN_ROWS_ONLY=0: the round-5
+# rows + planes set (A/B).  The fp8 mode keeps the planes (attention8.hip packs its value operand from them).
+ROWS_ONLY = os.environ.get("A3D_ATTN_ROWS_ONLY", "1") == "1"
+
+
+def _rows_only():
+    return ROWS_ONLY and ATTN_MODE != "fp8"
 
 
 def _alloc16(B, H, Lqp, Sp, device, need_bwd):
     hf = torch.float16
     Qr = torch.empty((B, H, Lqp, 32), device=device, dtype=hf)       # rows16: hi | lo
     Kr = torch.empty((B, H, Sp, 32), device=device, dtype=hf)
+    if _rows_only():
+        return Qr, Kr, None, None, None, torch.empty((B, H, Sp, 32), device=device, dtype=hf)
     Vp = torch.empty((B, H, 2, 16, Sp), device=device, dtype=hf)     # planes16: hi and lo planes, transposed
-    Qp = Kp = Vr = None
+    Vr = None
     if need_bwd:
-        Qp = torch.empty((B, H, PLANE_PARTS, 16, Lqp), device=device, dtype=hf)
-        Kp = torch.empty((B, H, PLANE_PARTS, 16, Sp), device=device, dtype=hf)
         Vr = torch.empty((B, H, Sp, 32), device=device, dtype=hf)
-    return Qr, Kr, Vp, Qp, Kp, Vr
+    return Qr, Kr, Vp, None, None, Vr                                # (q / k planes: not read by any kernel since round 6)
 
 
 def attn_operands16(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
@@ -201,8 +212,9 @@ def attn_operands16(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz
     nz = lambda t: None if t is None else t.data_ptr()
     L.call("a3d_rope_split16", q_pre_ptr, ldq, qx, freq.data_ptr(), scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS, B, Lq, Lqp, E, H, st)
     L.call("a3d_rope_split16", k_pre_ptr, ldk, kx, freq.data_ptr(), 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS, B, S, Sp, E, H, st)
-    L.call("a3d_rope_split16", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vr), Vp.data_ptr(), V_PLANES, B, S, Sp, E, H, st)
-    return Qr, Kr, Vp, Lqp, Sp, scale, freq, (Qp, Kp, Vr)
+    L.call("a3d_rope_split16", v_pre_ptr, ldv, None, freq.data_ptr(), 1.0, nz(Vr), nz(Vp), V_ROWS if Vp is None else V_PLANES,
+           B, S, Sp, E, H, st)
+    return Qr, Kr, (Vr if Vp is None else Vp), Lqp, Sp, scale, freq, (Qp, Kp, Vr)
 
 
 def attn_operands_fused16(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
@@ -224,7 +236,7 @@ def attn_operands_fused16(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S
 
     qb = (qx, scale, Qr.data_ptr(), nz(Qp), PLANE_PARTS)
     kb = (kx, 1.0, Kr.data_ptr(), nz(Kp), PLANE_PARTS)
-    vb = (None, 1.0, nz(Vr), Vp.data_ptr(), V_PLANES)
+    vb = (None, 1.0, nz(Vr), nz(Vp), V_ROWS if Vp is None else V_PLANES)
     if mode == "qk":
         proj(q_in, 0, qb, kb, Lq, Lqp)
         proj(v_in, 2 * E, vb, None, S, Sp)
@@ -235,7 +247,7 @@ def attn_operands_fused16(mode, q_in, k_in, v_in, wp, bp, q_xyz, k_xyz, B, Lq, S
         else:
             proj(k_in, E, kb, None, S, Sp)
             proj(v_in, 2 * E, vb, None, S, Sp)
-    return Qr, Kr, Vp, Lqp, Sp, scale, freq, (Qp, Kp, Vr)
+    return Qr, Kr, (Vr if Vp is None else Vp), Lqp, Sp, scale, freq, (Qp, Kp, Vr)
 
 
 def attn_operands(q_pre_ptr, ldq, k_pre_ptr, ldk, v_pre_ptr, ldv, q_xyz, k_xyz, B, Lq, S, E, H, device, need_bwd=False):
@@ -352,9 +364,10 @@ def dropout_mask(drop, site, n, bh=None, q=None):
     return out
 
 
-def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0, need_bwd=False):
+def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, site=0, need_bwd=False, nograd=False):
     """Attention core on pre-formatted operands; the operand dtype selects the kernel family (fp16: attention16.hip, whose
-    LSE is in log2 units; bf16: attention.hip)."""
+    LSE is in log2 units; bf16: attention.hip).  A 4-d fp16 Vt is the value ROWS of the rows-only operand set.  nograd: the caller
+    guarantees that no backward consumes this pass (a3d_attn16_fwd_rows then forms the low part of P only around dominant keys)."""
     dev = Qs.device
     E = H * 15
     O = torch.empty((B, Lq, E), device=dev, dtype=F32)
@@ -365,10 +378,18 @@ def attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=None, si
     if Qs.dtype == torch.float16:
         dropping = drop is not None and drop.p > 0
         if ATTN_MODE == "fp8" and not dropping and not need_bwd:
+            if Vt.dim() == 4:
+                raise RuntimeError("attn_core_fwd: the fp8 mode packs its value operand from value PLANES; these operands were built "
+                                   "in the rows-only set (build them with ops.ATTN_MODE == 'fp8')")
             ops8 = torch.empty((L.load().a3d_attn8_operand_bytes(B, H, Sp),), device=dev, dtype=torch.uint8)
             L.call("a3d_attn8_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), ops8.data_ptr(),
                    None if kmask is None else kmask.data_ptr(), O.data_ptr(), LSE.data_ptr(),
                    None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, L.stream())
+            return O, LSE
+        if Vt.dim() == 4:
+            L.call("a3d_attn16_fwd_rows", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
+                   O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
+                   drop.state.data_ptr() if dropping else None, int(site), drop.p if dropping else 0.0, 1 if nograd else 0, L.stream())
             return O, LSE
         L.call("a3d_attn16_fwd", Qs.data_ptr(), Ks.data_ptr(), Vt.data_ptr(), None if kmask is None else kmask.data_ptr(),
                O.data_ptr(), LSE.data_ptr(), None if ws is None else ws.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit,
@@ -392,11 +413,13 @@ def attn_core_bwd(Qs, Ks, Vt, kmask, O, dO, LSE, B, H, Lq, Lqp, S, Sp, nsplit, e
     dV = torch.empty((B, H, Sp, 16), device=dev, dtype=F32)
     km = None if kmask is None else kmask.data_ptr()
     if Qs.dtype == torch.float16:
-        Qp, Kp, Vr = extra
+        if extra is None or extra[2] is None:
+            raise RuntimeError("attn_core_bwd: the forward wrote no value rows (it ran with need_bwd=False on the planes operand set)")
+        Vr = extra[2]
         dOr = torch.empty((B, H, Lqp, 32), device=dev, dtype=torch.float16)          # row-normalised dO ln2: hi | lo
         dOp = torch.empty((L.load().a3d_attn16_bwd_pack_bytes(B, H, Lqp) // 2,), device=dev, dtype=torch.float16)
         rexp = torch.empty((B, H, Lqp), device=dev, dtype=torch.int32)
-        L.call("a3d_attn16_bwd", Qs.data_ptr(), Qp.data_ptr(), Ks.data_ptr(), Kp.data_ptr(), Vr.data_ptr(), km, O.data_ptr(),
+        L.call("a3d_attn16_bwd", Qs.data_ptr(), None, Ks.data_ptr(), None, Vr.data_ptr(), km, O.data_ptr(),
                dO.data_ptr(), LSE.data_ptr(), dOr.data_ptr(), dOp.data_ptr(), D.data_ptr(), rexp.data_ptr(), dQp.data_ptr(),
                dK.data_ptr(), dV.data_ptr(), B, H, Lq, Lqp, S, Sp, nsplit, drop.state.data_ptr() if dropping else None,
                int(site), drop.p if dropping else 0.0, L.stream())
@@ -574,7 +597,8 @@ class AttnBlockFn(torch.autograd.Function):
                                                               S, E, H, dev, need_bwd=need_bwd)
             del keep
         nsplit = pick_nsplit(B, H, Lqp, Sp)
-        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site, need_bwd=need_bwd)
+        O, LSE = attn_core_fwd(Qs, Ks, Vt, kmask, B, H, Lq, Lqp, S, Sp, nsplit, drop=drop, site=site, need_bwd=need_bwd,
+                               nograd=not need_bwd)
         Y = linear2d(O.view(B * Lq, E), out_w, out_b, drop=drop, site=site + 1)   # seq1 + dropout(attn_out): Y is the dropped branch
         y, mean, rstd = add_layernorm(resid.view(B * Lq, E), Y, ln_g, ln_b)
         ctx.save_for_backward(q_in, k_in, v_in, resid, Y, mean, rstd, Qs, Ks, Vt, O, LSE,
@@ -583,6 +607,7 @@ class AttnBlockFn(torch.autograd.Function):
                               kmask if kmask is not None else torch.empty(0, device=dev))
         ctx.params = (in_w, in_b, out_w, out_b, ln_g, ln_b)
         ctx.extra = extra
+        ctx.need_bwd = need_bwd
         ctx.drop, ctx.site = drop, site
         ctx.meta = (B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, q_xyz is not None, kmask is not None)
         # the usual post-norm layer: the query IS the residual stream -- its two gradients are summed by the dgrad kernel (in place, into
@@ -599,9 +624,10 @@ class AttnBlockFn(torch.autograd.Function):
         in_w, in_b, out_w, out_b, ln_g, ln_b = ctx.params
         B, Lq, S, E, H, Lqp, Sp, scale, nsplit, mode, has_xyz, has_mask = ctx.meta
         dev = dy.device
-        if Qs.dtype == torch.float16 and (ctx.extra is None or ctx.extra[0] is None):
-            raise RuntimeError("AttnBlockFn.backward: the forward ran with grad_mode=False (no backward operand formats were "
-                               "written); call it through ops.attn_block or pass grad_mode=torch.is_grad_enabled()")
+        if not ctx.need_bwd:
+            raise RuntimeError("AttnBlockFn.backward: the forward ran with grad_mode=False (a gradient-free pass: adaptive low part "
+                               "of P, no backward operand formats); call it through ops.attn_block or pass "
+                               "grad_mode=torch.is_grad_enabled()")
         if not has_xyz:
             q_xyz = k_xyz = None
         if not has_mask:

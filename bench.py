@@ -365,6 +365,7 @@ def cfg5_fp8_bench(a3d, device, B=16, steps=10, warmup=3):
         qc = torch.randn(B * Lq, Ed, generator=g).to(device)
         kc = torch.randn(B * S, Ed, generator=g).to(device)
         vc = torch.randn(B * S, Ed, generator=g).to(device)
+        O.ATTN_MODE = "fp8"           # both timings on the fp8 mode's operand set (value planes; the default set is rows-only)
         Qs, Ks, Vt, Lqp, Sp = O.attn_operands16(qc.data_ptr(), Ed, kc.data_ptr(), Ed, vc.data_ptr(), Ed, None, None, B, Lq, S, Ed, H,
                                                 device, need_bwd=False)[:5]
         ns = O.pick_nsplit(B, H, Lqp, Sp)

@@ -132,7 +132,8 @@ int a3d_dropout_mask(unsigned char* out, size_t n, const unsigned long long* dro
  * autograd) with half the MFMA work: q, k two-part fp16 (x = hi + lo, fp32-grade logits), P / dS / V / dO single fp16.
  * Operand formats "16": rows16 [B][H][Npad][32] fp16 = hi(16) | lo(16); planes16 [B][H][parts][16][Npad] fp16, transposed
  * (parts & 3 = 2: hi and lo planes, what the kernels read; 1: hi only; parts | 4: padded channel 15 of the hi plane = 1.0 --
- * REQUIRED for the value planes, it is the softmax-denominator channel of the forward's PV product).
+ * REQUIRED for the value planes, it is the softmax-denominator channel of the forward's PV product; parts | 8: the same 1.0 in
+ * channel 15 of the hi part of the ROWS -- REQUIRED for the value rows of a3d_attn16_fwd_rows).
  * q must carry log2(e) (pass scale * log2 e to the *_split16 writers; a3d_rope_merge_bwd takes the same scale): scores and
  * LSE2 are in log2 units.  drop_state NULL or drop_p == 0: no dropout; otherwise Philox keep flags as a3d_attn_fwd_dropout.
  * Sp <= 16384. */
@@ -145,7 +146,16 @@ int a3d_proj_rope_split16(const float* X, int ldx, const float* W, int ldw, cons
 int a3d_attn16_fwd(const void* Qr, const void* Kr, const void* Vp, const unsigned char* kmask, float* O, float* LSE2,
                    float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
                    const unsigned long long* drop_state, unsigned int drop_site, float drop_p, void* stream);
-/* Needs rows16 of q, k, v and two-part planes16 of q, k.  Scratch: dOr [B][H][Lqp][32] fp16 (hi | lo), pack
+/* The same forward on the ROWS-ONLY operand set (round 6, the default of ops.py): Vr = value rows16 whose padded channel 15 of the hi
+ * part is 1.0 (writers: parts | 8).  The V^T fragments of the PV product are transposed LDS reads (ds_read_b64_tr_b16) of the rows
+ * tile, so the projection writes ONE layout of K and of V -- half the stores of the planes + rows set, and a3d_attn16_bwd reads the
+ * same tensors.  nograd != 0: the caller keeps no gradient (evaluation, sampling): the low part of P is then formed only for
+ * chunks that hold a dominant key (weight > 2^-6 of the running denominator); NEVER set it on a pass whose backward will run. */
+int a3d_attn16_fwd_rows(const void* Qr, const void* Kr, const void* Vr, const unsigned char* kmask, float* O, float* LSE2,
+                        float* ws, int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit,
+                        const unsigned long long* drop_state, unsigned int drop_site, float drop_p, int nograd, void* stream);
+/* Needs rows16 of q, k, v (v rows with or without the ones channel).  Qp, Kp (planes16 of q, k) are accepted for ABI stability and
+ * IGNORED since round 6 (may be NULL): the dQ kernel forms K^T by transposed LDS reads of the K rows.  Scratch: dOr [B][H][Lqp][32] fp16 (hi | lo), pack
  * (a3d_attn16_bwd_pack_bytes: the query-side operands of the dK / dV kernel as 20 KB LDS images per 64 rows, rows sorted by
  * gradient magnitude -- block floating point over the query axis), D [B][H][Lqp] fp32, rexp [B][H][Lqp] int32.  Outputs:
  * dQp [nsplit][B][H][Lqp][16] (gradient w.r.t. the log2e-scaled, rotated q), dK, dV [B][H][Sp][16] fp32 -- the

@@ -42,7 +42,7 @@ def run_family(O, fam, q_pre, k_pre, v_pre, dO, H, time_it=False):
     Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = op(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None, B, Lq, S, E, H,
                                                  dev, need_bwd=True)
     ns = O.pick_nsplit(B, H, Lqp, Sp)
-    Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns)
+    Oo, LSE = O.attn_core_fwd(Qs, Ks, Vt, None, B, H, Lq, Lqp, S, Sp, ns, need_bwd=True)
     dQp, dK, dV = O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Lq, Lqp, S, Sp, ns, extra=extra)
     dq = torch.empty(B * Lq, E, device=dev)
     dk = torch.empty(B * S, E, device=dev)

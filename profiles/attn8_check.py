@@ -25,7 +25,11 @@ def operands(B, Lq, S, gain, seed):
     k_pre = (torch.randn(B, S, E, generator=g) * gain).to(dev)
     v_pre = torch.randn(B, S, E, generator=g).to(dev)
     qc, kc, vc = q_pre.reshape(B * Lq, E).contiguous(), k_pre.reshape(B * S, E).contiguous(), v_pre.reshape(B * S, E).contiguous()
-    ops = O.attn_operands16(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None, B, Lq, S, E, H, dev, need_bwd=False)
+    O.ATTN_MODE = "fp8"               # the fp8 mode's operand set (value planes)
+    try:
+        ops = O.attn_operands16(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None, B, Lq, S, E, H, dev, need_bwd=False)
+    finally:
+        O.ATTN_MODE = "f16"
     return q_pre, k_pre, v_pre, ops, (qc, kc, vc)
 
 

@@ -131,8 +131,13 @@ def _projected_case(a3d, dev, B, Lq, S, gain, seed, H=4):
     s = qh @ kh.transpose(-1, -2)
     o = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
     qc, kc, vc = q_pre.reshape(B * Lq, E).contiguous(), k_pre.reshape(B * S, E).contiguous(), v_pre.reshape(B * S, E).contiguous()
-    Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O_.attn_operands16(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None,
-                                                                 B, Lq, S, E, H, dev, need_bwd=False)
+    old = O_.ATTN_MODE
+    O_.ATTN_MODE = "fp8"              # the fp8 mode's operand set: value PLANES (attention8.hip packs from them; the default set is rows-only)
+    try:
+        Qs, Ks, Vt, Lqp, Sp, scale, freq, extra = O_.attn_operands16(qc.data_ptr(), E, kc.data_ptr(), E, vc.data_ptr(), E, None, None,
+                                                                     B, Lq, S, E, H, dev, need_bwd=False)
+    finally:
+        O_.ATTN_MODE = old
     return Qs, Ks, Vt, Lqp, Sp, o, (s.abs().max().item() * math.log2(math.e))
 
 

@@ -345,6 +345,55 @@ def test_attn_block_query_gradient_with_aliased_residual(a3d, dev):
     report("folded gradient = sum of the roles", xa.grad, (xq.grad + xr.grad).cpu(), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,Lq,S,E,H,masked,mode", [(2, 37, 131, 60, 4, False, "kv"), (1, 333, 4097, 60, 4, False, "kv"),
+                                                      (2, 16, 70, 120, 8, True, "qk"), (2, 50, 1026, 120, 8, True, "kv")])
+def test_rows_only_operand_set_equals_rows_plus_planes_bit_for_bit(a3d, dev, B, Lq, S, E, H, masked, mode):
+    """Round 6: the projection kernels write ONE layout of q, k, v (rows16; value rows with the ones channel) and the kernels form
+    V^T (forward) and K^T (dQ) with transposed LDS reads of the rows tiles.  Same fragments, same MFMA order: the block's output and
+    every gradient must equal the rows + planes operand set (A3D_ATTN_ROWS_ONLY=0, the round-5 data flow) BIT FOR BIT."""
+    O = a3d.ops
+    g = torch.Generator().manual_seed(S + Lq)
+    in_w, in_b, out_w, out_b = _mha_params(E, g, scale=2.0)
+    if mode == "qk":
+        S = Lq
+    x = torch.randn(B, Lq, E, generator=g)
+    c = x if mode == "qk" else torch.randn(B, S, E, generator=g)
+    v = c if mode == "kv" else torch.randn(B, S, E, generator=g)
+    q_xyz = torch.rand(B, Lq, 3, generator=g) * 2 - 0.5
+    k_xyz = q_xyz if mode == "qk" else torch.rand(B, S, 3, generator=g) * 2 - 0.5
+    kmask = None
+    if masked:
+        kmask = torch.zeros(B, S, dtype=torch.bool)
+        kmask[:, -(S // 4):] = True
+        kmask = kmask.to(dev)
+    dy = torch.randn(B, Lq, E, generator=g).to(dev)
+
+    def run(rows_only):
+        keep = O.ROWS_ONLY
+        O.ROWS_ONLY = rows_only
+        try:
+            mha, norm = _mk_modules(dev, in_w, in_b, out_w, out_b, torch.ones(E), torch.zeros(E))
+            xq = x.to(dev).requires_grad_()
+            xk = xq if mode == "qk" else c.to(dev).requires_grad_()
+            xv = xk if mode == "kv" else v.to(dev).requires_grad_()
+            r = torch.zeros(B, Lq, E, device=dev, requires_grad=True)
+            y = O.attn_block(xq, xk, xv, r, q_xyz.to(dev), k_xyz.to(dev), kmask, mha, norm, H)
+            y.backward(dy)
+            return [y.detach(), xq.grad, xk.grad, xv.grad, mha.in_proj_weight.grad, mha.in_proj_bias.grad]
+        finally:
+            O.ROWS_ONLY = keep
+
+    a, b = run(True), run(False)
+    names = ["y", "d q_in", "d k_in", "d v_in", "d in_proj_weight", "d in_proj_bias"]
+    for n, ta, tb in zip(names, a, b):
+        same = torch.equal(ta, tb)
+        print(f"[parity] rows-only vs rows + planes, {n}: {'bit-identical' if same else 'max diff %.3e' % (ta - tb).abs().max().item()}")
+        if n in ("y", "d q_in", "d k_in", "d v_in"):
+            assert same, n
+        else:                                   # float-atomic weight gradients: accumulation order varies from run to run
+            assert (ta - tb).abs().max().item() <= 1e-5 * max(1.0, tb.abs().max().item()), n
+
+
 def test_attn_softmax_rescale_spike(a3d, dev):
     """Online-softmax rescale path: one key with a huge score in a late chunk (cdna guide rule 26)."""
     O = a3d.ops
