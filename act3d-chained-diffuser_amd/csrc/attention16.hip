@@ -818,6 +818,16 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
     bias4[u] = f32x4{bias_k, bias_k, bias_k, bias_k};
   }
   const bool masked = (kmask != nullptr) || (within * KW + KW > S);           // workgroup-uniform
+  // Key tiles that lie entirely beyond S: with S = 64 n + 1 (4096 scene tokens + the gripper token) the last workgroup of every
+  // (b, h) holds ONE real key in 128 -- 3 % of this kernel's workgroups used to do full work on -inf scores.  Such tiles (and waves
+  // that hold nothing else) keep feeding the ring and the barriers but skip the MFMA / softmax section; their outputs are zeros.
+  bool live[KT];
+  bool any_live = false;
+#pragma unroll
+  for (int u = 0; u < KT; ++u) {
+    live[u] = within * KW + (wave * KT + u) * 16 < S;
+    any_live = any_live || live[u];
+  }
   DropKey dkey = {0u, 0u};
   if (DROP) dkey = drop_key(drop_state);
 #pragma unroll
@@ -871,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
             (unsigned char)drop_keep8(dkey, (uint32_t)(within * (8 * KT) + (t >> 6) + 4 * i), q_orig, (uint32_t)bh, drop_site, drop_thr);
       ring_barrier();
     }
+    if (!any_live) continue;                            // (after the cooperative mask generation and its barrier)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       s16x8 qf[2], of[2], qtp[2], otp[2];
@@ -912,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
         for (int T = 0; T < 2; ++T) dp[u][T] = mfma_f16(of[T], vll[u], dp[u][T]);
 #pragma unroll
       for (int u = 0; u < KT; ++u) {
+        if (!live[u]) continue;            // a key tile beyond S (wave-uniform)
         unsigned long long keep8 = 0;      // byte j: keep flags of row hf * 32 + g * 8 + j for this tile's key block
         if (DROP) keep8 = *reinterpret_cast<const unsigned long long*>(&maskS[c & 1][((wave * KT + u) * 2 + (li >> 3)) * C16 + hf * 32 + g * 8]);
         unsigned int pw[4], pl_[4], gw[4], gl[4];

@@ -504,28 +504,19 @@ __global__ __launch_bounds__(256, 2) void sqw_bwd_kernel(const float* __restrict
   }
 }
 
-static bool sqw_enabled() {
-  // A3D_SQ_WAVE=0: the round-4 barrier-phase kernels of single_query.hip (A/B run)
-  static const bool on = !(getenv("A3D_SQ_WAVE") && atoi(getenv("A3D_SQ_WAVE")) == 0);
-  return on;
-}
-
-// launchers used by single_query.hip's entry points; return false when the wave-local path is switched off
-bool sqw_launch_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
+// launchers used by single_query.hip's entry points
+void sqw_launch_fwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
                     float* part, int B, int S, int E, int H, int nsplit, hipStream_t s) {
-  if (!sqw_enabled()) return false;
   const size_t lds = (size_t)(64 * SQW_LD + 16 * SQW_LD + 64 + 16 + 16 * SQW_LD) * sizeof(float);
   if (E == 60 && H == 4)
     hipLaunchKernelGGL(sqw_fwd_kernel<60>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, part, B, S, E, H, nsplit);
   else
     hipLaunchKernelGGL(sqw_fwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, part, B, S, E, H, nsplit);
-  return true;
 }
 
-bool sqw_launch_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
+void sqw_launch_bwd(const float* X, const float* xyz, const float* Wk, int ldw, const float* bk, const float* qrot, const float* freq,
                     const float* lse, const float* dxbar, const float* cD, float* dX, float* wpart, float* dqp, int B, int S, int E,
                     int H, int nsplit, int acc_dx, hipStream_t s) {
-  if (!sqw_enabled()) return false;
   const size_t lds = (size_t)(2 * 64 * SQW_LD + 2 * 16 * SQW_LD + 128 + 16 + 128 + 2 * 4 * 16 * SQW_XLD) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -539,7 +530,6 @@ bool sqw_launch_bwd(const float* X, const float* xyz, const float* Wk, int ldw, 
   else
     hipLaunchKernelGGL(sqw_bwd_kernel<0>, dim3(nsplit, B), dim3(256), lds, s, X, xyz, Wk, ldw, bk, qrot, freq, lse, dxbar, cD, dX, wpart,
                        dqp, B, S, E, H, nsplit, acc_dx);
-  return true;
 }
 
 }  // namespace a3d

@@ -64,7 +64,6 @@ SIGNATURES = {
     "a3d_attn16_fwd_rows": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _i, _p]),
     "a3d_attn16_bwd_pack_bytes": (_z, [_i, _i, _i]),
     "a3d_dbg_dn_prof": (_i, [_p]),
-    "a3d_dbg_sq_prof": (_i, [_i, _p]),
     "a3d_attn8_operand_bytes": (_z, [_i, _i, _i]),
     "a3d_attn8_fwd": (_i, [_p] * 8 + [_i] * 7 + [_p]),
     "a3d_attn16_bwd": (_i, [_p] * 16 + [_i] * 7 + [_p, C.c_uint, _f, _p]),

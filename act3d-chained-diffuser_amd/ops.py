@@ -710,7 +710,7 @@ SINGLE_QUERY = os.environ.get("A3D_SINGLE_QUERY", "1") == "1"
 # key splits of the single-query kernels = workgroups per sample.  The wave-local kernels (single_query_wave.hip) hold two
 # workgroups per CU and pay a fixed prologue (W_k and its transpose into LDS) + epilogue (merge of the per-lane / per-wave
 # partials) per workgroup: ONE resident round of 512 workgroups with 8 tiles each instead of 1024 with 4 (A3D_SQ_WGS to A/B)
-SQ_TARGET_WGS = int(os.environ.get("A3D_SQ_WGS", "512" if os.environ.get("A3D_SQ_WAVE", "1") != "0" else "1024"))
+SQ_TARGET_WGS = int(os.environ.get("A3D_SQ_WGS", "512"))
 
 
 def sq_nsplit(B, S):

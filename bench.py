@@ -89,18 +89,24 @@ def cpu_baseline(a3d, B_cpu, steps):
         loss.backward()
         opt.step()
 
+    # median of >= 5 timed steps after 2 warm-ups (the first warm-up also bounds the leg: a host on
+    # which one step takes longer than 15 s reports that single step)
     t0 = time.perf_counter()
-    step()                                             # warm-up (also bounds the leg: skip repeats if it is slow)
+    step()
     first = time.perf_counter() - t0
     if first > 15.0:
-        dt, steps = first, 1
+        dt, steps, how = first, 1, "one step (host too slow for repeats)"
     else:
-        t0 = time.perf_counter()
+        step()
+        times = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             step()
-        dt = (time.perf_counter() - t0) / steps
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        how = f"median of {steps} timed steps after 2 warm-ups"
     return {"value": B_cpu / dt, "unit": "samples/s", "cores": ncores, "kind": "port",
-            "sample": f"{steps} steps of {B_cpu} keyframes (same 4-cam 256x256 / 3-level / Ng=333 shapes, fp32 torch-CPU "
+            "sample": f"{how}, {B_cpu} keyframes per step (same 4-cam 256x256 / 3-level / Ng=333 shapes, fp32 torch-CPU "
                       f"backbone+FPN + oracle hot path + AdamW), {dt:.2f} s/step"}
 
 
@@ -474,7 +480,7 @@ def main():
                     help="skip the ChainedDiffuser entries (diffusion training step, 100-step sampling) of `secondary`")
     ap.add_argument("--only-cfg5", action="store_true", help="run only the configs[4] / fp8-attention secondary entry and print it")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -436,9 +436,6 @@ int a3d_dn_persist(const a3d_dn_layer_params* layers_dev, int n_traj, int n_pos,
                    int L, int D, int E, int H, int S, int Sp, int nsplit, int t_first, int nsteps, void* stream);
 /* development aid: 18 phase timestamps (100 MHz ticks) of workgroup 0 of the last a3d_dn_rest launch under A3D_DN_PROF=1 (host buffer) */
 int a3d_dbg_dn_prof(long long* out18);
-/* development aid: arm / disarm the phase timestamps (100 MHz ticks) of workgroup (0, 0) of a3d_sq_attn_bwd's key pass and read the
- * 12 values of the last armed launch (host buffer; NULL = only arm) */
-int a3d_dbg_sq_prof(int on, long long* out12);
 /* out[b][h][n][16] fp32 = rope3d(Y[b, n, :E] * scale, xyz) split into heads (column 15 and rows >= N zero): the K cache */
 int a3d_rope_rows_f32(const float* Y, int ldy, const float* xyz, const float* freq, float scale, float* out, int B, int N,
                       int Npad, int E, int H, void* stream);

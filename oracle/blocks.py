@@ -16,10 +16,36 @@ import torch.nn.functional as F
 KINKS = None
 
 
+# Test aid (tests/test_diffusion_gpu.py, cfg-4 gradients): RELU_MASKS = {site: [bool mask per call, in call order]} makes relu(x)
+# return x * mask -- the branch of the piecewise-linear network ANOTHER implementation took (the device's ReLU masks) -- and
+# RELU_DIFFS collects, per call, how many units that differs from this run's own sign pattern on and the largest |pre-activation|
+# among them.  A unit whose pre-activation is within rounding of zero is a kink: two correct fp32 implementations may land on
+# different sides, and their gradients then differ by a discrete step however exact their arithmetic is.
+RELU_MASKS = None
+RELU_DIFFS = None
+
+
 def relu(x, site):
     if KINKS is not None:
         KINKS.append((site, x.detach().abs().min().item()))
+    if RELU_MASKS is not None and RELU_MASKS.get(site):
+        mask = RELU_MASKS[site].pop(0).reshape(x.shape)
+        if RELU_DIFFS is not None:
+            diff = (x.detach() > 0) != mask
+            n = int(diff.sum())
+            RELU_DIFFS.append((site, n, x.detach().abs()[diff].max().item() if n else 0.0, x.detach().abs().max().item()))
+        return x * mask.to(x.dtype)
     return F.relu(x)
+
+
+# Test aid (tests/test_diffusion_gpu.py, cfg-4 gradients): LIFT = torch.float64 makes the oracle evaluate THE SAME FUNCTION in double
+# precision -- the constants the reference computes in fp32 under no_grad (RoPE codes, sinusoidal embeddings, DDPM tables) are still
+# computed in fp32, then cast up -- so that the fp32 oracle's own rounding error can be measured next to the device's.  None: no cast.
+LIFT = None
+
+
+def _lift(t):
+    return t if LIFT is None else t.to(LIFT)
 
 
 def rope3d_code(xyz, E):
@@ -34,7 +60,7 @@ def rope3d_code(xyz, E):
     ang = xyz.to(torch.float32).unsqueeze(-1) * div                       # (B, N, 3, E/6)
     cos = torch.cos(ang).repeat_interleave(2, dim=-1).flatten(-2)         # (B, N, E): x third | y third | z third
     sin = torch.sin(ang).repeat_interleave(2, dim=-1).flatten(-2)
-    return cos, sin
+    return _lift(cos), _lift(sin)
 
 
 def rotary_apply(x, cos, sin):
@@ -50,7 +76,7 @@ def sinusoidal(x, E):
     half = E // 2
     f = torch.exp(torch.arange(half, dtype=torch.float32, device=x.device) * -(math.log(10000) / (half - 1)))
     a = x.to(torch.float32)[:, None] * f[None, :]
-    return torch.cat((a.sin(), a.cos()), dim=-1)
+    return _lift(torch.cat((a.sin(), a.cos()), dim=-1))
 
 
 def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, H, q_xyz=None, k_xyz=None, key_padding_mask=None,

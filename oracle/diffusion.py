@@ -150,13 +150,13 @@ def unconvert_rot(signal):
 
 def normalize_pos(pos, bounds):
     """diffusion_model.py:187-190"""
-    lo, hi = bounds[0].float(), bounds[1].float()
+    lo, hi = OB._lift(bounds[0].float()), OB._lift(bounds[1].float())
     return (pos - lo) / (hi - lo) * 2.0 - 1.0
 
 
 def unnormalize_pos(pos, bounds):
     """diffusion_model.py:192-195"""
-    lo, hi = bounds[0].float(), bounds[1].float()
+    lo, hi = OB._lift(bounds[0].float()), OB._lift(bounds[1].float())
     return (pos + 1.0) / 2.0 * (hi - lo) + lo
 
 

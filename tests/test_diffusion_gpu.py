@@ -223,38 +223,109 @@ def test_cfg4_trajectory_half_per_gpu_shape_vs_oracle(a3d, dev):
     d = {k: v.to(dev) for k, v in inp.items()}
     for p in m.parameters():
         p.grad = None
-    loss = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"], noise=noise.to(dev),
-             timesteps=timesteps.to(dev), visual_tokens=tokens.to(dev))
-    loss.backward()
-    # oracle on leaf copies of the same parameters
-    leaf, Po = {}, {}
-    for n, t in P.items():
-        if id(t) not in leaf:
-            leaf[id(t)] = t.clone().requires_grad_(t.dtype.is_floating_point)
-        Po[n] = leaf[id(t)]
+    # the device's ReLU masks, per site (= qualified name of the MLP's first Linear, the oracle's site names) in call order
+    O_ = a3d.ops
+    site_of = {id(mod): name for name, mod in m.named_modules()}
+    dev_masks = {}
+    mlp_orig = O_.mlp
+
+    def mlp_recording(x, lin1, lin2, *a_, **k_):
+        h = O_.linear2d(x.detach().reshape(-1, x.shape[-1]).contiguous(), lin1.weight, lin1.bias, act=1)   # the kernel MLPFn runs
+        dev_masks.setdefault(site_of[id(lin1)], []).append((h > 0).cpu())
+        return mlp_orig(x, lin1, lin2, *a_, **k_)
+    O_.mlp = mlp_recording
+    try:
+        loss, pred, gt = m(d["trajectory"], d["mask"], None, d["pcd"], d["instr"], d["curr_gripper"], d["goal_gripper"], noise=noise.to(dev),
+                           timesteps=timesteps.to(dev), visual_tokens=tokens.to(dev), return_pred=True)
+    finally:
+        O_.mlp = mlp_orig
+    # the oracle on leaf copies of the same parameters, TWICE: in fp32 (the reference's arithmetic) and lifted to float64 (the same
+    # function, exact for this purpose: oracle.blocks.LIFT)
+    from oracle import blocks as OB
     bounds = torch.from_numpy(C.DIFFUSION_BOUNDS)
     pcdn = OD.normalize_pos(inp["pcd"].permute(0, 1, 3, 4, 2), bounds).permute(0, 1, 4, 2, 3).contiguous()
     cxyz_n = torch.from_numpy(OS.pcd_downsample(pcdn.numpy(), 8))
-    oloss, _, _ = OD.planner_loss(Po, OD.DDPMSchedules(100), inp["trajectory"], inp["mask"], tokens, None, inp["instr"], inp["curr_gripper"],
-                                  inp["goal_gripper"], bounds, noise, timesteps, H, ctx_xyz_norm=cxyz_n)
-    oloss.backward()
+
+    def oracle(dt, masks=None):
+        OB.LIFT = None if dt == torch.float32 else dt
+        OB.RELU_MASKS = None if masks is None else {k: list(v) for k, v in masks.items()}
+        OB.RELU_DIFFS = [] if masks is not None else None
+        try:
+            leaf, Po = {}, {}
+            for n, t in P.items():
+                if id(t) not in leaf:
+                    leaf[id(t)] = (t.to(dt) if t.dtype.is_floating_point else t).clone().requires_grad_(t.dtype.is_floating_point)
+                Po[n] = leaf[id(t)]
+            cv = lambda x: x.to(dt) if x.dtype.is_floating_point else x
+            ol, op, og = OD.planner_loss(Po, OD.DDPMSchedules(100), cv(inp["trajectory"]), inp["mask"], cv(tokens), None, cv(inp["instr"]),
+                                         cv(inp["curr_gripper"]), cv(inp["goal_gripper"]), cv(bounds), cv(noise), timesteps, H,
+                                         ctx_xyz_norm=cv(cxyz_n))
+            return Po, ol, op, og, OB.RELU_DIFFS
+        finally:
+            OB.LIFT = None
+            OB.RELU_MASKS = OB.RELU_DIFFS = None
+
+    # forward parity against the oracle as it is (its own ReLU branches)
+    _, oloss, opred, ogt, _ = oracle(torch.float32)
     scale_close("cfg4 trajectory-half loss", loss, oloss.detach(), 1e-3)
+    scale_close("cfg4 trajectory-half prediction", pred, opred.detach(), 5e-4)
+    # gradient parity ON THE DEVICE'S BRANCH of the piecewise-linear network: both oracle runs take the device's ReLU masks
+    Po, _, opred, ogt, diffs32 = oracle(torch.float32, dev_masks)
+    P64, l64, p64, g64, diffs64 = oracle(torch.float64, dev_masks)
+    scale_close("cfg4 trajectory-half prediction vs the float64 oracle", pred, p64.detach(), 5e-4)
+    nflip = sum(n for _, n, _, _ in diffs64)
+    print(f"[parity] cfg4 trajectory half: the device's ReLU masks differ from the float64 oracle's own sign pattern on {nflip} of "
+          f"{sum(mk.numel() for v in dev_masks.values() for mk in v)} units; "
+          + "; ".join(f"{site}: {n} unit(s), largest |pre-activation| {mx:.1e} (layer scale {sc:.1e})" for site, n, mx, sc in diffs64 if n))
+    assert all(mx <= 1e-4 * max(sc, 1.0) for _, n, mx, sc in diffs64 if n), "a ReLU unit far from its kink has the wrong sign on the device"
+    # Gradients.  Round 5 held them only in aggregate and blamed the L1 loss's kinks (a residual within rounding of zero flips
+    # sign(pred - gt)); the round-5 review asked for evidence.  Round 6 has it, and the L1 explanation was WRONG: all runs
+    # back-propagate the loss LINEARISED AT THE FLOAT64 ORACLE'S SIGN PATTERN (no L1 kink can act) and no residual is near a kink
+    # (count below).  The kinks that do act are the ReLUs of the FFNs: profiles/cfg4_grad_debug.py followed the gradient of every
+    # sub-block output down the stack (gpurun_out r06, profiles/r06_cfg4_grad_chain.txt) -- exact (7e-6) into the FFN block of
+    # traj_attention layer 3, 2e-3 out of it, ~1e-3 in everything upstream: ONE hidden unit of ONE token whose pre-activation is
+    # within rounding of zero sits on the other side of its kink on the device (count and magnitudes printed above), and the
+    # discrete gradient step propagates to every earlier layer (the fp32 ORACLE flips units of its own: against float64 it is up to
+    # 6e-3 of scale off on the same tensors when each run keeps its own branch).  Evaluated on the device's branch, every
+    # parameter gradient of the device is held ELEMENT-WISE against the float64 oracle to 2e-4 of the tensor's scale -- five times
+    # inside north_star's 1e-3 (observed 1.6e-5; the fp32 oracle itself: 2.3e-5).
+    resid = (p64 - g64).detach()
+    w = torch.empty_like(resid)
+    w[..., :3] = 100.0 / resid[..., :3].numel()
+    w[..., 3:] = 10.0 / resid[..., 3:].numel()
+    up = torch.sign(resid) * w
+    near = int((resid.abs() < 1e-6).sum())
+    flipped = int((torch.sign((pred.detach().cpu().double() - gt.detach().cpu().double())) != torch.sign(resid)).sum())
+    print(f"[parity] cfg4 trajectory half: {near} of {resid.numel()} residuals within 1e-6 of the L1 kink; the device's own sign pattern "
+          f"differs from the float64 oracle's in {flipped} entries")
+    (pred * up.float().to(dev)).sum().backward()
+    (opred * up.float()).sum().backward()
+    (p64 * up).sum().backward()
     named = dict(m.named_parameters())
-    checked = 0
-    for n in ("prediction_head.traj_encoder.0.weight", "prediction_head.traj_attention.0.layers.0.cross_12.in_proj_weight",
-              "prediction_head.traj_attention.0.layers.0.sa1.in_proj_weight", "prediction_head.traj_attention.0.layers.0.ffn_12.0.weight",
-              "prediction_head.pos_regressor.0.3.weight", "prediction_head.vl_attention.0.layers.0.cross_12.in_proj_weight"):
-        if n in named and n in Po and Po[n].grad is not None and named[n].grad is not None:
-            # 16 x 50 x 9 = 7200 L1 terms: a residual within rounding of zero flips its sign(pred - gt) between the two runs and moves
-            # every upstream gradient by a discrete 100 / N or 10 / N step (the golden fixtures are chosen away from such kinks, a
-            # full-shape random batch cannot be) -- so the tensors are held in aggregate (relative L2) and loosely element-wise
-            gd, go = named[n].grad.detach().float().cpu(), Po[n].grad.float()
-            rel = ((gd - go).norm() / go.norm()).item()
-            print(f"[parity] cfg4 grad {n}: relative L2 {rel:.3e}, max abs err {(gd - go).abs().max().item():.3e} of scale {go.abs().max().item():.3e}")
-            assert rel <= 3e-3, (n, rel)
-            scale_close("cfg4 grad " + n, named[n].grad, Po[n].grad, 5e-3, floor=1e-3)
-            checked += 1
-    assert checked >= 4, "too few gradient tensors were comparable (parameter names changed?)"
+    rows = []
+    for n, p in named.items():
+        if n in P64 and P64[n].grad is not None and p.grad is not None and "backbone" not in n:
+            gx = P64[n].grad
+            sc = gx.abs().max().item()
+            if sc < 1e-7:
+                continue
+            e_dev = (p.grad.detach().double().cpu() - gx).abs().max().item() / sc
+            e_o32 = (Po[n].grad.double() - gx).abs().max().item() / sc
+            l2_dev = ((p.grad.detach().double().cpu() - gx).norm() / gx.norm()).item()
+            rows.append((e_dev, e_o32, l2_dev, n))
+    rows.sort(reverse=True)
+    worst_o32 = max(r_[1] for r_ in rows)
+    med = sorted(r_[2] for r_ in rows)[len(rows) // 2]
+    print(f"[parity] cfg4 trajectory half, {len(rows)} parameter gradients against the float64 oracle: device worst {rows[0][0]:.2e} of scale "
+          f"({rows[0][3]}; the fp32 oracle on the same tensor: {rows[0][1]:.2e}); fp32 oracle worst {worst_o32:.2e}; device median "
+          f"relative L2 {med:.2e}; {sum(1 for r_ in rows if r_[0] > 1e-3)} tensors above 1e-3 (fp32 oracle: {sum(1 for r_ in rows if r_[1] > 1e-3)})")
+    for e_dev, e_o32, l2_dev, n in rows[:6]:
+        print(f"[parity] cfg4 grad {n}: device {e_dev:.2e} / fp32 oracle {e_o32:.2e} of scale vs float64; device relative L2 {l2_dev:.2e}")
+    assert len(rows) >= 40, "too few gradient tensors were comparable (parameter names changed?)"
+    # observed (round 6): device worst 1.6e-5 of scale, fp32 oracle worst 2.3e-5, device median relative L2 4.9e-6
+    bad = [(n, e_dev, e_o32) for e_dev, e_o32, _, n in rows if e_dev > max(2e-4, 3.0 * e_o32)]
+    assert not bad, bad
+    assert med <= 1e-4, med
 
 
 def test_persistent_sampler_script_horizon_50_vs_oracle(a3d, dev):
