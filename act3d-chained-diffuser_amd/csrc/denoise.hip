@@ -16,11 +16,15 @@
 //                 (AdaLN, q/k/v projection, RoPE, 16 x 16 softmax, out-proj, LayerNorm) -> AdaLN -> FFN -> LayerNorm
 //   a3d_dn_tail   per sample: position / rotation regressors -> trajectory update -> DDPM step (inpainting, clipping,
 //                 posterior mean + noise)                      (diffusion_head.py:268-272, diffusion_model.py:106-117)
-// Context K is cached as fp32 rows [B][H][Sp][16] (64 B per key and head) and multiplied with the exact-f32 MFMA
-// (v_mfma_f32_16x16x4_f32): fp32 logits at 2/3 of the bytes of the three-part bf16 rows; V stays two-part bf16 planes
-// (64 B): 128 B per key and head.  The kernel is HBM-bound (Lq = 16), so the slower f32 MFMA costs nothing.
-// All dense layers use the same exact-f32 MFMA as linear.hip (an fmaf chain in k order).
-#include "a3d_common.h"
+// Context cache (round 6): the operand formats of the split-fp16 attention (attention16.hip) -- K as rows16 [B][H][Sp][32] fp16 =
+// hi(16) | lo(16), V as planes16 [B][H][2][16][Sp] fp16 hi / lo with 1.0 in the padded channel 15 of the hi plane (the softmax
+// denominator rides on the PV MFMA) -- 128 B per key and head, written by ONE a3d_proj_rope_split16 launch per layer.  Per 32-key
+// half a wave issues 4 + 2 v_mfma_f32_16x16x32_f16 (two-part q and k: 22-bit logits; P single fp16 with the low part added only
+// around dominant keys: sampling keeps no gradient) instead of the 8 v_mfma_f32_16x16x4_f32 + 3 bf16 MFMAs of rounds 2 - 5
+// (fp32 K rows, two-part bf16 P and V): the round-5 phase probe showed the streaming loop MFMA / VALU-issue bound, not HBM bound
+// (8 f32 MFMAs = 256 issue cycles + ~150 vector instructions per half), so the exact-f32 logits were what the loop spent its time on.
+// All dense layers use the exact-f32 MFMA of linear.hip (an fmaf chain in k order).
+#include "attn_ring.h"
 #include "../../include/act3d_hip.h"
 #include <string.h>
 
@@ -361,6 +365,128 @@ __global__ __launch_bounds__(512) void dn_head_kernel(const float* __restrict__ 
   for (int i = threadIdx.x; i < L * E; i += blockDim.x) x_out[(size_t)b * L * E + i] = Xs[(i / E) * LDX + i % E];
 }
 
+// ------------------------------------------------------------------------------------------------ streaming attention core
+// One wave, 16 queries of one head against a key range of the cached context, 32 keys per step, fragments straight from global
+// memory (no LDS staging: a 16-query tile has no reuse to stage for).  Shared by dn_cross_kernel (per-phase launches) and the
+// persistent sampler's stream role: the same arithmetic, so the two paths agree to the summation order of their combines.
+//   scores : S^T = K Q^T on two 16-key tiles (rows interleaved so that a lane ends up with 8 consecutive keys, as attention16.hip):
+//            [k_hi | k_lo] . [q_hi | q_hi] + [k_hi | k_lo] . [q_lo | q_lo]; q carries log2(e) / sqrt(d): log2 units, and the MFMA
+//            accumulator is initialised with P_OFF - m: exp2 applies directly to the MFMA result
+//   weights: lazy running maximum (revised when a score exceeds it by 2^P_THR: a wave-uniform, rarely taken branch); P = fp16(p),
+//            plus its low part fp16(p - P) only for halves that hold a key within 2^-LO_SPAN of the running denominator (the
+//            gradient-free rule of attention16.hip: sampling never back-propagates)
+//   values : O^T += V^T P with two-part V; channel 15 of the hi plane is 1.0: the denominator accumulates on the MFMA
+struct DnKv16 { s16x8 k0, k1, vh, vl; };
+struct DnStream {
+  s16x8 qhh, qll;                 // B operands [q_hi | q_hi], [q_lo | q_lo] of the lane's query (li), channels (g & 1) * 8 .. + 7
+  f32x4 cin, acc;                 // P_OFF - m (score accumulator init), O^T accumulator (rows = channels 4 g + r, column = query li)
+  float m_run, thr;               // running maximum (log2 units), dominance threshold (units of the score tiles)
+  int n;                          // halves consumed so far
+};
+constexpr float DN_LO_SPAN = 6.0f;
+// q8: the 8 channels (g & 1) * 8 .. + 7 of the lane's query row, already scaled by 1 / sqrt(d) (natural-log logits)
+__device__ __forceinline__ void dn_stream_init(DnStream& st, const float (&q8)[8]) {
+  unsigned int h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pk_f16_2(q8[2 * i] * LOG2E_F, q8[2 * i + 1] * LOG2E_F, h[i], l[i]);
+  st.qhh = __builtin_bit_cast(s16x8, (u32x4_){h[0], h[1], h[2], h[3]});
+  st.qll = __builtin_bit_cast(s16x8, (u32x4_){l[0], l[1], l[2], l[3]});
+  st.cin = f32x4{P_OFF, P_OFF, P_OFF, P_OFF};
+  st.acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  st.m_run = 0.f;
+  st.thr = -INFINITY;
+  st.n = 0;
+}
+// Kb: this (sample, head)'s key rows [Sp][32]; Vhi / Vlo: the lane's channel row (li) of the hi / lo value plane [Sp]
+template <bool NONTEMPORAL>
+__device__ __forceinline__ DnKv16 dn_stream_load(const unsigned short* Kb, const unsigned short* Vhi, const unsigned short* Vlo, int hf,
+                                                 int li, int g) {
+  typedef const __attribute__((address_space(1))) s16x8* g_s16x8_p;
+  const int key0 = hf * 32;
+  const int r0 = key0 + (li >> 2) * 8 + (li & 3);
+  DnKv16 f;
+  if (NONTEMPORAL) {
+    // the K / V stream is read once per item: it must not push the layer weights the sample role re-reads out of the 4 MB L2s
+    // (global address space stated explicitly: the pointers come out of a device-memory table -> generic pointers, FLAT loads)
+    f.k0 = __builtin_nontemporal_load((g_s16x8_p)(Kb + (size_t)r0 * 32 + g * 8));
+    f.k1 = __builtin_nontemporal_load((g_s16x8_p)(Kb + (size_t)(r0 + 4) * 32 + g * 8));
+    f.vh = __builtin_nontemporal_load((g_s16x8_p)(Vhi + key0 + g * 8));
+    f.vl = __builtin_nontemporal_load((g_s16x8_p)(Vlo + key0 + g * 8));
+  } else {
+    f.k0 = *reinterpret_cast<const s16x8*>(Kb + (size_t)r0 * 32 + g * 8);
+    f.k1 = *reinterpret_cast<const s16x8*>(Kb + (size_t)(r0 + 4) * 32 + g * 8);
+    f.vh = *reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8);
+    f.vl = *reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8);
+  }
+  return f;
+}
+// s_lim: number of valid keys (keys >= s_lim are masked; 0 masks the whole half)
+__device__ __forceinline__ void dn_stream_consume(DnStream& st, const DnKv16& f, int hf, int s_lim, int g) {
+  const int key0 = hf * 32;
+  f32x4 s[2];
+  if (key0 + 32 > s_lim) {                                          // wave-uniform: only the last half of the context (or a dead one)
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      f32x4 c = st.cin;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = (key0 + g * 8 + T * 4 + r < s_lim) ? c[r] : -INFINITY;
+      s[T] = mfma_f16(T ? f.k1 : f.k0, st.qhh, c);
+    }
+  } else {
+    s[0] = mfma_f16(f.k0, st.qhh, st.cin);
+    s[1] = mfma_f16(f.k1, st.qhh, st.cin);
+  }
+  s[0] = mfma_f16(f.k0, st.qll, s[0]);
+  s[1] = mfma_f16(f.k1, st.qll, s[1]);
+  const float mx = fmaxf(max3f(s[0][0], s[0][1], s[0][2]), fmaxf(max3f(s[0][3], s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+  const bool first = st.n == 0;
+  bool lo_part = false;
+  if (first || __builtin_amdgcn_ballot_w64(mx > st.thr) != 0ull) {
+    lo_part = true;
+    if (first || __builtin_amdgcn_ballot_w64(mx > P_OFF + P_THR) != 0ull) {
+      const float cm = colmax4(mx);                                 // exact maximum of the lane's query over the half
+      float shift = first ? (cm - P_OFF) : fmaxf(cm - P_OFF, 0.f);
+      if (cm == -INFINITY) shift = 0.f;                             // every key so far masked
+      st.m_run += shift;
+      st.thr -= shift;
+      const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st.acc[r] *= alpha; st.cin[r] -= shift; s[0][r] -= shift; s[1][r] -= shift; }
+    }
+  }
+  float p[8];
+  unsigned int w[4];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      p[T * 4 + 2 * pr] = __builtin_amdgcn_exp2f(s[T][2 * pr]);
+      p[T * 4 + 2 * pr + 1] = __builtin_amdgcn_exp2f(s[T][2 * pr + 1]);
+      w[T * 2 + pr] = pk_f16(p[T * 4 + 2 * pr], p[T * 4 + 2 * pr + 1]);
+    }
+  const s16x8 pf = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
+  st.acc = mfma_f16(f.vh, pf, st.acc);
+  st.acc = mfma_f16(f.vl, pf, st.acc);
+  if (lo_part) {                                                    // wave-uniform
+    unsigned int wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wl[i] = lo_f16(p[2 * i], p[2 * i + 1], w[i]);
+    st.acc = mfma_f16(f.vh, __builtin_bit_cast(s16x8, (u32x4_){wl[0], wl[1], wl[2], wl[3]}), st.acc);
+  }
+  if ((st.n & 7) == 0) {
+    // refresh the dominance threshold from the running denominator (channel 15 = lane group 3, register 3); stale in between
+    // = smaller = conservative
+    const float lcol = colmax4((g == 3) ? st.acc[3] : 0.f);
+    st.thr = fminf(__builtin_amdgcn_logf(lcol) - DN_LO_SPAN, P_OFF + P_THR);
+  }
+  ++st.n;
+}
+// the running maximum in the units the combines use (natural log: they weight partials with exp(m_s - m)); any_valid == false
+// (the wave's range held no valid key): -inf, so that the split drops out of the maximum
+__device__ __forceinline__ float dn_stream_max_nat(const DnStream& st, bool any_valid) {
+  return any_valid ? (st.m_run - P_OFF) * LN2_F : -INFINITY;
+}
+
 // ------------------------------------------------------------------------------------------------ cross attention
 // grid: (sample, head, key split) flattened XCD-aware; workspace Op [nsplit][B][H][16][16] (column 15 = sum_k p), Mp [..][16]
 __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__ x, const float* __restrict__ traj, int D,
@@ -420,103 +546,50 @@ __global__ __launch_bounds__(256) void dn_cross_kernel(const float* __restrict__
     Qh[r * 16 + d] = (d < HD && r < L) ? Pre[r * 16 + (h * HD - c_lo) + d] : 0.f;
   }
   __syncthreads();
-  const float4 qb = *reinterpret_cast<const float4*>(&Qh[li * 16 + 4 * g]);     // B operand: channel 4 g + j of query li
+  float q8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q8[e] = Qh[li * 16 + (g & 1) * 8 + e];           // (channel 15 is the zero pad)
+  DnStream st;
+  dn_stream_init(st, q8);
 
   // ---- this wave's range of 32-key halves
   const int NH = Sp >> 5;
   const int parts = nsplit * 4, part = sp * 4 + wave;
   const int h_beg = (int)((long long)NH * part / parts), h_end = (int)((long long)NH * (part + 1) / parts);
-  const float* Kb = p.Kf + bh * (size_t)Sp * 16;
+  const unsigned short* Kb = reinterpret_cast<const unsigned short*>(p.Kf) + bh * (size_t)Sp * 32;
   const unsigned short* Vhi = p.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)Sp;
   const unsigned short* Vlo = p.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)Sp;
-  const int krow_off[2] = {(li >> 2) * 8 + (li & 3), (li >> 2) * 8 + (li & 3) + 4};
-  struct Frag { float4 k0, k1; s16x8 vh, vl; };
-  auto load = [&](int hf) {
-    Frag f;
-    const int key0 = hf * 32;
-    f.k0 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g);
-    f.k1 = *reinterpret_cast<const float4*>(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g);
-    f.vh = *reinterpret_cast<const s16x8*>(Vhi + key0 + g * 8);
-    f.vl = *reinterpret_cast<const s16x8*>(Vlo + key0 + g * 8);
-    return f;
-  };
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-  float m_run = -INFINITY;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // Three fragments in flight per wave in three FIXED register sets, the loop unrolled by three, unconditional clamped refills and
   // masked consumption (see the persistent sampler's stream role below for the why: with rotating sets -- cur = nxt -- the register
   // moves wait for loads in flight and the effective depth was one: 2 us per 32-key half, the bare memory latency)
   const int NHc = Sp >> 5;
-  auto consume = [&](const Frag& cur, int hf, bool live) {
-    const int s_lim = live ? S : 0;
-    const int key0 = hf * 32;
-    f32x4 s[2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
-      const float4 kf = T ? cur.k1 : cur.k0;
-      s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
-      s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
-      s[T] = mfma_f32_16x16x4(kf.z, qb.z, s[T]);
-      s[T] = mfma_f32_16x16x4(kf.w, qb.w, s[T]);
-    }
-    const float mt = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    const float m_new = fmaxf(m_run, colmax4(mt));
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float nm = -m_use * LOG2E_F;
-    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));
-    unsigned int hw[4], lw[4];
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr], LOG2E_F, nm)),
-                          __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr + 1], LOG2E_F, nm))};
-        const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
-        const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
-        hw[T * 2 + pr] = h2;
-        lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
-      }
-    }
-    const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-    const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-    const s16x8 vh = (li == 15) ? ones : cur.vh;        // pad channel 15 := 1: acc[15] = sum_k p on the MFMA pipe
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-    acc = mfma_bf16_16x16x32(vh, phi, acc);
-    acc = mfma_bf16_16x16x32(vh, plo, acc);
-    acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
-  };
-  Frag f0, f1, f2;
+  DnKv16 f0, f1, f2;
   __builtin_amdgcn_sched_barrier(0);
-  f0 = load(min(h_beg, NHc - 1));
+  f0 = dn_stream_load<false>(Kb, Vhi, Vlo, min(h_beg, NHc - 1), li, g);
   __builtin_amdgcn_sched_barrier(0);
-  f1 = load(min(h_beg + 1, NHc - 1));
+  f1 = dn_stream_load<false>(Kb, Vhi, Vlo, min(h_beg + 1, NHc - 1), li, g);
   __builtin_amdgcn_sched_barrier(0);
-  f2 = load(min(h_beg + 2, NHc - 1));
+  f2 = dn_stream_load<false>(Kb, Vhi, Vlo, min(h_beg + 2, NHc - 1), li, g);
   __builtin_amdgcn_sched_barrier(0);
   int hf = h_beg;
   for (; hf + 3 <= h_end; hf += 3) {
-    consume(f0, hf, true);
+    dn_stream_consume(st, f0, hf, S, g);
     __builtin_amdgcn_sched_barrier(0);
-    f0 = load(min(hf + 3, NHc - 1));
+    f0 = dn_stream_load<false>(Kb, Vhi, Vlo, min(hf + 3, NHc - 1), li, g);
     __builtin_amdgcn_sched_barrier(0);
-    consume(f1, hf + 1, true);
+    dn_stream_consume(st, f1, hf + 1, S, g);
     __builtin_amdgcn_sched_barrier(0);
-    f1 = load(min(hf + 4, NHc - 1));
+    f1 = dn_stream_load<false>(Kb, Vhi, Vlo, min(hf + 4, NHc - 1), li, g);
     __builtin_amdgcn_sched_barrier(0);
-    consume(f2, hf + 2, true);
+    dn_stream_consume(st, f2, hf + 2, S, g);
     __builtin_amdgcn_sched_barrier(0);
-    f2 = load(min(hf + 5, NHc - 1));
+    f2 = dn_stream_load<false>(Kb, Vhi, Vlo, min(hf + 5, NHc - 1), li, g);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (hf < h_end) consume(f0, hf, true);                      // the last one or two halves of the range (wave-uniform branches)
-  if (hf + 1 < h_end) consume(f1, hf + 1, true);
+  if (hf < h_end) dn_stream_consume(st, f0, hf, S, g);              // the last one or two halves of the range (wave-uniform branches)
+  if (hf + 1 < h_end) dn_stream_consume(st, f1, hf + 1, S, g);
+  const f32x4 acc = st.acc;
+  const float m_run = dn_stream_max_nat(st, h_beg < h_end && h_beg * 32 < S);
   // ---- combine the four waves (disjoint key ranges) and write this split's partial
 #pragma unroll
   for (int r = 0; r < 4; ++r) Cacc[wave][li][g * 4 + r] = acc[r];
@@ -989,10 +1062,6 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
   float* Op = a.part;
   float* Mp = a.part + (size_t)nse * U * a.H * 256;
   int* abort_flag = a.sync + 2;
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   int nprof = 0;
   for (;;) {
     __syncthreads();                                     // everybody has read the previous item's sh[]
@@ -1019,95 +1088,30 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       const int se = sp * a.nsub + sub;
       const size_t bh = (size_t)((b % U0) / a.NT) * a.H + h;
       const float* qrow = a.qbuf + ((size_t)b * 16 + li) * 128 + h * HD;       // rows >= L and columns >= E are published as zeros
-      float4 qb;                                         // B operand: channel 4 g + j of query li (channel 15 = pad)
-      qb.x = dnp_ld(qrow + 4 * g + 0);
-      qb.y = dnp_ld(qrow + 4 * g + 1);
-      qb.z = dnp_ld(qrow + 4 * g + 2);
-      qb.w = (4 * g + 3 < HD) ? dnp_ld(qrow + 4 * g + 3) : 0.f;
+      float q8[8];                                       // channels (g & 1) * 8 .. + 7 of query li (channel 15 = pad)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q8[e] = ((g & 1) * 8 + e < HD) ? dnp_ld(qrow + (g & 1) * 8 + e) : 0.f;
+      DnStream st;
+      dn_stream_init(st, q8);
       const int NH = a.Sp >> 5;
       const int h_beg = (int)((long long)NH * se / nse), h_end = (int)((long long)NH * (se + 1) / nse);
-      const float* Kb = c.Kf + bh * (size_t)a.Sp * 16;
+      const unsigned short* Kb = reinterpret_cast<const unsigned short*>(c.Kf) + bh * (size_t)a.Sp * 32;
       const unsigned short* Vhi = c.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)a.Sp;
       const unsigned short* Vlo = c.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)a.Sp;
-      const int krow_off[2] = {(li >> 2) * 8 + (li & 3), (li >> 2) * 8 + (li & 3) + 4};
-      struct Frag { float4 k0, k1; s16x8 vh, vl; };
-      auto load = [&](int hf) {
-        Frag f;
-        const int key0 = hf * 32;
-        // non-temporal: the K / V stream (205 MB per layer round) is read once -- it must not push the layer weights the sample
-        // role re-reads every layer out of the 4 MB L2s
-        // (global address space stated explicitly: the cache pointers come out of a device-memory table, which leaves the compiler
-        // with generic pointers and FLAT loads)
-        typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
-        typedef const __attribute__((address_space(1))) nt_f32x4* g_f32x4_p;
-        typedef const __attribute__((address_space(1))) s16x8* g_s16x8_p;
-        const nt_f32x4 a0 = __builtin_nontemporal_load((g_f32x4_p)(Kb + (size_t)(key0 + krow_off[0]) * 16 + 4 * g));
-        const nt_f32x4 a1 = __builtin_nontemporal_load((g_f32x4_p)(Kb + (size_t)(key0 + krow_off[1]) * 16 + 4 * g));
-        f.k0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
-        f.k1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
-        f.vh = __builtin_nontemporal_load((g_s16x8_p)(Vhi + key0 + g * 8));
-        f.vl = __builtin_nontemporal_load((g_s16x8_p)(Vlo + key0 + g * 8));
-        return f;
-      };
-      float m_run = -INFINITY;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       // Three fragments in flight per wave, in THREE FIXED register sets: the loop is unrolled by three and each set is refilled in
       // place right after its use.  (Rotating the sets -- cur = f0; f0 = f1; f1 = f2; f2 = load() -- compiles to register moves of
       // fragments whose loads are still in flight, i.e. a full s_waitcnt per iteration and an effective depth of ONE: the phase
       // probe showed 1.75 us per 32-key half, the bare memory latency, in this loop and in dn_cross_kernel's two-set version.)
-      // (Measured and reverted in round 5: THREE halves per softmax update with ping-pong fragment groups -- 24 independent score
-      // MFMAs, one rescale per 96 keys, three value accumulators, graded vmcnt(21 .. 12) waits -- made an item SLOWER, 20 -> 23.5 us
-      // for 12 halves, 0.768 -> 0.86 ms per denoise step: gpurun r05q.  The single-half body below stays.)
+      // (Measured and reverted in round 5: THREE halves per softmax update with ping-pong fragment groups made an item SLOWER,
+      // 20 -> 23.5 us for 12 halves: gpurun r05q.  The single-half body stays; round 6 changed what it issues, see the file header.)
       const int S_keys = a.S;               // read ONCE: a load of the argument block inside the loop is the newest load there and forces vmcnt(0)
-      auto consume = [&](const Frag& cur, int hf, bool live) {      // live == false: a half past the range, every key masked
-        const int key0 = hf * 32;
-        const int s_lim = live ? S_keys : 0;
-        f32x4 s[2];
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[T][r] = (key0 + g * 8 + T * 4 + r < s_lim) ? 0.f : -INFINITY;
-          const float4 kf = T ? cur.k1 : cur.k0;
-          s[T] = mfma_f32_16x16x4(kf.x, qb.x, s[T]);
-          s[T] = mfma_f32_16x16x4(kf.y, qb.y, s[T]);
-          s[T] = mfma_f32_16x16x4(kf.z, qb.z, s[T]);
-          s[T] = mfma_f32_16x16x4(kf.w, qb.w, s[T]);
-        }
-        const float mt = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-        const float m_new = fmaxf(m_run, colmax4(mt));
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float nm = -m_use * LOG2E_F;
-        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, LOG2E_F, nm));
-        unsigned int hw[4], lw[4];
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const f32x2 p2 = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr], LOG2E_F, nm)),
-                              __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][2 * pr + 1], LOG2E_F, nm))};
-            const unsigned int h2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, bf16x2));
-            const f32x2 r2 = p2 - (f32x2){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xFFFF0000u)};
-            hw[T * 2 + pr] = h2;
-            lw[T * 2 + pr] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
-          }
-        }
-        const s16x8 phi = __builtin_bit_cast(s16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-        const s16x8 plo = __builtin_bit_cast(s16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-        const s16x8 vh = (li == 15) ? ones : cur.vh;        // pad channel 15 := 1: acc[15] = sum_k p on the MFMA pipe
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-        acc = mfma_bf16_16x16x32(vh, phi, acc);
-        acc = mfma_bf16_16x16x32(vh, plo, acc);
-        acc = mfma_bf16_16x16x32(cur.vl, phi, acc);
-      };
-      Frag f0, f1, f2;
+      DnKv16 f0, f1, f2;
       __builtin_amdgcn_sched_barrier(0);
-      f0 = load(min(h_beg, NH - 1));                          // (an empty range -- more splits than halves -- loads one fragment it never uses)
+      f0 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg, NH - 1), li, g);      // (an empty range -- more splits than halves -- loads one fragment it never uses)
       __builtin_amdgcn_sched_barrier(0);
-      f1 = load(min(h_beg + 1, NH - 1));
+      f1 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg + 1, NH - 1), li, g);
       __builtin_amdgcn_sched_barrier(0);
-      f2 = load(min(h_beg + 2, NH - 1));
+      f2 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg + 2, NH - 1), li, g);
       __builtin_amdgcn_sched_barrier(0);
       // straight-line body: UNCONDITIONAL refills (clamped addresses) and masked consumption, so that the number of loads in
       // flight at every use is a compile-time constant and the compiler waits with vmcnt(8), not vmcnt(0)
@@ -1115,21 +1119,23 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
       // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
       int hf = h_beg;
       for (; hf + 3 <= h_end; hf += 3) {
-        consume(f0, hf, true);
+        dn_stream_consume(st, f0, hf, S_keys, g);
         __builtin_amdgcn_sched_barrier(0);
-        f0 = load(min(hf + 3, NH - 1));
+        f0 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 3, NH - 1), li, g);
         __builtin_amdgcn_sched_barrier(0);
-        consume(f1, hf + 1, true);
+        dn_stream_consume(st, f1, hf + 1, S_keys, g);
         __builtin_amdgcn_sched_barrier(0);
-        f1 = load(min(hf + 4, NH - 1));
+        f1 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 4, NH - 1), li, g);
         __builtin_amdgcn_sched_barrier(0);
-        consume(f2, hf + 2, true);
+        dn_stream_consume(st, f2, hf + 2, S_keys, g);
         __builtin_amdgcn_sched_barrier(0);
-        f2 = load(min(hf + 5, NH - 1));
+        f2 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 5, NH - 1), li, g);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (hf < h_end) consume(f0, hf, true);                  // the last one or two halves of the range (wave-uniform branches)
-      if (hf + 1 < h_end) consume(f1, hf + 1, true);
+      if (hf < h_end) dn_stream_consume(st, f0, hf, S_keys, g);     // the last one or two halves of the range (wave-uniform branches)
+      if (hf + 1 < h_end) dn_stream_consume(st, f1, hf + 1, S_keys, g);
+      const f32x4 acc = st.acc;
+      const float m_run = dn_stream_max_nat(st, h_beg < h_end && h_beg * 32 < S_keys);
       // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
       const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
       float* od = &Op[(row0 + li) * 16 + 4 * g];

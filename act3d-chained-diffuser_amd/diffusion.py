@@ -342,8 +342,8 @@ class DiffusionHead(nn.Module):
     # ---- inference, fused: 18 launches per network evaluation (csrc/denoise.hip)
     @torch.no_grad()
     def build_fused(self, ctx, ctx_xyz, instr, kmask, time_sin, Ln):
-        """Step-invariant state of the fused sampling path for one trajectory batch: the context K (fp32 rows) / V (bf16
-        planes) of every cross-attention layer, the instruction tokens through traj_lang_attention's k | v projection, and
+        """Step-invariant state of the fused sampling path for one trajectory batch: the context K (fp16 hi | lo rows) / V (fp16
+        hi / lo planes) of every cross-attention layer, the instruction tokens through traj_lang_attention's k | v projection, and
         the AdaLN modulation of every layer at every timestep (Linear(SiLU(sinusoidal(t))), layers.py:273-290).  Returns
         {"tensors": [...]} -- the list is what a captured graph must refresh in place -- plus per-layer pointer tables."""
         B, S, E = ctx.shape
@@ -358,13 +358,13 @@ class DiffusionHead(nn.Module):
         xyz = O._c(ctx_xyz.float())
         for lay in self._cross_layers():
             mha = lay.cross_12
-            kv = O.linear_raw(ctx.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
-                              mha.in_proj_bias.data_ptr() + E * f4, B * S, 2 * E, E, dev)
-            Kf = torch.empty((B, H, Sp, 16), device=dev, dtype=torch.float32)
-            Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.bfloat16)
-            O.L.call("a3d_rope_rows_f32", kv.data_ptr(), 2 * E, xyz.data_ptr(), freq.data_ptr(), 1.0, Kf.data_ptr(), B, S, Sp, E, H,
-                     O.L.stream())
-            O.L.call("a3d_split_vt", kv.data_ptr() + E * f4, 2 * E, Vt.data_ptr(), B, S, Sp, E, H, O.L.stream())
+            # the split-fp16 operand formats (csrc/denoise.hip header): K rows16, V planes16 with the ones channel -- projection, RoPE
+            # and formatting in ONE launch per layer (rounds 2 - 5: a [B S, 2E] fp32 projection in HBM + two formatting passes)
+            Kf = torch.empty((B, H, Sp, 32), device=dev, dtype=torch.float16)
+            Vt = torch.empty((B, H, 2, 16, Sp), device=dev, dtype=torch.float16)
+            O.L.call("a3d_proj_rope_split16", ctx.data_ptr(), E, mha.in_proj_weight.data_ptr() + E * E * f4, E,
+                     mha.in_proj_bias.data_ptr() + E * f4, E, xyz.data_ptr(), 1.0, Kf.data_ptr(), None, 2,
+                     None, 1.0, None, Vt.data_ptr(), 2 | 4, freq.data_ptr(), B, S, Sp, E, H, O.L.stream())
             mods = [O.linear2d(silu, a.modulation[1].weight, a.modulation[1].bias) for a in (lay.adaln_12, lay.adaln_1, lay.adaln_ff1)]
             st["layers"].append({"lay": lay, "Kf": Kf, "Vt": Vt, "mods": mods})
             st["tensors"] += [Kf, Vt] + mods

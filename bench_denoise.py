@@ -93,16 +93,16 @@ def cached_attention_roofline(a3d, B, Ln, S, dev, nlayers=8):
     shapes, timed with events on the launch stream AS THE SAMPLING LOOP RUNS IT: the launches rotate over the `nlayers`
     layers' distinct K/V caches (8 x 205 MB at cfg-3 -- a single cache re-read back to back would sit in the 256 MiB
     Infinity Cache and overstate the rate).  ALGORITHMIC bytes: a 16-channel bf16 K row and V row per key and
-    head (64 B) + the query rows and the partial outputs; `stored_bytes` is what the cache actually holds (fp32 K rows 64 B +
-    two-part bf16 V planes 64 B per key and head)."""
+    head (64 B) + the query rows and the partial outputs; `stored_bytes` is what the cache actually holds (two-part fp16 K rows 64 B +
+    two-part fp16 V planes 64 B per key and head: the operand formats of attention16.hip, round 6)."""
     import ctypes
     Lb = a3d.lib
     Sp = (S + 63) // 64 * 64
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, Ln, E, generator=g).to(dev)
     traj = torch.randn(B, Ln, 9, generator=g).to(dev)
-    Kf = [torch.randn(B, H, Sp, 16, device=dev) for _ in range(nlayers)]
-    Vt = [torch.randn(B, H, 2, 16, Sp, device=dev).to(torch.bfloat16) for _ in range(nlayers)]
+    Kf = [torch.randn(B, H, Sp, 32, device=dev).to(torch.float16) for _ in range(nlayers)]        # rows16: hi | lo
+    Vt = [torch.randn(B, H, 2, 16, Sp, device=dev).to(torch.float16) for _ in range(nlayers)]     # planes16: hi / lo
     qw, qb = (torch.randn(E, E, generator=g) / 11).to(dev), torch.randn(E, generator=g).to(dev)
     mod, sem = (torch.randn(2 * E, generator=g) * 0.1).to(dev), torch.randn(Ln, E, generator=g).to(dev)
     freq = a3d.ops.rope_freq(E, dev)
@@ -118,7 +118,7 @@ def cached_attention_roofline(a3d, B, Ln, S, dev, nlayers=8):
     t = _time(one_round, 5) / nlayers
     alg = B * H * S * 64.0 + B * Ln * E * 4.0 + ns * B * H * 16 * 17 * 4.0
     stored = B * H * Sp * 128.0
-    return {"bound": "hbm", "kernel": "dn_cross (trajectory -> context cross-attention against the fp32-K / bf16-V cache)",
+    return {"bound": "hbm", "kernel": "dn_cross (trajectory -> context cross-attention against the two-part fp16 K / V cache)",
             "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 1e9 / 8000.0, "ms": t * 1e3,
             "timing": f"mean over launches rotating through {nlayers} distinct caches ({nlayers * stored / 1e9:.2f} GB working set)",
             "traffic": _pmc_bytes("r05_pmc_denoise_perphase.json", "dn_cross") if (B, Ln, S) == (64, 16, 3074) else None,

@@ -377,8 +377,9 @@ typedef struct {
   const float* mod;          /* [2E] AdaLN (scale | shift) of this layer at this timestep, NULL: no AdaLN */
   const float *q_w, *q_b;    /* rows 0..E-1 of cross_12.in_proj_weight / bias */
   const float* freq;         /* E/6 RoPE frequencies, NULL: no rotation */
-  const float* Kf;           /* context keys, projected + rotated, fp32 rows [B][H][Sp][16] (a3d_rope_rows_f32) */
-  const unsigned short* Vt;  /* context values, bf16 hi / lo planes [B][H][2][16][Sp] (a3d_split_vt) */
+  const void* Kf;            /* context keys, projected + rotated: rows16 [B][H][Sp][32] fp16 = hi(16) | lo(16) (round 6; was fp32 rows) */
+  const unsigned short* Vt;  /* context values: planes16 [B][H][2][16][Sp] fp16 hi / lo, 1.0 in channel 15 of the hi plane
+                              * (both written by ONE a3d_proj_rope_split16 launch: k block rows, parts 2; v block planes, parts 2 | 4) */
 } a3d_dn_cross_params;
 typedef struct {
   const float *c_out_w, *c_out_b, *c_ln_g, *c_ln_b;                       /* cross_12.out_proj, norm_12 */
