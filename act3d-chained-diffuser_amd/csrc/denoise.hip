@@ -384,6 +384,13 @@ struct DnStream {
   int n;                          // halves consumed so far
 };
 constexpr float DN_LO_SPAN = 6.0f;
+// K / V fragments in flight per wave of the persistent stream role.  3; measured in round 6 against 6 (A3D_HIPCC_FLAGS=-DDN_DEPTH=6):
+// 0.761 vs 0.835 ms per denoise step at cfg-3 -- the key loop takes ~1 us per 32-key half per wave at EITHER depth and with 2.4x
+// less issue work than in round 5: 8 waves x 4 KB per us = ~30 GB/s per CU, the per-CU share of the chip's HBM bandwidth
+// (MI355X_MICROARCH.md: ~10 B / cycle / CU for an HBM-missing stream).  The streaming role is bound by the NUMBER OF CUs it owns.
+#ifndef DN_DEPTH
+#define DN_DEPTH 3
+#endif
 // q8: the 8 channels (g & 1) * 8 .. + 7 of the lane's query row, already scaled by 1 / sqrt(d) (natural-log logits)
 __device__ __forceinline__ void dn_stream_init(DnStream& st, const float (&q8)[8]) {
   unsigned int h[4], l[4];
@@ -1000,7 +1007,8 @@ constexpr int DNP_XDONE0 = 16;                      // sync words: [16 + 16 v] c
 __host__ __device__ __forceinline__ int dnp_kvdone0(int B, int NT) { return DNP_XDONE0 + 16 * 2 * B * NT; }          // [+ 16 (role B + b)]
 __host__ __device__ __forceinline__ int dnp_xtready0(int B, int NT) { return dnp_kvdone0(B, NT) + 16 * 2 * B; }      // [+ 16 u]
 __host__ __device__ __forceinline__ int dnp_rdone0(int B, int NT) { return dnp_xtready0(B, NT) + 16 * B * NT; }       // [+ 16 u]
-__host__ __device__ __forceinline__ int dnp_queue0(int B, int NT) { return dnp_rdone0(B, NT) + 16 * B * NT; }
+__host__ __device__ __forceinline__ int dnp_grp0(int B, int NT) { return dnp_rdone0(B, NT) + 16 * B * NT; }           // [+ 16 (role B + b)] publishes of the group's tiles
+__host__ __device__ __forceinline__ int dnp_queue0(int B, int NT) { return dnp_grp0(B, NT) + 16 * 2 * B; }
 
 // thread 0 of the workgroup spins until *flag >= target (acquire, agent scope); returns false when the kernel is aborting
 // (the polls are RELAXED agent-scope loads; no acquire fence follows: see dnp_ld)
@@ -1035,6 +1043,8 @@ __device__ __forceinline__ void dnp_st(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (Round 6 measured 16-byte write-through stores -- inline-asm global_store_dwordx4 sc1 + an explicit vmcnt drain -- for the partials
+// and the published queries: neither phase got shorter (partials + completion 5 us, publish 1.7 us), so the scalar forms stay.)
 // The argument block is re-read through an opaque copy of its pointer at every phase: otherwise the compiler hoists ALL its (loop-
 // invariant) pointer loads to the top of the role function and keeps ~150 SGPRs live across the step / layer loops (755 SGPR spills).
 __device__ __forceinline__ const DnPersist& dnp_args(const DnPersist* p) {
@@ -1049,6 +1059,86 @@ __device__ __forceinline__ int dnp_opaque(int v) {
   return __builtin_amdgcn_readfirstlane(v);          // uniform again (a scalar register) as far as the compiler is concerned
 }
 
+// One queue item: (role, sample bs, layer, key split) against ALL NTL row tiles of the trajectory (round 6; rounds 5's items were per
+// tile, so that at the reference's horizon L = 50 every one of the 4 tiles streamed the sample's K / V slice separately: 4x the
+// algorithmic reads, 0.022 of the HBM roofline).  A wave (one head, one key sub-range) loads each 32-key fragment ONCE and runs the
+// NTL tiles' score / softmax / PV sequences against it -- independent instruction streams the scheduler interleaves.
+template <int NTL>
+__device__ __forceinline__ void dnp_stream_item(const DnPersist& a, const a3d_dn_cross_params& c, int bs, int v0, int sp, float* Op,
+                                                float* Mp, int wave, int li, int g, long long* pmark) {
+  const int U = 2 * a.B * a.NT;
+  const int nse = a.nsplit * a.nsub;
+  const int h = wave % a.H, sub = wave / a.H;
+  const int se = sp * a.nsub + sub;
+  const size_t bh = (size_t)bs * a.H + h;
+  DnStream st[NTL];
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl) {
+    const float* qrow = a.qbuf + ((size_t)(v0 + tl) * 16 + li) * 128 + h * HD;     // rows >= L and columns >= E are published as zeros
+    float q8[8];                                       // channels (g & 1) * 8 .. + 7 of query li (channel 15 = pad)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q8[e] = ((g & 1) * 8 + e < HD) ? dnp_ld(qrow + (g & 1) * 8 + e) : 0.f;
+    dn_stream_init(st[tl], q8);
+  }
+  if (pmark && wave == 0 && (li | g) == 0) pmark[0] = wall_clock64();           // (development aid: the queries have arrived)
+  const int NH = a.Sp >> 5;
+  const int h_beg = (int)((long long)NH * se / nse), h_end = (int)((long long)NH * (se + 1) / nse);
+  const unsigned short* Kb = reinterpret_cast<const unsigned short*>(c.Kf) + bh * (size_t)a.Sp * 32;
+  const unsigned short* Vhi = c.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)a.Sp;
+  const unsigned short* Vlo = c.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)a.Sp;
+  // Three fragments in flight per wave, in THREE FIXED register sets: the loop is unrolled by three and each set is refilled in
+  // place right after its use.  (Rotating the sets -- cur = f0; f0 = f1; f1 = f2; f2 = load() -- compiles to register moves of
+  // fragments whose loads are still in flight, i.e. a full s_waitcnt per iteration and an effective depth of ONE: the phase
+  // probe showed 1.75 us per 32-key half, the bare memory latency, in this loop and in dn_cross_kernel's two-set version.)
+  // (Measured and reverted in round 5: THREE halves per softmax update with ping-pong fragment groups made an item SLOWER,
+  // 20 -> 23.5 us for 12 halves: gpurun r05q.  The single-half body stays; round 6 changed what it issues, see the file header.)
+  const int S_keys = a.S;               // read ONCE: a load of the argument block inside the loop is the newest load there and forces vmcnt(0)
+  auto consume = [&](const DnKv16& f, int hf) {
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) dn_stream_consume(st[tl], f, hf, S_keys, g);
+  };
+  // DN_DEPTH fragments (4 loads of 1 KB per wave each) in flight per wave, in FIXED register sets refilled in place right after their
+  // use.  (Rotating the sets -- cur = f0; f0 = f1; ... -- compiles to register moves of fragments whose loads are still in flight,
+  // i.e. a full s_waitcnt per iteration and an effective depth of ONE: round 5.)  Round 6's phase marks
+  // (profiles/r06_dn_persist_phases.json) put an item at ~20 us: queries 2, first fragments 2, key loop 11 - 14 (12 halves),
+  // partials + completion 5.
+  DnKv16 f[DN_DEPTH];
+#pragma unroll
+  for (int i = 0; i < DN_DEPTH; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
+    f[i] = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg + i, NH - 1), li, g);      // (past the range: clamped, loaded, never used)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // straight-line body: UNCONDITIONAL refills (clamped addresses) and masked consumption, so that the number of loads in
+  // flight at every use is a compile-time constant and the compiler waits with a counted vmcnt, not vmcnt(0)
+  // (the scheduling barriers pin the order consume | refill | consume ...: left alone, the machine scheduler sinks all the
+  // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
+  int hf = h_beg;
+  if (pmark && wave == 0 && (li | g) == 0) pmark[1] = wall_clock64();           // (the loads are issued; the loop's first use waits for them)
+  for (; hf + DN_DEPTH <= h_end; hf += DN_DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DN_DEPTH; ++i) {
+      consume(f[i], hf + i);
+      __builtin_amdgcn_sched_barrier(0);
+      f[i] = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + DN_DEPTH + i, NH - 1), li, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DN_DEPTH - 1; ++i)
+    if (hf + i < h_end) consume(f[i], hf + i);                  // the last halves of the range (wave-uniform branches)
+  if (pmark && wave == 0 && (li | g) == 0) pmark[2] = wall_clock64();           // (the key range is consumed)
+  const bool any_valid = h_beg < h_end && h_beg * 32 < S_keys;
+  // this wave's partials: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query, one block per tile's unit
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl) {
+    const size_t row0 = (((size_t)se * U + (v0 + tl)) * a.H + h) * 16;
+    float* od = &Op[(row0 + li) * 16 + 4 * g];
+    dnp_st(od, st[tl].acc[0]); dnp_st(od + 1, st[tl].acc[1]); dnp_st(od + 2, st[tl].acc[2]); dnp_st(od + 3, st[tl].acc[3]);
+    if (g == 0) dnp_st(&Mp[row0 + li], dn_stream_max_nat(st[tl], any_valid));
+  }
+}
+
 // ---- stream role
 __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem) {
   const DnPersist& a = dnp_args(ap);
@@ -1057,7 +1147,8 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
   const int li = lane & 15, g = lane >> 4;
   const int NL = a.n_traj + a.n_pos + a.n_rot;
   const int U0 = a.B * a.NT, U = 2 * U0;            // U: streaming units (primaries + helpers)
-  const long long total = (long long)a.nsteps * NL * U0 * a.nsplit;
+  const int G = 2 * a.B;                            // groups: (role, sample) = the NT row tiles that share one K / V pass
+  const long long total = (long long)a.nsteps * NL * a.B * a.nsplit;
   const int nse = a.nsplit * a.nsub;
   float* Op = a.part;
   float* Mp = a.part + (size_t)nse * U * a.H * 256;
@@ -1081,72 +1172,22 @@ __device__ __forceinline__ void dnp_stream_role(const DnPersist* ap, float* smem
     __syncthreads();
     const int sp = sh[0], code = sh[1];
     if (sp < 0 || code == 0) break;
-    const int gl = (code - 1) / U, b = (code - 1) - gl * U;          // gl: the layer; b: the streaming unit, its sample = (b mod U0) / NT
+    const int gl = (code - 1) / G, grp = (code - 1) - gl * G;        // gl: the layer; grp = role B + sample
+    const int role = grp / a.B, bs = grp - role * a.B;
+    const int v0 = role * U0 + bs * a.NT;                             // first streaming unit (row tile 0) of the group
     const a3d_dn_cross_params& c = dnp_args(ap).layers[gl].c;
     if (wave < a.H * a.nsub) {
-      const int h = wave % a.H, sub = wave / a.H;
-      const int se = sp * a.nsub + sub;
-      const size_t bh = (size_t)((b % U0) / a.NT) * a.H + h;
-      const float* qrow = a.qbuf + ((size_t)b * 16 + li) * 128 + h * HD;       // rows >= L and columns >= E are published as zeros
-      float q8[8];                                       // channels (g & 1) * 8 .. + 7 of query li (channel 15 = pad)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q8[e] = ((g & 1) * 8 + e < HD) ? dnp_ld(qrow + (g & 1) * 8 + e) : 0.f;
-      DnStream st;
-      dn_stream_init(st, q8);
-      const int NH = a.Sp >> 5;
-      const int h_beg = (int)((long long)NH * se / nse), h_end = (int)((long long)NH * (se + 1) / nse);
-      const unsigned short* Kb = reinterpret_cast<const unsigned short*>(c.Kf) + bh * (size_t)a.Sp * 32;
-      const unsigned short* Vhi = c.Vt + ((bh * 2 + 0) * 16 + li) * (size_t)a.Sp;
-      const unsigned short* Vlo = c.Vt + ((bh * 2 + 1) * 16 + li) * (size_t)a.Sp;
-      // Three fragments in flight per wave, in THREE FIXED register sets: the loop is unrolled by three and each set is refilled in
-      // place right after its use.  (Rotating the sets -- cur = f0; f0 = f1; f1 = f2; f2 = load() -- compiles to register moves of
-      // fragments whose loads are still in flight, i.e. a full s_waitcnt per iteration and an effective depth of ONE: the phase
-      // probe showed 1.75 us per 32-key half, the bare memory latency, in this loop and in dn_cross_kernel's two-set version.)
-      // (Measured and reverted in round 5: THREE halves per softmax update with ping-pong fragment groups made an item SLOWER,
-      // 20 -> 23.5 us for 12 halves: gpurun r05q.  The single-half body stays; round 6 changed what it issues, see the file header.)
-      const int S_keys = a.S;               // read ONCE: a load of the argument block inside the loop is the newest load there and forces vmcnt(0)
-      DnKv16 f0, f1, f2;
-      __builtin_amdgcn_sched_barrier(0);
-      f0 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg, NH - 1), li, g);      // (an empty range -- more splits than halves -- loads one fragment it never uses)
-      __builtin_amdgcn_sched_barrier(0);
-      f1 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg + 1, NH - 1), li, g);
-      __builtin_amdgcn_sched_barrier(0);
-      f2 = dn_stream_load<true>(Kb, Vhi, Vlo, min(h_beg + 2, NH - 1), li, g);
-      __builtin_amdgcn_sched_barrier(0);
-      // straight-line body: UNCONDITIONAL refills (clamped addresses) and masked consumption, so that the number of loads in
-      // flight at every use is a compile-time constant and the compiler waits with vmcnt(8), not vmcnt(0)
-      // (the scheduling barriers pin the order consume | refill | consume ...: left alone, the machine scheduler sinks all twelve
-      // loads to the end of the body to save registers and the next iteration opens with vmcnt(0) again)
-      int hf = h_beg;
-      for (; hf + 3 <= h_end; hf += 3) {
-        dn_stream_consume(st, f0, hf, S_keys, g);
-        __builtin_amdgcn_sched_barrier(0);
-        f0 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 3, NH - 1), li, g);
-        __builtin_amdgcn_sched_barrier(0);
-        dn_stream_consume(st, f1, hf + 1, S_keys, g);
-        __builtin_amdgcn_sched_barrier(0);
-        f1 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 4, NH - 1), li, g);
-        __builtin_amdgcn_sched_barrier(0);
-        dn_stream_consume(st, f2, hf + 2, S_keys, g);
-        __builtin_amdgcn_sched_barrier(0);
-        f2 = dn_stream_load<true>(Kb, Vhi, Vlo, min(hf + 5, NH - 1), li, g);
-        __builtin_amdgcn_sched_barrier(0);
+      long long* pmark = (a.prof && (int)blockIdx.x == U && nprof < 14) ? a.prof + 208 + 3 * nprof : nullptr;     // prof words [208, 250)
+      switch (a.NT) {
+        case 1: dnp_stream_item<1>(a, c, bs, v0, sp, Op, Mp, wave, li, g, pmark); break;
+        case 2: dnp_stream_item<2>(a, c, bs, v0, sp, Op, Mp, wave, li, g, pmark); break;
+        case 3: dnp_stream_item<3>(a, c, bs, v0, sp, Op, Mp, wave, li, g, pmark); break;
+        default: dnp_stream_item<4>(a, c, bs, v0, sp, Op, Mp, wave, li, g, pmark); break;
       }
-      if (hf < h_end) dn_stream_consume(st, f0, hf, S_keys, g);     // the last one or two halves of the range (wave-uniform branches)
-      if (hf + 1 < h_end) dn_stream_consume(st, f1, hf + 1, S_keys, g);
-      const f32x4 acc = st.acc;
-      const float m_run = dn_stream_max_nat(st, h_beg < h_end && h_beg * 32 < S_keys);
-      // this wave's partial: acc[r] = o[query li][d = 4 g + r] (d = 15: sum_k p), running maximum per query
-      const size_t row0 = (((size_t)se * U + b) * a.H + h) * 16;
-      float* od = &Op[(row0 + li) * 16 + 4 * g];
-      dnp_st(od, acc[0]); dnp_st(od + 1, acc[1]); dnp_st(od + 2, acc[2]); dnp_st(od + 3, acc[3]);
-      if (g == 0) dnp_st(&Mp[row0 + li], m_run);
     }
     __syncthreads();
-    if (t == 0) {
-      __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.prof && (int)blockIdx.x == U && nprof < 32) { a.prof[nprof * 3 + 2] = wall_clock64(); ++nprof; }
-    }
+    if (t < a.NT) __hip_atomic_fetch_add(&a.sync[DNP_XDONE0 + 16 * (v0 + t)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && a.prof && (int)blockIdx.x == U && nprof < 32) { a.prof[nprof * 3 + 2] = wall_clock64(); ++nprof; }
   }
 }
 
@@ -1409,8 +1450,15 @@ __device__ __forceinline__ void dnp_sample_role(const DnPersist* ap, float* smem
         }
         __syncthreads();
         if (t == 0) {
-          const int slot = atomicAdd(&a.sync[1], 1);
-          __hip_atomic_store(&a.sync[dnp_queue0(a.B, NT) + slot], 1 + l * U + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the NT row tiles of a (role, sample) share one K / V pass: whoever publishes last queues the group's item.  (The tiles
+          // of a sample advance layer by layer together -- each needs the group's item of layer l to finish layer l -- so the
+          // k-th multiple of NT is the k-th layer of this role's stacks.)
+          const int grp = role * a.B + bs;
+          const int cnt = __hip_atomic_fetch_add(&a.sync[dnp_grp0(a.B, NT) + 16 * grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          if (cnt % NT == 0) {
+            const int slot = atomicAdd(&a.sync[1], 1);
+            __hip_atomic_store(&a.sync[dnp_queue0(a.B, NT) + slot], 1 + l * (2 * a.B) + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       DNP_MARK(96 + 7 * l + 2);

@@ -40,6 +40,12 @@ for l in range(nl):
     layers.append({"q projection + rope": us(k[0], k[1]), "publish (write q, release, enqueue)": us(k[1], k[2]), "stage vectors / warm L2 / table": us(k[2], k[3]),
                    "wait for the streamers": us(k[3], k[4]), "combine": us(k[4], k[5]), "layer remainder (13 ops)": us(k[5], k[6]), "layer total": us(k[0], k[6])})
 items = [{"wait for ticket + entry": us(t[3 * i], t[3 * i + 1]), "stream + publish": us(t[3 * i + 1], t[3 * i + 2])} for i in range(32) if t[3 * i + 2]]
+# wave 0 of streamer 0, first 14 items (round 6): entry ready -> queries loaded -> fragment loads issued -> key range consumed -> item done
+for i in range(min(14, len(items))):
+    k = t[208 + 3 * i: 208 + 3 * i + 3]
+    if k[2]:
+        items[i].update({"q loads": us(t[3 * i + 1], k[0]), "issue first fragments": us(k[0], k[1]), "key loop": us(k[1], k[2]),
+                         "partials + completion": us(k[2], t[3 * i + 2])})
 print(json.dumps({"shape": {"B": B, "L": Ln, "S": C * 1024 + 2, "nsplit": ps["nsplit"], "n_steps": n_steps},
                   "sample_0_step_1": {"head_us": us(t[250], t[96]), "layers": layers, "tail_us": us(t[251], t[252]), "step_us": us(t[250], t[252])},
                   "streamer_0_items": items, "abort_word": int(ps["sync"][2].item())}, indent=1))
