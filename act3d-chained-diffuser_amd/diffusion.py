@@ -220,6 +220,10 @@ class DiffusionHead(nn.Module):
         if self.use_instruction:
             traj_feats = self.traj_lang_attention[0](traj_feats, trajectory_mask, instr, seq1_sem_pos=sem, drop=drop)
         kw = dict(seq1_xyz=traj_xyz, seq2_xyz=ctx_xyz, seq1_sem_pos=sem, silu_t=silu_t, drop=drop)
+        # the context feeds the k | v projections of all 8 cross-attention layers: one shared gradient sink (ops.GradSink: the
+        # projections' input and weight gradients run as ONE GEMM each when the last layer's backward has parked its rows)
+        self._ctx_sinks = []
+        ctx = O.attach_grad_sink(ctx, self._ctx_sinks)
         traj_feats = self.traj_attention[0](traj_feats, trajectory_mask, ctx, **kw)
         pos_feats = self.pos_attention[0](traj_feats, trajectory_mask, ctx, **kw)
         rot_feats = self.rot_attention[0](traj_feats, trajectory_mask, ctx, **kw)

@@ -134,8 +134,10 @@ class ParallelAttentionLayer(nn.Module):
         rope = self.rotary_pe
         q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
         qa = self.adaln_12(q1, silu_t) if (self.adaln_12 is not None and silu_t is not None) else q1
+        # (seq2 may carry a shared gradient sink -- DiffusionHead.forward_tokens attaches one to the context all its cross-attention
+        # layers read: their k | v projection gradients are then parked and run as ONE input- and ONE weight-gradient GEMM)
         seq1 = O.attn_block(qa, seq2, seq2, seq1, seq1_xyz if rope else None, seq2_xyz if rope else None, None,
-                            self.cross_12, self.norm_12, self.n_heads, drop=drop, site=sb)
+                            self.cross_12, self.norm_12, self.n_heads, drop=drop, site=sb, sink=getattr(seq2, "_a3d_sink", None))
         if self.self_attention1:
             q1 = seq1 if seq1_sem_pos is None else O.AddRowsFn.apply(seq1, seq1_sem_pos)
             if self.adaln_1 is not None and silu_t is not None:

@@ -457,6 +457,16 @@ def rope_merge(dR, nsplit, xyz, freq, scale, out_ptr, ldy, B, N, Npad, E, H):
 CTX_GRAD_SINK = os.environ.get("A3D_CTX_SINK", "1") not in ("0", "", "off")
 
 
+# Deferred projection gradients (round 6).  Every attention block that reads the shared tensor X through a packed k | v projection
+# owes it d X += dKV_l W_l ([B S, 2E] x [2E, E]) and owes its own weights dW_l += dKV_l^T X.  Run per block these are 2 n GEMM
+# launches that each re-read X (weight gradient) or read-modify-write the shared gradient (input gradient): at the trajectory
+# model's script shape 16 + 16 launches, 2.3 of the 16 ms step, moving ~1.8 GB.  Deferred, the blocks only park their dKV rows
+# side by side in ONE [B S, n 2E] buffer; when the last consumer has run, the gate issues ONE input-gradient GEMM with K = n 2E
+# against the stacked weights and ONE weight-gradient GEMM with N = n 2E (X and the shared gradient are touched once), then adds
+# the n slices of the stacked weight gradient to the parameters' own.  A3D_CTX_DEFER=0: per-block GEMMs (A/B).
+CTX_DEFER = os.environ.get("A3D_CTX_DEFER", "1") not in ("0", "", "off")
+
+
 class GradSink:
     live = []                                     # the sinks of the last forward pass (tests look at them)
 
@@ -464,6 +474,51 @@ class GradSink:
         self.shape, self.device = tuple(shape), device
         self.buf, self.event = None, None
         self.writers = 0                          # consumers that wrote during the current backward pass
+        self.expected = 0                         # packed-k|v attention blocks that registered during the forward pass
+        self.dkv, self.parked, self.x = None, [], None
+
+    def park(self, x, E2):
+        """-> (pointer, row stride in floats) of the next free [M, E2] slice of the shared dKV buffer; the caller fills it (on the
+        current stream, ordered by begin / end like any writer) and then calls parked_done()."""
+        cur = torch.cuda.current_stream(self.device)
+        if self.event is not None:
+            cur.wait_event(self.event)
+        M = self.shape[0] * self.shape[1]
+        cap = max(self.expected, len(self.parked) + 1)
+        if self.dkv is None:
+            self.dkv = torch.empty((M, cap * E2), device=self.device, dtype=F32)
+            self.x = x
+        else:
+            self.dkv.record_stream(cur)
+        if (len(self.parked) + 1) * E2 > self.dkv.shape[1]:
+            raise RuntimeError("GradSink.park: more deferred writers than registered consumers")
+        return self.dkv.data_ptr() + len(self.parked) * E2 * 4, self.dkv.shape[1]
+
+    def parked_done(self, w_kv, gw_kv, gb_kv):
+        """w_kv [E2, E]: the block's k | v weight rows (a view of in_proj_weight); gw_kv / gb_kv: the matching views of the
+        parameters' gradient buffers."""
+        self.parked.append((w_kv, gw_kv, gb_kv))
+        return self.end()
+
+    def _flush_parked(self):
+        n = len(self.parked)
+        E2, E = self.parked[0][0].shape
+        M, K, ld = self.dkv.shape[0], n * E2, self.dkv.shape[1]
+        wstack = torch.cat([w for w, _, _ in self.parked], dim=0)                        # [n E2, E]
+        acc = self.buf is not None
+        if not acc:
+            self.buf = torch.empty(self.shape, device=self.device, dtype=F32)
+        # d X (+)= [dKV_0 | dKV_1 | ...] [W_0; W_1; ...]
+        linear_raw(self.dkv.data_ptr(), ld, wstack.data_ptr(), E, None, M, E, K, self.device, act=3 if acc else 0, transposed=True,
+                   out=self.buf.view(M, E))
+        # [dW_0; dW_1; ...] = [dKV_0 | dKV_1 | ...]^T X, the bias gradients alongside
+        gstack = torch.zeros((K, E), device=self.device, dtype=F32)
+        gbstack = torch.zeros((K,), device=self.device, dtype=F32)
+        wgrad_raw(self.dkv.data_ptr(), ld, self.x.data_ptr(), E, gstack.data_ptr(), E, gbstack.data_ptr(), M, K, E, self.device)
+        for i, (_, gw, gb) in enumerate(self.parked):
+            gw.add_(gstack[i * E2:(i + 1) * E2])
+            gb.add_(gbstack[i * E2:(i + 1) * E2])
+        self.dkv, self.parked, self.x = None, [], None
 
     def begin(self):
         """-> (buffer, accumulate): this writer runs after the previous one, whatever stream that was on"""
@@ -487,11 +542,16 @@ class GradSink:
 
     def drain(self):
         """gate backward: the total of this pass (None when no consumer wrote), ordered after the last writer"""
+        cur = torch.cuda.current_stream(self.device)
+        if self.event is not None:
+            cur.wait_event(self.event)
+        if self.parked:
+            if self.buf is not None:
+                self.buf.record_stream(cur)
+            self.dkv.record_stream(cur)
+            self._flush_parked()
         out = self.buf
         if out is not None:
-            cur = torch.cuda.current_stream(self.device)
-            if self.event is not None:
-                cur.wait_event(self.event)
             out.record_stream(cur)
         self.buf, self.event, self.writers = None, None, 0
         return out
@@ -517,16 +577,18 @@ def begin_grad_sinks():
     behind -- e.g. an exception between a writer and the gate -- is dropped with them)."""
     for sk in GradSink.live:
         sk.buf, sk.event, sk.writers = None, None, 0
+        sk.dkv, sk.parked, sk.x = None, [], None
     GradSink.live = []
 
 
-def attach_grad_sink(t):
+def attach_grad_sink(t, registry=None):
     """-> the tensor the consumers of the (B, S, E) fp32 tensor t should read: t itself, or -- when its gradient is needed -- a
-    view of it behind a gate node that owns a GradSink (as ._a3d_sink); the consumers pick the sink up from there."""
+    view of it behind a gate node that owns a GradSink (as ._a3d_sink); the consumers pick the sink up from there.  registry: the
+    list that keeps the sink for inspection (default: GradSink.live, which begin_grad_sinks() resets per Act3D forward pass)."""
     if not (CTX_GRAD_SINK and t.is_cuda and t.requires_grad and t.dtype == F32 and torch.is_grad_enabled()):
         return t
     sk = GradSink(t.shape, t.device)
-    GradSink.live.append(sk)
+    (GradSink.live if registry is None else registry).append(sk)
     out = _SinkGateFn.apply(t, sk)
     out._a3d_sink = sk
     return out
@@ -616,6 +678,8 @@ class AttnBlockFn(torch.autograd.Function):
         # the context's gradient goes into its shared buffer (packed k,v projection of ONE input only: a single dgrad GEMM)
         ctx.sink = sink if (sink is not None and need_bwd and mode == "kv" and ctx.needs_input_grad[1] and
                             tuple(k_in.shape) == sink.shape) else None
+        if ctx.sink is not None:
+            ctx.sink.expected += 1
         return y.view(B, Lq, E)
 
     @staticmethod
@@ -675,7 +739,14 @@ class AttnBlockFn(torch.autograd.Function):
                 dgrad2d(dq_pre, in_w[:E], accum_into=dS)
             elif need_q:
                 d_q_in = dgrad2d(dq_pre, in_w[:E]).view(B, Lq, E)
-            if mode == "kv":
+            if mode == "kv" and ctx.sink is not None and CTX_DEFER:
+                # park dK | dV next to the other blocks' (GradSink, "deferred projection gradients"): the input- and the weight-
+                # gradient GEMMs of all blocks that read this context run once, at the gate
+                ptr, ld = ctx.sink.park(k_in, 2 * E)
+                rope_merge(dK, 1, k_xyz, freq, 1.0, ptr, ld, B, S, Sp, E, H)
+                rope_merge(dV, 1, None, freq, 1.0, ptr + E * f4, ld, B, S, Sp, E, H)
+                d_k_in = ctx.sink.parked_done(in_w[E:], gW[E:], gb[E:])
+            elif mode == "kv":
                 dkv = torch.empty((B * S, 2 * E), device=dev, dtype=F32)
                 rope_merge(dK, 1, k_xyz, freq, 1.0, dkv.data_ptr(), 2 * E, B, S, Sp, E, H)
                 rope_merge(dV, 1, None, freq, 1.0, dkv.data_ptr() + E * f4, 2 * E, B, S, Sp, E, H)
