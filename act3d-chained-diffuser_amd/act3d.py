@@ -164,15 +164,17 @@ class Act3D(nn.Module):
         with torch.no_grad():
             feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32,
                                         normalize=self.normalize)
-        out_bias = {}
+        out_bias, out_ctx = {}, {}
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):
                 # channel count padded to a multiple of 64 for MIOpen; the hot path reads the first E channels of each row.
                 # The 3x3 output convolutions run bias-free: their bias travels with the tokens (ops.TokenMap.row_bias) and is added
                 # to the rows a level gathers
                 E_ = self.curr_gripper_embed.weight.shape[1]
-                pyr, out_bias = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64,
-                                                     defer_output_bias=bool(x.is_cuda))
+                res = self.feature_pyramid(feats, needed=self._needed_maps(), pad_to=(E_ + 63) // 64 * 64,
+                                           defer_output_bias=bool(x.is_cuda), sparse_ncam=ncam if x.is_cuda else None)
+                pyr, out_bias = res[0], res[1]
+                out_ctx = res[2] if len(res) > 2 else {}
         else:
             pyr = self.feature_pyramid(feats, needed=self._needed_maps())
         tokens = {}
@@ -180,7 +182,7 @@ class Act3D(nn.Module):
             n, E, h, w = fm.shape                    # E: the map's channel count incl. padding (bf16 path)
             # (cam, h, w, E) rows of the channels-last map: a view, in the FPN's own dtype -- a bf16 map is gathered in place
             # by a3d_build_context_bf16 (no fp32 copy of the 128 x 128 map, of which a level reads 6 % of the rows)
-            tokens[name] = O.TokenMap(fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E), out_bias.get(name))
+            tokens[name] = O.TokenMap(fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E), out_bias.get(name), out_ctx.get(name))
         return [tokens[self.feature_map_pyramid[i]] for i in range(self.num_sampling_level)]
 
     # ------------------------------------------------------------------------------------------------ ghost points
@@ -271,7 +273,8 @@ class Act3D(nn.Module):
                 idx = None
             else:
                 idx = O.knn_topk(prev_pos, pcd_pyramid[i], 32 * 32 * ncam)
-            ctx = O.BuildContextFn.apply(feats[i].tokens, idx, grip_tok, accum[id(feats[i].tokens)], feats[i].row_bias)
+            ctx = O.BuildContextFn.apply(feats[i].tokens, idx, grip_tok, accum[id(feats[i].tokens)], feats[i].row_bias,
+                                         feats[i].conv_ctx)
             ctx_xyz = O.gather_rows(pcd_pyramid[i], idx, grip_xyz[:, None])
             topk_pyramid.append(idx)
             if self.use_instruction:

@@ -224,6 +224,38 @@ def fpn_top_down(lat, last, bias=None):
     return lat if last is None else lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
 
 
+class _LayerConv3x3Fn(torch.autograd.Function):
+    """The FPN's 3x3 output convolution (bias-free, stride 1, padding 1, bf16 channels_last, 64 channels) with a SPLIT backward:
+    the input gradient is the library's (MIOpen), the weight gradient is taken from the map's gather consumers when they have
+    computed it token-sparsely (ops.SparseConvCtx / csrc/fpn_sparse.hip) -- the dense weight-gradient kernel (0.72 ms per step at
+    the bench shape, over a gradient map that is non-zero on 6 - 12 % of its pixels) then does not run at all."""
+
+    @staticmethod
+    def forward(ctx, x, w, cc):
+        w16 = w.to(x.dtype)
+        y = F.conv2d(x, w16, None, padding=1)
+        ctx.save_for_backward(x, w16)
+        ctx.cc = cc
+        cc.x, cc.dw, cc.dense = x, None, False
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        cc = ctx.cc
+        sparse = cc.dw is not None and not cc.dense
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        if need_x or (need_w and not sparse):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                            (need_x, need_w and not sparse, False))
+        if need_w and sparse:
+            dw = cc.dw.permute(2, 3, 0, 1).contiguous()        # [kh][kw][co][ci] -> the weight's [co][ci][kh][kw]
+        cc.dw = None
+        return dx, (None if dw is None else dw.float()), None
+
+
 class FeaturePyramidNetwork(nn.Module):
     """torchvision.ops.FeaturePyramidNetwork (0.14 naming: inner_blocks.i.0 / layer_blocks.i.0), restated: 1x1 lateral
     convs, nearest top-down pathway, 3x3 output convs.  Runs on PyTorch-ROCm/MIOpen (adjacent to the hot path,
@@ -239,7 +271,7 @@ class FeaturePyramidNetwork(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, feats, needed=None, pad_to=None, defer_output_bias=None):
+    def forward(self, feats, needed=None, pad_to=None, defer_output_bias=None, sparse_ncam=None):
         """pad_to: run every convolution with its output (and, for the 3x3 layer blocks, input) channel count zero-padded
         to this width and return the padded maps (pad channels are exact zeros).  MIOpen's bf16 NHWC kernels for C = 60
         are ~2x slower than for C = 64 (measured on MI355X, N = 256 at 128 x 128: forward + backward 5.2 ms vs 2.6 ms);
@@ -249,7 +281,10 @@ class FeaturePyramidNetwork(nn.Module):
         that reads the lateral map anyway (forward) / reduced by the kernel that reads its gradient anyway (backward).
         defer_output_bias=True also runs the 3x3 output convolutions bias-free: the consumer adds the bias to the token rows
         it gathers (ops.BuildContextFn) -- a level reads 6 % of the fine map.  Whenever the keyword is passed (True OR False)
-        the return value is the pair (maps, {name: bias Parameter owed}); without it, the plain dict of maps."""
+        the return value is the pair (maps, {name: bias Parameter owed}); without it, the plain dict of maps.
+        sparse_ncam (cameras per sample; only with defer_output_bias=True): the caller reads the output maps through
+        ops.BuildContextFn gathers and passes each map's ops.SparseConvCtx on to them -- the return value is then the triple
+        (maps, biases, {name: SparseConvCtx}) and the output convolutions' weight gradients come from the gathers (_LayerConv3x3Fn)."""
         names = list(feats.keys())
         xs = list(feats.values())
         C = self.inner_blocks[0][0].out_channels
@@ -274,13 +309,19 @@ class FeaturePyramidNetwork(nn.Module):
                 return lat if last is None else fpn_top_down(lat, last)
             return fpn_top_down(conv(m, x, wpad, False), last, m.bias)      # bias-free convolution, bias in the top-down kernel
 
-        out_bias = {}
+        out_bias, out_ctx = {}, {}
 
         def layer(i, x):
             m = self.layer_blocks[i][0]
             defer = defer_output_bias and x.is_cuda
             if defer:
                 out_bias[names[i]] = m.bias
+            if (defer and sparse_ncam and O.SPARSE_FPN_WGRAD and C + pad == 64 and x.dtype == torch.bfloat16 and x.shape[1] == 64
+                    and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] % sparse_ncam == 0):
+                cc = O.SparseConvCtx(sparse_ncam)
+                out_ctx[names[i]] = cc
+                w = F.pad(m.weight, (0, 0, 0, 0, 0, pad, 0, pad)) if pad else m.weight
+                return _LayerConv3x3Fn.apply(x, w, cc)
             return conv(m, x, (0, 0, 0, 0, 0, pad, 0, pad), not defer, padding=1)
 
         last = inner(len(xs) - 1, xs[-1], None)
@@ -292,7 +333,9 @@ class FeaturePyramidNetwork(nn.Module):
             last = inner(i, xs[i], last)
             if needed is None or names[i] in needed:
                 out[names[i]] = layer(i, last)
-        return out if defer_output_bias is None else (out, out_bias)
+        if defer_output_bias is None:
+            return out
+        return (out, out_bias, out_ctx) if sparse_ncam else (out, out_bias)
 
 
 class _Bottleneck(nn.Module):

@@ -1147,15 +1147,33 @@ class GradAccum:
         self.buf, self.pending = None, 0
 
 
+# Token-sparse weight gradient of the FPN's 3x3 output convolution (csrc/fpn_sparse.hip, round 6): a map whose gradient arrives only
+# through BuildContextFn's gathers gets its convolution's weight gradient from those gathers' own backward inputs (indices + context
+# gradient rows) instead of a dense library kernel over the zero-filled, scattered map.  A3D_FPN_SPARSE_WGRAD=0: dense (A/B).
+SPARSE_FPN_WGRAD = os.environ.get("A3D_FPN_SPARSE_WGRAD", "1") == "1"
+
+
+class SparseConvCtx:
+    """Shared by the FPN's output convolution of one map (nn._LayerConv3x3Fn) and the map's gather consumers (BuildContextFn):
+    x: the convolution's input (bf16 channels_last, 64 channels), ncam: cameras per sample (the token index of a sample runs over
+    (camera, h, w)); dw: the weight gradient [3][3][64 co][64 ci] the gathers' backward passes have accumulated so far (None: none
+    yet); dense: some consumer read the map densely (idx None) -- its gradient is not in dw, the convolution falls back to the
+    library's dense weight gradient."""
+    __slots__ = ("x", "ncam", "dw", "dense")
+
+    def __init__(self, ncam):
+        self.x, self.ncam, self.dw, self.dense = None, ncam, None, False
+
+
 class TokenMap:
     """One level's visual tokens (B, ncam*h*w, ld) plus the bias that is still OWED to the rows a level gathers: the FPN's 3x3
     output convolution runs bias-free on the bf16 path (nn.FeaturePyramidNetwork.forward(defer_output_bias=True)) and
     BuildContextFn adds `row_bias` to the gathered rows.  An explicit pair instead of an attribute on the tensor: any tensor
     op (.float(), .detach(), slicing, save / load) would silently drop an attribute and run the model on bias-free features."""
-    __slots__ = ("tokens", "row_bias")
+    __slots__ = ("tokens", "row_bias", "conv_ctx")
 
-    def __init__(self, tokens, row_bias=None):
-        self.tokens, self.row_bias = tokens, row_bias
+    def __init__(self, tokens, row_bias=None, conv_ctx=None):
+        self.tokens, self.row_bias, self.conv_ctx = tokens, row_bias, conv_ctx      # conv_ctx: SparseConvCtx of the producing convolution or None
 
     @staticmethod
     def of(x):
@@ -1165,8 +1183,9 @@ class TokenMap:
         return TokenMap(self.tokens.detach(), self.row_bias)
 
     def leaf(self):
-        """detached leaf of the tokens that records a gradient (engine._split_backward); the bias keeps its own graph"""
-        return TokenMap(self.tokens.detach().requires_grad_(self.tokens.requires_grad), self.row_bias)
+        """detached leaf of the tokens that records a gradient (engine._split_backward); the bias keeps its own graph, the
+        convolution context travels along (the leaf's gradient goes back through the same convolution)"""
+        return TokenMap(self.tokens.detach().requires_grad_(self.tokens.requires_grad), self.row_bias, self.conv_ctx)
 
     def with_bias(self):
         """the tokens with the owed bias added (what the reference's feature map holds, act3d.py:352), fp32"""
@@ -1181,10 +1200,11 @@ class BuildContextFn(torch.autograd.Function):
     channels-last output read in place: no fp32 copy of the map, the gradient goes back as one bf16 map); extra (B, X, E)."""
 
     @staticmethod
-    def forward(ctx, feat, idx, extra, accum=None, bias=None):
+    def forward(ctx, feat, idx, extra, accum=None, bias=None, conv_ctx=None):
         """bias: fp32 Parameter (E,) added to the gathered rows of a bf16 map (the deferred bias of the FPN's 3x3 output
         convolution, nn.FeaturePyramidNetwork.forward(defer_output_bias=True)); its gradient -- the column sums of d(ctx)
-        over the gathered rows -- is accumulated into bias.grad by the backward."""
+        over the gathered rows -- is accumulated into bias.grad by the backward.  conv_ctx: SparseConvCtx of the convolution that
+        produced the map: the backward then also accumulates that convolution's WEIGHT gradient from (idx, d ctx rows)."""
         L.require_gpu(feat)
         feat, extra = _c(feat), _c(extra)
         B, Npts, ldf = feat.shape
@@ -1206,6 +1226,9 @@ class BuildContextFn(torch.autograd.Function):
         ctx.idx = idx
         ctx.accum = accum
         ctx.bias = bias
+        ctx.conv_ctx = conv_ctx if (bf and ctx.needs_input_grad[0]) else None
+        if ctx.conv_ctx is not None and idx is None:
+            ctx.conv_ctx.dense = True                  # a dense reader: its gradient is not covered by the token-sparse path
         if accum is not None:
             accum.pending += 1
         ctx.meta = (B, Npts, k, X, E, bf, ldf)
@@ -1222,6 +1245,16 @@ class BuildContextFn(torch.autograd.Function):
             ws = torch.empty((L.load().a3d_colsum_rows_ws_floats(B, k, E),), device=dctx.device, dtype=F32)
             gb = grad_buf(ctx.bias)
             L.call("a3d_colsum_rows", dctx.data_ptr(), B, k + X, k, E, E, gb.data_ptr(), E, ws.data_ptr(), L.stream())
+        cc = ctx.conv_ctx
+        if (cc is not None and not cc.dense and idx is not None and SPARSE_FPN_WGRAD and cc.x is not None and cc.x.shape[1] == 64
+                and cc.ncam * cc.x.shape[2] * cc.x.shape[3] == Npts and E <= 64):
+            # the producing convolution's weight gradient, straight from this gather's indices and gradient rows
+            acc = cc.dw is not None
+            if not acc:
+                cc.dw = torch.empty((3, 3, 64, 64), device=dctx.device, dtype=F32)
+            ws = torch.empty((L.load().a3d_conv3x3_wgrad_tokens_ws_floats(),), device=dctx.device, dtype=F32)
+            L.call("a3d_conv3x3_wgrad_tokens", cc.x.data_ptr(), idx.data_ptr(), dctx.data_ptr(), k + X, E, ws.data_ptr(),
+                   cc.dw.data_ptr(), 1 if acc else 0, B, k, cc.ncam, cc.x.shape[2], cc.x.shape[3], L.stream())
         if ctx.needs_input_grad[0]:
             dt = torch.bfloat16 if bf else F32
             if accum is not None and accum.buf is None and accum.pending == 1:
@@ -1248,7 +1281,7 @@ class BuildContextFn(torch.autograd.Function):
                 dfeat = None                    # a later backward of the same map returns the shared buffer
             else:
                 accum.buf = None
-        return dfeat, None, dextra, None, None
+        return dfeat, None, dextra, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ heads / losses

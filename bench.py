@@ -154,14 +154,18 @@ def kernel_rooflines(a3d, device, B):
     if f16:
         hf = torch.float16
         Kr = torch.empty((B, H, Spad, 32), device=device, dtype=hf)
-        Kp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
         Vr = torch.empty((B, H, Spad, 32), device=device, dtype=hf)
-        Vp = torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
+        rows_only = O._rows_only()
+        Kp = None if rows_only else torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
+        Vp = None if rows_only else torch.empty((B, H, 2, 16, Spad), device=device, dtype=hf)
+        nz = lambda t_: None if t_ is None else t_.data_ptr()
+        # the call ops.attn_operands_fused16 makes: rows-only operand set since round 6 (K rows + V rows with the ones channel);
+        # A3D_ATTN_ROWS_ONLY=0: rows + planes of both, the round-5 set
         t_proj = time_kernel(lambda: O.L.call(
             "a3d_proj_rope_split16", x.data_ptr(), E, w.data_ptr() + E * E * 4, E, bb.data_ptr() + E * 4, E,
-            k_xyz.data_ptr(), 1.0, Kr.data_ptr(), Kp.data_ptr(), 2, None, 1.0, Vr.data_ptr(), Vp.data_ptr(), O.V_PLANES,
+            k_xyz.data_ptr(), 1.0, Kr.data_ptr(), nz(Kp), 2, None, 1.0, Vr.data_ptr(), nz(Vp), O.V_ROWS if rows_only else O.V_PLANES,
             freq.data_ptr(), B, S, Spad, E, H, O.L.stream()))
-        bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (32 + 32 + 32 + 32))      # x rows + K rows/planes + V rows/planes
+        bytes_proj = B * (S * E * 4.0 + H * Spad * 2.0 * (32 + 32) * (1 if rows_only else 2))      # x rows + K, V rows (+ planes)
         # v_mfma_f32_16x16x32_{f16,bf16} = 16384 FLOP each; per (64 keys x 16 queries) the forward issues 8 score + 6 PV,
         # dQ 8 score + 8 dP + 6 dQ, dK/dV 8 score + 8 dP + 6 dV + 6 dK (two-part operands, d 15 -> 16)
         per_fwd, per_bwd, dt = 14, 22 + 28, "fp16 / bf16 MFMA on two-part operands (x = hi + lo; fp32 accumulate)"
@@ -193,7 +197,7 @@ def kernel_rooflines(a3d, device, B):
                      "unit": "TFLOP/s", "ms": t_bwd, "launches_per_step": 6, "dtype": dt, "family": O.ATTN_MODE,
                      "executed_tflops": x_bwd / (t_bwd * 1e-3) / 1e12, "mfma_util_executed": x_bwd / (t_bwd * 1e-3) / 2.5e15},
         # achieved / frac: SURVEY 8(d)'s ALGORITHMIC bytes -- the fp32 context rows in + ONE 16-bit K and ONE 16-bit V out
-        # (B S (4 E + 2 * 2 E)); stored_*: what the kernel really writes (four two-part operand tensors), the figure rounds 1 - 4
+        # (B S (4 E + 2 * 2 E)); stored_*: what the kernel really writes (two two-part operand tensors since round 6, four before), the figure rounds 1 - 4
         # reported as "achieved" (flattering: the review's recomputation gave 0.11 where the bench line said 0.30)
         "kv_proj_rope": {"bound": "hbm", "achieved": B * S * E * 8.0 / (t_proj * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "algorithmic_bytes": B * S * E * 8.0, "stored_bytes": bytes_proj,
@@ -284,7 +288,7 @@ def pmc_record(B):
     """HBM traffic / MFMA utilisation of the same kernels from the committed rocprofv3 --pmc passes (profiles/run_pmc.sh;
     counters cannot be read from inside this process).  None when no record exists for this batch size."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for rnd in ("r05", "r04"):                       # the newest committed counter record for this batch size
+    for rnd in ("r06", "r05", "r04"):                       # the newest committed counter record for this batch size
         path = os.path.join(here, "profiles", f"{rnd}_pmc_B{B}.json")
         try:
             with open(path) as fh:

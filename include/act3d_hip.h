@@ -243,6 +243,16 @@ int a3d_build_context_bf16(const void* feat, int ldf, const long long* idx, cons
                            int B, int Npts, int k, int X, int W, void* stream);
 int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* dfeat, int ldf, float* dextra, int B,
                                int Npts, int k, int X, int W, int accumulate, void* stream);
+/* Token-sparse WEIGHT gradient of the FPN's 3x3 output convolution (torchvision FeaturePyramidNetwork.layer_blocks, stride 1,
+ * padding 1, 64 -> 64 channels on the bf16 NHWC path; act3d.py:76-77) for a map that is read only through a3d_build_context_bf16's
+ * gathers (act3d.py:244-260): dW[tap][co][ci] (+)= sum over b, j < k of G[b][j][co] X[pixel(idx[b][j]) + offset(tap)][ci], computed
+ * from the gather's own backward inputs (idx and the fp32 context-gradient rows G [B][g_rows][E], g_rows >= k, E <= 64) -- 12 % of
+ * the dense library kernel's work and no dense gradient map.  X: the convolution's INPUT, bf16 [B ncam][H][W][64]; dW fp32
+ * [3][3][64 co][64 ci] (tap-major; the caller permutes it to the weight's layout); ws: a3d_conv3x3_wgrad_tokens_ws_floats() floats.
+ * Replaces the weight-gradient half of F.conv2d's autograd for that layer (csrc/fpn_sparse.hip). */
+size_t a3d_conv3x3_wgrad_tokens_ws_floats(void);
+int a3d_conv3x3_wgrad_tokens(const void* X, const long long* idx, const float* G, int g_rows, int E, float* ws, float* dW,
+                             int accumulate, int B, int k, int ncam, int H, int W, void* stream);
 /* out[c] += sum over b < B, s < k of src[b][s][c]  (src fp32 [B][S][ld], c < nout <= C <= 64; two launches, fixed summation
  * order; ws: a3d_colsum_rows_ws_floats(B, k, C) floats). */
 size_t a3d_colsum_rows_ws_floats(int B, int k, int C);

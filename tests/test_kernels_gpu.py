@@ -868,6 +868,82 @@ def test_fpn_with_folded_biases_matches_plain_convolutions(a3d, dev):
     assert gp["layer_blocks.1.0.bias"].grad is None                                    # maps nobody reads stay untouched
 
 
+@pytest.mark.parametrize("B,ncam,hw,k", [(2, 2, 32, 128), (3, 1, 16, 100), (2, 4, 32, 64)])
+def test_fpn_output_convolution_token_sparse_weight_gradient(a3d, dev, B, ncam, hw, k):
+    """The FPN's 3x3 output convolution with its weight gradient computed from the gathers (csrc/fpn_sparse.hip through
+    ops.SparseConvCtx / nn._LayerConv3x3Fn) against the library's dense backward of the same bf16 convolution: TWO gather
+    levels on the same map (overlapping index sets: duplicates add up), tokens indexed over (camera, h, w), border pixels
+    included (zero padding), k not a multiple of 64 (masked tail), plus the deferred bias and the input gradient, which stay on
+    the library / column-sum path.  Also: a dense reader (idx None) switches the map back to the dense weight gradient."""
+    import copy
+    torch.manual_seed(5)
+    E, Cin = 60, [64, 256, 512, 1024, 2048]
+    N = B * ncam
+    fpn = a3d.nn.FeaturePyramidNetwork(Cin, E).to(dev)
+    ref = copy.deepcopy(fpn)
+    g = torch.Generator().manual_seed(6)
+    sizes = [hw, hw // 2, hw // 4, hw // 8, hw // 16]
+    feats = {f"res{i + 1}": (torch.randn(N, c, s_, s_, generator=g) * 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+             for i, (c, s_) in enumerate(zip(Cin, sizes))}
+    npts = ncam * hw * hw
+    # two levels' index sets: unique within a level (as k-NN indices are; the map's scatter relies on it), half of level 2 shared
+    # with level 1 (the same pixel in both levels: the contributions add up), the image corners included (zero padding)
+    rows1, rows2 = [], []
+    for _ in range(B):
+        perm = torch.randperm(npts - 2, generator=g) + 1                       # 1 .. npts - 2: the corners are placed by hand
+        r1 = torch.cat([torch.tensor([0]), perm[:k - 1]])
+        r2 = torch.cat([torch.tensor([npts - 1]), r1[k // 2:], perm[k - 1:k - 1 + (k - 1 - (k - k // 2))]])
+        assert r1.unique().numel() == k and r2.unique().numel() == k
+        rows1.append(r1)
+        rows2.append(r2)
+    idx1, idx2 = torch.stack(rows1).to(dev), torch.stack(rows2).to(dev)
+    extra = torch.randn(B, 1, E, generator=g).to(dev)
+    wts = [torch.randn(B, k + 1, E, generator=g).to(dev) for _ in range(2)]
+
+    def run(model, sparse, dense_reader=False):
+        for p in model.parameters():
+            p.grad = None
+        keep = a3d.ops.SPARSE_FPN_WGRAD
+        a3d.ops.SPARSE_FPN_WGRAD = sparse
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                res = model(feats, needed=["res1"], pad_to=64, defer_output_bias=True, sparse_ncam=ncam)
+            pyr, ob = res[0], res[1]
+            cc = res[2].get("res1") if len(res) > 2 else None
+            assert (cc is not None) == sparse
+            fm = pyr["res1"]
+            tok = fm.permute(0, 2, 3, 1).reshape(B, npts, fm.shape[1])
+            accum = a3d.ops.GradAccum()
+            loss = 0
+            for idx, w in ((idx1, wts[0]), (idx2, wts[1])):
+                loss = loss + (a3d.ops.BuildContextFn.apply(tok, idx, extra, accum, ob["res1"], cc) * w).sum()
+            if dense_reader:
+                loss = loss + a3d.ops.BuildContextFn.apply(tok, None, extra, accum, ob["res1"], cc).sum() * 0.01
+            loss.backward()
+            return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            a3d.ops.SPARSE_FPN_WGRAD = keep
+
+    gs, gd = run(fpn, True), run(ref, False)
+    assert set(gs) == set(gd)
+    bad = []
+    for n in sorted(gd):
+        err = (gs[n] - gd[n]).abs().max().item()
+        sc = gd[n].abs().max().item()
+        print(f"[parity] fpn token-sparse backward, grad {n}: max abs err {err:.3e} (scale {sc:.3e})")
+        # bf16 operands on both sides (the dense path rounds the SUMMED gradient map to bf16, the sparse one each gradient row)
+        if err > 2e-2 * sc + 1e-6:
+            bad.append((n, err, sc))
+    assert not bad, bad
+    w_err = (gs["layer_blocks.0.0.weight"] - gd["layer_blocks.0.0.weight"]).norm() / gd["layer_blocks.0.0.weight"].norm()
+    print(f"[parity] fpn token-sparse weight gradient of the output convolution: relative L2 {w_err.item():.3e}")
+    assert w_err.item() <= 5e-3
+    # a dense reader of the same map: the sparse context is marked and the library's dense weight gradient takes over
+    gs2, gd2 = run(fpn, True, dense_reader=True), run(ref, False, dense_reader=True)
+    w2 = (gs2["layer_blocks.0.0.weight"] - gd2["layer_blocks.0.0.weight"]).abs().max().item()
+    assert w2 <= 1e-3 * max(1.0, gd2["layer_blocks.0.0.weight"].abs().max().item()), w2      # the same library kernel on both sides
+
+
 @pytest.mark.parametrize("mode,B,Lq,S,E,H", [("kv", 2, 37, 131, 60, 4), ("qk", 2, 70, 70, 120, 8), ("none", 1, 5, 64, 60, 4),
                                              ("kv", 1, 1, 1, 60, 4)])
 def test_fused_projection_equals_unfused_operands(a3d, dev, mode, B, Lq, S, E, H):
