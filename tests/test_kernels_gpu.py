@@ -941,7 +941,7 @@ def test_fpn_output_convolution_token_sparse_weight_gradient(a3d, dev, B, ncam, 
     # a dense reader of the same map: the sparse context is marked and the library's dense weight gradient takes over
     gs2, gd2 = run(fpn, True, dense_reader=True), run(ref, False, dense_reader=True)
     w2 = (gs2["layer_blocks.0.0.weight"] - gd2["layer_blocks.0.0.weight"]).abs().max().item()
-    assert w2 <= 1e-3 * max(1.0, gd2["layer_blocks.0.0.weight"].abs().max().item()), w2      # the same library kernel on both sides
+    assert w2 <= 1e-2 * max(1.0, gd2["layer_blocks.0.0.weight"].abs().max().item()), w2      # the same library kernel on both sides (its bf16 result: one ulp)
 
 
 @pytest.mark.parametrize("mode,B,Lq,S,E,H", [("kv", 2, 37, 131, 60, 4), ("qk", 2, 70, 70, 120, 8), ("none", 1, 5, 64, 60, 4),
