@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
     else dma_plane_subtile(Vbase, Sp, (size_t)cc * C16, &Vsm[slot][wave * 512], lane);
   };
 
-  int koff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) koff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
+  // LDS fragment addresses: ONE base per tile and slot, everything else an immediate of the ds_read.  Score tile j of a chunk reads
+  // row (j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4: the swizzle key (0 - (row >> 3)) & 3 does not depend on j, so
+  // koff[j] = koff0 + FWD_KJ(j); likewise tr_off(.., hf, rr) = tr_off(.., 0, 0) + (hf * 32 + rr * 4) * 32 (row >> 3 = hf * 4 + g).
+  // (Round 5 kept 12 offset registers and paid one v_lshl_or per read and chunk to add the runtime slot base: 12 of ~130 VALU.)
+#define FWD_KJ(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 32)
+  const int koff0 = tile_off((li >> 2) * 8 + (li & 3), g);
   const int voff = plane_off(li, g);
-  int vtr[2][2][2];                                           // VR: [part][half][row block] offsets of the transposed reads
-#pragma unroll
-  for (int i = 0; i < 8; ++i) vtr[i >> 2][(i >> 1) & 1][i & 1] = tr_off(li, g, i >> 2, (i >> 1) & 1, i & 1);
+  const int vtr0 = tr_off(li, g, 0, 0, 0), vtr1 = tr_off(li, g, 1, 0, 0);       // VR: hi / lo part of the transposed value reads
 
   float m_run[QT], l_run[QT];            // running max (log2 units, exact per query column); l_run: DROP only
   float thr[QT];                         // PP == 2: a chunk maximum above it (same units as the score tiles) asks for the low part of P
@@ -179,45 +180,54 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
     if (!any_active) continue;                                // a wave of padding queries only feeds the ring
 
     s16x8 kf[4], vh[2], vl[2];
+    {
+      const unsigned short* kb = &Ksm[slot][koff0];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const s16x8*>(&Ksm[slot][koff[j]]);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+      for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const s16x8*>(kb + FWD_KJ(j));
       if (VR) {
-        vh[hf] = tr_frag(Vsm[slot], vtr[0][hf][0], vtr[0][hf][1]);
-        vl[hf] = tr_frag(Vsm[slot], vtr[1][hf][0], vtr[1][hf][1]);
+        const unsigned short *vb0 = &Vsm[slot][vtr0], *vb1 = &Vsm[slot][vtr1];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          vh[hf] = tr_frag(vb0 + hf * 1024, 0, 128);
+          vl[hf] = tr_frag(vb1 + hf * 1024, 0, 128);
+        }
       } else {
-        vh[hf] = *reinterpret_cast<const s16x8*>(&Vsm[slot][((0 * 2 + hf) * 16) * 32 + voff]);
-        vl[hf] = *reinterpret_cast<const s16x8*>(&Vsm[slot][((1 * 2 + hf) * 16) * 32 + voff]);
+        const unsigned short* vb = &Vsm[slot][voff];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          vh[hf] = *reinterpret_cast<const s16x8*>(vb + ((0 * 2 + hf) * 16) * 32);
+          vl[hf] = *reinterpret_cast<const s16x8*>(vb + ((1 * 2 + hf) * 16) * 32);
+        }
       }
     }
+    // Order of one chunk: score MFMAs of all tiles, then per tile { rescale? | exp + pack | PV }.  Round 6 also built the tile-pipelined
+    // order (scores(0) | rescale(0)? | scores(1) beside exp(0) | rescale(1)? | PV(0) beside exp(1) | PV(1); -DA3D_ATTN_FWD_TILE_PIPE):
+    // 128.1 vs 125.7 us per launch at the bench shape (profiles/r06_attn_ab.txt) -- on this SIMD vector work next to an MFMA is close
+    // to ADDITIVE (profiles/r06_coissue.txt: 1 MFMA + 8 v_exp = 31.2 ns against 27.2 + 8.1), so re-pairing matrix and vector work of
+    // different tiles buys nothing and the longer live ranges cost.  A sched_group_barrier interleave on top of it changed the
+    // results of this kernel (different digests of O on identical inputs) and was dropped.
     f32x4 s[QT][4];
-    if (masked) {
+    s16x8 pf[QT][2];
+    float pv[QT][2][8];                    // the fp32 weights, kept for the low part
+    bool lo_part[QT];
+    auto scores = [&](const int u) {
+      if (masked) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 b4 = bias_of(maskW[c * 2 + (j >> 1)], g, j & 1);
-#pragma unroll
-        for (int u = 0; u < QT; ++u) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u] + b4);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < QT; ++u)
+        for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u] + bias_of(maskW[c * 2 + (j >> 1)], g, j & 1));
+      } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qhi[u], cin[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < QT; ++u)
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[u][j] = mfma_f16(kf[j], qlo[u], s[u][j]);
-
-#pragma unroll
-    for (int u = 0; u < QT; ++u) {
+    };
+    auto rescale = [&](const int u) {
       // s = s2 - m_run + P_OFF.  Common path: nothing exceeds 2^(P_OFF + P_THR) -> exponentiate as is; PP == 2: and nothing is
       // within 2^-LO_SPAN of the running denominator (thr <= P_OFF + P_THR: ONE wave-uniform test guards both rare paths)
       const float mx = max16(s[u][0], s[u][1], s[u][2], s[u][3]);
-      bool lo_part = (PP == 3);
+      lo_part[u] = (PP == 3);
       if (first || __builtin_amdgcn_ballot_w64(mx > (PP == 2 ? thr[u] : P_OFF + P_THR)) != 0ull) {
-        if (PP == 2) lo_part = true;
+        if (PP == 2) lo_part[u] = true;
         if (PP != 2 || first || __builtin_amdgcn_ballot_w64(mx > P_OFF + P_THR) != 0ull) {
           const float cm = colmax4(mx);                                       // exact chunk max of the lane's query
           float shift = first ? (cm - P_OFF) : fmaxf(cm - P_OFF, 0.f);
@@ -234,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
             for (int r = 0; r < 4; ++r) s[u][j][r] -= shift;
         }
       }
-      s16x8 pf[2], pl[2];
-      float pv[2][8];                      // the fp32 weights, kept for the low part
+    };
+    auto weights = [&](const int u) {
       float l_tile = 0.f;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -254,26 +264,28 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
               p0 = ((keep >> j) & 1u) ? p0 * drop_scale : 0.f;
               p1 = ((keep >> (j + 1)) & 1u) ? p1 * drop_scale : 0.f;
             }
-            const unsigned int h2 = pk_f16(p0, p1);
-            w[T * 2 + pr] = h2;
-            if (PP >= 2) { pv[hf][T * 4 + 2 * pr] = p0; pv[hf][T * 4 + 2 * pr + 1] = p1; }
+            w[T * 2 + pr] = pk_f16(p0, p1);
+            if (PP >= 2) { pv[u][hf][T * 4 + 2 * pr] = p0; pv[u][hf][T * 4 + 2 * pr + 1] = p1; }
           }
         }
-        pf[hf] = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
+        pf[u][hf] = __builtin_bit_cast(s16x8, (u32x4_){w[0], w[1], w[2], w[3]});
       }
       if (DROP) l_run[u] += l_tile;
+    };
+    auto values = [&](const int u) {
       // V keeps both parts: O = sum_k p~_k v_k / sum_k p~_k is an exactly normalised average of the 22-bit v rows, so
       // what is left of the P rounding is proportional to the spread of v under the weights, not to |v|
-      acc0[u] = mfma_f16(vh[0], pf[0], acc0[u]);
-      acc1[u] = mfma_f16(vh[1], pf[1], acc1[u]);
-      acc0[u] = mfma_f16(vl[0], pf[0], acc0[u]);
-      acc1[u] = mfma_f16(vl[1], pf[1], acc1[u]);
-      if (PP >= 2 && lo_part) {                                  // wave-uniform
+      acc0[u] = mfma_f16(vh[0], pf[u][0], acc0[u]);
+      acc1[u] = mfma_f16(vh[1], pf[u][1], acc1[u]);
+      acc0[u] = mfma_f16(vl[0], pf[u][0], acc0[u]);
+      acc1[u] = mfma_f16(vl[1], pf[u][1], acc1[u]);
+      if (PP >= 2 && lo_part[u]) {                               // wave-uniform
+        s16x8 pl[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           unsigned int wl[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wl[i] = lo_f16(pv[hf][2 * i], pv[hf][2 * i + 1], (unsigned int)__builtin_bit_cast(u32x4_, pf[hf])[i]);
+          for (int i = 0; i < 4; ++i) wl[i] = lo_f16(pv[u][hf][2 * i], pv[u][hf][2 * i + 1], (unsigned int)__builtin_bit_cast(u32x4_, pf[u][hf])[i]);
           pl[hf] = __builtin_bit_cast(s16x8, (u32x4_){wl[0], wl[1], wl[2], wl[3]});
         }
         acc0[u] = mfma_f16(vh[0], pl[0], acc0[u]);
@@ -286,8 +298,26 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(
         const float lcol = colmax4(lsum);
         thr[u] = fminf(__builtin_amdgcn_logf(lcol) - LO_SPAN, P_OFF + P_THR);
       }
+    };
+#ifndef A3D_ATTN_FWD_TILE_PIPE
+#pragma unroll
+    for (int u = 0; u < QT; ++u) scores(u);
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { rescale(u); weights(u); values(u); }
+#else
+    scores(0);
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      rescale(u);
+      if (u + 1 < QT) scores(u + 1);
+      if (u > 0) values(u - 1);
+      weights(u);
+      A3D_PIN(pf[u][0]); A3D_PIN(pf[u][1]);                  // (otherwise hipcc sinks the exponentials past the next rescale branch, next to their PV)
     }
+    values(QT - 1);
+#endif
   }
+#undef FWD_KJ
   wait_vm<0>();                                               // the trailing dummy fetches must not outlive the workgroup
 
 #pragma unroll
@@ -573,6 +603,10 @@ __global__ __launch_bounds__(256) void attn16_bwd_prep_kernel(
       } else if (t == 64) {
         // E_c; a chunk that starts beyond the drop span (or in the padding) is dead, and so is everything after it
         reinterpret_cast<int*>(pk + PK_HDR)[0] = (rank_c == 0xFFFFu || rank_c > rank0 + DROP_SPAN) ? -1000 : 300 - (int)rank_c;
+      } else if (t == 65) {
+        // live 32-row halves of the chunk (the rows are sorted: if row 32 is dead, so are rows 33 .. 63)
+        const unsigned int rank_h = sortS[c * 64 + 32] >> 16;
+        reinterpret_cast<int*>(pk + PK_HDR)[1] = (rank_h == 0xFFFFu || rank_h > rank0 + DROP_SPAN) ? 1 : 2;
       }
     }
     __syncthreads();
@@ -594,8 +628,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
     int B, int H, int Lq, int Lqp, int S, int Sp, int nsplit, const unsigned long long* __restrict__ drop_state,
     unsigned int drop_site, unsigned int drop_thr, float drop_scale) {
   // (round 6: no K planes -- the K^T fragments of dQ^T = K^T G^T are transposed reads of the K rows tile, attn_ring.h tr_frag)
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[DQ_NB][C16 * 32];      // [k_hi | k_lo] rows tile
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[DQ_NB][C16 * 32];      // [v_hi | v_lo] rows tile
+  __shared__ __attribute__((aligned(16))) unsigned short KVsm[DQ_NB][2][C16 * 32];  // [k_hi | k_lo] rows tile, [v_hi | v_lo] rows tile
   __shared__ unsigned int maskW[MASKW];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // scalar control flow (see the forward kernel)
@@ -659,16 +692,15 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
   const unsigned short* Vbase = Vr + bh * Sp * 32;
   auto issue = [&](int c, int slot) {
     const int cc = min(c, c_end - 1);
-    dma_rows_tile(Kbase + (size_t)cc * C16 * 32, 32, Ksm[slot], wave, lane);
-    dma_rows_tile(Vbase + (size_t)cc * C16 * 32, 32, Vsm[slot], wave, lane);
+    dma_rows_tile(Kbase + (size_t)cc * C16 * 32, 32, KVsm[slot][0], wave, lane);
+    dma_rows_tile(Vbase + (size_t)cc * C16 * 32, 32, KVsm[slot][1], wave, lane);
   };
 
-  int koff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) koff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
-  int ktr[2][2][2];                                           // [part][half][row block] offsets of the transposed K reads
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ktr[i >> 2][(i >> 1) & 1][i & 1] = tr_off(li, g, i >> 2, (i >> 1) & 1, i & 1);
+  // one LDS base per tile and slot, immediates for the rest (see the forward kernel): score tile (hf, T) = koff0 + DQ_KJ(hf * 2 + T),
+  // V = K + one tile, transposed K reads = ktr{0,1} + (hf * 32 + rr * 4) * 32
+#define DQ_KJ(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 32)
+  const int koff0 = tile_off((li >> 2) * 8 + (li & 3), g);
+  const int ktr0 = tr_off(li, g, 0, 0, 0), ktr1 = tr_off(li, g, 1, 0, 0);
 
   f32x4 acc0[QT], acc1[QT];
 #pragma unroll
@@ -686,16 +718,20 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
     issue(c + DQ_NB - 1, (slot + DQ_NB - 1) % DQ_NB);
     const bool masked = any_masked && ((kmask != nullptr) || ((c + 1) * C16 > S));
     if (!any_active) continue;
+    const unsigned short* kb = &KVsm[slot][0][koff0];
+    const unsigned short *tb0 = &KVsm[slot][0][ktr0], *tb1 = &KVsm[slot][0][ktr1];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      // S = 64 n + 1 (4096 scene tokens + the gripper token): the last chunk holds one real key -- its second half is all padding
+      if (hf == 1 && c * C16 + 32 >= S) continue;                  // wave-uniform; masked keys contribute exact zeros
       s16x8 kf[2], vf[2], kp[2];
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
-        kf[T] = *reinterpret_cast<const s16x8*>(&Ksm[slot][koff[hf * 2 + T]]);
-        vf[T] = *reinterpret_cast<const s16x8*>(&Vsm[slot][koff[hf * 2 + T]]);
+        kf[T] = *reinterpret_cast<const s16x8*>(kb + DQ_KJ(hf * 2 + T));
+        vf[T] = *reinterpret_cast<const s16x8*>(kb + C16 * 32 + DQ_KJ(hf * 2 + T));
       }
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) kp[pl] = tr_frag(Ksm[slot], ktr[pl][hf][0], ktr[pl][hf][1]);
+      kp[0] = tr_frag(tb0 + hf * 1024, 0, 128);
+      kp[1] = tr_frag(tb1 + hf * 1024, 0, 128);
       f32x4 sT[QT][2], dpT[QT][2];
       if (masked) {
         const unsigned int word = maskW[c * 2 + hf];
@@ -755,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(
     }
   }
   wait_vm<0>();
+#undef DQ_KJ
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     if (!active[u]) continue;
@@ -843,9 +880,9 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
     for (int i = 0; i < 5; ++i) glds16(src + i * 512, &pk[slot][wave * 2560 + i * 512]);
   };
 
-  int qoff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) qoff[j] = tile_off((j >> 1) * 32 + (li >> 2) * 8 + (li & 3) + (j & 1) * 4, g);
+  // one LDS base per tile and slot, immediates for the rest (see the forward kernel)
+#define DKV_QJ(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 32)
+  const int qoff0 = tile_off((li >> 2) * 8 + (li & 3), g);
   const int poff = plane_off(li, g);
 
   f32x4 dk0[KT], dk1[KT], dv0[KT], dv1[KT];
@@ -862,6 +899,9 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
     const unsigned short* P = pk[slot];
     const int e_c = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(P + PK_HDR));
     if (e_c <= -1000) continue;                       // nothing but padding / dropped rows from here on (sorted)
+    // rows are sorted, dead ones (padding, all-zero dO, beyond the drop span) last: a chunk whose row 32 is dead has a dead second half
+    // (Lq = 333 in 6 chunks of 64: the last one holds 13 live rows -- one twelfth of this kernel's matrix and softmax work was on zeros)
+    const int halves = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(P + PK_HDR)[1]);
     if (e_c != e_ref) {
       if (e_ref > -1000) {
         const float f = ldexpf(1.0f, min(e_ref - e_c, 126));
@@ -882,21 +922,24 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
       ring_barrier();
     }
     if (!any_live) continue;                            // (after the cooperative mask generation and its barrier)
+    const unsigned short *Pq = P + qoff0, *Pp = P + poff;
+    const float* Pn = reinterpret_cast<const float*>(P + PK_NL) + g * 8;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if (hf == 1 && halves < 2) continue;             // wave-uniform; dead rows have P' = 2^-inf = 0: identical bits
       s16x8 qf[2], of[2], qtp[2], otp[2];
       f32x4 nl4[2], nd4[2];
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
-        qf[T] = *reinterpret_cast<const s16x8*>(P + PK_QROWS + qoff[hf * 2 + T]);
-        of[T] = *reinterpret_cast<const s16x8*>(P + PK_OROWS + qoff[hf * 2 + T]);
-        nl4[T] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(P + PK_NL) + hf * 32 + g * 8 + T * 4);
-        nd4[T] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(P + PK_ND) + hf * 32 + g * 8 + T * 4);
+        qf[T] = *reinterpret_cast<const s16x8*>(Pq + PK_QROWS + DKV_QJ(hf * 2 + T));
+        of[T] = *reinterpret_cast<const s16x8*>(Pq + PK_OROWS + DKV_QJ(hf * 2 + T));
+        nl4[T] = *reinterpret_cast<const f32x4*>(Pn + hf * 32 + T * 4);
+        nd4[T] = *reinterpret_cast<const f32x4*>(Pn + (PK_ND - PK_NL) / 2 + hf * 32 + T * 4);
       }
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
-        qtp[pl] = *reinterpret_cast<const s16x8*>(P + PK_QPL + ((pl * 2 + hf) * 16) * 32 + poff);
-        otp[pl] = *reinterpret_cast<const s16x8*>(P + PK_OPL + ((pl * 2 + hf) * 16) * 32 + poff);
+        qtp[pl] = *reinterpret_cast<const s16x8*>(Pp + PK_QPL + ((pl * 2 + hf) * 16) * 32);
+        otp[pl] = *reinterpret_cast<const s16x8*>(Pp + PK_OPL + ((pl * 2 + hf) * 16) * 32);
       }
       f32x4 s[KT][2], dp[KT][2];
       if (masked) {
@@ -945,8 +988,13 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
               g0 = p0 * dp[u][T][2 * pr];
               g1 = p1 * dp[u][T][2 * pr + 1];
             }
+#ifdef A3D_BF16_SPLIT_RNE
             pk_bf16_2(p0, p1, pw[T * 2 + pr], pl_[T * 2 + pr]);
             pk_bf16_2(g0, g1, gw[T * 2 + pr], gl[T * 2 + pr]);
+#else
+            pk_bf16_2t(p0, p1, pw[T * 2 + pr], pl_[T * 2 + pr]);
+            pk_bf16_2t(g0, g1, gw[T * 2 + pr], gl[T * 2 + pr]);
+#endif
           }
         }
         const s16x8 pf = __builtin_bit_cast(s16x8, (u32x4_){pw[0], pw[1], pw[2], pw[3]});
@@ -963,6 +1011,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(
     }
   }
   wait_vm<0>();
+#undef DKV_QJ
   const float sk = (e_ref > -1000) ? ldexpf(1.0f, e_ref - (int)B_OFF) : 0.f, sv = sk * LOG2E_F;
 #pragma unroll
   for (int u = 0; u < KT; ++u) {

@@ -60,6 +60,25 @@ __device__ __forceinline__ void pk_bf16_2(float a, float b, unsigned int& hi, un
   const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
   lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){ra, rb}, bf16x2_));
 }
+// The same split by TRUNCATION (round 6, the dK / dV kernel): hi = the top 16 bits of a and b (ONE v_perm_b32), lo = the top 16 bits of
+// x - hi (two v_and, two v_sub, one v_perm_b32) instead of two v_cvt_pk_bf16_f32 + shift + mask + two v_sub.  Priced by
+// profiles/ubench/coissue.hip: a v_cvt_pk costs three plain VALU operations next to MFMAs (3.3 ns vs 1.1 ns per wave instruction and
+// SIMD), so a pair costs 6.6 ns instead of 11.0 -- the two splits (P' and G') were 88 of the ~124 ns of vector work per (16 keys x 32
+// rows).  x - hi is in [0, 2^-7 |x|) and keeps 8 bits: hi + lo carries 15 - 16 significant bits, truncated toward zero (the rounded
+// split carried 17).  Measured (profiles/r06_attn_ab.txt, float64 reference): dK / dV errors 7.4e-6 / 8.6e-6 -> 1.6e-5 / 2.0e-5 of
+// scale at mild logits, 2.3e-5 / 1.2e-5 -> 2.8e-5 / 1.6e-5 at sharp ones, backward launch 0.372 -> 0.357 ms.  A3D_BF16_SPLIT_RNE
+// builds the rounded split; A3D_BF16_SPLIT_TRUNC1 truncates hi only (lo rounded: 8.8 ns per pair, 1.0e-5 / 1.6e-5, 0.367 ms).
+__device__ __forceinline__ void pk_bf16_2t(float a, float b, unsigned int& hi, unsigned int& lo) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  const unsigned int ua = __float_as_uint(a), ub = __float_as_uint(b);
+  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                       // (b & 0xFFFF0000) | (a >> 16)
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+#ifdef A3D_BF16_SPLIT_TRUNC1
+  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2_){ra, rb}, bf16x2_));
+#else
+  lo = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+#endif
+}
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float max16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
   const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], b[0], b[1]), m2 = max3f(b[2], b[3], c[0]);
@@ -74,11 +93,9 @@ __device__ __forceinline__ float max16(const f32x4& a, const f32x4& b, const f32
 // loads, and an uncounted op only ever makes a compiler-placed vmcnt(k) wait longer, never shorter -- returns are in order).
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
   const unsigned int dst = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(lds_void_t*)lds);
-  unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(g), "s"(dst)
-               : "memory");
+  // m0 is declared clobbered instead of saved and restored around the load (round 6: two SALU instructions less per piece; nothing else
+  // in these kernels reads m0 -- gfx9 LDS instructions take no bound from it)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(dst) : "memory", "m0");
 }
 // rows tile [64 rows][32 halfs] (4 KB, tile_off swizzle): wave w brings rows w*16 .. w*16+15.  `row_halfs` = source row
 // length in halfs (32: hi | lo rows; 16: single rows duplicated into both halves of the tile row)

@@ -345,7 +345,7 @@ class DiffusionHead(nn.Module):
 
     # ---- inference, fused: 18 launches per network evaluation (csrc/denoise.hip)
     @torch.no_grad()
-    def build_fused(self, ctx, ctx_xyz, instr, kmask, time_sin, Ln):
+    def build_fused(self, ctx, ctx_xyz, instr, kmask, time_sin, Ln, with_persist=True):
         """Step-invariant state of the fused sampling path for one trajectory batch: the context K (fp16 hi | lo rows) / V (fp16
         hi / lo planes) of every cross-attention layer, the instruction tokens through traj_lang_attention's k | v projection, and
         the AdaLN modulation of every layer at every timestep (Linear(SiLU(sinusoidal(t))), layers.py:273-290).  Returns
@@ -384,7 +384,9 @@ class DiffusionHead(nn.Module):
         nws = O.L.load().a3d_dn_cross_ws_floats(B, H, st["nsplit"])
         st["ws"] = torch.empty((nws,), device=dev, dtype=torch.float32)
         st["ws_side"] = torch.empty((nws,), device=dev, dtype=torch.float32)      # rotation branch, concurrent
-        st["persist"] = self._build_persist(st, B, Ln, H, E, Sp, time_sin.shape[0], dev) if DN_PERSIST else None
+        # with_persist=False: the caller is about to replay a captured graph that owns its persistent-sampler state (tables, exchange
+        # buffers, synchronisation words) -- only the refreshed K / V / modulation tensors of this call are needed
+        st["persist"] = self._build_persist(st, B, Ln, H, E, Sp, time_sin.shape[0], dev) if (DN_PERSIST and with_persist) else None
         return st
 
     def _build_persist(self, st, B, Ln, H, E, Sp, T, dev):
@@ -720,7 +722,14 @@ class DiffusionPlanner(nn.Module):
             state, static = None, list(toks) + list(xyzs) + [instruction, cg, gg]
             tmask = trajectory_mask.bool()
         elif fused:
-            state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln)
+            # a replay of the captured loop addresses the state retained in self._graph: skip building a second set of persistent-
+            # sampler buffers (a ctypes table, a pageable host-to-device copy = a host sync, five allocations) that would be thrown away
+            gr_ = self._graph
+            reuse = (use_graph and not return_trace and gr_ is not None and gr_["key"][:3] == (B, Ln, tuple(steps)) and
+                     isinstance(gr_.get("state"), dict) and gr_["state"].get("persist") is not None)
+            state = head.build_fused(ctx, ctx_xyz, instr, kmask, self._time_tables["sin"], Ln, with_persist=not reuse)
+            if reuse:
+                state["persist"] = gr_["state"]["persist"]
             static = list(state["tensors"])
             if Ln > 16 and state.get("persist") is None:           # too many units for the CU count: the op-by-op path serves it
                 fused = False
@@ -760,6 +769,10 @@ class DiffusionPlanner(nn.Module):
 
         if use_graph and not return_trace:
             key = (B, Ln, tuple(steps), fused, tuple((tuple(t_.shape), t_.dtype) for t_ in static))
+            if self._graph is not None and self._graph["key"] != key and fused and state.get("persist") is self._graph["state"].get("persist"):
+                # the shapes changed after all (another context size): this call needs its own persistent-sampler state
+                state["persist"] = head._build_persist(state, B, Ln, head.num_attn_heads, E, state["Sp"], self.n_steps, dev) if DN_PERSIST else None
+                persist = fused and state.get("persist") is not None and all(a_ - b_ == 1 for a_, b_ in zip(steps, steps[1:]))
             if self._graph is None or self._graph["key"] != key:
                 static_in = traj.clone()
                 side = torch.cuda.Stream()

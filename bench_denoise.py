@@ -78,6 +78,10 @@ def _time(fn, iters):
 PMC_DN_CROSS_BYTES = (111215.5 * 2 + 1088.0) * 1024      # round 2 (superseded by the committed round-5 records read below)
 
 
+# committed counter records of the persistent sampler, by (B, horizon, context tokens)
+_PERSIST_PMC = {(64, 16, 3074): "r06_pmc_denoise_persist.json", (24, 50, 3074): "r06_pmc_denoise_persist_L50.json"}
+
+
 def _pmc_bytes(fname, key):
     """HBM bytes per launch of `key` from a committed counter record (profiles/pmc_json_cmd.sh), or None"""
     import json
@@ -203,9 +207,9 @@ def sampling_bench(a3d, dev, B=64, Ln=16, C=3, reps=5, graph=True):
     loop = {"bound": "hbm", "kernel": "sampling loop (a3d_dn_persist: one launch)" if "persistent" in str(getattr(m, "last_sampler_path", "")) else "sampling loop",
             "achieved": alg_step / step_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg_step / step_s / 1e9 / 8000.0,
             "algorithmic_bytes_per_step": alg_step, "stored_bytes_per_step": stored_step, "stored_frac": stored_step / step_s / 1e9 / 8000.0,
-            "traffic": (lambda v: None if v is None else v / 100.0)(_pmc_bytes("r05_pmc_denoise_persist.json", "dn_persist"))
-            if (B, Ln, S) == (64, 16, 3074) and "persistent" in str(getattr(m, "last_sampler_path", "")) else None,
-            "traffic_source": "profiles/r05_pmc_denoise_persist.json: dn_persist_kernel, one launch = 100 steps (FETCH_SIZE x2 + WRITE_SIZE) / 100",
+            "traffic": (lambda v: None if v is None else v / 100.0)(_pmc_bytes(_PERSIST_PMC.get((B, Ln, S), "none"), "dn_persist"))
+            if "persistent" in str(getattr(m, "last_sampler_path", "")) else None,
+            "traffic_source": "profiles/%s: dn_persist_kernel, one launch = 100 steps (FETCH_SIZE x2 + WRITE_SIZE) / 100" % _PERSIST_PMC.get((B, Ln, S), "(no counter record for this shape)"),
             "note": "whole denoise step incl. the per-sample chain (head, 8 layer remainders, tail) and the per-call context build "
                                      "amortised over 100 steps; the streaming itself is VALU / MFMA-issue bound (exp2, bf16 split, fp32 QK^T), see DESIGN 4"}
     return {
