@@ -60,11 +60,15 @@ constexpr int c3_lds_bytes(int halves, int nt) { return halves * 9 * 16 * nt * 6
 // COUT = 16 NT output channels per workgroup: blockIdx.y selects the block of COUT channels of the layer's `ctot` (64 -> 64 runs as
 // two 32-channel blocks: half the weights per workgroup = two workgroups per CU instead of one, which hides the per-step barrier /
 // LDS / global-load latencies a single wave per SIMD exposes: 105 -> see profiles/r04_conv3x3_probe.json)
-template <int HALVES, int NT, int D>
+// LIST (round 6, the token-sparse input gradient of the FPN's output convolution, a3d_conv3x3_dgrad_tiles): the workgroups walk the
+// ACTIVE tiles of `tlist` ((image << 16) | (tile row << 8) | tile column, tlist[-2] = their number) instead of every tile of the map,
+// and afterwards zero-fill the inactive ones (listed from the END of the same array, tlist[-1] = their number): a tile whose 10 x 34
+// halo holds no non-zero input pixel has an all-zero output.
+template <int HALVES, int NT, int D, bool LIST = false>
 __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 2 : 1)) void conv3x3_stream_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ in_scale,
     const float* __restrict__ in_shift, int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial, int nimg, int H,
-    int W, int ctot) {
+    int W, int ctot, const int* __restrict__ tlist = nullptr) {
   constexpr int CIN = 32 * HALVES, COUT = 16 * NT;
   const int co0 = blockIdx.y * COUT;
   static_assert(D % HALVES == 0, "the half of a step must be a compile-time function of its slot");
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 
   const int nwg = gridDim.x;
   const int lb = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int tiles_x = W / C3_TW, tiles_y = H / C3_TH, tpi = tiles_x * tiles_y;
-  const int ntiles = nimg * tpi;                                  // < 2^30: checked by the host
+  const int ntiles = LIST ? __builtin_amdgcn_readfirstlane(tlist[-2]) : nimg * tpi;      // < 2^30: checked by the host
   for (int i = t; i < HALVES * 9 * COUT * 4; i += 256) {
     const int seg = i & 3, r = i >> 2, co = r % COUT, tap = (r / COUT) % 9, h = r / (COUT * 9);
     *reinterpret_cast<uint4*>(&Ws[c3_woff((h * 9 + tap) * COUT + co, seg)]) =
@@ -104,11 +108,20 @@ __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 
   // one-time divisions: the first tile and the per-tile advance (grid size) in (image, tile row, tile column) digits
   const int dimg = nwg / tpi, dty = (nwg - dimg * tpi) / tiles_x, dtx = nwg - dimg * tpi - dty * tiles_x;
   C3Cursor cl;                                                    // the LOAD stream's tile (D steps ahead of the compute stream's)
-  cl.img = lb / tpi;
-  cl.ty = (lb - cl.img * tpi) / tiles_x;
-  cl.tx = lb - cl.img * tpi - cl.ty * tiles_x;
+  auto from_list = [&](int ordinal) {                             // LIST: this workgroup's ordinal-th active tile
+    const int e = __builtin_amdgcn_readfirstlane(tlist[lb + ordinal * nwg]);
+    return C3Cursor{e >> 16, (e >> 8) & 255, e & 255};
+  };
+  if (LIST) {
+    cl = my_tiles > 0 ? from_list(0) : C3Cursor{0, 0, 0};
+  } else {
+    cl.img = lb / tpi;
+    cl.ty = (lb - cl.img * tpi) / tiles_x;
+    cl.tx = lb - cl.img * tpi - cl.ty * tiles_x;
+  }
   C3Cursor cc = cl;                                               // the compute stream's tile
   int lk = 0, lhalf = 0;                                          // load stream: tile ordinal, half
+  int ck = 0;                                                     // compute stream: tile ordinal (LIST)
   auto load_next = [&](uint4 (&r)[C3_XL]) {
     const int y0 = cl.ty * C3_TH, x0 = cl.tx * C3_TW;
     // uniform 64-bit image base + 32-bit byte offset per lane (one image is at most 2^31 bytes: checked by the host)
@@ -121,7 +134,10 @@ __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 
     }
     if (++lhalf == HALVES) {
       lhalf = 0;
-      if (lk + 1 < my_tiles) { ++lk; cl.advance(dimg, dty, dtx, tiles_y, tiles_x); }   // past the end: the last tile again (never staged)
+      if (lk + 1 < my_tiles) {                                    // past the end: the last tile again (never staged)
+        ++lk;
+        if (LIST) cl = from_list(lk); else cl.advance(dimg, dty, dtx, tiles_y, tiles_x);
+      }
     }
   };
   // BatchNorm-apply + ReLU of the producer on 8 channels: packed fma, hardware bf16 rounding (v_cvt_pk_bf16_f32, RNE), ReLU as a
@@ -227,9 +243,22 @@ __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 
 #pragma unroll
             for (int q = 0; q < NT / 2; ++q) dst[q] = c3_u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
           }
-          cc.advance(dimg, dty, dtx, tiles_y, tiles_x);
+          if (LIST) { if (++ck < my_tiles) cc = from_list(ck); } else cc.advance(dimg, dty, dtx, tiles_y, tiles_x);
         }
       }
+    }
+  }
+  if (LIST) {
+    // zero-fill of the inactive tiles: 8 x 32 pixels x COUT channels = one pixel's COUT-channel slice per thread
+    const int nzero = __builtin_amdgcn_readfirstlane(tlist[-1]);
+    const int last = nimg * tpi - 1;                              // inactive tiles are listed downwards from the end of the array
+    for (int k = lb; k < nzero; k += nwg) {
+      const int e = __builtin_amdgcn_readfirstlane(tlist[last - k]);
+      const int img = e >> 16, oy = ((e >> 8) & 255) * C3_TH + (t >> 5), ox = (e & 255) * C3_TW + (t & 31);
+      char* ybase = reinterpret_cast<char*>(y + (size_t)img * H * W * ctot + co0);
+      c3_u32x4* dst = reinterpret_cast<c3_u32x4*>(ybase + (unsigned int)((oy * W + ox) * ctot) * 2u);
+#pragma unroll
+      for (int q = 0; q < COUT / 8; ++q) dst[q] = c3_u32x4{0u, 0u, 0u, 0u};
     }
   }
   if (!partial) return;
@@ -254,6 +283,58 @@ __global__ __launch_bounds__(256, (2 * c3_lds_bytes(HALVES, NT) <= 160 * 1024 ? 
     p[t] = sv;
     p[ctot + t] = q;
   }
+}
+
+// ---- token-sparse input gradient of the FPN's 3x3 output convolution (round 6) ----------------------------------------------------------
+// The gradient map of that convolution's output is non-zero only on the pixels the pyramid levels gathered (act3d.py:244-260), so its
+// input gradient is non-zero only on their 3x3 neighbourhoods.  mark: every gathered token marks the (at most four) 8 x 32 output tiles
+// its neighbourhood touches; compact: the marks become the list the LIST variant of the stream kernel walks.
+__global__ __launch_bounds__(256) void c3_mark_tiles_kernel(const long long* __restrict__ idx, long long ntok, int k, int ncam, int H,
+                                                          int W, unsigned char* __restrict__ mask) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntok) return;
+  const long long p = idx[i];
+  const int b = (int)(i / k);
+  const int cam = (int)(p / ((long long)H * W));
+  const int rem = (int)(p - (long long)cam * H * W);
+  const int h = rem / W, w0 = rem - h * W;
+  const int tiles_x = W / C3_TW, tiles_y = H / C3_TH;
+  const int img = b * ncam + cam;
+  const int ty0 = max(h - 1, 0) / C3_TH, ty1 = min(h + 1, H - 1) / C3_TH, tx0 = max(w0 - 1, 0) / C3_TW, tx1 = min(w0 + 1, W - 1) / C3_TW;
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) mask[((size_t)img * tiles_y + ty) * tiles_x + tx] = 1;       // (racing stores of the same value)
+}
+
+// one workgroup of 1024 threads: active tiles in ascending order from the front of tlist, inactive ones from the back; the two
+// counts in front of it (tlist[-2], tlist[-1]).  Deterministic (an exclusive scan, no atomics).
+__global__ __launch_bounds__(1024) void c3_compact_tiles_kernel(const unsigned char* __restrict__ mask, int ntiles, int tiles_x,
+                                                              int tiles_y, int* __restrict__ tlist) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tpi = tiles_x * tiles_y;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int id = base + t;
+    const int on = (id < ntiles && mask[id]) ? 1 : 0;
+    const unsigned long long bal = __ballot(on);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = carry;
+    for (int w2 = 0; w2 < wave; ++w2) off += wsum[w2];
+    if (id < ntiles) {
+      const int img = id / tpi, r = id - img * tpi, ty = r / tiles_x, tx = r - ty * tiles_x;
+      const int e = (img << 16) | (ty << 8) | tx;
+      const int pos_on = off + before;                            // active tiles before this one
+      if (on) tlist[pos_on] = e; else tlist[ntiles - 1 - (id - pos_on)] = e;
+    }
+    __syncthreads();
+    if (t == 0) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += wsum[w2]; carry += tot; }
+    __syncthreads();
+  }
+  if (t == 0) { tlist[-2] = carry; tlist[-1] = ntiles - carry; }
 }
 
 }  // namespace a3d
@@ -311,4 +392,52 @@ extern "C" int a3d_conv3x3_bn_fwd(const void* x, const void* w, const float* in_
   else A3D_C3S(2, 4, 2);
 #undef A3D_C3S
   return check_launch("a3d_conv3x3_bn_fwd");
+}
+
+// ---- token-sparse input gradient (see the kernels above).  ws: ints = a3d_conv3x3_dgrad_tiles_ws_ints: [2 counts | tile list];
+// mask: one byte per 8 x 32 tile of the map, zeroed by the caller before the first a3d_conv3x3_mark_tiles of a backward pass.
+extern "C" size_t a3d_conv3x3_tile_count(size_t nimg, int H, int W) {
+  return (H > 0 && W > 0 && (H % C3_TH) == 0 && (W % C3_TW) == 0) ? nimg * (size_t)(H / C3_TH) * (size_t)(W / C3_TW) : 0;
+}
+extern "C" size_t a3d_conv3x3_dgrad_tiles_ws_ints(size_t nimg, int H, int W) { return a3d_conv3x3_tile_count(nimg, H, W) + 4; }
+
+extern "C" int a3d_conv3x3_mark_tiles(const long long* idx, int B, int k, int ncam, int H, int W, unsigned char* mask, void* stream) {
+  if (!idx || !mask || B <= 0 || k <= 0 || ncam <= 0 || a3d_conv3x3_tile_count(1, H, W) == 0 || H / C3_TH > 255 || W / C3_TW > 255) {
+    set_error("a3d_conv3x3_mark_tiles: bad argument (B=%d k=%d ncam=%d H=%d W=%d; H a multiple of 8, W of 32)", B, k, ncam, H, W);
+    return A3D_ERR_ARG;
+  }
+  const long long ntok = (long long)B * k;
+  hipLaunchKernelGGL(c3_mark_tiles_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, ntok, k, ncam, H, W, mask);
+  return check_launch("a3d_conv3x3_mark_tiles");
+}
+
+// dx = the 3x3 (stride 1, padding 1) convolution of dy with wt on the tiles marked in `mask`, zeros elsewhere.  dy, dx bf16 NHWC
+// [nimg][H][W][64]; wt bf16 [64 ci][3][3][64 co] = the forward weight flipped and transposed, wt[ci][kh][kw][co] = w[co][ci][2-kh][2-kw].
+extern "C" int a3d_conv3x3_dgrad_tiles(const void* dy, const void* wt, const unsigned char* mask, int* ws, void* dx, size_t nimg, int H,
+                                       int W, void* stream) {
+  if (!dy || !wt || !mask || !ws || !dx || nimg == 0 || nimg >= 32768 || !c3_serves(64, 64, H, W) || H / C3_TH > 255 || W / C3_TW > 255 ||
+      (size_t)H * (size_t)W * 128 >= ((size_t)1 << 31) || ((((uintptr_t)dy | (uintptr_t)wt | (uintptr_t)dx) & 15) != 0)) {
+    set_error("a3d_conv3x3_dgrad_tiles: bad argument (images=%zu H=%d W=%d; 64 channels, H a multiple of 8, W of 32, < 32768 images)", nimg, H, W);
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int ntiles = (int)a3d_conv3x3_tile_count(nimg, H, W);
+  int* tlist = ws + 2;
+  hipLaunchKernelGGL(c3_compact_tiles_kernel, dim3(1), dim3(1024), 0, s, mask, ntiles, W / C3_TW, H / C3_TH, tlist);
+  int rc = check_launch("a3d_conv3x3_dgrad_tiles(compact)");
+  if (rc) return rc;
+  const int slabs = c3_slabs(nimg, H, W, 64, 64);
+  const size_t lds = c3_lds(64, 64);
+  const int cb = c3_cblock(64, 64);
+  static bool once = false;
+  if (cb == 32) {
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; }
+    hipLaunchKernelGGL((conv3x3_stream_kernel<2, 2, 2, true>), dim3(slabs, 2), dim3(256), lds, s, (const unsigned short*)dy, (const unsigned short*)wt,
+                       (const float*)nullptr, (const float*)nullptr, 0, (unsigned short*)dx, (float*)nullptr, (int)nimg, H, W, 64, (const int*)tlist);
+  } else {
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv3x3_stream_kernel<2, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; }
+    hipLaunchKernelGGL((conv3x3_stream_kernel<2, 4, 2, true>), dim3(slabs, 1), dim3(256), lds, s, (const unsigned short*)dy, (const unsigned short*)wt,
+                       (const float*)nullptr, (const float*)nullptr, 0, (unsigned short*)dx, (float*)nullptr, (int)nimg, H, W, 64, (const int*)tlist);
+  }
+  return check_launch("a3d_conv3x3_dgrad_tiles");
 }

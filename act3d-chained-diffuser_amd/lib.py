@@ -62,6 +62,10 @@ SIGNATURES = {
     "a3d_proj_rope_split16": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _p, _p, _i, _p, _f, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "a3d_attn16_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _p]),
     "a3d_attn16_fwd_rows": (_i, [_p] * 7 + [_i] * 7 + [_p, C.c_uint, _f, _i, _p]),
+    "a3d_conv3x3_tile_count": (_z, [_z, _i, _i]),
+    "a3d_conv3x3_dgrad_tiles_ws_ints": (_z, [_z, _i, _i]),
+    "a3d_conv3x3_mark_tiles": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "a3d_conv3x3_dgrad_tiles": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_conv3x3_wgrad_tokens_ws_floats": (_z, []),
     "a3d_conv3x3_wgrad_tokens": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "a3d_attn16_bwd_pack_bytes": (_z, [_i, _i, _i]),

@@ -237,6 +237,11 @@ class _LayerConv3x3Fn(torch.autograd.Function):
         ctx.save_for_backward(x, w16)
         ctx.cc = cc
         cc.x, cc.dw, cc.dense = x, None, False
+        cc.mask, cc.ntok = None, 0
+        if O.SPARSE_FPN_DGRAD and ctx.needs_input_grad[0] and O.L.load().a3d_conv3x3_tile_count(x.shape[0], x.shape[2], x.shape[3]) > 0 \
+                and x.shape[2] // 8 <= 255 and x.shape[3] // 32 <= 255:
+            # tile marks of this step's backward (a fill KERNEL: captured memsets replay wrong on this stack)
+            cc.mask = torch.zeros((O.L.load().a3d_conv3x3_tile_count(x.shape[0], x.shape[2], x.shape[3]),), device=x.device, dtype=torch.uint8)
         return y
 
     @staticmethod
@@ -246,13 +251,26 @@ class _LayerConv3x3Fn(torch.autograd.Function):
         sparse = cc.dw is not None and not cc.dense
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
+        # token-sparse input gradient: every consumer of the map was a gather that marked its tiles, and together they hold at most
+        # SPARSE_FPN_DGRAD_MAX of the map's pixels (a static bound: the marked-tile count lives on the device)
+        N, _, H, W = x.shape
+        sparse_x = (need_x and sparse and cc.mask is not None and 0 < cc.ntok <= O.SPARSE_FPN_DGRAD_MAX * N * H * W and dy.dtype == torch.bfloat16)
+        if sparse_x:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            wt = w16.flip(2, 3).permute(1, 2, 3, 0).contiguous()            # wt[ci][kh][kw][co] = w[co][ci][2 - kh][2 - kw]
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            ws = torch.empty((O.L.load().a3d_conv3x3_dgrad_tiles_ws_ints(N, H, W),), device=x.device, dtype=torch.int32)
+            O.L.call("a3d_conv3x3_dgrad_tiles", dy.data_ptr(), wt.data_ptr(), cc.mask.data_ptr(), ws.data_ptr(), dx.data_ptr(), N, H, W, O.L.stream())
+            need_x = False
         if need_x or (need_w and not sparse):
             dy = dy.contiguous(memory_format=torch.channels_last)
-            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                            (need_x, need_w and not sparse, False))
+            dxl, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                             (need_x, need_w and not sparse, False))
+            if need_x:
+                dx = dxl
         if need_w and sparse:
             dw = cc.dw.permute(2, 3, 0, 1).contiguous()        # [kh][kw][co][ci] -> the weight's [co][ci][kh][kw]
-        cc.dw = None
+        cc.dw, cc.mask = None, None
         return dx, (None if dw is None else dw.float()), None
 
 

@@ -1151,6 +1151,10 @@ class GradAccum:
 # through BuildContextFn's gathers gets its convolution's weight gradient from those gathers' own backward inputs (indices + context
 # gradient rows) instead of a dense library kernel over the zero-filled, scattered map.  A3D_FPN_SPARSE_WGRAD=0: dense (A/B).
 SPARSE_FPN_WGRAD = os.environ.get("A3D_FPN_SPARSE_WGRAD", "1") == "1"
+# the same convolution's INPUT gradient on the 8 x 32-pixel tiles the gathered tokens' neighbourhoods touch (csrc/conv3x3.hip LIST
+# variant) instead of the library's dense igemm_bwd; the library serves maps more than SPARSE_FPN_DGRAD_MAX of whose pixels were gathered
+SPARSE_FPN_DGRAD = os.environ.get("A3D_FPN_SPARSE_DGRAD", "1") == "1"
+SPARSE_FPN_DGRAD_MAX = float(os.environ.get("A3D_FPN_SPARSE_DGRAD_MAX", "0.25"))
 
 
 class SparseConvCtx:
@@ -1159,10 +1163,14 @@ class SparseConvCtx:
     (camera, h, w)); dw: the weight gradient [3][3][64 co][64 ci] the gathers' backward passes have accumulated so far (None: none
     yet); dense: some consumer read the map densely (idx None) -- its gradient is not in dw, the convolution falls back to the
     library's dense weight gradient."""
-    __slots__ = ("x", "ncam", "dw", "dense")
+    __slots__ = ("x", "ncam", "dw", "dense", "mask", "ntok")
 
     def __init__(self, ncam):
         self.x, self.ncam, self.dw, self.dense = None, ncam, None, False
+        # mask: one byte per 8 x 32-pixel tile of the map, set by the gathers' backward passes for the tiles the 3x3 neighbourhoods of
+        # their tokens touch (a3d_conv3x3_mark_tiles) -- the convolution's input gradient is then computed on those tiles only
+        # (a3d_conv3x3_dgrad_tiles); ntok: tokens marked so far (the static coverage bound the convolution decides by)
+        self.mask, self.ntok = None, 0
 
 
 class TokenMap:
@@ -1255,6 +1263,9 @@ class BuildContextFn(torch.autograd.Function):
             ws = torch.empty((L.load().a3d_conv3x3_wgrad_tokens_ws_floats(),), device=dctx.device, dtype=F32)
             L.call("a3d_conv3x3_wgrad_tokens", cc.x.data_ptr(), idx.data_ptr(), dctx.data_ptr(), k + X, E, ws.data_ptr(),
                    cc.dw.data_ptr(), 1 if acc else 0, B, k, cc.ncam, cc.x.shape[2], cc.x.shape[3], L.stream())
+            if SPARSE_FPN_DGRAD and cc.mask is not None:
+                L.call("a3d_conv3x3_mark_tiles", idx.data_ptr(), B, k, cc.ncam, cc.x.shape[2], cc.x.shape[3], cc.mask.data_ptr(), L.stream())
+                cc.ntok += B * k
         if ctx.needs_input_grad[0]:
             dt = torch.bfloat16 if bf else F32
             if accum is not None and accum.buf is None and accum.pending == 1:

@@ -253,6 +253,20 @@ int a3d_build_context_bwd_bf16(const float* dctx, const long long* idx, void* df
 size_t a3d_conv3x3_wgrad_tokens_ws_floats(void);
 int a3d_conv3x3_wgrad_tokens(const void* X, const long long* idx, const float* G, int g_rows, int E, float* ws, float* dW,
                              int accumulate, int B, int k, int ncam, int H, int W, void* stream);
+/* Token-sparse INPUT gradient of the same convolution (the library's dense igemm_bwd over a gradient map that is non-zero on 6 - 12 %
+ * of its pixels: 0.65 ms per step at the bench shape).  The output gradient dy (bf16 NHWC [B ncam][H][W][64], scattered into by
+ * a3d_build_context_bwd_bf16) is non-zero only on gathered pixels, so dx is non-zero only on their 3x3 neighbourhoods:
+ * a3d_conv3x3_mark_tiles marks, per gathered token, the 8 x 32-pixel output tiles its neighbourhood touches (mask: one byte per tile,
+ * a3d_conv3x3_tile_count(B ncam, H, W) bytes, zeroed by the caller before the first gather of a backward pass marks it);
+ * a3d_conv3x3_dgrad_tiles compacts the marks into a tile list and runs the implicit-GEMM stream kernel of a3d_conv3x3_bn_fwd over the
+ * marked tiles only, writing zeros to the others: dx = conv3x3(dy, wt), wt bf16 [64 ci][3][3][64 co] with
+ * wt[ci][kh][kw][co] = w[co][ci][2 - kh][2 - kw].  ws: a3d_conv3x3_dgrad_tiles_ws_ints(..) ints.  Replaces the input-gradient half of
+ * F.conv2d's autograd for that layer (torchvision FeaturePyramidNetwork.layer_blocks; csrc/conv3x3.hip). */
+size_t a3d_conv3x3_tile_count(size_t images, int H, int W);
+size_t a3d_conv3x3_dgrad_tiles_ws_ints(size_t images, int H, int W);
+int a3d_conv3x3_mark_tiles(const long long* idx, int B, int k, int ncam, int H, int W, unsigned char* mask, void* stream);
+int a3d_conv3x3_dgrad_tiles(const void* dy, const void* wt, const unsigned char* mask, int* ws, void* dx, size_t images, int H, int W,
+                            void* stream);
 /* out[c] += sum over b < B, s < k of src[b][s][c]  (src fp32 [B][S][ld], c < nout <= C <= 64; two launches, fixed summation
  * order; ws: a3d_colsum_rows_ws_floats(B, k, C) floats). */
 size_t a3d_colsum_rows_ws_floats(int B, int k, int C);

@@ -944,6 +944,57 @@ def test_fpn_output_convolution_token_sparse_weight_gradient(a3d, dev, B, ncam, 
     assert w2 <= 1e-2 * max(1.0, gd2["layer_blocks.0.0.weight"].abs().max().item()), w2      # the same library kernel on both sides (its bf16 result: one ulp)
 
 
+@pytest.mark.parametrize("B,ncam,H,W,k", [(2, 2, 32, 64, 90), (1, 3, 16, 32, 40), (3, 1, 64, 128, 300)])
+def test_conv3x3_token_sparse_input_gradient_vs_library(a3d, dev, B, ncam, H, W, k):
+    """a3d_conv3x3_mark_tiles + a3d_conv3x3_dgrad_tiles (the LIST variant of the 3x3 stream kernel over the 8 x 32-pixel tiles the
+    gathered tokens' neighbourhoods touch, zeros elsewhere) against the library's dense input gradient of the same bf16 convolution
+    (torch.ops.aten.convolution_backward) on a gradient map that is non-zero only on the gathered pixels: clustered tokens (whole
+    tiles stay unmarked), the image corners and borders included, one sample without any token in one camera."""
+    g = torch.Generator().manual_seed(B * 100 + k)
+    N = B * ncam
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    # clustered pixel sets: k tokens per sample around a few centres (plus the two extreme corners), over (camera, h, w)
+    npts = ncam * H * W
+    rows = []
+    for b in range(B):
+        cams = torch.randint(0, ncam if b else max(1, ncam - 1), (4,), generator=g)           # sample 0 leaves the last camera empty
+        cy, cx = torch.randint(0, H, (4,), generator=g), torch.randint(0, W, (4,), generator=g)
+        pts = {0, (int(cams[0]) * H + H - 1) * W + W - 1}
+        while len(pts) < k:
+            c = int(torch.randint(0, 4, (1,), generator=g))
+            y = int((cy[c] + torch.randint(-5, 6, (1,), generator=g)).clamp(0, H - 1))
+            x_ = int((cx[c] + torch.randint(-9, 10, (1,), generator=g)).clamp(0, W - 1))
+            pts.add((int(cams[c]) * H + y) * W + x_)
+        rows.append(torch.tensor(sorted(pts))[torch.randperm(k, generator=g)])
+    idx = torch.stack(rows).to(dev)
+    dy = torch.zeros(B, npts, 64, device=dev, dtype=torch.bfloat16)
+    dy.scatter_(1, idx[..., None].expand(B, k, 64), torch.randn(B, k, 64, generator=g).to(dev).to(torch.bfloat16))
+    dy4 = dy.view(B, ncam, H, W, 64).reshape(N, H, W, 64).permute(0, 3, 1, 2)                # NCHW view of NHWC storage
+    assert dy4.is_contiguous(memory_format=torch.channels_last)
+    x = torch.zeros(N, 64, H, W, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref, _, _ = torch.ops.aten.convolution_backward(dy4, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))
+    L = a3d.lib
+    lib = L.load()
+    nt = lib.a3d_conv3x3_tile_count(N, H, W)
+    assert nt == N * (H // 8) * (W // 32)
+    mask = torch.zeros(nt, device=dev, dtype=torch.uint8)
+    L.call("a3d_conv3x3_mark_tiles", idx.data_ptr(), B, k, ncam, H, W, mask.data_ptr(), L.stream())
+    ws = torch.empty(lib.a3d_conv3x3_dgrad_tiles_ws_ints(N, H, W), device=dev, dtype=torch.int32)
+    wt = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+    dx = torch.full((N, H, W, 64), float("nan"), device=dev, dtype=torch.bfloat16)            # every pixel must be written
+    L.call("a3d_conv3x3_dgrad_tiles", dy4.data_ptr(), wt.data_ptr(), mask.data_ptr(), ws.data_ptr(), dx.data_ptr(), N, H, W, L.stream())
+    torch.cuda.synchronize()
+    n_on, n_off = int(ws[0]), int(ws[1])
+    assert n_on + n_off == nt and n_on == int(mask.sum()) and 0 < n_on < nt
+    got = dx.permute(0, 3, 1, 2).float()
+    assert torch.isfinite(got).all()
+    report(f"conv3x3 token-sparse input gradient ({n_on} of {nt} tiles)", got, ref.float(), 1e-3, 1.6e-2)     # fp32 accumulation in different orders on the two sides, one bf16 rounding each: <= 2 ulp
+    # unmarked tiles hold exact zeros, and the reference is zero there too (nothing outside the marked tiles was skipped wrongly)
+    tile_on = mask.view(N, H // 8, W // 32).bool()
+    pix_on = tile_on.repeat_interleave(8, 1).repeat_interleave(32, 2)
+    assert (got.abs().amax(1)[~pix_on] == 0).all() and (ref.float().abs().amax(1)[~pix_on] == 0).all()
+
+
 @pytest.mark.parametrize("mode,B,Lq,S,E,H", [("kv", 2, 37, 131, 60, 4), ("qk", 2, 70, 70, 120, 8), ("none", 1, 5, 64, 60, 4),
                                              ("kv", 1, 1, 1, 60, 4)])
 def test_fused_projection_equals_unfused_operands(a3d, dev, mode, B, Lq, S, E, H):
