@@ -244,4 +244,10 @@ static inline int xcd_grid(int ngroups, int per_group) { return ((ngroups + 7) /
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// deep-layer 1x1 convolution GEMM (conv1x1_deep.hip), dispatched to by a3d_conv1x1_bn_fwd (conv1x1.hip)
+bool conv1x1_deep_serves(int K, int N);
+int conv1x1_deep_slabs(size_t M, int K, int N);
+int conv1x1_deep_launch(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y, float* partial,
+                        size_t M, int K, int N, hipStream_t s);
+
 }  // namespace a3d

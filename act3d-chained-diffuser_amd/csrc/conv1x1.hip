@@ -211,22 +211,39 @@ static int c1_slabs(size_t M, int K, int N) {
   return (int)std::min<size_t>(mtiles, (size_t)std::max(1, 256 * per_cu / ntiles));
 }
 
-extern "C" int a3d_conv1x1_streams(int K, int N) { return (K > 0 && N > 0 && c1_streams(K, N)) ? 1 : 0; }
+// the deep-layer GEMM (conv1x1_deep.hip) takes the shapes the resident-weight kernel refuses; A3D_CONV1X1_DEEP=0: those stay with the library (A/B)
+// Measured (round 6, 256 images): in isolation (profiles/r06_conv1x1_layers.json: the GEMM with its folded passes against MIOpen's convolution +
+// the BatchNorm passes it needs) it wins on five of the ten deep shapes and loses up to 16 % on the others -- its 64 x 64 wave tiles read
+// 0.5 KB of LDS per MFMA, the LDS port's rate, so it runs at 0.43 - 0.72 PFLOP/s where CK reaches 0.6 - 0.86 -- but in the captured
+// training step serving EVERY deep shape is fastest (profiles/r06_conv1x1_deep_ab.json: 21.01 ms per step against 21.24 with the five
+// isolated winners only and 21.34 with none).  A3D_CONV1X1_DEEP=0 / a3d_conv1x1_deep_mode(0): those shapes stay with the library (A/B).
+static int c1_deep_mode = getenv("A3D_CONV1X1_DEEP") ? atoi(getenv("A3D_CONV1X1_DEEP")) : 1;
+extern "C" int a3d_conv1x1_deep_mode(int mode) {                // sets the mode (0 / 1) and returns the previous one; mode < 0: query only
+  const int prev = c1_deep_mode;
+  if (mode >= 0) c1_deep_mode = mode > 0 ? 1 : 0;
+  return prev;
+}
+static bool c1_deep(int K, int N) { return c1_deep_mode != 0 && !c1_streams(K, N) && conv1x1_deep_serves(K, N); }
+
+extern "C" int a3d_conv1x1_streams(int K, int N) { return (K > 0 && N > 0 && (c1_streams(K, N) || c1_deep(K, N))) ? 1 : 0; }
 
 extern "C" int a3d_conv1x1_nslab(size_t M, int K, int N) {
-  if (M == 0 || N <= 0 || K <= 0 || !c1_streams(K, N)) return 0;
-  return c1_slabs(M, K, N);
+  if (M == 0 || N <= 0 || K <= 0) return 0;
+  if (c1_streams(K, N)) return c1_slabs(M, K, N);
+  return c1_deep(K, N) ? conv1x1_deep_slabs(M, K, N) : 0;
 }
 
 extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu,
                                   void* y, float* partial, size_t M, int K, int N, void* stream) {
-  if (!x || !w || !y || M == 0 || K <= 0 || N <= 0 || !c1_streams(K, N) || (in_scale && !in_shift) ||
+  if (!x || !w || !y || M == 0 || K <= 0 || N <= 0 || !(c1_streams(K, N) || c1_deep(K, N)) || (in_scale && !in_shift) ||
       ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
     set_error("a3d_conv1x1_bn_fwd: bad argument (M=%zu K=%d N=%d; served shapes: K in {64, 128, 256}, N in {64, 128, 256 j}, weight block "
-              "+ buffers within 96 KB of LDS -- a3d_conv1x1_streams; 16-byte aligned operands)", M, K, N);
+              "+ buffers within 96 KB of LDS (the resident-weight kernel), or K = 64 j in 128 .. 2048 and N = 128 j up to 2048 (the deep-layer "
+              "GEMM) -- a3d_conv1x1_streams; 16-byte aligned operands)", M, K, N);
     return A3D_ERR_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (!c1_streams(K, N)) return conv1x1_deep_launch(x, w, in_scale, in_shift, in_relu, y, partial, M, K, N, s);
   const unsigned short* xs = (const unsigned short*)x;
   const unsigned short* ws = (const unsigned short*)w;
   unsigned short* ys = (unsigned short*)y;

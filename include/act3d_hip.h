@@ -517,6 +517,10 @@ int a3d_conv1x1_streams(int K, int N);
 int a3d_conv1x1_nslab(size_t M, int K, int N);
 int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
                        float* partial, size_t M, int K, int N, void* stream);
+/* Whether the deep-layer GEMM of a3d_conv1x1_bn_fwd (K = 64 j in 128 .. 2048, N = 128 j up to 2048: the 1x1 convolutions of CLIP
+ * ModifiedResNet layers 2 - 4, model/utils/clip.py:28-43) takes its shapes: 1 yes (default; A3D_CONV1X1_DEEP), 0 they stay with the
+ * library.  Sets the mode and returns the previous one; mode < 0 only queries.  Affects a3d_conv1x1_streams / _nslab / _bn_fwd alike. */
+int a3d_conv1x1_deep_mode(int mode);
 
 /* 3x3 stride-1 padding-1 convolution of the frozen backbone's narrow layers (the stem's conv2 / conv3, layer1's conv2:
  * model/utils/clip.py:22-43, torch.nn.Conv2d(.., 3, padding=1, bias=False)) as a bf16 MFMA implicit GEMM with the BatchNorm work

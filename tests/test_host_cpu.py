@@ -596,10 +596,17 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, None, 1, dummy, None, 128, 64, 64, None) == -22     # scale without shift
     assert b"a3d_conv1x1_bn_fwd" in lib.a3d_last_error_string()
     # slab planning is pure host code and consistent with the tile table (64 / 128 / >= 256 output channels)
-    # the resident-weight streaming kernel serves K <= 256 with an LDS block <= 96 KB; other shapes are refused (MIOpen's)
+    # the resident-weight streaming kernel serves K <= 256 with an LDS block <= 96 KB; the deep-layer GEMM (round 6) K = 64 j in
+    # 128 .. 2048 with N = 128 j up to 2048; other shapes are refused (MIOpen's)
     assert lib.a3d_conv1x1_streams(64, 256) == 1 and lib.a3d_conv1x1_streams(256, 128) == 1 and lib.a3d_conv1x1_streams(128, 512) == 1
-    assert lib.a3d_conv1x1_streams(256, 512) == 0 and lib.a3d_conv1x1_streams(512, 128) == 0 and lib.a3d_conv1x1_streams(96, 64) == 0
-    assert lib.a3d_conv1x1_nslab(1 << 20, 512, 64) == 0 and lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 512, 128, None) == -22
+    # (a3d_conv1x1_deep_mode(0): the deep shapes stay with the library)
+    assert lib.a3d_conv1x1_streams(1024, 2048) == 1 and lib.a3d_conv1x1_deep_mode(0) == 1 and lib.a3d_conv1x1_streams(1024, 2048) == 0
+    assert lib.a3d_conv1x1_streams(64, 256) == 1 and lib.a3d_conv1x1_deep_mode(1) == 0 and lib.a3d_conv1x1_deep_mode(-1) == 1
+    assert lib.a3d_conv1x1_streams(256, 512) == 1 and lib.a3d_conv1x1_streams(512, 128) == 1 and lib.a3d_conv1x1_streams(2048, 512) == 1
+    assert lib.a3d_conv1x1_streams(96, 64) == 0 and lib.a3d_conv1x1_streams(512, 64) == 0 and lib.a3d_conv1x1_streams(4096, 128) == 0
+    assert lib.a3d_conv1x1_nslab(1 << 20, 512, 64) == 0 and lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 512, 64, None) == -22
+    assert lib.a3d_conv1x1_nslab(1 << 16, 256, 1024) == 64 and lib.a3d_conv1x1_nslab(1 << 14, 2048, 512) == 128      # 512 resident workgroups / N blocks
+    assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, dummy, 1, dummy, None, 128, 2048, 512, None) == -22           # folded apply: K <= 1024
     assert lib.a3d_conv1x1_nslab(1 << 20, 64, 256) == 512 and lib.a3d_conv1x1_nslab(1 << 18, 128, 512) == 256 and lib.a3d_conv1x1_nslab(100, 64, 64) == 1
     assert lib.a3d_dropout(dummy, dummy, 16, dummy, 8, 1.5, None) == -22                             # p outside [0, 1)
     # the 3x3 implicit GEMM serves the narrow layers only (weights resident in LDS), on maps of 8 j x 32 k pixels

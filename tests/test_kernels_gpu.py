@@ -1180,7 +1180,10 @@ def test_option_head_kernels(a3d, dev):
                                        # every (waves along N, K steps) instance, workgroups with fewer steps than the prefetch depth
                                        # and with many tiles, ragged last tiles
                                        (5000, 64, 64, True), (3000, 256, 128, True), (70001, 128, 512, False), (100000, 64, 256, True),
-                                       (400003, 64, 256, False), (150000, 128, 128, True), (9000, 64, 128, False), (33000, 128, 64, True)])
+                                       (400003, 64, 256, False), (150000, 128, 128, True), (9000, 64, 128, False), (33000, 128, 64, True),
+                                       # the deep-layer GEMM (conv1x1_deep.hip): every backbone shape class, ragged M, one / many tiles per workgroup
+                                       (16384, 512, 2048, False), (16384, 2048, 512, False), (65536, 1024, 256, False), (65536, 256, 1024, True),
+                                       (70001, 512, 128, True), (300, 1024, 2048, False), (40000, 512, 1024, True), (130, 128, 128, True)])
 def test_conv1x1_gemm_with_folded_batchnorm(a3d, dev, M, K, N, pro):
     """a3d_conv1x1_bn_fwd: y = bf16(f(x) w^T) with f = the producer's BatchNorm-apply + ReLU (rounded to bf16 as the unfused
     path materialises it), fp32 accumulation, and the per-slab (sum, sum of squares) of the rounded outputs."""
