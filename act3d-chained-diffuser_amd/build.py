@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG_DIR, _OUT)
 if _OUT != "libact3d_hip.so":
     OBJ_DIR = os.path.join(CSRC, "obj_" + _OUT[len("libact3d_hip_"):-3])
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
-SOURCES = ["api.hip", "linear.hip", "linear_split.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "attention16.hip", "attention8.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip", "denoise.hip", "single_query.hip", "single_query_wave.hip", "query_stream.hip", "data.hip", "conv1x1.hip", "conv1x1_deep.hip", "conv3x3.hip", "fpn_sparse.hip"]
+SOURCES = ["api.hip", "linear.hip", "linear_split.hip", "rope.hip", "attention.hip", "attention_bwd.hip", "attention16.hip", "attention8.hip", "scene.hip", "heads.hip", "diffusion.hip", "vision.hip", "dropout.hip", "denoise.hip", "single_query.hip", "single_query_wave.hip", "query_stream.hip", "data.hip", "conv1x1.hip", "conv1x1_deep.hip", "conv3x3.hip", "fpn_sparse.hip", "stem.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # The attention kernels never produce NaNs on their own (masked rows are handled explicitly, -inf only enters exp2):
 # without IEEE-mode sNaN quieting hipcc drops the canonicalising v_max_f32 x, x it otherwise puts in front of every fmaxf

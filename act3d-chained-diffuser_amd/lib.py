@@ -145,6 +145,8 @@ SIGNATURES = {
     "a3d_conv1x1_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _p]),
     "a3d_conv3x3_serves": (_i, [_i, _i, _i, _i]),
     "a3d_conv1x1_deep_mode": (_i, [_i]),
+    "a3d_stem_conv_nslab": (_i, [_z, _i, _i]),
+    "a3d_stem_conv_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "a3d_conv3x3_nslab": (_i, [_z, _i, _i, _i, _i]),
     "a3d_conv3x3_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "a3d_bn_stats": (_i, [_p, _p, _z, _i, _i, _p]),

@@ -507,6 +507,34 @@ def conv3x3_bn(x, conv, in_scale=None, in_relu=False, want_stats=True):
     return y, partial
 
 
+FUSED_STEM = os.environ.get("A3D_FUSED_STEM", "1") == "1"
+
+
+def stem_serves(x, conv, normalize):
+    """conv1 of the CLIP stem on the raw fp32 images x with ClipNormalize in front is one a3d_stem_conv_bn_fwd serves"""
+    return bool(FUSED_STEM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous() and
+                isinstance(normalize, ClipNormalize) and isinstance(conv, nn.Conv2d) and conv.in_channels == 3 and conv.out_channels == 32 and
+                conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.bias is None and
+                conv.weight.dtype == torch.bfloat16 and O.L.load().a3d_stem_conv_nslab(x.shape[0], x.shape[2], x.shape[3]) > 0)
+
+
+def stem_conv_bn(x, conv, normalize, want_stats=True):
+    """CLIP normalisation + the stem's strided conv1 + the partial statistics of its output in one launch (csrc/stem.hip): the
+    normalised bf16 image is never written, the 268 MB output never re-read for its BatchNorm.  Returns (y, partial or None)."""
+    N, _, H, W = x.shape
+    w2 = conv.weight.reshape(32, 27)                 # [co][ci][kh][kw] whatever the memory format of the 4-d weight
+    if not w2.is_contiguous():
+        w2 = conv.weight.contiguous().reshape(32, 27)
+    y = torch.empty((N, 32, H // 2, W // 2), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    partial = None
+    if want_stats:
+        partial = torch.empty((O.L.load().a3d_stem_conv_nslab(N, H, W), 2, 32), device=x.device, dtype=torch.float32)
+    O.L.call("a3d_stem_conv_bn_fwd", x.data_ptr(), normalize.mean.reshape(-1).contiguous().data_ptr(),
+             normalize.std.reshape(-1).contiguous().data_ptr(), w2.data_ptr(), y.data_ptr(), None if partial is None else partial.data_ptr(),
+             N, H, W, O.L.stream())
+    return y, partial
+
+
 def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None, residual_scale=None):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
     bf16 channels_last activation (vision.hip).  Three launches: stats (skipped when the producer left `partial` sums),
@@ -544,7 +572,7 @@ def _pool2_ok(m, t):
     return isinstance(m, nn.AvgPool2d) and m.kernel_size in (2, (2, 2)) and t.shape[-1] % 2 == 0 and t.shape[-2] % 2 == 0
 
 
-def fused_frozen_backbone_forward(bb, x):
+def fused_frozen_backbone_forward(bb, x, stem=None):
     """SyntheticCLIPResNet50.forward with MIOpen bf16 NHWC convolutions and the fused BatchNorm of vision.hip.
     Same dataflow as the module's own forward (CLIP ModifiedResNet, model/utils/clip.py:28-43); every AvgPool2d(2) is
     folded into the BatchNorm-apply kernel that produces its input (the block output also feeds the next block's
@@ -560,8 +588,10 @@ def fused_frozen_backbone_forward(bb, x):
             return conv3x3_bn(t, m, in_scale=bn_scale_shift(t, bn_in, p_in), in_relu=True, want_stats=want_stats)
         return conv(m, bn_act(t, bn_in, partial=p_in)), None
 
-    c1 = conv(bb.conv1, x)
-    c2, p2 = conv3(bb.conv2, c1, bb.bn1, None, bb.bn2.training)
+    # stem: (raw output of conv1, partial statistics) from a3d_stem_conv_bn_fwd (normalisation + convolution + statistics in one
+    # launch, stem_conv_bn), else the library's convolution of the normalised bf16 image x
+    c1, p1 = stem if stem is not None else (conv(bb.conv1, x), None)
+    c2, p2 = conv3(bb.conv2, c1, bb.bn1, p1, bb.bn2.training)
     c3, p3 = conv3(bb.conv3, c2, bb.bn2, p2, bb.bn3.training)
     if _pool2_ok(bb.avgpool, c3):
         x0, x = bn_act(c3, bb.bn3, pool=True, partial=p3)
@@ -675,8 +705,11 @@ def run_frozen_backbone(backbone, x, dtype, keep_dtype=False, normalize=None):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         backbone._conv_dtype = dtype
     if fused:
-        xb = normalize_to_nhwc_bf16(x, normalize) if normalize is not None else x.to(dtype).contiguous(memory_format=torch.channels_last)
-        feats = fused_frozen_backbone_forward(backbone, xb)
+        if normalize is not None and stem_serves(x, backbone.conv1, normalize):
+            feats = fused_frozen_backbone_forward(backbone, None, stem=stem_conv_bn(x, backbone.conv1, normalize, want_stats=backbone.bn1.training))
+        else:
+            xb = normalize_to_nhwc_bf16(x, normalize) if normalize is not None else x.to(dtype).contiguous(memory_format=torch.channels_last)
+            feats = fused_frozen_backbone_forward(backbone, xb)
     else:
         feats = backbone(x.to(dtype))
     return feats if keep_dtype else {k: v.float() for k, v in feats.items()}

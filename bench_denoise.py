@@ -151,14 +151,16 @@ def training_attention_roofline(a3d, B, Ln, S, dev):
     tb = _time(lambda: O.attn_core_bwd(Qs, Ks, Vt, None, Oo, dO, LSE, B, H, Ln, Lqp, S, Sp, ns, extra=extra), 20)
     fl = 14.0 * Ln * S * E * B
     traffic, src = None, None
-    try:          # HBM bytes of the same micro-benchmark from the committed counter passes (profiles/pmc_json_cmd.sh)
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r04_pmc_diffusion_attn_B{B}_L{Ln}.json")
-        with open(path) as fh:
-            k = json.load(fh)["kernels"]
-        traffic = k["attn_fwd"]["hbm_bytes"] + k["attn_bwd"]["hbm_bytes"]
-        src = f"profiles/r04_pmc_diffusion_attn_B{B}_L{Ln}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, forward + backward launch)"
-    except Exception:
-        pass
+    for rnd in ("r06", "r04"):          # HBM bytes of the same micro-benchmark from the newest committed counter passes (profiles/pmc_json_cmd.sh)
+        try:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_pmc_diffusion_attn_B{B}_L{Ln}.json")
+            with open(path) as fh:
+                k = json.load(fh)["kernels"]
+            traffic = k["attn_fwd"]["hbm_bytes"] + k["attn_bwd"]["hbm_bytes"]
+            src = f"profiles/{rnd}_pmc_diffusion_attn_B{B}_L{Ln}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, forward + backward launch)"
+            break
+        except Exception:
+            continue
     return {"bound": "mfma", "kernel": "attn_fwd + attn_bwd (trajectory -> context cross-attention)", "traffic_source": src,
             "achieved": fl / (tf + tb) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / (tf + tb) / 1e12 / 2500.0,
             "ms": (tf + tb) * 1e3, "ms_fwd": tf * 1e3, "ms_bwd": tb * 1e3, "traffic": traffic, "launches_per_step": 8,

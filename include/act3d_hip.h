@@ -521,6 +521,15 @@ int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, cons
  * ModifiedResNet layers 2 - 4, model/utils/clip.py:28-43) takes its shapes: 1 yes (default; A3D_CONV1X1_DEEP), 0 they stay with the
  * library.  Sets the mode and returns the previous one; mode < 0 only queries.  Affects a3d_conv1x1_streams / _nslab / _bn_fwd alike. */
 int a3d_conv1x1_deep_mode(int mode);
+/* The stem's first convolution (CLIP ModifiedResNet conv1, model/utils/clip.py:22-43: nn.Conv2d(3, 32, 3, stride=2, padding=1, bias=False))
+ * on the RAW images with CLIP's normalisation (act3d.py:365) in front of it and the statistics of the BatchNorm behind it folded in:
+ * y = bf16(conv(bf16((rgb - mean) / std), w)), zero padding of the NORMALISED map (what F.conv2d does to the map
+ * a3d_rgb_normalize_nhwc_bf16 writes).  rgb fp32 planar [N][3][H][W]; w bf16 [32][27] (the torch weight [co][ci][kh][kw]); y bf16 NHWC
+ * [N][H/2][W/2][32]; partial (or NULL): [a3d_stem_conv_nslab(..)][2][32] per-workgroup (sum, sum of squares) of the rounded outputs
+ * for a3d_bn_finalize.  H a multiple of 16, W of 64 (a3d_stem_conv_nslab returns 0 otherwise).  csrc/stem.hip. */
+int a3d_stem_conv_nslab(size_t images, int H, int W);
+int a3d_stem_conv_bn_fwd(const float* rgb, const float* mean, const float* stdv, const void* w, void* y, float* partial, size_t images,
+                         int H, int W, void* stream);
 
 /* 3x3 stride-1 padding-1 convolution of the frozen backbone's narrow layers (the stem's conv2 / conv3, layer1's conv2:
  * model/utils/clip.py:22-43, torch.nn.Conv2d(.., 3, padding=1, bias=False)) as a bf16 MFMA implicit GEMM with the BatchNorm work

@@ -9,12 +9,15 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 GROUPS = {
-    "attn_fwd": ["attn_fwd_kernel", "attn_combine_kernel", "attn16_fwd_kernel", "attn16_combine_kernel"],
-    "attn_bwd": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel", "attn16_bwd_prep_kernel",
-                 "attn16_bwd_dq_kernel", "attn16_bwd_dkv_kernel"],
+    # (the split-bf16 A/B family has its own groups since round 6: bench.py --kernels-only times both families in one run)
+    "attn_fwd": ["attn16_fwd_kernel", "attn16_combine_kernel"],
+    "attn_bwd": ["attn16_bwd_prep_kernel", "attn16_bwd_dq_kernel", "attn16_bwd_dkv_kernel"],
+    "attn_fwd_bf16x3": ["attn_fwd_kernel", "attn_combine_kernel"],
+    "attn_bwd_bf16x3": ["attn_bwd_prep_bf16_kernel", "attn_bwd_dq_bf16_kernel", "attn_bwd_dkv_bf16_kernel"],
     "kv_proj_rope": ["proj_rope_split_kernel"],
     "sq_fwd": ["sq_fwd_kernel", "sqw_fwd_kernel", "sq_combine_kernel"],
     "sq_bwd": ["sq_bwd_kernel", "sqw_bwd_kernel"],
@@ -23,6 +26,8 @@ GROUPS = {
     "dn_persist": ["dn_persist_kernel"],
     "knn_topk": ["knn_dist_hist_kernel", "knn_select_sort_kernel"],
     "bn_stats": ["bn_stats_kernel"],
+    "attn8_fwd": ["attn8_fwd_kernel", "attn8_amax_kernel", "attn8_pack_kernel"],
+    "conv1x1_deep": ["conv1x1_deep_kernel"],
 }
 
 
@@ -31,7 +36,9 @@ def means(pmc_dir, name):
     for f in glob.glob(os.path.join(pmc_dir, name, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                k = row.get("Kernel_Name", "")
+                # by base name: template instances of one kernel (attn16_fwd_kernel<false, 2, 3, true> / <false, 2, 2, true>) are averaged
+                # together over their dispatches, not added up as if they were different kernels of one launch
+                k = re.split(r"[<(]", row.get("Kernel_Name", ""))[0].strip()
                 agg[(k, row["Counter_Name"])][0] += 1
                 agg[(k, row["Counter_Name"])][1] += float(row["Counter_Value"])
     return {k: v[1] / v[0] for k, v in agg.items()}
@@ -48,14 +55,14 @@ def main():
         found = False
         for kn in kernels:
             for (name, ctr), v in fetch.items():
-                if kn in name and ctr == "FETCH_SIZE":
+                if name.endswith(kn) and ctr == "FETCH_SIZE":
                     fb += v * 1024 * 2
                     found = True
             for (name, ctr), v in write.items():
-                if kn in name and ctr == "WRITE_SIZE":
+                if name.endswith(kn) and ctr == "WRITE_SIZE":
                     wb += v * 1024
             for (name, ctr), v in derived.items():
-                if kn in name and ctr in ("MfmaUtil", "VALUBusy"):
+                if name.endswith(kn) and ctr in ("MfmaUtil", "VALUBusy"):
                     util.setdefault(kn, {})[ctr] = round(v, 1)
         if found:
             out["kernels"][key] = {"hbm_read_bytes": fb, "hbm_write_bytes": wb, "hbm_bytes": fb + wb, "pmc": util}

@@ -18,6 +18,17 @@ for f in ("r06_pmc_B64", "r06_pmc_denoise_persist", "r06_pmc_denoise_persist_L50
         print(f, "ERR", e)
 P
   ;;
+pmc5)
+  bash profiles/pmc_json_cmd.sh $O/r06_pmc_cfg5.json 16 python "$PWD/bench.py" --only-cfg5
+  python -c "
+import json; d=json.load(open('$O/r06_pmc_cfg5.json'))['kernels']; print({k: (round(v['hbm_bytes']/1e6,1), v.get('pmc')) for k,v in d.items()})"
+  ;;
+pmcdt)
+  # the trajectory -> context cross-attention of the diffusion training step (bench_denoise.py's roofline entries)
+  for shape in "22 50" "64 16"; do set -- $shape
+    bash profiles/pmc_json_cmd.sh $O/r06_pmc_diffusion_attn_B$1_L$2.json $1 python "$PWD/bench_denoise.py" --mode attn --batch $1 --horizon $2
+  done
+  ;;
 trace)
   ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace -d "$GRAFT_REPO_ROOT/$O/trace" -o kp -- python "$GRAFT_REPO_ROOT/bench.py" --skip-secondary --skip-cpu-baseline --no-graph --steps 10 --warmup 4 > "$GRAFT_REPO_ROOT/$O/trace.log" 2>&1 )
   DB=$(find $O/trace -name '*.db' | head -1); python profiles/summarize.py "$DB" > $O/r06_kernel_trace_B64.txt 2>&1; rm -rf $O/trace

@@ -1261,6 +1261,43 @@ def test_conv3x3_gemm_with_folded_batchnorm(a3d, dev, N, H, W, Cin, Cout, pro):
     assert p2 is None and torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (3, 32, 128), (1, 256, 256), (5, 16, 64)])
+@pytest.mark.parametrize("stats", [True, False])
+def test_stem_convolution_with_folded_normalisation_and_statistics(a3d, dev, N, H, W, stats):
+    """a3d_stem_conv_bn_fwd: y = bf16(conv_{3x3, stride 2, pad 1}(bf16((rgb - mean) / std), w)) on the raw fp32 images (clip.py:22-43
+    conv1 behind act3d.py:365's normalisation), zero padding of the NORMALISED map, fp32 accumulation, and the per-slab (sum, sum of
+    squares) of the rounded outputs; the reference is F.conv2d in float64 on the bf16-rounded normalised image and the bf16 weight."""
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    x = torch.rand(N, 3, H, W, generator=g)
+    norm = a3d.nn.ClipNormalize()
+    conv = torch.nn.Conv2d(3, 32, 3, stride=2, padding=1, bias=False)
+    conv.weight.data = torch.randn(32, 3, 3, 3, generator=g) / 27 ** 0.5
+    conv = conv.to(dev).to(torch.bfloat16)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)      # as run_frozen_backbone stores the frozen weights
+    xd, normd = x.to(dev), a3d.nn.ClipNormalize().to(dev)
+    assert a3d.nn.stem_serves(xd, conv, normd)
+    y, part = a3d.nn.stem_conv_bn(xd, conv, normd, want_stats=stats)
+    torch.cuda.synchronize()
+    assert y.shape == (N, 32, H // 2, W // 2) and y.is_contiguous(memory_format=torch.channels_last)
+    xn = ((x - norm.mean) / norm.std).to(torch.bfloat16).double()
+    ref = F.conv2d(xn, conv.weight.detach().cpu().double(), stride=2, padding=1)
+    got = y.float().cpu()
+    err = (got.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-3          # one bf16 rounding of an fp32-accumulated sum
+    assert torch.isfinite(got).all()
+    assert (err <= tol).all(), f"max err {err.max().item():.3e} at {torch.nonzero(err > tol)[:3].tolist()}"
+    print(f"[parity] stem conv {N}x{H}x{W}: max_abs_err={err.max().item():.3e} ref_absmax={ref.abs().max().item():.3e}")
+    if stats:
+        assert part.shape == (a3d.lib.load().a3d_stem_conv_nslab(N, H, W), 2, 32)
+        s_ = part.sum(0).cpu()
+        report("stem conv sum", s_[0], got.sum((0, 2, 3)), 1e-2, 1e-4)
+        report("stem conv sum of squares", s_[1], (got * got).sum((0, 2, 3)), 1e-2, 1e-4)
+    else:
+        assert part is None
+    # shapes it refuses fall back to the library path
+    assert not a3d.nn.stem_serves(torch.zeros(1, 3, 24, 64, device=dev), conv, normd)
+
+
 def test_backbone_with_fused_1x1_convolutions_matches_miopen_path(a3d, dev):
     """The backbone path with the layer-1 / layer-2 1x1 convolutions through a3d_conv1x1_bn_fwd (bn2-apply folded into conv3's
     operand load, output statistics from the GEMM epilogue; default) must be as close to the fp32 module as the all-MIOpen bf16
