@@ -114,6 +114,7 @@ class DiffusionHead(nn.Module):
         for p in self.backbone.parameters():
             p.requires_grad = False
         self.backbone_dtype = torch.float32
+        self.fpn_dtype = torch.float32           # set to torch.bfloat16 to run the FPN convolutions under autocast (as Act3D.fpn_dtype)
         self.feature_pyramid = FeaturePyramidNetwork([64, 256, 512, 1024, 2048], E)
         self.feature_map_pyramid = ['res3', 'res1', 'res1', 'res1'] if self.image_size == (256, 256) else ['res2', 'res1', 'res1', 'res1']
         self.downscaling_factor_pyramid = [8, 2, 2, 2] if self.image_size == (256, 256) else [4, 2, 2, 2]
@@ -171,15 +172,32 @@ class DiffusionHead(nn.Module):
         feat_scales_to_use = 1 (the res3 map at 1/8), a list [res3 @ 1/8, res1 @ 1/2, ...] otherwise."""
         B, ncam = rgb.shape[:2]
         x = rgb.flatten(0, 1)
+        low = self.fpn_dtype != torch.float32 and x.is_cuda
         with torch.no_grad():
-            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, normalize=self.normalize)
+            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=low, normalize=self.normalize)
+        return self.tokens_from_backbone_maps(feats, B, ncam)
+
+    def tokens_from_backbone_maps(self, feats, B, ncam):
+        """The FPN + token layout half of encode_images on the backbone's maps {res1..res5} of the B * ncam views (bf16 maps when
+        fpn_dtype is bf16, fp32 maps otherwise)."""
+        low = self.fpn_dtype != torch.float32 and next(iter(feats.values())).is_cuda
         names = self.feature_map_pyramid[:self.feat_scales]
-        pyr = self.feature_pyramid(feats, needed=sorted(set(names)))
+        E_ = self.curr_gripper_embed.weight.shape[1]
+        if low:
+            # round 6: the FPN in bf16 on the backbone's bf16 maps (channels padded to a multiple of 64 for MIOpen, the lateral biases
+            # folded into the top-down kernel) -- the fp32 path converted all five backbone maps to fp32 (277 MB for res1 alone at the
+            # script shape) and ran the FPN's convolutions, forward and backward, on MIOpen's fp32 kernels; only the map(s) the head
+            # reads are converted now
+            with torch.autocast("cuda", dtype=self.fpn_dtype):
+                pyr = self.feature_pyramid(feats, needed=sorted(set(names)), pad_to=(E_ + 63) // 64 * 64)
+        else:
+            pyr = self.feature_pyramid(feats, needed=sorted(set(names)))
         toks = {}
         for name in set(names):
             fm = pyr[name]
             n, E, h, w = fm.shape
-            toks[name] = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+            tk = fm.permute(0, 2, 3, 1).reshape(B, ncam * h * w, E)
+            toks[name] = tk[..., :E_].float() if low else tk
         out = [toks[n] for n in names]
         return out[0] if self.feat_scales == 1 else out
 
@@ -555,7 +573,9 @@ FUSED_DENOISE = os.environ.get("A3D_DN_FUSED", "1") == "1"
 # the sampling loop as ONE launch of the persistent two-role kernel (a3d_dn_persist); A3D_DN_PERSIST=0: one launch per phase
 # (head, per layer cross + rest, tail: 18 per step).  A3D_DN_PERSIST_SPLIT: key splits per (sample, layer) = items of the ready queue.
 DN_PERSIST = os.environ.get("A3D_DN_PERSIST", "1") == "1"
-DN_PERSIST_SPLIT = int(os.environ.get("A3D_DN_PERSIST_SPLIT", "8"))
+# (round 6: 6 -- 0.730 ms per denoise step at cfg-3 against 0.755 with 8 and 0.749 with 4, profiles/r06_sampler_split.json: fewer,
+# longer items amortise the ~9 us of per-item overhead until the sample role starts to wait for its last item)
+DN_PERSIST_SPLIT = int(os.environ.get("A3D_DN_PERSIST_SPLIT", "6"))
 # An aborted persistent launch (a co-resident workgroup never arrived) poisons the whole trajectory batch with NaN inside the launch
 # sequence itself (dn_persist_poison_kernel), so the failure is visible in the result without a host synchronisation, eager or
 # replayed.  A3D_DN_PERSIST_CHECK=1 additionally synchronises after every launch and raises on the abort word.

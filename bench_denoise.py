@@ -39,6 +39,8 @@ def build_planner(a3d, dev, train):
             torch.nn.init.normal_(mod.modulation[1].weight, std=0.02)
     m.train(train)
     m.prediction_head.backbone_dtype = torch.bfloat16
+    if os.environ.get("A3D_DIFFUSION_FPN_FP32", "0") != "1":       # A/B: the FPN in fp32 on fp32 copies of the backbone maps (rounds 1 - 5)
+        m.prediction_head.fpn_dtype = torch.bfloat16
     return m
 
 
