@@ -31,11 +31,16 @@ __device__ __forceinline__ int c1_woff(int row, int seg) { return row * 32 + ((s
 // (tile, K step) pairs of a workgroup form one flat sequence of steps whose activation chunks are fetched D steps ahead into
 // registers (~32 KB in flight per workgroup, unconditional clamped loads), one barrier per step, two LDS buffers.
 //   LDS: W KS x BN x 64 B (8 - 64 KB) | X 2 x BM x 64 B | the producer's BatchNorm scale / shift (K floats each)
-template <int WN, int KS>
+// EP (round 6, the FPN's lateral convolutions -- torchvision FeaturePyramidNetwork.inner_blocks + the top-down add): the epilogue adds
+// the convolution's bias (fp32, the first nbias channels) and the nearest-2x-upsampled coarser map top [images][H/2][W/2][N] bf16 to
+// the fp32 accumulators before the ONE rounding, y = x w^T + bias + up2(top): the lateral map is never written and re-read by a
+// top-down pass (a3d_upsample2_add_fwd: 1.2 GB of traffic for the 128 x 128 level of 256 images).
+struct C1Epilogue { const float* bias; int nbias; const unsigned short* top; int H, W; };
+template <int WN, int KS, bool EP = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                              int in_relu, unsigned short* __restrict__ y, float* __restrict__ partial,
-                                                             long long M, int N) {
+                                                             long long M, int N, C1Epilogue ep) {
   constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN, K = KS * 32;
   constexpr int XL = BM * 4 / 256;                                // 16-byte segments each thread stages per step: 1, 2 or 4
   constexpr int D = 8 / XL;                                       // steps in flight: 8 x 16 B per thread = 32 KB per workgroup
@@ -61,6 +66,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[a][r] = 0.f; ssq[a][r] = 0.f; }
+  float epb[16];                                                  // EP: the bias of the lane's 16 consecutive channels
+  if (EP) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = n0 + wn * 64 + g * 16 + j;
+      epb[j] = (ep.bias && c < ep.nbias) ? ep.bias[c] : 0.f;       // pad channels carry no bias
+    }
+  }
   const long long my_tiles = blockIdx.x < mtiles ? (mtiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const long long total = my_tiles * KS;                          // flat steps: s -> (tile blockIdx.x + (s / KS) gridDim.x, K step s % KS)
   auto load = [&](long long s, uint4 (&r)[XL]) {
@@ -121,6 +134,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
           wb[tn] = *reinterpret_cast<const s16x8*>(&Ws[ks * BN * 32 + c1_woff(wn * 64 + (li >> 2) * 16 + tn * 4 + (li & 3), g)]);
+        uint4 tv[4][2];                                           // EP: the top map's 16 channels under each of the lane's 4 rows
+        if (EP && ks == KS - 1 && ep.top) {                       // issued ahead of the MFMAs whose epilogue consumes them
+          const long long m0 = (blockIdx.x + (s / KS) * gridDim.x) * BM;
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) {
+            const long long m = m0 + wm * 64 + tm * 16 + li;
+            const unsigned int mm = (unsigned int)(m < M ? m : M - 1);
+            const unsigned int hq = mm / (unsigned int)ep.W, w_ = mm - hq * (unsigned int)ep.W;
+            const unsigned int n_ = hq / (unsigned int)ep.H, h_ = hq - n_ * (unsigned int)ep.H;
+            const size_t tr = ((size_t)n_ * (ep.H >> 1) + (h_ >> 1)) * (ep.W >> 1) + (w_ >> 1);
+            const uint4* src = reinterpret_cast<const uint4*>(ep.top + tr * N + n0 + wn * 64 + g * 16);
+            tv[tm][0] = src[0];
+            tv[tm][1] = src[1];
+          }
+        }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -142,8 +170,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
               // pair conversion is RNE with the same bits
 #pragma unroll
               for (int r2 = 0; r2 < 2; ++r2) {
-                const unsigned int u = pk_bf16(acc[tn][tm][2 * r2], acc[tn][tm][2 * r2 + 1]);
-                if (ok) {
+                float a0 = acc[tn][tm][2 * r2], a1 = acc[tn][tm][2 * r2 + 1];
+                if (EP) {                                        // word 2 tn + r2 of the lane's 16 channels = channels 4 tn + 2 r2, + 1
+                  a0 += epb[4 * tn + 2 * r2];
+                  a1 += epb[4 * tn + 2 * r2 + 1];
+                  if (ep.top) {
+                    const uint4 q = tv[tm][tn >> 1];
+                    const unsigned int tw = (tn & 1) ? (r2 ? q.w : q.z) : (r2 ? q.y : q.x);
+                    a0 += __uint_as_float(tw << 16);
+                    a1 += __uint_as_float(tw & 0xFFFF0000u);
+                  }
+                }
+                const unsigned int u = pk_bf16(a0, a1);
+                if (!EP && ok) {                                 // (the EP instances carry no statistics: partial is null there)
                   const float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xFFFF0000u);
                   ssum[tn][2 * r2] += v0;
                   ssq[tn][2 * r2] += v0 * v0;
@@ -164,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const unsigned s
       }
     }
   }
-  if (!partial) return;
+  if (EP || !partial) return;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -254,7 +293,7 @@ extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_
   do {                                                                                                                           \
     static bool once = false;                                                                                                    \
     if (!once) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<WNV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); once = true; } \
-    hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV>), grid, dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, N); \
+    hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV>), grid, dim3(256), lds, s, xs, ws, in_scale, in_shift, in_relu, ys, partial, (long long)M, N, C1Epilogue{nullptr, 0, nullptr, 0, 0}); \
   } while (0)
   const int wn = c1_wn(N), ks = K / 32;
   if (wn == 4 && ks == 2) A3D_C1S(4, 2);
@@ -268,4 +307,40 @@ extern "C" int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_
   else { set_error("a3d_conv1x1_bn_fwd: no streaming instance for K=%d N=%d", K, N); return A3D_ERR_ARG; }
 #undef A3D_C1S
   return check_launch("a3d_conv1x1_bn_fwd");
+}
+
+extern "C" int a3d_conv1x1_topdown_serves(int K, int N) { return (c1_streams(K, N) && N <= 128) ? 1 : 0; }
+
+extern "C" int a3d_conv1x1_topdown_fwd(const void* x, const void* w, const float* bias, int nbias, const void* top, void* y,
+                                       size_t images, int H, int W, int K, int N, void* stream) {
+  const size_t M = images * (size_t)H * (size_t)W;
+  if (!x || !w || !y || images == 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0 || !a3d_conv1x1_topdown_serves(K, N) || M > 0xFFFFFFFFull ||
+      (top && ((H & 1) || (W & 1))) || (bias && (nbias <= 0 || nbias > N)) ||
+      ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)top) & 15) != 0)) {
+    set_error("a3d_conv1x1_topdown_fwd: bad argument (images=%zu H=%d W=%d K=%d N=%d nbias=%d; served: K in {64, 128, 256}, N in {64, 128}, "
+              "H and W even with a top map, at most 2^32 rows, 0 < nbias <= N with a bias, 16-byte aligned operands)", images, H, W, K, N, nbias);
+    return A3D_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int slabs = c1_slabs(M, K, N);
+  const size_t lds = c1_stream_lds(K, N);
+  const dim3 grid(slabs, 1);
+  const C1Epilogue ep{bias, bias ? nbias : 0, (const unsigned short*)top, H, W};
+#define A3D_C1E(WNV, KSV)                                                                                                         \
+  do {                                                                                                                           \
+    static bool once = false;                                                                                                    \
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel<WNV, KSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); once = true; } \
+    hipLaunchKernelGGL((conv1x1_stream_kernel<WNV, KSV, true>), grid, dim3(256), lds, s, (const unsigned short*)x, (const unsigned short*)w, \
+                       (const float*)nullptr, (const float*)nullptr, 0, (unsigned short*)y, (float*)nullptr, (long long)M, N, ep);  \
+  } while (0)
+  const int wn = c1_wn(N), ks = K / 32;
+  if (wn == 2 && ks == 2) A3D_C1E(2, 2);
+  else if (wn == 2 && ks == 4) A3D_C1E(2, 4);
+  else if (wn == 2 && ks == 8) A3D_C1E(2, 8);
+  else if (wn == 1 && ks == 2) A3D_C1E(1, 2);
+  else if (wn == 1 && ks == 4) A3D_C1E(1, 4);
+  else if (wn == 1 && ks == 8) A3D_C1E(1, 8);
+  else { set_error("a3d_conv1x1_topdown_fwd: no streaming instance for K=%d N=%d", K, N); return A3D_ERR_ARG; }
+#undef A3D_C1E
+  return check_launch("a3d_conv1x1_topdown_fwd");
 }

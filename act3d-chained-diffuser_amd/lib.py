@@ -143,6 +143,8 @@ SIGNATURES = {
     "a3d_conv1x1_streams": (_i, [_i, _i]),
     "a3d_conv1x1_nslab": (_i, [_z, _i, _i]),
     "a3d_conv1x1_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _p]),
+    "a3d_conv1x1_topdown_serves": (_i, [_i, _i]),
+    "a3d_conv1x1_topdown_fwd": (_i, [_p, _p, _p, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "a3d_conv3x3_serves": (_i, [_i, _i, _i, _i]),
     "a3d_conv1x1_deep_mode": (_i, [_i]),
     "a3d_stem_conv_nslab": (_i, [_z, _i, _i]),

@@ -183,23 +183,77 @@ class _Upsample2AddFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        N, C, H, W = dy.shape
-        bias = ctx.bias
-        want_top = ctx.has_top and ctx.needs_input_grad[1]
-        want_bias = bias is not None and bias.requires_grad
-        dtop = None
-        if want_top or want_bias:
-            dy = dy.contiguous(memory_format=torch.channels_last)
-            if want_top:
-                dtop = torch.empty((N, C, H // 2, W // 2), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
-            ws = gb = None
-            if want_bias:
-                ws = torch.empty((O.L.load().a3d_upsample2_add_bwd_ws_floats(N, H, W, C),), device=dy.device, dtype=torch.float32)
-                gb = O.grad_buf(bias)
-            O.L.call("a3d_upsample2_add_bwd", dy.data_ptr(), None if dtop is None else dtop.data_ptr(),
-                     None if gb is None else gb.data_ptr(), 0 if gb is None else gb.numel(), None if ws is None else ws.data_ptr(),
-                     N, H, W, C, O.L.stream())
+        dy, dtop = _top_down_backward(dy, ctx.bias, ctx.has_top and ctx.needs_input_grad[1])
         return (dy if ctx.needs_input_grad[0] else None), dtop, None
+
+
+def _top_down_backward(dy, bias, want_top):
+    """backward of y = lat + bias + up2(top) from dy (N, C, H, W) bf16: d top = the 2x2 sums of dy, d bias accumulated straight into
+    bias.grad (the lateral branch's gradient is dy itself).  Returns (dy channels_last, d top or None)."""
+    N, C, H, W = dy.shape
+    want_bias = bias is not None and bias.requires_grad
+    dtop = None
+    if want_top or want_bias:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if want_top:
+            dtop = torch.empty((N, C, H // 2, W // 2), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
+        ws = gb = None
+        if want_bias:
+            ws = torch.empty((O.L.load().a3d_upsample2_add_bwd_ws_floats(N, H, W, C),), device=dy.device, dtype=torch.float32)
+            gb = O.grad_buf(bias)
+        O.L.call("a3d_upsample2_add_bwd", dy.data_ptr(), None if dtop is None else dtop.data_ptr(),
+                 None if gb is None else gb.data_ptr(), 0 if gb is None else gb.numel(), None if ws is None else ws.data_ptr(),
+                 N, H, W, C, O.L.stream())
+    return dy, dtop
+
+
+# The FPN's lateral 1x1 convolutions of the fine levels (K <= 256 input channels: res1 / res2 of the CLIP ResNet) as ONE launch with the
+# bias and the top-down add in the epilogue (a3d_conv1x1_topdown_fwd) instead of library convolution + a3d_upsample2_add_fwd: at the
+# bench shape 332 + 375 us -> one ~1.2 GB pass for the 128 x 128 level (profiles/r06_fpn_fwd_probe.json).  A3D_FPN_LATERAL=0: A/B.
+FUSED_FPN_LATERAL = os.environ.get("A3D_FPN_LATERAL", "1") not in ("0", "", "off")
+# The FPN's 3x3 output convolutions (64 padded channels) through the backbone's implicit-GEMM stream kernel (a3d_conv3x3_bn_fwd without
+# its BatchNorm folds) instead of the library: 911 -> 405 us for the 128 x 128 level of 256 images.  A3D_FPN_OUT3X3=0: A/B.
+FUSED_FPN_OUT3X3 = os.environ.get("A3D_FPN_OUT3X3", "1") not in ("0", "", "off")
+
+
+class _LateralTopDownFn(torch.autograd.Function):
+    """bf16(conv1x1(x, w) + bias + up2(top)) in one launch (torchvision FPN: inner_blocks[i] + the top-down add).  x bf16 channels_last
+    (the frozen backbone's map), w the fp32 weight (Co, K, 1, 1) (already zero-padded to the map width), bias the fp32 Parameter
+    (<= Co entries), top bf16 channels_last at half the resolution.  Backward: (d top, d bias) as _Upsample2AddFn, d w from the library's
+    weight-gradient kernel (the same one the unfused convolution's autograd runs), d x only when asked for."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, top):
+        N, K, H, W = x.shape
+        Co = w.shape[0]
+        w16 = w.detach().to(torch.bfloat16).reshape(Co, K).contiguous()
+        y = torch.empty((N, Co, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        O.L.call("a3d_conv1x1_topdown_fwd", x.data_ptr(), w16.data_ptr(), None if bias is None else bias.data_ptr(),
+                 0 if bias is None else bias.numel(), None if top is None else top.data_ptr(), y.data_ptr(), N, H, W, K, Co, O.L.stream())
+        ctx.save_for_backward(x, w16)
+        ctx.bias = bias
+        ctx.has_top = top is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy, dtop = _top_down_backward(dy, ctx.bias, ctx.has_top and ctx.needs_input_grad[3])
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        if need_x or need_w:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            w4 = w16.view(w16.shape[0], w16.shape[1], 1, 1)
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w4, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (need_x, need_w, False))
+        return dx, (None if dw is None else dw.float()), None, dtop
+
+
+def _fused_lateral_ok(x, Co, last):
+    cl = torch.channels_last
+    return bool(FUSED_FPN_LATERAL and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=cl)
+                and O.L.load().a3d_conv1x1_topdown_serves(x.shape[1], Co)
+                and (last is None or (last.dtype == torch.bfloat16 and last.is_contiguous(memory_format=cl) and last.shape[1] == Co
+                                      and x.shape[-2] == 2 * last.shape[-2] and x.shape[-1] == 2 * last.shape[-1])))
 
 
 def _fused_top_down_ok(lat, last, with_bias=False):
@@ -233,7 +287,16 @@ class _LayerConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, cc):
         w16 = w.to(x.dtype)
-        y = F.conv2d(x, w16, None, padding=1)
+        if (FUSED_FPN_OUT3X3 and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+                and O.L.load().a3d_conv3x3_serves(x.shape[1], w16.shape[0], x.shape[2], x.shape[3])):
+            # the backbone's implicit-GEMM stream kernel without its BatchNorm folds (a3d_conv3x3_bn_fwd; w [Cout][3][3][Cin] in memory)
+            w16 = w16.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((x.shape[0], w16.shape[0], x.shape[2], x.shape[3]), device=x.device, dtype=torch.bfloat16,
+                            memory_format=torch.channels_last)
+            O.L.call("a3d_conv3x3_bn_fwd", x.data_ptr(), w16.data_ptr(), None, None, 0, y.data_ptr(), None, x.shape[0], x.shape[2], x.shape[3],
+                     x.shape[1], w16.shape[0], O.L.stream())
+        else:
+            y = F.conv2d(x, w16, None, padding=1)
         ctx.save_for_backward(x, w16)
         ctx.cc = cc
         cc.x, cc.dw, cc.dense = x, None, False
@@ -325,6 +388,8 @@ class FeaturePyramidNetwork(nn.Module):
             if not fuse:
                 lat = conv(m, x, wpad, True)
                 return lat if last is None else fpn_top_down(lat, last)
+            if _fused_lateral_ok(x, Co, last):                              # convolution + bias + top-down add in one launch
+                return _LateralTopDownFn.apply(x, F.pad(m.weight, wpad) if pad else m.weight, m.bias, last)
             return fpn_top_down(conv(m, x, wpad, False), last, m.bias)      # bias-free convolution, bias in the top-down kernel
 
         out_bias, out_ctx = {}, {}

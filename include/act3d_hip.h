@@ -517,6 +517,17 @@ int a3d_conv1x1_streams(int K, int N);
 int a3d_conv1x1_nslab(size_t M, int K, int N);
 int a3d_conv1x1_bn_fwd(const void* x, const void* w, const float* in_scale, const float* in_shift, int in_relu, void* y,
                        float* partial, size_t M, int K, int N, void* stream);
+/* The FPN's lateral 1x1 convolution with its bias and the top-down add in the epilogue (torchvision FeaturePyramidNetwork.forward:
+ * inner_lateral = inner_blocks[i](x); last_inner = inner_lateral + F.interpolate(last_inner, nearest) -- act3d.py:76-77, :363-369):
+ *   y[n][h][w][:] = bf16( x[n][h][w][:] w^T + bias[:] + top[n][h/2][w/2][:] ),  ONE rounding of the fp32 sum
+ * x [images][H][W][K] bf16 (NHWC), w [N][K] bf16, bias fp32 (the first nbias <= N channels; NULL: none), top [images][H/2][W/2][N] bf16
+ * (NULL: the pyramid's top level), y [images][H][W][N] bf16.  The resident-weight streaming kernel of a3d_conv1x1_bn_fwd with another
+ * epilogue: the lateral map is never written and re-read by a3d_upsample2_add_fwd.  Served (a3d_conv1x1_topdown_serves == 1): K in
+ * {64, 128, 256}, N in {64, 128}; H and W even with a top map; at most 2^32 rows; operands 16-byte aligned.  The backward is
+ * a3d_upsample2_add_bwd's (d top, d bias) plus the convolution's weight gradient. */
+int a3d_conv1x1_topdown_serves(int K, int N);
+int a3d_conv1x1_topdown_fwd(const void* x, const void* w, const float* bias, int nbias, const void* top, void* y, size_t images,
+                            int H, int W, int K, int N, void* stream);
 /* Whether the deep-layer GEMM of a3d_conv1x1_bn_fwd (K = 64 j in 128 .. 2048, N = 128 j up to 2048: the 1x1 convolutions of CLIP
  * ModifiedResNet layers 2 - 4, model/utils/clip.py:28-43) takes its shapes: 1 yes (default; A3D_CONV1X1_DEEP), 0 they stay with the
  * library.  Sets the mode and returns the previous one; mode < 0 only queries.  Affects a3d_conv1x1_streams / _nslab / _bn_fwd alike. */

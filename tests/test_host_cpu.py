@@ -595,6 +595,15 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 64, 320, None) == -22     # N not 256 j
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, None, 1, dummy, None, 128, 64, 64, None) == -22     # scale without shift
     assert b"a3d_conv1x1_bn_fwd" in lib.a3d_last_error_string()
+    # the FPN's lateral convolution with the top-down add in its epilogue: the resident-weight kernel's shapes with N <= 128
+    assert lib.a3d_conv1x1_topdown_serves(64, 64) == 1 and lib.a3d_conv1x1_topdown_serves(256, 64) == 1
+    assert lib.a3d_conv1x1_topdown_serves(256, 128) == 1 and lib.a3d_conv1x1_topdown_serves(512, 64) == 0
+    assert lib.a3d_conv1x1_topdown_serves(64, 256) == 0 and lib.a3d_conv1x1_topdown_serves(64, 60) == 0
+    assert lib.a3d_conv1x1_topdown_fwd(dummy, dummy, None, 0, dummy, dummy, 2, 8, 8, 512, 64, None) == -22      # K not served
+    assert lib.a3d_conv1x1_topdown_fwd(dummy, dummy, None, 0, dummy, dummy, 2, 7, 8, 64, 64, None) == -22       # odd H with a top map
+    assert lib.a3d_conv1x1_topdown_fwd(dummy, dummy, dummy, 65, None, dummy, 2, 8, 8, 64, 64, None) == -22      # more bias entries than channels
+    assert lib.a3d_conv1x1_topdown_fwd(dummy, dummy, None, 0, ctypes.c_void_p(72), dummy, 2, 8, 8, 64, 64, None) == -22   # alignment
+    assert b"a3d_conv1x1_topdown_fwd" in lib.a3d_last_error_string()
     # slab planning is pure host code and consistent with the tile table (64 / 128 / >= 256 output channels)
     # the resident-weight streaming kernel serves K <= 256 with an LDS block <= 96 KB; the deep-layer GEMM (round 6) K = 64 j in
     # 128 .. 2048 with N = 128 j up to 2048; other shapes are refused (MIOpen's)

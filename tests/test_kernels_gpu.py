@@ -798,6 +798,57 @@ def test_fpn_top_down_fused(a3d, dev):
     assert a3d.nn.fpn_top_down(odd, top[:1, :, :3, :4].contiguous()).shape == odd.shape
 
 
+@pytest.mark.parametrize("images,H,W,K,N,nbias,with_top", [(3, 16, 32, 64, 64, 60, True), (2, 8, 8, 256, 64, 64, True),
+                                                          (1, 6, 10, 128, 128, 120, True), (5, 7, 9, 64, 64, 0, False),
+                                                          (2, 64, 64, 256, 128, 128, True)])
+def test_fpn_lateral_convolution_with_top_down_epilogue(a3d, dev, images, H, W, K, N, nbias, with_top):
+    """a3d_conv1x1_topdown_fwd: y = bf16(x w^T + bias + up2(top)) with ONE rounding of the fp32 sum, against torch in fp32 on the same
+    bf16 operands (tile tails: rows not a multiple of the 64 / 128 / 256-row tile; pad channels without bias; the pyramid's top level
+    without a top map), and nn._LateralTopDownFn's backward against the unfused path's autograd (library convolution + top-down kernel)."""
+    g = torch.Generator().manual_seed(images * 1000 + K + N)
+    cl = torch.channels_last
+    x = torch.randn(images, K, H, W, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(N, K, 1, 1, generator=g) * K ** -0.5).to(dev)
+    bias = (torch.randn(nbias, generator=g).to(dev) if nbias else None)
+    top = torch.randn(images, N, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=cl) if with_top else None
+    w16 = w.to(torch.bfloat16)
+    ref = F.conv2d(x.float(), w16.float())
+    if bias is not None:
+        ref = ref + F.pad(bias, (0, N - nbias)).view(1, N, 1, 1)
+    if top is not None:
+        ref = ref + F.interpolate(top.float(), size=(H, W), mode="nearest")
+    y = torch.full((images, N, H, W), float("nan"), device=dev, dtype=torch.bfloat16).contiguous(memory_format=cl)
+    L = a3d.lib
+    assert L.load().a3d_conv1x1_topdown_serves(K, N) == 1
+    L.call("a3d_conv1x1_topdown_fwd", x.data_ptr(), w16.reshape(N, K).contiguous().data_ptr(), None if bias is None else bias.data_ptr(),
+           nbias, None if top is None else top.data_ptr(), y.data_ptr(), images, H, W, K, N, L.stream())
+    torch.cuda.synchronize()
+    # one bf16 rounding of an fp32 sum whose accumulation order differs from torch's: half an ulp (2^-9 relative) plus summation noise
+    report(f"fpn lateral + top-down K={K} N={N}", y, ref, 1e-3, 2.0 ** -8)
+    if not with_top or (H % 2) or (W % 2):
+        return
+    # autograd: fused Function vs library convolution + top-down kernel
+    res = {}
+    for tag in ("fused", "unfused"):
+        wp = w.clone().requires_grad_()
+        bp = bias.clone().requires_grad_() if bias is not None else None
+        tp = top.clone().requires_grad_()
+        if tag == "fused":
+            out = a3d.nn._LateralTopDownFn.apply(x, wp, bp, tp)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = a3d.nn.fpn_top_down(F.conv2d(x, wp), tp, bp)
+        dy = torch.randn(images, N, H, W, generator=torch.Generator().manual_seed(7)).to(dev).to(torch.bfloat16).contiguous(memory_format=cl)
+        out.backward(dy)
+        res[tag] = (out.detach(), wp.grad, None if bp is None else bp.grad, tp.grad)
+    # one rounding against two: the unfused path rounds the lateral map before the add, an ulp of the LARGER of |lateral|, |sum|
+    report(f"fused vs unfused lateral map K={K} N={N}", res["fused"][0], res["unfused"][0], 2.0 ** -7 * res["unfused"][0].abs().max().item())
+    report_scaled(f"fused lateral weight gradient K={K} N={N}", res["fused"][1], res["unfused"][1], 1e-2)        # the same library kernel on the same dy (its bf16 result: an ulp where its atomics reorder)
+    if bias is not None:
+        report_scaled(f"fused lateral bias gradient K={K} N={N}", res["fused"][2], res["unfused"][2], 1e-5)
+    assert torch.equal(res["fused"][3], res["unfused"][3])
+
+
 def test_fpn_with_folded_biases_matches_plain_convolutions(a3d, dev):
     """nn.FeaturePyramidNetwork on bf16 channels-last maps: the lateral convolutions run bias-free with their bias added by the
     top-down kernel (forward) and reduced by it (backward), and the output convolutions' bias is deferred to the token
