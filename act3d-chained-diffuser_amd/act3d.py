@@ -156,14 +156,24 @@ class Act3D(nn.Module):
     def _needed_maps(self):
         return sorted(set(self.feature_map_pyramid[:self.num_sampling_level]))
 
-    def compute_visual_tokens(self, visible_rgb):
-        """normalize -> frozen backbone -> FPN (act3d.py:363-369), returned token-major per level: (B, ncam*h*w, E).
-        Convolutions run channels-last so the (cam, h, w, E) token rows are contiguous and need no transpose."""
-        B, ncam = visible_rgb.shape[:2]
+    def backbone_maps(self, visible_rgb, out=None):
+        """The frozen half of compute_visual_tokens: normalize -> backbone under no_grad (act3d.py:363-366), {res1..res5} of the
+        B * ncam views.  No gradient flows through it and its weights never change, so a training loop may compute the maps of
+        batch k + 1 while step k runs (engine.GraphedStep(prefetch=...)) and hand them to compute_visual_tokens(maps=...).
+        out: preallocated maps to write into (same shapes / dtypes / memory format as a previous call returned)."""
         x = visible_rgb.flatten(0, 1)
         with torch.no_grad():
             feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=self.fpn_dtype != torch.float32,
-                                        normalize=self.normalize)
+                                        normalize=self.normalize, out=out)
+        return feats
+
+    def compute_visual_tokens(self, visible_rgb, maps=None):
+        """normalize -> frozen backbone -> FPN (act3d.py:363-369), returned token-major per level: (B, ncam*h*w, E).
+        Convolutions run channels-last so the (cam, h, w, E) token rows are contiguous and need no transpose.
+        maps: the backbone's maps of these views when the caller already has them (backbone_maps)."""
+        B, ncam = visible_rgb.shape[:2]
+        x = visible_rgb.flatten(0, 1)
+        feats = maps if maps is not None else self.backbone_maps(visible_rgb)
         out_bias, out_ctx = {}, {}
         if self.fpn_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.fpn_dtype):

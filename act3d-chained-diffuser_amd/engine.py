@@ -341,7 +341,9 @@ def _split_backward(tokens, run_hot, on_hot_done):
 
 def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=None):
     """forward + loss + backward of main_keypose.py:207-224 with the backward split at the FPN tokens"""
-    tokens = model.compute_visual_tokens(sample["rgbs"])
+    tokens = model.compute_visual_tokens(sample["rgbs"], maps=sample.get("backbone_maps"))   # maps: prefetched by the previous step
+    if sample.get("_after_tokens") is not None:
+        sample["_after_tokens"]()                    # GraphedStep(prefetch=...) with A3D_PREFETCH_FORK=tokens forks the next backbone here
 
     def hot(leaves):
         out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"],
@@ -460,6 +462,13 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
     return d.get("iter", 0), d.get("best_loss", None)
 
 
+# A/B switch (measured, round 6: both lose -- "main" 23.0 ms, default 18.9 ms per keypose step): "main" captures the prefetching step on
+# a high-priority stream, "side" gives the prefetch stream the high priority instead
+PREFETCH_HIPRIO = os.environ.get("A3D_PREFETCH_HIPRIO", "0")
+# where the next batch's backbone is forked: "start" of the step, or after the FPN forward ("tokens": engine.fwd_bwd_keypose's hook)
+PREFETCH_FORK = os.environ.get("A3D_PREFETCH_FORK", "start")
+
+
 class GraphedStep:
     """Captures one full training step into hipGraphs and replays it.
 
@@ -471,75 +480,144 @@ class GraphedStep:
                    fwd_bwd_trajectory).  Three graphs around the two collectives:
                    [zero_grad + forward + hot-path backward] -> all-reduce(hot segments) on a side stream, concurrent with
                    [FPN backward] -> all-reduce(FPN segment) -> [AdamW with 1/world].
-    The collectives themselves are issued eagerly between the replays (RCCL calls are not captured)."""
+    The collectives themselves are issued eagerly between the replays (RCCL calls are not captured).
 
-    def __init__(self, step_fwd_bwd, optimizer, static_inputs, ddp=None, warmup=3):
+    prefetch (round 6; `model.backbone_maps`, a callable (rgbs, out=None) -> {name: map}): the FROZEN backbone of the NEXT batch runs
+    on a side stream inside step k's graph, next to step k's FPN + hot path + backward + AdamW, which read the maps step k - 1
+    left for them (`inputs["backbone_maps"]`, engine.fwd_bwd_keypose).  The backbone has no gradient and its weights never change,
+    so the result of every step is the one of the sequential order (act3d.py:363-366 runs under no_grad in the reference too); what
+    changes is that its ~9 ms of HBM-bound kernels fill the chip while the hot path's launch- and issue-bound kernels run.  Two map
+    sets and two graph sets alternate (step k reads set k % 2 and writes set (k + 1) % 2).  Contract: launch(inputs, next_rgbs)
+    -- `next_rgbs` are the images of the batch the NEXT launch will pass (None: the same static images again, a fixed synthetic
+    batch); the first launch primes its own maps eagerly."""
+
+    def __init__(self, step_fwd_bwd, optimizer, static_inputs, ddp=None, warmup=3, prefetch=None):
         self.static_inputs = static_inputs
         self.optimizer = optimizer
         self.ddp = ddp
         self.world = ddp.world if ddp is not None else 1
+        self.prefetch = prefetch
         split = self.world > 1
-        call = (lambda cb: step_fwd_bwd(static_inputs, cb)) if split else (lambda cb: step_fwd_bwd(static_inputs))
+        self.parity = 0
+        self._primed = False
+        sets = 1
+        gkw = {}
+        if prefetch is not None:
+            sets = 2
+            self.next_rgbs = static_inputs["rgbs"].clone()
+            with torch.no_grad():
+                m0 = prefetch(static_inputs["rgbs"])
+            self.maps = [m0, {k: torch.empty_like(v) for k, v in m0.items()}]
+            self._pf_stream = torch.cuda.Stream(priority=-1) if PREFETCH_HIPRIO == "side" else torch.cuda.Stream()
+            if PREFETCH_HIPRIO in ("1", "main"):     # capture stream above the prefetch stream: the hot path's short kernels dispatch first
+                gkw["stream"] = torch.cuda.Stream(priority=-1)
+        inputs = [dict(static_inputs) for _ in range(sets)]
+        if prefetch is not None:
+            for p_ in range(sets):
+                inputs[p_]["backbone_maps"] = self.maps[p_]
+        call = (lambda p_, cb: step_fwd_bwd(inputs[p_], cb)) if split else (lambda p_, cb: step_fwd_bwd(inputs[p_]))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 optimizer.zero_grad()
-                call(ddp.hot_path_done if split else None)
+                call(0, ddp.hot_path_done if split else None)
                 scale = ddp.sync_gradients() if ddp is not None else 1.0
                 optimizer.step(grad_scale=scale)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.g_fb = torch.cuda.CUDAGraph()
-        self.g_late = self.g_opt = None
-        if not split:
-            with torch.cuda.graph(self.g_fb):
+
+        def fork(p_, late=False):
+            """the next batch's backbone on the side stream (joined by join()); no-op without prefetch"""
+            if prefetch is None or (PREFETCH_FORK == "tokens") != late:
+                return
+            self._pf_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pf_stream), torch.no_grad():
+                prefetch(self.next_rgbs, out=self.maps[1 - p_])
+
+        def join():
+            if prefetch is not None:
+                torch.cuda.current_stream().wait_stream(self._pf_stream)
+
+        self.g_fb, self.g_late, self.loss = [], [], []
+        self.g_opt = None
+        pool = None
+        if prefetch is not None and PREFETCH_FORK == "tokens":
+            for p_ in range(sets):
+                inputs[p_]["_after_tokens"] = (lambda q=p_: fork(q, late=True))
+        for p_ in range(sets):
+            g = torch.cuda.CUDAGraph()
+            self.g_fb.append(g)
+            if not split:
+                with (torch.cuda.graph(g, **gkw) if pool is None else torch.cuda.graph(g, pool=pool, **gkw)):
+                    fork(p_)
+                    optimizer.zero_grad()
+                    self.loss.append(call(p_, None))
+                    optimizer.step(grad_scale=1.0)
+                    join()
+                pool = g.pool()
+                continue
+            # world > 1: the capture of the first graph ends inside the callback (hot path done), the second one starts there
+            g2 = torch.cuda.CUDAGraph()
+            self.g_late.append(g2)
+            ctx = {}
+
+            def switch_graphs():
+                join()                               # the prefetched backbone overlaps the forward + hot-path backward
+                ctx["first"].__exit__(None, None, None)
+                ctx["second"] = torch.cuda.graph(g2, pool=g.pool() if pool is None else pool, **gkw)
+                ctx["second"].__enter__()
+
+            ctx["first"] = torch.cuda.graph(g, **gkw) if pool is None else torch.cuda.graph(g, pool=pool, **gkw)
+            ctx["first"].__enter__()
+            try:
+                fork(p_)
                 optimizer.zero_grad()
-                self.loss = call(None)
-                optimizer.step(grad_scale=1.0)
-            return
-        # world > 1: the capture of the first graph ends inside the callback (hot path done), the second one starts there
-        self.g_late = torch.cuda.CUDAGraph()
-        ctx = {}
+                self.loss.append(call(p_, switch_graphs))
+            finally:
+                (ctx.get("second") or ctx["first"]).__exit__(None, None, None)
+            pool = g.pool()
+        if split:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=pool, **gkw):
+                optimizer.step(grad_scale=1.0 / self.world)
+        self._last = 0
 
-        def switch_graphs():
-            ctx["first"].__exit__(None, None, None)
-            ctx["second"] = torch.cuda.graph(self.g_late, pool=self.g_fb.pool())
-            ctx["second"].__enter__()
-
-        ctx["first"] = torch.cuda.graph(self.g_fb)
-        ctx["first"].__enter__()
-        try:
-            optimizer.zero_grad()
-            self.loss = call(switch_graphs)
-        finally:
-            (ctx.get("second") or ctx["first"]).__exit__(None, None, None)
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
-            optimizer.step(grad_scale=1.0 / self.world)
-
-    def launch(self, inputs=None):
+    def launch(self, inputs=None, next_rgbs=None):
         """Enqueue the step up to (not including) the point where the gradient reductions must have finished: input copies,
-        forward + backward replay(s) and, under DP, the all-reduces (started, not awaited).  finish() completes the step."""
+        forward + backward replay(s) and, under DP, the all-reduces (started, not awaited).  finish() completes the step.
+        next_rgbs (prefetch only): the images of the batch the next launch will pass; None: the static images again."""
         if inputs is not None:
             for k, v in inputs.items():
                 if torch.is_tensor(v) and k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
                     self.static_inputs[k].copy_(v, non_blocking=True)
-        self.g_fb.replay()
+        p_ = 0
+        if self.prefetch is not None:
+            p_ = self.parity
+            if not self._primed:                 # the first launch computes its own maps (nobody prefetched them)
+                with torch.no_grad():
+                    self.prefetch(self.static_inputs["rgbs"], out=self.maps[p_])
+                self._primed = True
+            src = next_rgbs if next_rgbs is not None else self.static_inputs["rgbs"]
+            if src.data_ptr() != self.next_rgbs.data_ptr():
+                self.next_rgbs.copy_(src, non_blocking=True)
+            self.parity ^= 1
+        self._last = p_
+        self.g_fb[p_].replay()
         if self.world > 1:
             self.ddp.arm(True)
             self.ddp.hot_path_done()           # hot segments on the side stream (whole buffer later if overlap is off) ...
-            self.g_late.replay()               # ... while the FPN backward runs
+            self.g_late[p_].replay()           # ... while the FPN backward runs
             self.ddp.begin_sync()
 
     def finish(self):
         if self.world > 1:
             self.ddp.finish_sync()
             self.g_opt.replay()
-        return self.loss
+        return self.loss[self._last]
 
-    def __call__(self, inputs=None):
-        self.launch(inputs)
+    def __call__(self, inputs=None, next_rgbs=None):
+        self.launch(inputs, next_rgbs)
         return self.finish()
 
 

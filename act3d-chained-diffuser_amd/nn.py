@@ -600,12 +600,15 @@ def stem_conv_bn(x, conv, normalize, want_stats=True):
     return y, partial
 
 
-def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None, residual_scale=None):
+def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=None, residual_scale=None, out=None):
     """Fused BatchNorm2d (batch statistics when bn.training, running-stat update) + optional residual add + ReLU on a
     bf16 channels_last activation (vision.hip).  Three launches: stats (skipped when the producer left `partial` sums),
     finalize, apply.  pool=True also applies the nn.AvgPool2d(2) that follows in the CLIP ResNet inside the apply kernel and
-    returns (full, pooled); full is None when keep_full=False.  bn=None: no normalisation (plain 2x2 average pool of x)."""
+    returns (full, pooled); full is None when keep_full=False.  bn=None: no normalisation (plain 2x2 average pool of x).
+    out: a preallocated tensor for the full-resolution result (the backbone's returned maps, run_frozen_backbone(out=...))."""
     N, C, H, W = x.shape
+    if out is not None:
+        assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous(memory_format=torch.channels_last)
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
     if residual is not None:
         assert residual.shape == x.shape and residual.dtype == x.dtype and \
@@ -619,13 +622,13 @@ def bn_act(x, bn, relu=True, residual=None, pool=False, keep_full=True, partial=
         sc_ptr, sh_ptr = scale[0].data_ptr(), scale[1].data_ptr()
     res_ptr = None if residual is None else residual.data_ptr()
     if not pool:
-        y = torch.empty_like(x)
+        y = out if out is not None else torch.empty_like(x)
         O.L.call("a3d_bn_apply", x.data_ptr(), res_ptr, None if residual_scale is None else residual_scale[0].data_ptr(),
                  None if residual_scale is None else residual_scale[1].data_ptr(), sc_ptr, sh_ptr, y.data_ptr(), rows, C,
                  1 if relu else 0, st)
         return y
     assert residual_scale is None, "the pooled apply takes a materialised residual"
-    y = torch.empty_like(x) if keep_full else None
+    y = (out if out is not None else torch.empty_like(x)) if keep_full else None
     yp = torch.empty((N, C, H // 2, W // 2), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
     O.L.call("a3d_bn_apply_pool2", x.data_ptr(), res_ptr, sc_ptr, sh_ptr, None if y is None else y.data_ptr(), yp.data_ptr(),
              N, H, W, C, 1 if relu else 0, st)
@@ -637,13 +640,15 @@ def _pool2_ok(m, t):
     return isinstance(m, nn.AvgPool2d) and m.kernel_size in (2, (2, 2)) and t.shape[-1] % 2 == 0 and t.shape[-2] % 2 == 0
 
 
-def fused_frozen_backbone_forward(bb, x, stem=None):
+def fused_frozen_backbone_forward(bb, x, stem=None, out=None):
     """SyntheticCLIPResNet50.forward with MIOpen bf16 NHWC convolutions and the fused BatchNorm of vision.hip.
     Same dataflow as the module's own forward (CLIP ModifiedResNet, model/utils/clip.py:28-43); every AvgPool2d(2) is
     folded into the BatchNorm-apply kernel that produces its input (the block output also feeds the next block's
-    downsample branch pooled, so that kernel emits both)."""
+    downsample branch pooled, so that kernel emits both).  out: {res1..res5} preallocated maps the five returned maps are written
+    into by the kernels that produce them (no copy)."""
     conv = lambda m, t: F.conv2d(t, m.weight, None, m.stride, m.padding)
     fuse3 = FUSED_CONV3X3
+    o_ = (lambda k: None) if out is None else (lambda k, _maps=out: _maps[k])        # (`out` is rebound as a local further down)
 
     def conv3(m, t, bn_in, p_in, want_stats):
         """3x3 convolution m of relu(bn_in(t)) (t = the raw output of the previous convolution, p_in its partial statistics or
@@ -659,9 +664,9 @@ def fused_frozen_backbone_forward(bb, x, stem=None):
     c2, p2 = conv3(bb.conv2, c1, bb.bn1, p1, bb.bn2.training)
     c3, p3 = conv3(bb.conv3, c2, bb.bn2, p2, bb.bn3.training)
     if _pool2_ok(bb.avgpool, c3):
-        x0, x = bn_act(c3, bb.bn3, pool=True, partial=p3)
+        x0, x = bn_act(c3, bb.bn3, pool=True, partial=p3, out=o_("res1"))
     else:
-        x0 = bn_act(c3, bb.bn3, partial=p3)
+        x0 = bn_act(c3, bb.bn3, partial=p3, out=o_("res1"))
         x = bb.avgpool(x0)
     outs = [x0]
     bns = [bb.bn1, bb.bn2, bb.bn3]
@@ -716,10 +721,11 @@ def fused_frozen_backbone_forward(bb, x, stem=None):
             idn, idn_scale = cd, bn_scale_shift(cd, blk.downsample[2], pd)
         else:
             idn = bn_act(cd, blk.downsample[2], relu=False, partial=pd)
+        o_x = o_("res%d" % (len(outs) + 1)) if id(blk) in last_of_layer else None      # a layer's last block writes the returned map
         if want_pooled:
-            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True, partial=p3)
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, pool=True, partial=p3, out=o_x)
         else:
-            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, partial=p3, residual_scale=idn_scale), None
+            x, x_pooled = bn_act(o3, blk.bn3, relu=True, residual=idn, partial=p3, residual_scale=idn_scale, out=o_x), None
         bns += [blk.bn1, blk.bn2, blk.bn3]
         if id(blk) in last_of_layer:
             outs.append(x)
@@ -751,18 +757,27 @@ def normalize_to_nhwc_bf16(x, normalize):
     return y
 
 
-def run_frozen_backbone(backbone, x, dtype, keep_dtype=False, normalize=None):
+def run_frozen_backbone(backbone, x, dtype, keep_dtype=False, normalize=None, out=None):
     """Forward of the frozen backbone under no_grad.  `normalize`: the ClipNormalize module when `x` are the RAW images
     (None: already normalised).  For a reduced dtype the convolution weights are converted ONCE
     (the backbone is frozen, so there is no master copy to keep) instead of being re-cast by autocast at every step;
     BatchNorm keeps fp32 parameters / running statistics and, as in the reference's train() mode, batch statistics.
-    On the GPU with bf16 the BatchNorm + ReLU + residual chain runs as the fused HIP kernels of vision.hip."""
+    On the GPU with bf16 the BatchNorm + ReLU + residual chain runs as the fused HIP kernels of vision.hip.
+    out: {res1..res5} preallocated maps (as a previous call returned them) to write the result into -- the fused path's kernels
+    write them directly, the other paths copy."""
+    def deliver(feats):
+        if out is None:
+            return feats
+        for k, v in feats.items():
+            if v.data_ptr() != out[k].data_ptr():
+                out[k].copy_(v)
+        return out
     fused = FUSED_BN and x.is_cuda and dtype == torch.bfloat16 and isinstance(backbone, SyntheticCLIPResNet50)
     if normalize is not None and not (fused and isinstance(normalize, ClipNormalize) and (x.shape[-1] * x.shape[-2]) % 4 == 0):
         x = normalize(x).contiguous(memory_format=torch.channels_last)
         normalize = None
     if dtype == torch.float32:
-        return backbone(x)
+        return deliver(backbone(x))
     if getattr(backbone, "_conv_dtype", None) != dtype:
         for m in backbone.modules():
             if isinstance(m, nn.Conv2d):
@@ -771,10 +786,11 @@ def run_frozen_backbone(backbone, x, dtype, keep_dtype=False, normalize=None):
         backbone._conv_dtype = dtype
     if fused:
         if normalize is not None and stem_serves(x, backbone.conv1, normalize):
-            feats = fused_frozen_backbone_forward(backbone, None, stem=stem_conv_bn(x, backbone.conv1, normalize, want_stats=backbone.bn1.training))
+            feats = fused_frozen_backbone_forward(backbone, None, stem=stem_conv_bn(x, backbone.conv1, normalize, want_stats=backbone.bn1.training),
+                                                  out=out if keep_dtype else None)
         else:
             xb = normalize_to_nhwc_bf16(x, normalize) if normalize is not None else x.to(dtype).contiguous(memory_format=torch.channels_last)
-            feats = fused_frozen_backbone_forward(backbone, xb)
+            feats = fused_frozen_backbone_forward(backbone, xb, out=out if keep_dtype else None)
     else:
         feats = backbone(x.to(dtype))
-    return feats if keep_dtype else {k: v.float() for k, v in feats.items()}
+    return deliver(feats if keep_dtype else {k: v.float() for k, v in feats.items()})

@@ -23,6 +23,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The frozen backbone of the NEXT batch runs on a side stream inside the current step's graph (engine.GraphedStep(prefetch=...)): every
+# timed step still executes one backbone pass, one FPN / hot-path forward + backward and one AdamW step; the backbone pass it executes
+# belongs to the batch the next step consumes (the maps the first timed step reads come from the last warm-up step, the maps the last
+# timed step writes are read after the timed region: K timed steps = K backbone passes + K of everything else).  The line also
+# carries `sequential_step`: the same K steps with the backbone inside its own step (A3D_PREFETCH_BACKBONE=0 makes that the headline).
+PREFETCH_BACKBONE = os.environ.get("A3D_PREFETCH_BACKBONE", "1") == "1"
 PERACT_BOUNDS = np.array([[-0.1101, -0.5558, 0.7129], [0.6481, 0.5184, 1.5116]])
 
 
@@ -559,7 +565,7 @@ def main():
     graph_err = None
     if not args.no_graph:
         try:
-            graphed = E.GraphedStep(fwd_bwd, opt, batch, ddp=ddp, warmup=2)
+            graphed = E.GraphedStep(fwd_bwd, opt, batch, ddp=ddp, warmup=2, prefetch=model.backbone_maps if PREFETCH_BACKBONE else None)
         except Exception as e:                         # capture can fail (e.g. library versions); fall back to eager
             graph_err = repr(e)[:200]
             graphed = None
@@ -622,12 +628,29 @@ def main():
                                    "+ trainable FPN included in the step",
                        "per_gpu_batch_keyframes": B, "global_batch": world * B, "parallelism": f"dp{world}",
                        "batch_note": "keyframe rows; reference default = 16 episodes x <=5 keyframes per step",
-                       "hipgraph": was_graphed, "final_loss": loss_val,
+                       "hipgraph": was_graphed, "final_loss": loss_val, "backbone_prefetch": bool(was_graphed and PREFETCH_BACKBONE),
                        "allreduce": None if ddp is None else ("hot-path segments overlapped with the FPN backward" if ddp.overlap
                                                               else "one all-reduce after backward")},
         }
         if graph_err:
             res["config"]["graph_capture_error"] = graph_err
+        if was_graphed and PREFETCH_BACKBONE and world == 1 and not args.skip_secondary:
+            # the same step without the cross-step overlap: backbone -> FPN -> hot path -> backward -> AdamW strictly in order
+            try:
+                seq = E.GraphedStep(fwd_bwd, opt, batch, warmup=1)
+                for _ in range(args.warmup):
+                    seq()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    seq()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                res["sequential_step"] = {"samples_per_s": B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                                          "note": "one graph per step, the frozen backbone inside its own step (no prefetch of the next batch's maps)"}
+                del seq
+            except Exception as e:
+                res["sequential_step"] = {"error": repr(e)[:200]}
         # hot-path-only throughput (pre-computed visual tokens): informational
         try:
             with torch.no_grad():

@@ -90,6 +90,60 @@ def test_cfg1_end_to_end_128px_one_level(a3d, dev, train):
     assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
 
 
+def test_graphed_step_with_prefetched_backbone_equals_the_sequential_step(a3d, dev):
+    """GraphedStep(prefetch=model.backbone_maps): the frozen backbone of batch k + 1 runs on a side stream inside step k's graph and
+    step k + 1 reads its maps.  Over a sequence of DIFFERENT batches: (i) the maps every step consumes are, bit for bit, the
+    backbone's maps of THAT step's images (deterministic library solvers for this check), also when the two graph sets alternate
+    and when the first launch passes other images than the capture saw; (ii) the losses equal those of the sequential GraphedStep
+    on an identically initialised model fed the same sequence."""
+    E = a3d.engine
+    keep = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        def make():
+            torch.manual_seed(0)
+            m = a3d.Act3D(image_size=(128, 128), embedding_dim=60, num_attn_heads=4, gripper_loc_bounds=C.PERACT_BOUNDS,
+                          num_ghost_points=128, num_ghost_points_val=128, num_sampling_level=2, sampler_seed=5).to(dev)
+            m.backbone_dtype = m.fpn_dtype = torch.bfloat16
+            return m.train()
+
+        seq = [_sample(2, 2, 128, dev, 40 + i) for i in range(5)]
+        crit = a3d.LossAndMetrics(position_loss="ce", rotation_parametrization="quat_from_query", ground_truth_gaussian_spread=0.01)
+        mA, mB = make(), make()
+        flatA, optA = E.get_optimizer(mA, lr=1e-4)
+        flatB, optB = E.get_optimizer(mB, lr=1e-4)
+        cap = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in seq[0].items()}      # static buffers of the two captures
+        capB = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in seq[0].items()}
+        gA = E.GraphedStep(lambda smp: E.fwd_bwd_keypose(mA, crit, smp), optA, cap, warmup=2)
+        gB = E.GraphedStep(lambda smp: E.fwd_bwd_keypose(mB, crit, smp), optB, capB, warmup=2, prefetch=mB.backbone_maps)
+        assert len(gB.g_fb) == 2 and len(gA.g_fb) == 1
+        with torch.no_grad():                       # same state before the compared sequence (captures / warm-ups drew the same numbers)
+            flatB.flat.copy_(flatA.flat)
+            optB.exp_avg.copy_(optA.exp_avg)
+            optB.exp_avg_sq.copy_(optA.exp_avg_sq)
+        assert torch.equal(optA.step_count, optB.step_count) and torch.equal(mA._rng_state, mB._rng_state)
+        order = [1, 2, 3, 4, 0, 2]                  # the first launch passes other images than the capture saw
+        for i, k in enumerate(order):
+            nxt = seq[order[i + 1]]["rgbs"] if i + 1 < len(order) else None
+            lA = gA(seq[k]).clone()
+            used = gB.maps[gB.parity]               # the set this launch reads (launch() flips the parity afterwards)
+            lB = gB(seq[k], next_rgbs=nxt).clone()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ref = mA.backbone_maps(seq[k]["rgbs"])
+            for name in ref:
+                assert torch.equal(used[name], ref[name]), (i, k, name)
+            print(f"[parity] prefetched-backbone step {i} (batch {k}): loss {lB.item():.6f} vs sequential {lA.item():.6f}")
+            assert abs(lA.item() - lB.item()) <= (2e-5 if i == 0 else 2e-3) * max(1.0, abs(lA.item())), (i, lA.item(), lB.item())
+        # the maps the LAST launch prefetched are those of its next_rgbs default (the same static images again)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = mA.backbone_maps(seq[order[-1]]["rgbs"])
+        assert all(torch.equal(gB.maps[gB.parity][n], ref[n]) for n in ref)
+    finally:
+        torch.backends.cudnn.deterministic = keep
+
+
 def test_graphed_step_equals_eager_train_one_step(a3d, dev):
     """GraphedStep (capture of zero_grad + forward + loss + backward + AdamW, what bench.py replays) against the eager
     engine.train_one_step on an identically initialised model: same losses and parameters after every step.  The device
@@ -195,7 +249,7 @@ def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
             """engine.fwd_bwd_keypose with the k-NN centres teacher-forced to the ground truth: the gradients are then a
             smooth function of the features (no argmax cascade), so that two runs of the same batch agree to rounding
             whatever convolution algorithm MIOpen picked; the data-parallel machinery under test is untouched."""
-            tokens = model.compute_visual_tokens(sample["rgbs"])
+            tokens = model.compute_visual_tokens(sample["rgbs"], maps=sample.get("backbone_maps"))
 
             def hot(leaves):
                 out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"], gt_action=sample["action"],
@@ -231,7 +285,8 @@ def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
             def fwd_bwd(sample, cb=None):
                 return fwd_bwd_tf(m, sample, cb)
             state = m._rng_state.clone()
-            step = E.GraphedStep(fwd_bwd, opt, batches[rank], ddp=ddp, warmup=1)
+            # graphed == "prefetch": the next batch's frozen backbone forked inside the first of the three graphs, joined where it ends
+            step = E.GraphedStep(fwd_bwd, opt, batches[rank], ddp=ddp, warmup=1, prefetch=m.backbone_maps if graphed == "prefetch" else None)
             # the warm-up step moved the weights: restore the broadcast state (in place) and replay ONE step
             flat.flat.copy_(p0)
             opt.reset_state()
@@ -262,7 +317,7 @@ def _dp_gpu_worker(rank, world, port, overlap, graphed, q):
         q.put({"rank": rank, "error": traceback.format_exc()[-1500:]})
 
 
-@pytest.mark.parametrize("overlap,graphed", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("overlap,graphed", [(False, False), (True, False), (True, True), (True, "prefetch")])
 def test_data_parallel_two_ranks_equals_mean_of_rank_gradients(dev, overlap, graphed):
     """FlatDataParallel on the device: averaged 2-rank gradients == the mean of the two per-batch gradients (DDP's
     mean-of-means), with the hot-path segments reduced early on the side stream (overlap) or in one piece, eagerly and

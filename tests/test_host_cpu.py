@@ -757,7 +757,8 @@ def test_data_parallel_schedule_three_messages_and_one_shot(monkeypatch):
                 rec.log.append(("replay", self.name))
         gs = object.__new__(E.GraphedStep)
         gs.static_inputs, gs.optimizer, gs.ddp, gs.world = {}, None, ddp, ddp.world
-        gs.g_fb, gs.g_late, gs.g_opt, gs.loss = G("fwd+hot-bwd"), G("fpn-bwd"), G("adamw"), "loss"
+        gs.g_fb, gs.g_late, gs.g_opt, gs.loss = [G("fwd+hot-bwd")], [G("fpn-bwd")], G("adamw"), ["loss"]
+        gs.prefetch, gs.parity, gs._last = None, 0, 0
         rec.log.clear()
         assert gs() == "loss"
         calls = [c for c in rec.log if c[0] in ("replay", "all_reduce", "work.wait")]
@@ -775,3 +776,42 @@ def test_data_parallel_schedule_three_messages_and_one_shot(monkeypatch):
         else:
             assert calls == [("replay", "fwd+hot-bwd"), ("replay", "fpn-bwd"), ("all_reduce", 0, 1000, False), ("replay", "adamw")], calls
         assert ddp.finish_sync() == 1.0 / 8
+
+
+def test_graphed_step_prefetch_schedule_on_cpu_tensors():
+    """GraphedStep(prefetch=...)'s launch logic without a GPU (graphs and the backbone mocked): the first launch primes ITS maps
+    eagerly into the set its graph reads, the two graph sets alternate, the next batch's images land in the static buffer the
+    captured backbone reads (default: the static images again), finish() returns the loss of the graph that ran."""
+    a3d = load_pkg()
+    E = a3d.engine
+    import torch
+    log = []
+
+    class G:
+        def __init__(self, n):
+            self.n = n
+
+        def replay(self):
+            log.append(("replay", self.n))
+
+    gs = object.__new__(E.GraphedStep)
+    gs.static_inputs, gs.optimizer, gs.ddp, gs.world = {"rgbs": torch.zeros(2, 3)}, None, None, 1
+    gs.g_fb, gs.g_late, gs.g_opt, gs.loss = [G(0), G(1)], [], None, ["loss0", "loss1"]
+    gs.maps = [{"res1": torch.zeros(1)}, {"res1": torch.zeros(1)}]
+    gs.next_rgbs = torch.zeros(2, 3)
+    gs.parity, gs._primed, gs._last = 0, False, 0
+
+    def prefetch(rgbs, out=None):
+        log.append(("prefetch", float(rgbs.sum()), id(out)))
+        return out
+    gs.prefetch = prefetch
+    a, b = torch.ones(2, 3), torch.full((2, 3), 2.0)
+    assert gs({"rgbs": a}, next_rgbs=b) == "loss0"
+    assert log == [("prefetch", 6.0, id(gs.maps[0])), ("replay", 0)]            # primed with a's images into the set graph 0 reads
+    assert float(gs.next_rgbs.sum()) == 12.0 and float(gs.static_inputs["rgbs"].sum()) == 6.0
+    log.clear()
+    assert gs({"rgbs": b}) == "loss1"                                            # no priming any more; graph 1 reads what graph 0 prefetched
+    assert log == [("replay", 1)] and float(gs.next_rgbs.sum()) == 12.0        # next defaults to the static images (b)
+    log.clear()
+    assert gs() == "loss0" and log == [("replay", 0)] and gs.parity == 1
+
