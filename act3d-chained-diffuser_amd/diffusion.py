@@ -167,15 +167,20 @@ class DiffusionHead(nn.Module):
         return O.DropCtx(snap, self.dropout_p)
 
     # ---- vision (adjacent): one scale
-    def encode_images(self, rgb, pcd_norm):
+    def encode_images(self, rgb, pcd_norm, maps=None):
         """encoder.py:115-167: FPN tokens (B, ncam*h*w, E) of the scales the head uses -- one tensor for
         feat_scales_to_use = 1 (the res3 map at 1/8), a list [res3 @ 1/8, res1 @ 1/2, ...] otherwise."""
         B, ncam = rgb.shape[:2]
+        return self.tokens_from_backbone_maps(maps if maps is not None else self.backbone_maps(rgb), B, ncam)
+
+    def backbone_maps(self, rgb, out=None):
+        """The frozen half of encode_images (normalize -> backbone under no_grad): {res1..res5} of the B * ncam views; `out`:
+        preallocated maps to write into.  No gradient flows through it and its weights never change, so a training loop may compute
+        the maps of batch k + 1 while step k runs (engine.GraphedStep(prefetch=...)) and pass them to encode_images(maps=...)."""
         x = rgb.flatten(0, 1)
         low = self.fpn_dtype != torch.float32 and x.is_cuda
         with torch.no_grad():
-            feats = run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=low, normalize=self.normalize)
-        return self.tokens_from_backbone_maps(feats, B, ncam)
+            return run_frozen_backbone(self.backbone, x, self.backbone_dtype, keep_dtype=low, normalize=self.normalize, out=out)
 
     def tokens_from_backbone_maps(self, feats, B, ncam):
         """The FPN + token layout half of encode_images on the backbone's maps {res1..res5} of the B * ncam views (bf16 maps when

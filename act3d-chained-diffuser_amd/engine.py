@@ -355,7 +355,7 @@ def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=
 
 def fwd_bwd_trajectory(model, criterion, sample, on_hot_done=None):
     """forward + loss + backward of main_trajectory.py:177-195 with the backward split at the FPN tokens"""
-    tokens = model.prediction_head.encode_images(sample["rgbs"], None)
+    tokens = model.prediction_head.encode_images(sample["rgbs"], None, maps=sample.get("backbone_maps"))   # maps: prefetched by the previous step
     multi = isinstance(tokens, (list, tuple))                  # one token tensor per scale for a multi-scale head
 
     # additive test hooks: a batch may carry the DDPM noise / timesteps to use instead of the device draws

@@ -471,8 +471,9 @@ def joint_step_bench(a3d, device, B=16, steps=10, warmup=3, world=1, rank=0):
         tddp = E.FlatDataParallel(tflat, overlap=overlap, model=planner)
         kddp.broadcast_parameters()
         tddp.broadcast_parameters()
-    step = E.GraphedJointStep(E.GraphedStep(kp_fwd_bwd, kopt, kb, ddp=kddp, warmup=2),
-                              E.GraphedStep(tr_fwd_bwd, topt, tb, ddp=tddp, warmup=2))
+    step = E.GraphedJointStep(E.GraphedStep(kp_fwd_bwd, kopt, kb, ddp=kddp, warmup=2, prefetch=model.backbone_maps if PREFETCH_BACKBONE else None),
+                              E.GraphedStep(tr_fwd_bwd, topt, tb, ddp=tddp, warmup=2,
+                                            prefetch=planner.prediction_head.backbone_maps if PREFETCH_BACKBONE else None))
     for _ in range(warmup):
         lk, lt = step()
     if world > 1:
@@ -497,7 +498,7 @@ def joint_step_bench(a3d, device, B=16, steps=10, warmup=3, world=1, rank=0):
             "config": {"workload": f"BASELINE configs[3]: Act3D keypose step (B={B} keyframes per GPU, 4 cameras, 3 levels) + "
                                    f"DiffusionPlanner step (B={B} trajectories per GPU, horizon 50, 3 cameras, dropout 0.1), both with "
                                    "backbone + FPN + AdamW; hipGraph replays, joint iteration = engine.GraphedJointStep",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "hipgraph": True,
+                       "global_batch": world * B, "parallelism": f"dp{world}", "hipgraph": True, "backbone_prefetch": PREFETCH_BACKBONE,
                        "allreduce": None if world == 1 else "RCCL all-reduce of both models' flat gradient buffers per iteration; hot-path "
                                     "segments start during the FPN backward, the keypose reductions complete behind the trajectory step",
                        "final_losses": [float(lk.item()), float(lt.item())]}}

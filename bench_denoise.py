@@ -234,9 +234,14 @@ def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
     s = synthetic_inputs(B, Ln, C, dev)
     crit = a3d.TrajectoryCriterion()
 
+    prefetch = graph and os.environ.get("A3D_PREFETCH_BACKBONE", "1") == "1"      # as bench.py: the next batch's frozen backbone inside this step's graph
+
     def fwd_bwd(sample):
+        kw = {}
+        if sample.get("backbone_maps") is not None:
+            kw["visual_tokens"] = m.prediction_head.encode_images(sample["rgbs"], None, maps=sample["backbone_maps"])
         loss = crit.compute_loss(m(sample["trajectory"], sample["trajectory_mask"], sample["rgbs"], sample["pcds"],
-                                   sample["instr"], sample["curr_gripper"], sample["action"]))
+                                   sample["instr"], sample["curr_gripper"], sample["action"], **kw))
         loss.backward()
         return loss.detach()
 
@@ -245,7 +250,7 @@ def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
     graphed, err = None, None
     if graph:
         try:
-            graphed = Eg.GraphedStep(fwd_bwd, opt, s, warmup=2)
+            graphed = Eg.GraphedStep(fwd_bwd, opt, s, warmup=2, prefetch=m.prediction_head.backbone_maps if prefetch else None)
         except Exception as e:                               # recorded in the output: never a silent fallback
             err = repr(e)[:200]
             torch.cuda.synchronize()
@@ -278,6 +283,7 @@ def training_bench(a3d, dev, B=22, Ln=50, C=3, steps=10, warmup=3, graph=True):
         "config": {"workload": f"DiffusionPlanner training step (main_trajectory.py:177-204): B={B} trajectories, horizon "
                                f"{Ln}, {C} cameras 256x256 (S={S}), E=120, H=8, dropout 0.1, frozen synthetic CLIP-RN50-shaped "
                                "backbone + trainable FPN included", "hipgraph": graphed is not None,
+                   "backbone_prefetch": bool(graphed is not None and prefetch),
                    "final_loss": float(loss.item())},
         "roofline": rl,
     }

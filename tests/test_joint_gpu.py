@@ -307,12 +307,14 @@ def _joint_vs_separate(E, joint, ks, ts, kcrit, tcrit, kA, kB, tA, tB, kfA, kfB,
 
 
 # ------------------------------------------------------------------------------------------------ graph replays of the trajectory step
-def test_graphed_trajectory_step_gradients_equal_eager_on_every_replay(a3d, dev):
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_graphed_trajectory_step_gradients_equal_eager_on_every_replay(a3d, dev, prefetch):
     """The captured diffusion training step (engine.GraphedStep over fwd_bwd_trajectory, what bench.py replays) against the eager
     step, over FOUR replays from the same weights / batch / dropout state (learning rate 0, so every replay must reproduce the
     same gradients).  Horizon 40 puts a3d_adaln_bwd on its split path (per-split partial sums accumulated into a zeroed dmod):
     that zeroing was a captured hipMemsetAsync, which this stack replays right once and stale afterwards (round-5 advisor
-    finding) -- it is a kernel node now, and this test is what would have caught it."""
+    finding) -- it is a kernel node now, and this test is what would have caught it.
+    prefetch: the next batch's frozen backbone forked inside the step's graph (two alternating graph / map sets; round 6)."""
     E = a3d.engine
     tcrit = a3d.TrajectoryCriterion()
     ts = _tr_sample(3, 40, 1, dev, 91)
@@ -330,7 +332,9 @@ def test_graphed_trajectory_step_gradients_equal_eager_on_every_replay(a3d, dev)
     l_again, g_again = eager()                                       # run-to-run noise of the eager step itself (float atomics)
     gs = g_ref.abs().max().item()
     noise = (g_again - g_ref).abs().max().item()
-    graphed = E.GraphedStep(lambda s: E.fwd_bwd_trajectory(tr, tcrit, s), opt, ts, warmup=2)
+    graphed = E.GraphedStep(lambda s: E.fwd_bwd_trajectory(tr, tcrit, s), opt, ts, warmup=2,
+                            prefetch=tr.prediction_head.backbone_maps if prefetch else None)
+    assert len(graphed.g_fb) == (2 if prefetch else 1)
     mods = [n for n in flat.slices if "adaln" in n and "modulation" in n]
     assert mods
     for rep in range(4):
