@@ -341,7 +341,8 @@ def _split_backward(tokens, run_hot, on_hot_done):
 
 def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=None):
     """forward + loss + backward of main_keypose.py:207-224 with the backward split at the FPN tokens"""
-    tokens = model.compute_visual_tokens(sample["rgbs"], maps=sample.get("backbone_maps"))   # maps: prefetched by the previous step
+    maps = sample.get("backbone_maps")               # prefetched by the previous step (GraphedStep(prefetch=...)); else computed here
+    tokens = model.compute_visual_tokens(sample["rgbs"]) if maps is None else model.compute_visual_tokens(sample["rgbs"], maps=maps)
     if sample.get("_after_tokens") is not None:
         sample["_after_tokens"]()                    # GraphedStep(prefetch=...) with A3D_PREFETCH_FORK=tokens forks the next backbone here
 
@@ -355,7 +356,9 @@ def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=
 
 def fwd_bwd_trajectory(model, criterion, sample, on_hot_done=None):
     """forward + loss + backward of main_trajectory.py:177-195 with the backward split at the FPN tokens"""
-    tokens = model.prediction_head.encode_images(sample["rgbs"], None, maps=sample.get("backbone_maps"))   # maps: prefetched by the previous step
+    maps = sample.get("backbone_maps")               # prefetched by the previous step (GraphedStep(prefetch=...)); else computed here
+    head = model.prediction_head
+    tokens = head.encode_images(sample["rgbs"], None) if maps is None else head.encode_images(sample["rgbs"], None, maps=maps)
     multi = isinstance(tokens, (list, tuple))                  # one token tensor per scale for a multi-scale head
 
     # additive test hooks: a batch may carry the DDPM noise / timesteps to use instead of the device draws
