@@ -305,6 +305,19 @@ def other_kernel_rooflines(a3d, device, B, x, k_xyz, w, bb, freq):
                      "launches_per_step": per_step,
                      "note": f"{cin} -> {cout} channels, {nimg} maps of {hw} x {hw}; BatchNorm-apply of the producer and statistics of the output folded in"}
         del xin
+    # the FPN's fine-level lateral convolution with bias + top-down add in the epilogue (a3d_conv1x1_topdown_fwd): algorithmic
+    # bytes = one read of the backbone map and of the coarser FPN map + one write of the level's inner map
+    hw, cin, cout = 128, 64, 64
+    xin = torch.randn(nimg, cin, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    top = torch.randn(nimg, cout, hw // 2, hw // 2, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wlat, blat = torch.randn(cout, cin, 1, 1, device=device) * cin ** -0.5, torch.randn(60, device=device)
+    with torch.no_grad():
+        t = time_kernel(lambda: a3d.nn._LateralTopDownFn.apply(xin, wlat, blat, top))
+    by = (xin.numel() + top.numel() + nimg * cout * hw * hw) * 2.0
+    out["fpn_lateral_topdown"] = {"bound": "hbm", "achieved": by / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "ms": t,
+                                  "frac": by / (t * 1e-3) / 8e12, "launches_per_step": 1,
+                                  "note": f"{cin} -> {cout} channels + bias + 2x-upsampled coarser map, {nimg} maps of {hw} x {hw}, one rounding (incl. the bf16 cast of the weight)"}
+    del xin, top
     return out
 
 
