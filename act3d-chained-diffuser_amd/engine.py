@@ -468,6 +468,8 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
 # A/B switch (measured, round 6: both lose -- "main" 23.0 ms, default 18.9 ms per keypose step): "main" captures the prefetching step on
 # a high-priority stream, "side" gives the prefetch stream the high priority instead
 PREFETCH_HIPRIO = os.environ.get("A3D_PREFETCH_HIPRIO", "0")
+# A3D_PREFETCH_CHECK=1: every launch verifies that its images are the ones the previous launch announced (one host sync per step)
+PREFETCH_CHECK = os.environ.get("A3D_PREFETCH_CHECK", "0") == "1"
 # where the next batch's backbone is forked: "start" of the step, or after the FPN forward ("tokens": engine.fwd_bwd_keypose's hook)
 PREFETCH_FORK = os.environ.get("A3D_PREFETCH_FORK", "start")
 
@@ -597,6 +599,10 @@ class GraphedStep:
         p_ = 0
         if self.prefetch is not None:
             p_ = self.parity
+            if self._primed and PREFETCH_CHECK and not torch.equal(self.static_inputs["rgbs"], self.next_rgbs):
+                # (a host synchronisation per step: a debugging aid, off by default)
+                raise RuntimeError("GraphedStep(prefetch): this launch's images are not the next_rgbs the previous launch was given -- "
+                                   "the maps prefetched for it belong to another batch")
             if not self._primed:                 # the first launch computes its own maps (nobody prefetched them)
                 with torch.no_grad():
                     self.prefetch(self.static_inputs["rgbs"], out=self.maps[p_])

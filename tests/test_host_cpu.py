@@ -814,4 +814,12 @@ def test_graphed_step_prefetch_schedule_on_cpu_tensors():
     assert log == [("replay", 1)] and float(gs.next_rgbs.sum()) == 12.0        # next defaults to the static images (b)
     log.clear()
     assert gs() == "loss0" and log == [("replay", 0)] and gs.parity == 1
+    # A3D_PREFETCH_CHECK: a launch whose images are not the announced ones is refused instead of training on another batch's maps
+    E.PREFETCH_CHECK = True
+    try:
+        gs({"rgbs": b}, next_rgbs=a)                                         # b was announced (the static images again): fine
+        with pytest.raises(RuntimeError, match="next_rgbs"):
+            gs({"rgbs": b})                                                  # a was announced
+    finally:
+        E.PREFETCH_CHECK = False
 
