@@ -343,8 +343,6 @@ def fwd_bwd_keypose(model, criterion, sample, use_gt_sampling=True, on_hot_done=
     """forward + loss + backward of main_keypose.py:207-224 with the backward split at the FPN tokens"""
     maps = sample.get("backbone_maps")               # prefetched by the previous step (GraphedStep(prefetch=...)); else computed here
     tokens = model.compute_visual_tokens(sample["rgbs"]) if maps is None else model.compute_visual_tokens(sample["rgbs"], maps=maps)
-    if sample.get("_after_tokens") is not None:
-        sample["_after_tokens"]()                    # GraphedStep(prefetch=...) with A3D_PREFETCH_FORK=tokens forks the next backbone here
 
     def hot(leaves):
         out = model(sample["rgbs"], sample["pcds"], sample["instr"], sample["curr_gripper"],
@@ -470,8 +468,8 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
 PREFETCH_HIPRIO = os.environ.get("A3D_PREFETCH_HIPRIO", "0")
 # A3D_PREFETCH_CHECK=1: every launch verifies that its images are the ones the previous launch announced (one host sync per step)
 PREFETCH_CHECK = os.environ.get("A3D_PREFETCH_CHECK", "0") == "1"
-# where the next batch's backbone is forked: "start" of the step, or after the FPN forward ("tokens": engine.fwd_bwd_keypose's hook)
-PREFETCH_FORK = os.environ.get("A3D_PREFETCH_FORK", "start")
+# (forking the backbone after the FPN forward instead of at the start of the step measured the same, 18.86 vs 18.91 ms,
+# profiles/r06_prefetch_ab.json: the knob was removed)
 
 
 class GraphedStep:
@@ -532,9 +530,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
-        def fork(p_, late=False):
+        def fork(p_):
             """the next batch's backbone on the side stream (joined by join()); no-op without prefetch"""
-            if prefetch is None or (PREFETCH_FORK == "tokens") != late:
+            if prefetch is None:
                 return
             self._pf_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._pf_stream), torch.no_grad():
@@ -547,9 +545,6 @@ class GraphedStep:
         self.g_fb, self.g_late, self.loss = [], [], []
         self.g_opt = None
         pool = None
-        if prefetch is not None and PREFETCH_FORK == "tokens":
-            for p_ in range(sets):
-                inputs[p_]["_after_tokens"] = (lambda q=p_: fork(q, late=True))
         for p_ in range(sets):
             g = torch.cuda.CUDAGraph()
             self.g_fb.append(g)
