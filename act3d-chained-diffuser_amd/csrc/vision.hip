@@ -471,6 +471,13 @@ extern "C" int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int
   return check_launch("a3d_bn_finalize");
 }
 
+// workgroups of the BatchNorm-apply passes (grid-stride loops).  A3D_BN_GRID: A/B of smaller grids, which leave wave slots to the kernels
+// of a concurrent stream (the hot path next to the prefetched backbone, engine.GraphedStep(prefetch=...))
+static int bn_grid_cap() {
+  static const int v = getenv("A3D_BN_GRID") ? std::max(256, atoi(getenv("A3D_BN_GRID"))) : 16384;
+  return v;
+}
+
 extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,
                             const float* shift, void* y, size_t rows, int C, int relu, void* stream) {
   if (!x || !scale || !shift || !y || rows == 0 || C <= 0 || (C % 8) != 0 || (res_scale && (!res_shift || !residual)) ||
@@ -479,7 +486,7 @@ extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* re
     return A3D_ERR_ARG;
   }
   const size_t nvec = rows * (size_t)(C / 8);
-  const int grid = (int)std::min<size_t>((nvec + 255) / 256, 16384);
+  const int grid = (int)std::min<size_t>((nvec + 255) / 256, (size_t)bn_grid_cap());
   if (res_scale)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)residual,
                        scale, shift, res_scale, res_shift, (uint4*)y, nvec, C / 8, relu);
@@ -499,7 +506,7 @@ extern "C" int a3d_bn_apply_pool2(const void* x, const void* residual, const flo
   }
   const size_t nout = (size_t)N * (H / 2) * (W / 2) * (C / 8);
   if (nout >= ((size_t)1 << 31)) { set_error("a3d_bn_apply_pool2: map too large (%zu 16-byte outputs)", nout); return A3D_ERR_ARG; }
-  const int grid = (int)std::min<size_t>((nout + 255) / 256, 16384);
+  const int grid = (int)std::min<size_t>((nout + 255) / 256, (size_t)bn_grid_cap());
   hipLaunchKernelGGL(bn_apply_pool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
                      (const uint4*)residual, scale, shift, (uint4*)y_full, (uint4*)y_pool, N, H, W, C / 8, relu);
   return check_launch("a3d_bn_apply_pool2");
