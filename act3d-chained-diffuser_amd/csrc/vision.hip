@@ -471,11 +471,16 @@ extern "C" int a3d_bn_finalize(const float* partial, int nslab, size_t rows, int
   return check_launch("a3d_bn_finalize");
 }
 
-// workgroups of the BatchNorm-apply passes (grid-stride loops).  A3D_BN_GRID: A/B of smaller grids, which leave wave slots to the kernels
-// of a concurrent stream (the hot path next to the prefetched backbone, engine.GraphedStep(prefetch=...))
-static int bn_grid_cap() {
-  static const int v = getenv("A3D_BN_GRID") ? std::max(256, atoi(getenv("A3D_BN_GRID"))) : 16384;
-  return v;
+// Workgroups of the BatchNorm-apply passes (grid-stride loops): 16384 by default.  A smaller grid leaves wave slots to the kernels of
+// a concurrent stream: the backbone that engine.GraphedStep(prefetch=...) runs next to the hot path is captured with 256 (one
+// workgroup per CU) -- 18.87 -> 18.45 ms per keypose step, while the same grid costs the stand-alone backbone ~0.1 ms
+// (profiles/r06_prefetch_ab.json).  A3D_BN_GRID sets the process default; a3d_bn_grid_cap(cap) sets it (cap > 0) and returns the previous value.
+static int g_bn_grid_cap = getenv("A3D_BN_GRID") ? std::max(64, atoi(getenv("A3D_BN_GRID"))) : 16384;
+static int bn_grid_cap() { return g_bn_grid_cap; }
+extern "C" int a3d_bn_grid_cap(int cap) {
+  const int prev = g_bn_grid_cap;
+  if (cap > 0) g_bn_grid_cap = std::max(64, cap);
+  return prev;
 }
 
 extern "C" int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, const float* res_shift, const float* scale,

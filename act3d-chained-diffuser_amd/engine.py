@@ -466,6 +466,8 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
 # A/B switch (measured, round 6: both lose -- "main" 23.0 ms, default 18.9 ms per keypose step): "main" captures the prefetching step on
 # a high-priority stream, "side" gives the prefetch stream the high priority instead
 PREFETCH_HIPRIO = os.environ.get("A3D_PREFETCH_HIPRIO", "0")
+# BatchNorm-apply workgroups of the prefetched backbone (a3d_bn_grid_cap; 0: leave the library default)
+PREFETCH_BN_GRID = int(os.environ.get("A3D_PREFETCH_BN_GRID", "256"))
 # A3D_PREFETCH_CHECK=1: every launch verifies that its images are the ones the previous launch announced (one host sync per step)
 PREFETCH_CHECK = os.environ.get("A3D_PREFETCH_CHECK", "0") == "1"
 # (forking the backbone after the FPN forward instead of at the start of the step measured the same, 18.86 vs 18.91 ms,
@@ -535,8 +537,16 @@ class GraphedStep:
             if prefetch is None:
                 return
             self._pf_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._pf_stream), torch.no_grad():
-                prefetch(self.next_rgbs, out=self.maps[1 - p_])
+            # the overlapped backbone's BatchNorm-apply passes with one workgroup per CU: the hot path's kernels find free wave slots
+            # (18.87 -> 18.45 ms per keypose step; grids are baked into the captured graph, so only this capture sees the setting)
+            lib = L.load()
+            prev = lib.a3d_bn_grid_cap(PREFETCH_BN_GRID) if PREFETCH_BN_GRID > 0 else 0
+            try:
+                with torch.cuda.stream(self._pf_stream), torch.no_grad():
+                    prefetch(self.next_rgbs, out=self.maps[1 - p_])
+            finally:
+                if PREFETCH_BN_GRID > 0:
+                    lib.a3d_bn_grid_cap(prev)
 
         def join():
             if prefetch is not None:

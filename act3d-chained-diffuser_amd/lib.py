@@ -140,6 +140,7 @@ SIGNATURES = {
     "a3d_dbg_mfma_f32": (_i, [_p, _p, _p, _p]),
     "a3d_dbg_cvt_pk_bf16": (_i, [_p, _p, _i, _p]),
     "a3d_bn_nslab": (_i, [_z, _i]),
+    "a3d_bn_grid_cap": (_i, [_i]),
     "a3d_conv1x1_streams": (_i, [_i, _i]),
     "a3d_conv1x1_nslab": (_i, [_z, _i, _i]),
     "a3d_conv1x1_bn_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _z, _i, _i, _p]),

@@ -483,6 +483,11 @@ int a3d_bn_apply(const void* x, const void* residual, const float* res_scale, co
  * y_full [N][H][W][C] is also written unless NULL.  scale == NULL: identity (plain average pool of x).  H, W even. */
 int a3d_bn_apply_pool2(const void* x, const void* residual, const float* scale, const float* shift, void* y_full,
                        void* y_pool, int N, int H, int W, int C, int relu, void* stream);
+/* Workgroups of a3d_bn_apply / a3d_bn_apply_pool2 (grid-stride loops; default 16384, A3D_BN_GRID): cap > 0 sets the cap (at least 64)
+ * and returns the previous one, cap <= 0 only queries.  A capture of the frozen backbone that is to run BESIDE other kernels
+ * (engine.GraphedStep(prefetch=...)) uses one workgroup per CU so that the concurrent stream finds free wave slots; grids are
+ * baked into a captured graph, so the setting only matters while launches are being issued.  (clip.py:28-43 BatchNorm passes.) */
+int a3d_bn_grid_cap(int cap);
 /* FPN top-down step, bf16 NHWC, exact 2x: y = lat + bias + nearest_up2(top)  (torchvision FeaturePyramidNetwork.forward as the
  * reference instantiates it, act3d.py:60-66, with the lateral 1x1 convolution's bias folded in: the convolution runs
  * bias-free; bias fp32 [nbias <= C] or NULL, channels >= nbias are MIOpen's zero padding; top NULL at the pyramid's top level).  Backward: dtop = 2x2 block sums of dy (dlat = dy;

@@ -595,6 +595,10 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, None, None, 0, dummy, None, 128, 64, 320, None) == -22     # N not 256 j
     assert lib.a3d_conv1x1_bn_fwd(dummy, dummy, dummy, None, 1, dummy, None, 128, 64, 64, None) == -22     # scale without shift
     assert b"a3d_conv1x1_bn_fwd" in lib.a3d_last_error_string()
+    # the BatchNorm-apply grid cap: set + query, floor of 64, restored
+    prev = lib.a3d_bn_grid_cap(0)
+    assert prev >= 64 and lib.a3d_bn_grid_cap(256) == prev and lib.a3d_bn_grid_cap(-1) == 256
+    assert lib.a3d_bn_grid_cap(1) == 256 and lib.a3d_bn_grid_cap(prev) == 64 and lib.a3d_bn_grid_cap(0) == prev
     # the FPN's lateral convolution with the top-down add in its epilogue: the resident-weight kernel's shapes with N <= 128
     assert lib.a3d_conv1x1_topdown_serves(64, 64) == 1 and lib.a3d_conv1x1_topdown_serves(256, 64) == 1
     assert lib.a3d_conv1x1_topdown_serves(256, 128) == 1 and lib.a3d_conv1x1_topdown_serves(512, 64) == 0
