@@ -585,6 +585,8 @@ class GraphedStep:
                 optimizer.zero_grad()
                 self.loss.append(call(p_, switch_graphs))
             finally:
+                if "second" not in ctx:
+                    join()                           # a step that never reached its split point: do not leave the side stream unjoined
                 (ctx.get("second") or ctx["first"]).__exit__(None, None, None)
             pool = g.pool()
         if split:

@@ -827,3 +827,34 @@ def test_graphed_step_prefetch_schedule_on_cpu_tensors():
     finally:
         E.PREFETCH_CHECK = False
 
+
+def test_backbone_maps_into_preallocated_buffers_on_cpu():
+    """Act3D.backbone_maps / DiffusionHead.backbone_maps(out=...) on the CPU (fp32 torch path of run_frozen_backbone: the maps are
+    copied into the caller's buffers; on the GPU's fused path the producing kernels write them in place): same values, the caller's
+    storage, and compute_visual_tokens(maps=...) equals compute_visual_tokens() -- the contract engine.GraphedStep(prefetch=...) builds on."""
+    a3d = load_pkg()
+    import torch
+    torch.manual_seed(0)
+    m = a3d.Act3D(image_size=(128, 128), embedding_dim=60, num_attn_heads=4, gripper_loc_bounds=[[-1, -1, -1], [1, 1, 1]],
+                  num_ghost_points=16, num_ghost_points_val=16, num_sampling_level=1)
+    rgb = torch.rand(1, 2, 3, 128, 128)
+    ref = m.backbone_maps(rgb)
+    assert sorted(ref) == ["res1", "res2", "res3", "res4", "res5"] and not any(v.requires_grad for v in ref.values())
+    out = {k: torch.full_like(v, float("nan")) for k, v in ref.items()}
+    got = m.backbone_maps(rgb, out=out)
+    for k in ref:
+        assert got[k].data_ptr() == out[k].data_ptr() and torch.allclose(out[k], ref[k], rtol=1e-5, atol=1e-6), k
+    ta = m.compute_visual_tokens(rgb)
+    tb = m.compute_visual_tokens(rgb, maps=out)
+    assert len(ta) == len(tb) == 1
+    assert torch.allclose(a3d.ops.TokenMap.of(ta[0]).tokens, a3d.ops.TokenMap.of(tb[0]).tokens, rtol=1e-4, atol=1e-5)
+    head = a3d.DiffusionHead(embedding_dim=120, num_attn_heads=8, output_dim=7) if hasattr(a3d, "DiffusionHead") else None
+    if head is not None:
+        r2 = torch.rand(1, 1, 3, 256, 256)
+        hm = head.backbone_maps(r2)
+        ho = {k: torch.zeros_like(v) for k, v in hm.items()}
+        head.backbone_maps(r2, out=ho)
+        assert all(torch.allclose(ho[k], hm[k], rtol=1e-5, atol=1e-6) for k in hm)
+        t1, t2 = head.encode_images(r2, None), head.encode_images(r2, None, maps=ho)
+        assert torch.allclose(t1, t2, rtol=1e-4, atol=1e-5)
+
